@@ -1,0 +1,77 @@
+"""Deterministic, platform-independent test inputs shared by `oracle/gen_golden.py` (build container,
+reference available) and the tests (both boxes).  Everything is drawn from a seeded CPU
+`torch.Generator`, so the GPU box can regenerate the exact weights / feature maps a golden fixture
+was produced from without the fixture having to store them."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+# the shipped Cityscapes config (configs/_base_/models/polyphonic_former.py:1-6,111-126)
+FULL = dict(C=256, F=2048, heads=8, groups=32, n_thing=8, n_stuff=11, Nq=100, S=3)
+# reduced dims for fast oracle-vs-reference checks (the reference classes are parametric)
+MINI = dict(C=32, F=64, heads=4, groups=4, n_thing=3, n_stuff=2, Nq=7, S=2)
+
+
+def seeded_fill(shapes, seed):
+    """shapes: {key: shape}.  Returns {key: fp32 tensor}; keys are visited in sorted order and all
+    values come from ONE generator, so the result depends only on (key set, shapes, seed)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        t = torch.randn(shp, generator=g)
+        if len(shp) >= 2:                       # linear / conv weights: xavier-like scale
+            fan_out = shp[0]
+            fan_in = int(np.prod(shp[1:]))
+            t = t * float(np.sqrt(2.0 / (fan_in + fan_out)))
+            if k.endswith("init_kernels.weight"):
+                t = t * 4.0                     # kernels need O(1) logits to give non-trivial masks
+        elif k.endswith("weight"):              # LayerNorm / GroupNorm gains
+            t = 1.0 + 0.1 * t
+        else:                                   # biases
+            t = 0.1 * t
+        out[k] = t.contiguous()
+    return out
+
+
+def iter_inputs(seed, B, N, C, H, W, mask_bias=0.0):
+    """Isolated-IterHead inputs as BASELINE.md section 2 defines them."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    dfe = torch.randn(B, C, H, W, generator=g)
+    k0 = torch.randn(B, N, C, 1, 1, generator=g)
+    dker = torch.randn(1, 1, C, 1, 1, generator=g)
+    q0 = dker.expand(B, N, C, 1, 1)           # stride-0 view, like kernel_head.py:336
+    m0 = torch.randn(B, N, H, W, generator=g) + mask_bias
+    dpr = torch.randn(B, 1, H, W, generator=g)
+    return dict(x=x, dfe=dfe, k0=k0, q0=q0, m0=m0, depth_pred=dpr)
+
+
+def neck_inputs(seed, B, C, H, W):
+    """Post-neck maps ~ ReLU(N(0,1)) (they follow a ReLU in semantic_fpn.py:158-178)."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, C, H, W, generator=g).relu() for _ in range(3)]
+
+
+def img_meta(h, w, pad_to=None, ori=None):
+    bh, bw = pad_to if pad_to else (h, w)
+    oh, ow = ori if ori else (h, w)
+    return dict(img_shape=(h, w, 3), ori_shape=(oh, ow, 3), batch_input_shape=(bh, bw))
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| -- the '1e-3 relative' of BASELINE.json:north_star."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
