@@ -1,0 +1,151 @@
+/*
+ * polyhead.h -- C ABI of libpolyhead.so: the MI355X (gfx950) implementation of PolyphonicFormer's
+ * unified-query decode hot path.  Plain pointers, sizes and a hipStream_t (passed as void*); no
+ * torch types.  Every entry point
+ *   - returns 0 on success or a negative PH_E* code (never throws, see ph_last_error_string),
+ *   - never allocates and never synchronises: the caller owns every buffer and passes the stream,
+ *   - is thread-compatible (no mutable globals besides a thread-local error string).
+ *
+ * The reference is 100 % Python: there is no FFI in it to mirror.  Each function
+ * below therefore cites the reference *Python* lines whose device work it replaces; the Python
+ * classes in polyphonicformer_amd/ keep the reference's registry names / kwargs / state_dict keys
+ * and call these through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Internal device formats:
+ *   feature planes  : uint16 (bf16 bits) [P][B][256][HWp], HWp = HW rounded up to 128, zero padded.
+ *                     P = 1 for PH_PREC_BF16; P = 2 (hi, lo with x ~= hi + lo to 2^-17) for
+ *                     PH_PREC_SPLIT, the fp32-grade mode used for the 1e-3 parity runs.
+ *   mask bits       : uint32 [B][Npad][HWp/32], bit j of word w = 1[logit(pixel 32w+j) > 0];
+ *                     Npad = N rounded up to 32; rows >= N and pixels >= HW are 0.
+ *   query matrices  : fp32 [B][N][256] row major at the API; bf16 planes [P][...][Npad][256] inside.
+ */
+#ifndef POLYHEAD_H_
+#define POLYHEAD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_VERSION 100
+
+enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWORKSPACE = -4 };
+enum { PH_PREC_BF16 = 1, PH_PREC_SPLIT = 3 };   /* number of bf16 MFMA products per logical product */
+enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1 };
+
+#define PH_C 256          /* channels: in_channels == out_channels == feat_channels == 256 */
+#define PH_HEADS 8        /* num_heads (head dim 32) */
+
+int         ph_version(void);
+const char* ph_last_error_string(void);
+
+/* ---- geometry helpers ------------------------------------------------------------------- */
+static inline int64_t ph_hw_padded(int64_t hw) { return (hw + 127) / 128 * 128; }
+static inline int     ph_n_padded(int n) { return (n + 31) / 32 * 32; }
+
+/* ---- feature-map ingest ------------------------------------------------------------------
+ * fp32 NCHW [B][256][HW] (what KernelHead hands over, kernel_head.py:347 x_feats/depth_feats)
+ * -> bf16 planes [P][B][256][HWp].  Replaces nothing arithmetic in the reference; it is the
+ * format change at the boundary. */
+int ph_ingest_features(const float* src, uint16_t* planes, int B, int64_t HW, int prec, void* stream);
+
+/* fp32 mask logits [B][N][HW] -> mask bits.  kernel_update_head.py:236-238
+ * (sigmoid -> > hard_mask_thr(0.5) -> float), stated as logit > 0. */
+int ph_binarize(const float* logits, uint32_t* bits, int B, int N, int64_t HW, void* stream);
+
+/* ---- A7: masked pooling -------------------------------------------------------------------
+ * kernel_update_head.py:241-242  einsum('bnhw,bchw->bnc') for x and depth_feats in one pass
+ * (and kernel_head.py:320 with only `xplanes`).  Split over `nsplit` pixel ranges; the
+ * deterministic partial sums land in partial[B][nsplit][Npad][512] (cols 0..255 = x,
+ * 256..511 = depth_feats) and are summed in fixed order by the consumer. `dplanes` may be NULL. */
+int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial,
+            int B, int N, int64_t HW, int nsplit, int prec, void* stream);
+
+/* ---- packed per-stage weights -------------------------------------------------------------
+ * One KernelUpdateHead stage (kernel_update_head.py:21-191 parameters) packed by the host into
+ *   wb : uint16 [P][wb_plane_elems]   bf16 MFMA B-fragments, tile-major
+ *   wf : float  [..]                  biases, LayerNorm affine, folded vectors
+ * with offsets (in elements) indexed by the enums below; branch 0 = mask, 1 = depth. */
+enum {
+    PH_W_DYN = 0,   /* dynamic_layer folded with feat_transform: [512][256]   kernel_updator.py:58, kernel_update_head.py:225 */
+    PH_W_INP,       /* input_layer [512][256]                                  kernel_updator.py:64 */
+    PH_W_IG,        /* input_gate  [256][256]                                  :73 */
+    PH_W_UG,        /* update_gate [256][256]                                  :74 */
+    PH_W_FC,        /* fc_layer    [256][256]                                  :89 */
+    PH_W_QKV,       /* attn.in_proj_weight [768][256]                          kernel_update_head.py:112-115 */
+    PH_W_OUT,       /* attn.out_proj [256][256] */
+    PH_W_FFN1,      /* ffn.layers.0.0 [F][256]                                 :146-151 */
+    PH_W_FFN2,      /* ffn.layers.1   [256][F] */
+    PH_W_H0A,       /* cls_fcs.0 (mask branch) / depth_regs.0 (depth branch)   :161-187 */
+    PH_W_H0B,       /* mask_fcs.0 (mask branch only) */
+    PH_W_CLS,       /* fc_cls [Lpad][256] (mask branch only)                   :169-172 */
+    PH_W_KERN,      /* fc_mask / fc_depth folded with feat_(depth_)transform: [272][256]; row 256 = bias dot  :189-190,225-226 */
+    PH_W_COUNT
+};
+enum {
+    PH_V_DYN_CNT = 0, /* [512] dynamic_layer.weight @ feat_transform.bias (multiplies the pixel count) */
+    PH_V_DYN_B, PH_V_INP_B, PH_V_IG_B, PH_V_UG_B,
+    PH_V_LN_IG_G, PH_V_LN_IG_B,   /* input_norm_in   kernel_updator.py:73 */
+    PH_V_LN_UG_G, PH_V_LN_UG_B,   /* norm_in         :74 */
+    PH_V_LN_PO_G, PH_V_LN_PO_B,   /* norm_out        :78 */
+    PH_V_LN_IO_G, PH_V_LN_IO_B,   /* input_norm_out  :79 */
+    PH_V_FC_B, PH_V_LN_FC_G, PH_V_LN_FC_B,
+    PH_V_QKV_B, PH_V_OUT_B, PH_V_LN_ATT_G, PH_V_LN_ATT_B,
+    PH_V_FFN1_B, PH_V_FFN2_B, PH_V_LN_FFN_G, PH_V_LN_FFN_B,
+    PH_V_LN_H0A_G, PH_V_LN_H0A_B, PH_V_LN_H0B_G, PH_V_LN_H0B_B,
+    PH_V_CLS_B, PH_V_KERN_B,       /* [272] folded fc_mask/fc_depth bias (entry 256 = bias . transform bias) */
+    PH_V_COUNT
+};
+typedef struct {
+    int64_t w[2][PH_W_COUNT];   /* element offsets into one plane of wb */
+    int64_t v[2][PH_V_COUNT];   /* element offsets into wf */
+    int64_t wb_plane_elems;     /* distance between the hi and lo plane */
+    int32_t ffn_dim;            /* F, multiple of 256 */
+    int32_t num_classes;        /* L */
+} ph_stage_layout;
+
+/* ---- A8-A12: the query side of one stage ---------------------------------------------------
+ * kernel_update_head.py:245-288 + funcs/kernel_updator.py:55-93 for both branches:
+ *   pre : partial-sum reduce, KernelUpdator x2, attention in-projection
+ *   post: self-attention per branch, out-proj + LN, FFN + LN, cls / mask-kernel / depth-kernel heads
+ * Inputs  k_in, q_in fp32 [B][N][256] (proposal_feat, depth_proposal); bits for the pixel counts.
+ * Outputs obj, dobj fp32 [B][N][256]; cls fp32 [B][N][L]; kern planes [P][2][B][Npad][256] and
+ *         kbias fp32 [2][B][Npad]: the dynamic 1x1 conv kernels already folded with
+ *         feat_transform, i.e. new_mask_logits = kern[0] . x + kbias[0]  (kernel_update_head.py:317-329).
+ * Workspace (ph_query_workspace_bytes): q/k/v planes + residual. */
+enum { PH_QUERY_PRE = 1, PH_QUERY_POST = 2, PH_QUERY_BOTH = 3 };
+size_t ph_query_workspace_bytes(int B, int N, int prec);
+/* byte offset, inside the workspace, of the fp32 [B][2][Npad][256] KernelUpdator outputs
+ * (funcs/kernel_updator.py:93) that the PRE phase leaves behind for the POST phase. */
+size_t ph_query_workspace_updator_offset(int B, int N, int prec);
+int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits,
+                   const float* k_in, const float* q_in,
+                   const uint16_t* wb, const float* wf, const ph_stage_layout* layout,
+                   float* obj, float* dobj, float* cls, int cls_sigmoid /* kernel_update.py:396-397 */,
+                   uint16_t* kern, float* kbias,
+                   void* workspace, size_t workspace_bytes,
+                   int B, int N, int64_t HW, int prec, int phases, void* stream);
+
+/* ---- A13: dynamic 1x1 convolution -----------------------------------------------------------
+ * kernel_update_head.py:317-329: logits[b][n][hw] = sum_c kern[b][n][c] * feat[b][c][hw] + kbias[b][n].
+ * Either writes the mask bits the next stage pools with (bits_out != NULL; the logits of a
+ * non-final stage are consumed only through `> 0`, kernel_update_head.py:236-238) or the logits
+ * themselves (logits_out, dtype out_dtype, [B][N][HW]). `kern`/`kbias` point at ONE branch. */
+int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_stride,
+               const float* kbias, uint32_t* bits_out, void* logits_out, int out_dtype,
+               int B, int N, int64_t HW, int prec, void* stream);
+
+/* ---- A14: x2 bilinear upsample, align_corners=False (kernel_update.py:131-143) ------------- */
+int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes /* B*N */, int H, int W, void* stream);
+
+/* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
+int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);
+int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);
+int ph_selftest_trread(const uint16_t* src /*[16][16]*/, uint16_t* out /*[64][4]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYHEAD_H_ */

@@ -1,0 +1,81 @@
+"""ctypes binding of libpolyhead.so (include/polyhead.h).  The library is the ONLY compute path:
+if it is missing or fails to load this module raises -- there is no CPU or PyTorch fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpolyhead.so")
+
+PH_PREC_BF16, PH_PREC_SPLIT = 1, 3
+PH_OUT_F32, PH_OUT_BF16 = 0, 1
+
+W_NAMES = ["DYN", "INP", "IG", "UG", "FC", "QKV", "OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN"]
+V_NAMES = ["DYN_CNT", "DYN_B", "INP_B", "IG_B", "UG_B", "LN_IG_G", "LN_IG_B", "LN_UG_G", "LN_UG_B",
+           "LN_PO_G", "LN_PO_B", "LN_IO_G", "LN_IO_B", "FC_B", "LN_FC_G", "LN_FC_B", "QKV_B", "OUT_B",
+           "LN_ATT_G", "LN_ATT_B", "FFN1_B", "FFN2_B", "LN_FFN_G", "LN_FFN_B", "LN_H0A_G", "LN_H0A_B",
+           "LN_H0B_G", "LN_H0B_B", "CLS_B", "KERN_B"]
+W_IDX = {n: i for i, n in enumerate(W_NAMES)}
+V_IDX = {n: i for i, n in enumerate(V_NAMES)}
+
+
+class StageLayout(C.Structure):
+    _fields_ = [("w", (C.c_int64 * len(W_NAMES)) * 2), ("v", (C.c_int64 * len(V_NAMES)) * 2),
+                ("wb_plane_elems", C.c_int64), ("ffn_dim", C.c_int32), ("num_classes", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/polyhead.h declares
+_P, _I, _L, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+SIGNATURES = {
+    "ph_version": (C.c_int, []),
+    "ph_last_error_string": (C.c_char_p, []),
+    "ph_ingest_features": (C.c_int, [_P, _P, _I, _L, _I, _P]),
+    "ph_binarize": (C.c_int, [_P, _P, _I, _I, _L, _P]),
+    "ph_pool": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
+    "ph_query_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
+                                 _P, _Z, _I, _I, _L, _I, _I, _P]),
+    "ph_query_workspace_updator_offset": (C.c_size_t, [_I, _I, _I]),
+    "ph_dynconv": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
+    "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
+    "ph_selftest_trread": (C.c_int, [_P, _P, _P]),
+}
+
+_lib = None
+
+
+class PolyheadError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PolyheadError(
+            f"{LIB_PATH} is missing: build it with `python -m polyphonicformer_amd.build` "
+            "(needs hipcc, gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ph_last_error_string()
+        raise PolyheadError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """raw device (or host) pointer of a torch tensor; None -> NULL"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,70 @@
+"""Builds `libpolyhead.so` (every HIP source under csrc/) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU; the resulting .so travels with the repository snapshot to the
+GPU box (it is git-ignored, not gpurun-ignored)."""
+import hashlib
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpolyhead.so")
+OBJ = os.path.join(CSRC, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libpolyhead.so cannot be built (no CPU fallback exists)")
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build_library(force=False, verbose=False):
+    srcs = sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "polyhead.h")]
+    stamp = os.path.join(OBJ, "stamp")
+    dig = _digest(deps)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+
+    def cc(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

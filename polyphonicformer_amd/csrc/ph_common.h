@@ -1,0 +1,84 @@
+// Shared device helpers for libpolyhead (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/polyhead.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+
+#define PH_LDS __attribute__((address_space(3)))
+
+void ph_set_error(const char* fmt, ...);
+
+#define PH_CHECK_ARG(cond, msg)                                        \
+    do {                                                               \
+        if (!(cond)) {                                                 \
+            ph_set_error("%s: %s", __func__, msg);                     \
+            return PH_EINVAL;                                          \
+        }                                                              \
+    } while (0)
+
+#define PH_CHECK_LAUNCH()                                                          \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ph_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return PH_ELAUNCH;                                                     \
+        }                                                                          \
+    } while (0)
+
+// ---- bf16 bit helpers (round to nearest even; inputs are finite in this code base) ----------
+__device__ __forceinline__ uint32_t f2bf(float x) {
+    uint32_t u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+// x ~= hi + lo, |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ void f2bf_split(float x, uint32_t& hi, uint32_t& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+__device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return a | (b << 16); }
+
+// ---- MFMA wrappers.  Fragment maps (verified on hardware by ph_selftest_*):
+//  16x16x32: A lane l: row l&15, k = (l>>4)*8 + e;  B lane l: col l&15, k = (l>>4)*8 + e;
+//            D lane l, reg r: row (l>>4)*4 + r, col l&15.
+//  32x32x16: A lane l: row l&31, k = (l>>5)*8 + e;  B lane l: col l&31, k = (l>>5)*8 + e;
+//            D lane l, reg r: row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// Transposing LDS read: within each 16-lane group the lanes point at 16 8-byte chunks forming a
+// [4 rows][16 cols] bf16 block (lane i -> row i>>2, cols (i&3)*4..+3); lane i receives column i,
+// i.e. element j = block[j][i].
+__device__ __forceinline__ uint2 lds_read_tr16(const uint16_t* p) {
+    bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((PH_LDS bf16x4_t*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+__device__ __forceinline__ float wave_group16_sum(float t) {
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
+    t += __shfl_xor(t, 8);
+    return t;
+}
+__device__ __forceinline__ float wave_group16_max(float t) {
+    t = fmaxf(t, __shfl_xor(t, 1));
+    t = fmaxf(t, __shfl_xor(t, 2));
+    t = fmaxf(t, __shfl_xor(t, 4));
+    t = fmaxf(t, __shfl_xor(t, 8));
+    return t;
+}

@@ -1,0 +1,52 @@
+// Hardware self tests of the fragment layouts every other kernel in this library assumes.
+#include "ph_common.h"
+
+__global__ void k_selftest_mfma16(const uint16_t* a, const uint16_t* bt, float* d) {
+    const int l = threadIdx.x;
+    uint4 av = *(const uint4*)(a + (l & 15) * 32 + (l >> 4) * 8);
+    uint4 bv = *(const uint4*)(bt + (l & 15) * 32 + (l >> 4) * 8);
+    f32x4_t acc = {0, 0, 0, 0};
+    acc = mfma16(av, bv, acc);
+    for (int r = 0; r < 4; ++r) d[((l >> 4) * 4 + r) * 16 + (l & 15)] = acc[r];
+}
+
+__global__ void k_selftest_mfma32(const uint16_t* a, const uint16_t* bt, float* d) {
+    const int l = threadIdx.x;
+    uint4 av = *(const uint4*)(a + (l & 31) * 16 + (l >> 5) * 8);
+    uint4 bv = *(const uint4*)(bt + (l & 31) * 16 + (l >> 5) * 8);
+    f32x16_t acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma32(av, bv, acc);
+    for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+}
+
+// src: [16 rows][16 cols]; group g (16 lanes) reads rows 4g..4g+3; out[lane][j] must equal
+// src[4g + j][lane & 15].
+__global__ void k_selftest_trread(const uint16_t* src, uint16_t* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[16 * 24];   // padded row stride 24 (48 B)
+    const int l = threadIdx.x;
+    for (int i = l; i < 256; i += 64) lds[(i >> 4) * 24 + (i & 15)] = src[i];
+    __syncthreads();
+    const int g = l >> 4, i = l & 15;
+    uint2 v = lds_read_tr16(&lds[(4 * g + (i >> 2)) * 24 + (i & 3) * 4]);
+    out[l * 4 + 0] = v.x & 0xFFFF;
+    out[l * 4 + 1] = v.x >> 16;
+    out[l * 4 + 2] = v.y & 0xFFFF;
+    out[l * 4 + 3] = v.y >> 16;
+}
+
+extern "C" int ph_selftest_mfma16(const uint16_t* a, const uint16_t* bt, float* d, void* stream) {
+    hipLaunchKernelGGL(k_selftest_mfma16, dim3(1), dim3(64), 0, (hipStream_t)stream, a, bt, d);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+extern "C" int ph_selftest_mfma32(const uint16_t* a, const uint16_t* bt, float* d, void* stream) {
+    hipLaunchKernelGGL(k_selftest_mfma32, dim3(1), dim3(64), 0, (hipStream_t)stream, a, bt, d);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+extern "C" int ph_selftest_trread(const uint16_t* src, uint16_t* out, void* stream) {
+    hipLaunchKernelGGL(k_selftest_trread, dim3(1), dim3(64), 0, (hipStream_t)stream, src, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

@@ -1,0 +1,170 @@
+"""GPU: every libpolyhead kernel in isolation against a plain torch fp32/fp64 reference of the same
+op, called through the C ABI (ctypes).  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers as Hh
+from polyphonicformer_amd import _lib, engine as E
+
+pytestmark = pytest.mark.gpu
+PRECS = [_lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT]
+
+
+def bf16_bits(t):
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+def planes_to_float(pl):
+    """int16 planes [P, ...] -> float64 sum of planes"""
+    return sum(pl[p].view(torch.bfloat16).double() for p in range(pl.shape[0]))
+
+
+def unpack_bits(bits, N, HW):
+    B, Npad, Wd = bits.shape
+    b = bits.cpu().numpy().view(np.uint32)
+    out = np.unpackbits(b.view(np.uint8).reshape(B, Npad, Wd, 4), axis=-1, bitorder="little")
+    return torch.from_numpy(out.reshape(B, Npad, Wd * 32)[:, :N, :HW].astype(np.float32))
+
+
+def test_selftest_mfma_layouts(gpu):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(16, 32, generator=g).to(torch.bfloat16)
+    b = torch.randn(32, 16, generator=g).to(torch.bfloat16)      # asymmetric B
+    d = torch.zeros(16, 16, device=gpu)
+    ad, bd = a.view(torch.int16).to(gpu), b.t().contiguous().view(torch.int16).to(gpu)   # keep alive
+    _lib.check(lib.ph_selftest_mfma16(_lib.ptr(ad), _lib.ptr(bd), _lib.ptr(d), _lib.stream_ptr()), "mfma16")
+    ref = a.double() @ b.double()
+    assert (d.cpu().double() - ref).abs().max() < 1e-4
+    a = torch.randn(32, 16, generator=g).to(torch.bfloat16)
+    b = torch.randn(16, 32, generator=g).to(torch.bfloat16)
+    d = torch.zeros(32, 32, device=gpu)
+    ad, bd = a.view(torch.int16).to(gpu), b.t().contiguous().view(torch.int16).to(gpu)
+    _lib.check(lib.ph_selftest_mfma32(_lib.ptr(ad), _lib.ptr(bd), _lib.ptr(d), _lib.stream_ptr()), "mfma32")
+    ref = a.double() @ b.double()
+    assert (d.cpu().double() - ref).abs().max() < 1e-4
+
+
+def test_selftest_transposing_lds_read(gpu):
+    lib = _lib.load()
+    src = torch.arange(256, dtype=torch.int16)
+    out = torch.zeros(64, 4, dtype=torch.int16, device=gpu)
+    srcd = src.to(gpu)
+    _lib.check(lib.ph_selftest_trread(_lib.ptr(srcd), _lib.ptr(out), _lib.stream_ptr()), "trread")
+    out = out.cpu().numpy()
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for j in range(4):
+            exp[l, j] = (4 * g + j) * 16 + i
+    assert np.array_equal(out, exp), f"ds_read_tr16_b64 semantics differ:\n{out}"
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("H,W", [(8, 16), (6, 13)])
+def test_ingest(gpu, prec, H, W):
+    x = torch.randn(2, 256, H, W, generator=torch.Generator().manual_seed(1))
+    pl = E.ingest(x.to(gpu), prec).cpu()
+    HW = H * W
+    rec = planes_to_float(pl)[..., :HW].reshape(2, 256, H, W)
+    tol = 2.0 ** -8 if prec == _lib.PH_PREC_BF16 else 2.0 ** -16
+    assert ((rec - x.double()).abs() <= tol * x.double().abs() + 1e-30).all()
+    assert (planes_to_float(pl)[..., HW:] == 0).all()        # zero padding
+    assert torch.equal(pl[0, :, :, :HW].reshape(2, 256, H, W), bf16_bits(x))   # hi plane == RNE bf16
+
+
+@pytest.mark.parametrize("N,H,W", [(111, 8, 16), (7, 6, 13), (153, 16, 24)])
+def test_binarize(gpu, N, H, W):
+    m = torch.randn(2, N, H, W, generator=torch.Generator().manual_seed(2))
+    m[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30])
+    bits = E.binarize(m.to(gpu))
+    got = unpack_bits(bits, N, H * W)
+    assert torch.equal(got, (m > 0).float().reshape(2, N, -1))
+    full = unpack_bits(bits, bits.shape[1], bits.shape[2] * 32)
+    assert full[:, N:].sum() == 0 and full[:, :, H * W:].sum() == 0
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("N,H,W,nsplit", [(111, 8, 16, 1), (153, 16, 32, 3), (40, 6, 13, 1), (253, 8, 48, 2)])
+def test_pool(gpu, prec, N, H, W, nsplit):
+    g = torch.Generator().manual_seed(3)
+    B, HW = 2, H * W
+    x, d = torch.randn(B, 256, H, W, generator=g), torch.randn(B, 256, H, W, generator=g)
+    m = torch.randn(B, N, H, W, generator=g)
+    xp, dp = E.ingest(x.to(gpu), prec), E.ingest(d.to(gpu), prec)
+    bits = E.binarize(m.to(gpu))
+    part = E.pool(xp, dp, bits, N, HW, prec, nsplit=nsplit).cpu().double()
+    got = part.sum(1)[:, :N]
+    M = (m > 0).double().reshape(B, N, HW)
+    xq, dq = planes_to_float(xp.cpu())[..., :HW], planes_to_float(dp.cpu())[..., :HW]
+    ref = torch.cat([torch.einsum("bnk,bck->bnc", M, xq), torch.einsum("bnk,bck->bnc", M, dq)], -1)
+    # exact products, fp32 accumulation over <= HW terms
+    assert (got - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert part.sum(1)[:, N:].abs().max() == 0
+    # vs the unquantised fp32 features: bf16 rounding (2^-9 rel per element) / split (2^-17)
+    ref32 = torch.cat([torch.einsum("bnk,bck->bnc", M, x.double().reshape(B, 256, HW)),
+                       torch.einsum("bnk,bck->bnc", M, d.double().reshape(B, 256, HW))], -1)
+    tol = 4e-3 if prec == _lib.PH_PREC_BF16 else 2e-5
+    assert Hh.rel_err(got, ref32) < tol
+    # x-only variant (KernelHead pooling)
+    part1 = E.pool(xp, None, bits, N, HW, prec, nsplit=nsplit).cpu().double().sum(1)[:, :N, :256]
+    assert (part1 - ref[..., :256]).abs().max() <= 1e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("N,H,W", [(111, 8, 16), (153, 16, 32), (40, 6, 13), (253, 8, 48)])
+def test_dynconv(gpu, prec, N, H, W):
+    g = torch.Generator().manual_seed(4)
+    B, HW = 2, H * W
+    P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+    Npad = E.n_padded(N)
+    x = torch.randn(B, 256, H, W, generator=g)
+    kern_f = torch.randn(2, B, Npad, 256, generator=g) * 0.1
+    kbias = torch.randn(2, B, Npad, generator=g) * 0.1
+    hi = kern_f.to(torch.bfloat16)
+    planes = [hi.view(torch.int16)]
+    if P == 2:
+        planes.append((kern_f - hi.float()).to(torch.bfloat16).view(torch.int16))
+    kern = torch.stack(planes, 0).contiguous().to(gpu)
+    xp = E.ingest(x.to(gpu), prec)
+    kq = planes_to_float(kern.cpu())
+    kbias_d = kbias.to(gpu)
+    xq = planes_to_float(xp.cpu())[..., :HW]
+    for br in (0, 1):
+        ref = torch.einsum("bnc,bck->bnk", kq[br, :, :N], xq) + kbias[br, :, :N, None].double()
+        out = torch.empty(B, N, H, W, device=gpu)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, logits_out=out)
+        # PREC bf16: exact products of the bf16 operands; split: drops lo*lo (2^-16 rel per product)
+        tol = 1e-5 if prec == _lib.PH_PREC_BF16 else 5e-5
+        assert Hh.rel_err(out.cpu().reshape(B, N, HW), ref) < tol
+        out16 = torch.empty(B, N, H, W, device=gpu, dtype=torch.bfloat16)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, logits_out=out16, out_dtype=_lib.PH_OUT_BF16)
+        assert Hh.rel_err(out16.float().cpu().reshape(B, N, HW), ref) < 5e-3
+        bits = torch.full((B, Npad, E.hw_padded(HW) // 32), -1, dtype=torch.int32, device=gpu)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, bits_out=bits)
+        got = unpack_bits(bits, N, HW)
+        want = (out.cpu().reshape(B, N, HW) > 0).float()
+        assert torch.equal(got, want)
+        full = unpack_bits(bits, Npad, bits.shape[2] * 32)
+        assert full[:, N:].sum() == 0 and full[:, :, HW:].sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(8, 16), (5, 7), (1, 3)])
+def test_upsample2x(gpu, dtype, H, W):
+    x = torch.randn(3, 5, H, W, generator=torch.Generator().manual_seed(5)).to(dtype)
+    out = E.upsample2x(x.to(gpu)).cpu().float()
+    ref = F.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=False)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert (out - ref).abs().max() <= tol * ref.abs().max()
+
+
+def test_errors_are_reported(gpu):
+    lib = _lib.load()
+    assert lib.ph_version() == 100
+    rc = lib.ph_pool(None, None, None, None, 1, 1, 128, 1, 1, None)
+    assert rc == -1 and b"ph_pool" in lib.ph_last_error_string()
+    with pytest.raises(_lib.PolyheadError):
+        E.ingest(torch.zeros(1, 256, 4, 4), _lib.PH_PREC_BF16)       # CPU tensor: no fallback
