@@ -1,0 +1,160 @@
+"""GPU parity proper: the HIP path, called through the drop-in modules / the C ABI, against
+(a) golden vectors produced by the reference itself and (b) the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star: 1e-3 relative fp32, relative = max|diff| / max|ref|):
+  * precision "fp32" (split-bf16 MFMA, fp32 accumulate): 1e-3 for every per-stage output with
+    teacher-forced inputs -- the contract; observed ~1e-5.
+  * precision "bf16" (the benchmark precision of BASELINE config 2): 3e-2 against the same oracle
+    (bf16 has 8 mantissa bits; LayerNorm keeps errors relative).  Documented, not the 1e-3 gate.
+  * free-running S stages: the hard threshold sigmoid(m) > 0.5 inside the recurrence can flip
+    pixels on rounding differences; we report the flip rate and bound the final error
+    loosely; the golden free-running fixture is additionally checked at 1e-3 in fp32 mode.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import poly_oracle as O
+from oracle.ref_loader import stage_cfg          # config dict builder only (no reference import)
+from polyphonicformer_amd import _lib, engine as E
+from polyphonicformer_amd.registry import HEADS, TRANSFORMER_LAYER
+import polyphonicformer_amd.kernel_update  # noqa: F401  (registers the heads)
+import polyphonicformer_amd.kernel_update_head  # noqa: F401
+import polyphonicformer_amd.kernel_updator  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+TOL = {"fp32": 1e-3, "bf16": 3e-2}
+
+
+def _full_weights():
+    with open(Hh.GOLDEN + "/full_state_keys.json") as f:
+        shapes = json.load(f)
+    return Hh.seeded_fill(shapes, 1234)
+
+
+def _iter_head(sd, S=3, n_thing=8, n_stuff=11, Nq=100, precision="fp32"):
+    L = n_thing + n_stuff
+    h = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=S, assign_stages=S, stage_loss_weights=[1] * S,
+                         num_proposals=Nq, num_thing_classes=n_thing, num_stuff_classes=n_stuff, do_panoptic=True,
+                         merge_joint=True, mask_head=stage_cfg(256, 2048, 8, L, n_thing, n_stuff),
+                         test_cfg=dict(max_per_img=Nq, mask_thr=0.5,
+                                       merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))))
+    h.load_state_dict({k[len("roi_head."):]: v for k, v in sd.items() if k.startswith("roi_head.")
+                       and int(k.split(".")[2]) < S})
+    h.eval().to("cuda:0")
+    h.set_precision(precision)
+    return h
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return _full_weights()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_kernel_updator_golden(gpu, weights, precision):
+    z = Hh.load_golden("full_updator.npz")
+    ku = TRANSFORMER_LAYER.build(dict(type="KernelUpdator", in_channels=256, feat_channels=256, out_channels=256,
+                                      input_feat_shape=3, act_cfg=dict(type="ReLU", inplace=True),
+                                      norm_cfg=dict(type="LN")))
+    pre = "roi_head.mask_head.0.kernel_update_conv."
+    ku.load_state_dict({k[len(pre):]: v for k, v in weights.items() if k.startswith(pre)})
+    ku.to(gpu)
+    ku.precision = precision
+    u, k = torch.from_numpy(z["u"]).to(gpu), torch.from_numpy(z["k"]).to(gpu)
+    out = ku(u, k[:, :, None, :])
+    B, N = z["u"].shape[:2]
+    assert out.shape == (B * N, 1, 256)
+    e = Hh.rel_err(out.cpu().reshape(B, N, 256), z["out"])
+    assert e < TOL[precision], e
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_stage_teacher_forced_golden(gpu, weights, precision):
+    """KernelUpdateHead.forward per stage on the reference's own stage inputs."""
+    z = Hh.load_golden("full_iter.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    cfg = m["cfg"]
+    inp = Hh.iter_inputs(m["iseed"], m["B"], m["N"], 256, m["H"], m["W"])
+    head = _iter_head(weights, cfg["S"], precision=precision)
+    x, dfe = inp["x"].to(gpu), inp["dfe"].to(gpu)
+    B, N = m["B"], m["N"]
+    worst = {}
+    for s in range(cfg["S"]):
+        k = torch.from_numpy(z[f"s{s}_in_k"]).to(gpu).reshape(B, N, 256, 1, 1)
+        q = torch.from_numpy(z[f"s{s}_in_q"]).to(gpu).reshape(B, N, 256, 1, 1)
+        mp = torch.from_numpy(z[f"s{s}_in_m"]).to(gpu)
+        cls, nm, obj, nd, dobj = head.mask_head[s](x, k, mp, depth_proposal=q, depth_feats=dfe)
+        got = dict(cls=cls, mask=nm, obj=obj.reshape(B, N, 256), depth=nd, dobj=dobj.reshape(B, N, 256))
+        for name, t in got.items():
+            e = Hh.rel_err(t.cpu(), z[f"s{s}_{name}"])
+            worst[(s, name)] = e
+            assert e < TOL[precision], (s, name, e)
+    print("teacher-forced rel err", precision, {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_iter_free_running_golden(gpu, weights):
+    """simple_test_mask_preds, S=3, fp32 mode, against the reference's free-running outputs."""
+    z = Hh.load_golden("full_iter.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    S, B, N = m["cfg"]["S"], m["B"], m["N"]
+    inp = {k: v.to(gpu) for k, v in Hh.iter_inputs(m["iseed"], B, N, 256, m["H"], m["W"]).items()}
+    inp["q0"] = inp["q0"][:1, :1].expand(B, N, 256, 1, 1)      # stride-0 view on the device, like kernel_head.py:336
+    head = _iter_head(weights, S, precision="fp32")
+    metas = [Hh.img_meta(m["H"] * 8, m["W"] * 8)] * B
+    assert not inp["q0"].is_contiguous()
+    obj, cls, mask, mask_up = head.simple_test_mask_preds(inp["x"], inp["k0"], inp["m0"], None, metas,
+                                                          depth_preds=inp["depth_pred"], depth_feats=inp["dfe"],
+                                                          depth_proposal=inp["q0"])
+    assert obj.shape == (B, N, 256, 1, 1) and mask_up.shape == (B, N, 2 * m["H"], 2 * m["W"])
+    flips = ((mask.cpu() > 0) != (torch.from_numpy(z[f"s{S - 1}_mask"]) > 0)).float().mean().item()
+    print("free-running sign flip rate of final mask logits:", flips)
+    assert Hh.rel_err(obj.cpu().reshape(B, N, 256), z["final_obj"]) < 1e-3
+    assert Hh.rel_err(cls.cpu(), z["final_cls"]) < 1e-3
+    assert Hh.rel_err(mask.cpu(), z[f"s{S - 1}_mask"]) < 1e-3
+    assert Hh.rel_err(mask_up.cpu(), z["mask_up"]) < 1e-3
+    plan = next(iter(head._plans.values()))
+    assert Hh.rel_err(plan.depth_up.cpu(), z["depth_up"]) < 1e-3
+
+
+@pytest.mark.parametrize("precision,N,H,W,B", [("fp32", 153, 16, 24, 1), ("fp32", 40, 6, 13, 3), ("fp32", 253, 6, 26, 1),
+                                                 ("bf16", 153, 16, 24, 2), ("bf16", 111, 9, 20, 1)])
+def test_stage_vs_oracle_random_shapes(gpu, weights, precision, N, H, W, B):
+    """one stage, ragged sizes (HW not a multiple of 128, N not a multiple of 32), oracle as checker."""
+    head = _iter_head(weights, 1, precision=precision)
+    inp = Hh.iter_inputs(1000 + N, B, N, 256, H, W, mask_bias=-0.5)
+    sd = {k[len("roi_head."):]: v for k, v in weights.items()}
+    ref = O.update_stage(sd, "mask_head.0.", inp["x"], inp["k0"].reshape(B, N, 256), inp["m0"],
+                         inp["q0"].reshape(B, N, 256), inp["dfe"])
+    g = {k: v.to(gpu) for k, v in inp.items()}
+    cls, nm, obj, nd, dobj = head.mask_head[0](g["x"], g["k0"], g["m0"], depth_proposal=g["q0"], depth_feats=g["dfe"])
+    for name, t, r in (("cls", cls, ref["cls"]), ("mask", nm, ref["mask"]), ("obj", obj.reshape(B, N, 256), ref["obj"]),
+                       ("depth", nd, ref["depth"]), ("dobj", dobj.reshape(B, N, 256), ref["dobj"])):
+        e = Hh.rel_err(t.cpu(), r)
+        assert e < TOL[precision], (name, e)
+
+
+def test_iter_bf16_vs_oracle_flip_rate(gpu, weights):
+    """bf16 free-running S=3: report the binarisation flip rate, bound the outputs loosely."""
+    B, N, H, W, S = 2, 111, 16, 32, 3
+    inp = Hh.iter_inputs(4242, B, N, 256, H, W)
+    sd = {k[len("roi_head."):]: v for k, v in weights.items()}
+    ref = O.iter_head_mask_preds(sd, S, inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])
+    head = _iter_head(weights, S, precision="bf16")
+    g = {k: v.to(gpu) for k, v in inp.items()}
+    obj, cls, mask, mask_up = head.simple_test_mask_preds(g["x"], g["k0"], g["m0"], None, [Hh.img_meta(H * 8, W * 8)] * B,
+                                                          depth_preds=g["depth_pred"], depth_feats=g["dfe"],
+                                                          depth_proposal=g["q0"])
+    flips = ((mask.cpu() > 0) != (ref["mask"] > 0)).float().mean().item()
+    print("bf16 free-running flip rate:", flips, "obj rel err:", Hh.rel_err(obj.cpu().reshape(B, N, 256), ref["obj"]))
+    assert flips < 0.05
+    assert Hh.rel_err(obj.cpu().reshape(B, N, 256), ref["obj"]) < 0.1
+    # determinism: a second run is bit identical (fixed-order split-K reduction, no atomics)
+    obj2, cls2, mask2, mask_up2 = head.simple_test_mask_preds(g["x"], g["k0"], g["m0"], None, [Hh.img_meta(H * 8, W * 8)] * B,
+                                                              depth_preds=g["depth_pred"], depth_feats=g["dfe"],
+                                                              depth_proposal=g["q0"])
+    assert torch.equal(mask_up, mask_up2) and torch.equal(obj, obj2)
