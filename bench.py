@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): frames/s of the kernel-update + mask/depth forward
+(`KernelUpdateIterHead.simple_test_mask_preds`) at 1024x2048, N=153, S=3.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over a batch of `--frames` synthetic frames per GPU, inputs
+resident in HBM, the whole launch sequence replayed from a HIP graph.  Frames are independent, so
+ranks share nothing on the data path ("weak" scaling, no collective inside the timed region).
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1024x2048 -> stride-8 128x256, N = 100 + 53 (class defaults), S = 3
+    "cfg2": dict(H=128, W=256, Nq=100, n_thing=80, n_stuff=53, S=3, F=2048),
+    # small variant for smoke runs
+    "tiny": dict(H=16, W=32, Nq=100, n_thing=8, n_stuff=11, S=3, F=2048),
+}
+
+
+def stage_cfg(L, n_thing, n_stuff, F):
+    return dict(type="KernelUpdateHead", num_thing_classes=n_thing, num_stuff_classes=n_stuff, num_classes=L,
+                num_ffn_fcs=2, num_heads=8, num_cls_fcs=1, num_mask_fcs=1, feedforward_channels=F, in_channels=256,
+                out_channels=256, dropout=0.0, mask_thr=0.5, conv_kernel_size=1, mask_upsample_stride=2,
+                ffn_act_cfg=dict(type="ReLU", inplace=True), with_ffn=True,
+                feat_transform_cfg=dict(conv_cfg=dict(type="Conv2d"), act_cfg=None),
+                kernel_updator_cfg=dict(type="KernelUpdator", in_channels=256, feat_channels=256, out_channels=256,
+                                        input_feat_shape=3, act_cfg=dict(type="ReLU", inplace=True),
+                                        norm_cfg=dict(type="LN")),
+                loss_cls=dict(type="FocalLoss", use_sigmoid=True), loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True),
+                loss_dice=dict(type="DiceLoss"), loss_depth=dict(type="DepthLoss"), depth_act_mode="sigmoid")
+
+
+def build_head(wl, precision, out_dtype, device, seed=0):
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_update  # noqa: F401
+    import polyphonicformer_amd.kernel_update_head  # noqa: F401
+    import polyphonicformer_amd.kernel_updator  # noqa: F401
+    L = wl["n_thing"] + wl["n_stuff"]
+    torch.manual_seed(seed)
+    head = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=wl["S"], assign_stages=wl["S"],
+                            stage_loss_weights=[1] * wl["S"], num_proposals=wl["Nq"], num_thing_classes=wl["n_thing"],
+                            num_stuff_classes=wl["n_stuff"], do_panoptic=True, merge_joint=True,
+                            mask_head=stage_cfg(L, wl["n_thing"], wl["n_stuff"], wl["F"]),
+                            test_cfg=dict(max_per_img=wl["Nq"])))
+    head.init_weights()                       # the reference's init (xavier-uniform, kernel_update_head.py:193-205)
+    head.eval().to(device)
+    head.set_precision(precision, out_dtype)
+    return head
+
+
+def synth_inputs(wl, B, seed):
+    """BASELINE.md section 2, isolated-IterHead inputs (dense ~50 % foreground masks)."""
+    g = torch.Generator().manual_seed(seed)
+    N = wl["Nq"] + wl["n_stuff"]
+    H, W = wl["H"], wl["W"]
+    return dict(x=torch.randn(B, 256, H, W, generator=g), dfe=torch.randn(B, 256, H, W, generator=g),
+                k0=torch.randn(B, N, 256, generator=g), q0=torch.randn(1, 1, 256, generator=g).expand(B, N, 256),
+                m0=torch.randn(B, N, H, W, generator=g))
+
+
+def time_op(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def kernel_breakdown(plan, iters=10):
+    """average duration (ms) of every launch class of one step, each timed on its own with HIP
+    events on the launch stream (torch's current stream = the stream the C ABI launches on)."""
+    from polyphonicformer_amd import engine as E
+    p = plan
+    o = p.stage_out[-1]
+    t = {}
+    t["ingest"] = time_op(lambda: E.ingest(p.x, p.prec, out=p.xp), iters)
+    t["binarize"] = time_op(lambda: E.binarize(p.m0, out=p.bits), iters)
+    t["pool"] = time_op(lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial), iters)
+    for name, ph in (("query_pre", 1), ("query_post", 2)):
+        t[name] = time_op(lambda ph=ph: E.query_stage(p.partial, p.bits, p.k0, p.q0, p.packs[0], p.N, p.HW,
+                                                      outs=p.stage_out[0], workspace=p.ws, phases=ph), iters)
+    t["dynconv_bits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.prec, bits_out=p.bits), iters)
+    t["dynconv_logits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.prec,
+                                                    logits_out=p.mask, out_dtype=p.out_code), iters)
+    t["upsample2x"] = time_op(lambda: E.upsample2x(p.mask, out=p.mask_up), iters)
+    counts = dict(ingest=2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
+                  dynconv_logits=2, upsample2x=2)
+    return t, counts
+
+
+def algorithmic_bytes(plan, kernel):
+    """ALGORITHMIC bytes one launch of `kernel` must move."""
+    p = plan
+    P = 2 if p.prec == 3 else 1
+    from polyphonicformer_amd.engine import hw_padded, n_padded
+    HWp, Npad = hw_padded(p.HW), n_padded(p.N)
+    eo = 4 if p.out_dtype == torch.float32 else 2
+    feat = p.B * 256 * p.HW * 2 * P            # one feature map, all planes
+    bits = p.B * p.N * p.HW // 8
+    if kernel == "pool":
+        return 2 * feat + bits
+    if kernel == "dynconv_bits":
+        return feat + bits
+    if kernel == "dynconv_logits":
+        return feat + p.B * p.N * p.HW * eo
+    if kernel == "upsample2x":
+        return p.B * p.N * p.HW * eo * 5
+    if kernel == "ingest":
+        return p.B * 256 * p.HW * 4 + feat
+    if kernel == "binarize":
+        return p.B * p.N * p.HW * 4 + bits
+    return None
+
+
+def cpu_baseline(wl, head, budget_s=20.0):
+    """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample"""
+    from oracle import poly_oracle as O
+    sd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    inp = synth_inputs(wl, 1, 1)
+    # 16 threads is the best of a {8,16,32,64,128}-thread sweep on the GPU box's 2 x EPYC 9575F
+    # (tools/cpu_sweep.py; more threads are slower: the path is memory/latency bound on CPU)
+    ncores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    S = wl["S"]
+    with torch.no_grad():
+        t0 = time.time()
+        O.iter_head_mask_preds(sd, S, inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])   # warm-up
+        warm = time.time() - t0
+        n, t1 = 0, time.time()
+        while n < 5 and (time.time() - t1) < budget_s - warm:
+            O.iter_head_mask_preds(sd, S, inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])
+            n += 1
+        dt = (time.time() - t1) / max(n, 1)
+    if n == 0:
+        n, dt = 1, warm
+    return dict(value=1.0 / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} frame(s) of the same workload (1024x2048, N=153, S=3), fp32, B=1, after 1 warm-up")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    B = args.frames
+    out_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    head = build_head(wl, args.precision, out_dtype, dev)
+    N = wl["Nq"] + wl["n_stuff"]
+    plan = head._plan(B, N, wl["H"], wl["W"], dev)
+    inp = synth_inputs(wl, B, seed=1234 + rank)         # each rank: its own frames
+    plan.set_inputs(inp["x"].to(dev), inp["dfe"].to(dev), inp["k0"].to(dev), inp["q0"].to(dev), inp["m0"].to(dev))
+    if args.no_graph:
+        step = plan.run
+    else:
+        plan.capture()
+        step = plan.replay
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * B * args.steps / dt
+
+    if rank == 0:
+        times, counts = kernel_breakdown(plan)
+        per_step = {k: times[k] * counts[k] for k in times}
+        dom = max((k for k in per_step if algorithmic_bytes(plan, k)), key=lambda k: per_step[k])
+        ab = algorithmic_bytes(plan, dom)
+        achieved = ab / (times[dom] * 1e-3) / 1e9
+        res = {
+            "metric": "frames/sec kernel-update+mask fwd, 1024x2048 N=153 S=3", "value": round(fps, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-grade split)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: KernelUpdateIterHead.simple_test_mask_preds, "
+                                   f"{wl['H'] * 8}x{wl['W'] * 8}, stride-8 {wl['H']}x{wl['W']}, N={N}, S={wl['S']}, "
+                                   f"L={wl['n_thing'] + wl['n_stuff']}, random-init weights",
+                       "frames_per_step_per_gpu": B, "hip_graph": not args.no_graph, "output_dtype": str(out_dtype),
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(times[dom], 4)},
+            "kernels_ms": {k: round(v, 4) for k, v in times.items()},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, head)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

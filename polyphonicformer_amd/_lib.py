@@ -3,6 +3,8 @@ if it is missing or fails to load this module raises -- there is no CPU or PyTor
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede dlopen: libpolyhead has to bind to the HIP runtime torch loaded
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
@@ -77,5 +79,4 @@ def ptr(t):
 
 
 def stream_ptr():
-    import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
