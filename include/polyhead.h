@@ -132,13 +132,36 @@ int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits,
  * kernel_update_head.py:317-329: logits[b][n][hw] = sum_c kern[b][n][c] * feat[b][c][hw] + kbias[b][n].
  * Either writes the mask bits the next stage pools with (bits_out != NULL; the logits of a
  * non-final stage are consumed only through `> 0`, kernel_update_head.py:236-238) or the logits
- * themselves (logits_out, dtype out_dtype, [B][N][HW]). `kern`/`kbias` point at ONE branch. */
-int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_stride,
-               const float* kbias, uint32_t* bits_out, void* logits_out, int out_dtype,
-               int B, int N, int64_t HW, int prec, void* stream);
+ * themselves (logits_out, dtype out_dtype).  `kern` is bf16 planes [P][..][Npad][256] (plane stride
+ * given), `kern_batch_stride` / `kbias_batch_stride` / `out_batch_stride` are the element distances
+ * between frames: Npad*256 / Npad / N*HW for per-frame dynamic kernels; 0 / 0 / rows*HW when the
+ * same static 1x1 conv weights serve every frame (kernel_head.py:256,285,295 init_kernels,
+ * conv_direct_depth, conv_seg), which also lets the output be a row slice of a larger tensor. */
+int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_stride, int64_t kern_batch_stride,
+               const float* kbias, int64_t kbias_batch_stride, uint32_t* bits_out, void* logits_out, int out_dtype,
+               int64_t out_batch_stride, int B, int N, int64_t HW, int prec, void* stream);
 
 /* ---- A14: x2 bilinear upsample, align_corners=False (kernel_update.py:131-143) ------------- */
 int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes /* B*N */, int H, int W, void* stream);
+
+/* ---- A1-A5: KernelHead after localization_fpn (kernel_head.py:245-347) ------------------------
+ * ph_khead_conv_gn: loc/sem/dfe = ReLU(GN(conv1x1(f0/f1/f2))) and x = sem + loc, from the three fp32
+ *   post-neck maps [B][256][HW] to bf16 planes (+ optional fp32 NCHW x_feats / depth_feats).
+ *   wplanes: bf16 planes [P][3][256][256] of {loc,seg,depth}_convs.0.conv.weight;
+ *   gn_affine: fp32 [3][2][256] (gamma, beta) of the three GroupNorms; eps 1e-5.
+ * The remaining 1x1 convs (init_kernels :256, conv_seg :295, conv_direct_depth :285) are ph_dynconv
+ * calls with static weights, the object pooling (:314-320) is ph_pool, and
+ * ph_khead_proposals forms proposal_feats = [init_kernels.weight + pooled ; conv_seg.weight[stuff]]
+ * (:299-300,324-335) as fp32 [B][n_thing_queries + n_stuff][256]. */
+size_t ph_khead_workspace_bytes(int B, int64_t HW, int groups);
+int ph_khead_conv_gn(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+                     const float* gn_affine, int groups, float eps,
+                     uint16_t* loc_planes, uint16_t* sem_planes, uint16_t* x_planes, uint16_t* dfe_planes,
+                     float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
+                     void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream);
+int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[Nq][256]*/,
+                       const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
+                       int B, int n_thing_queries, int n_stuff, void* stream);
 
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);

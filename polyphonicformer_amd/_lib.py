@@ -37,7 +37,10 @@ SIGNATURES = {
     "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
                                  _P, _Z, _I, _I, _L, _I, _I, _P]),
     "ph_query_workspace_updator_offset": (C.c_size_t, [_I, _I, _I]),
-    "ph_dynconv": (C.c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
+    "ph_dynconv": (C.c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _I, _L, _I, _I, _L, _I, _P]),
+    "ph_khead_workspace_bytes": (C.c_size_t, [_I, _L, _I]),
+    "ph_khead_conv_gn": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
+    "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),

@@ -20,9 +20,10 @@ __device__ __forceinline__ void st_out(uint16_t* p, float v) { *p = (uint16_t)f2
 template <int PA, int NRT, bool BITS, typename OutT>
 __global__ __launch_bounds__(NRT * 64) void k_dynconv(const uint16_t* __restrict__ planes,
                                                       const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
-                                                      const float* __restrict__ kbias, uint32_t* __restrict__ bits_out,
-                                                      OutT* __restrict__ logits_out, int B, int N, int64_t HW,
-                                                      int64_t HWp, int tiles_per_wg) {
+                                                      int64_t kern_batch_stride, const float* __restrict__ kbias,
+                                                      int64_t kbias_batch_stride, uint32_t* __restrict__ bits_out,
+                                                      OutT* __restrict__ logits_out, int64_t out_batch_stride, int B,
+                                                      int N, int64_t HW, int64_t HWp, int tiles_per_wg) {
     constexpr int Npad = NRT * 32, NT = NRT * 64;
     constexpr int PIECES = (256 * (CONV_T / 8) + NT - 1) / NT;   // 16-byte pieces per thread per plane
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [PA][256][CONV_LDT]
@@ -38,13 +39,13 @@ __global__ __launch_bounds__(NRT * 64) void k_dynconv(const uint16_t* __restrict
     uint4 af[PA][16];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const uint16_t* kr = kern + p * kern_plane_stride + ((int64_t)b * Npad + rt * 32 + (lane & 31)) * PH_C + g * 8;
+        const uint16_t* kr = kern + p * kern_plane_stride + (int64_t)b * kern_batch_stride + (rt * 32 + (lane & 31)) * PH_C + g * 8;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) af[p][ks] = *(const uint4*)(kr + ks * 16);
     }
     float kb[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) kb[r] = kbias[(int64_t)b * Npad + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+    for (int r = 0; r < 16; ++r) kb[r] = kbias[(int64_t)b * kbias_batch_stride + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
 
     const int ntiles = (int)(HWp / CONV_T);
     const int t0 = blockIdx.x * tiles_per_wg;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NRT * 64) void k_dynconv(const uint16_t* __restrict
                         w[4 * (HWp / 32)] = (uint32_t)(m >> 32);
                     }
                 } else {
-                    if (row < N && px < HW) st_out(logits_out + ((int64_t)b * N + row) * HW + px, v);
+                    if (row < N && px < HW) st_out(logits_out + (int64_t)b * out_batch_stride + (int64_t)row * HW + px, v);
                 }
             }
         }
@@ -125,8 +126,9 @@ __global__ __launch_bounds__(NRT * 64) void k_dynconv(const uint16_t* __restrict
 }
 
 template <int PA, int NRT>
-static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps, const float* kbias, uint32_t* bits_out,
-                       void* logits_out, int out_dtype, int B, int N, int64_t HW, hipStream_t s) {
+static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps, int64_t kbs, const float* kbias,
+                       int64_t bbs, uint32_t* bits_out, void* logits_out, int out_dtype, int64_t obs, int B, int N,
+                       int64_t HW, hipStream_t s) {
     const int64_t HWp = ph_hw_padded(HW);
     const int ntiles = (int)(HWp / CONV_T);
     int tpw = (int)(((int64_t)ntiles * B + 1023) / 1024);
@@ -142,8 +144,8 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
             once = true;                                                                                             \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_dynconv<PA, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbias, bits_out,   \
-                           (T*)logits_out, B, N, HW, HWp, tpw);                                                      \
+        hipLaunchKernelGGL((k_dynconv<PA, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
+                           bits_out, (T*)logits_out, obs, B, N, HW, HWp, tpw);                                       \
     } while (0)
     if (bits_out) PH_CONV_LAUNCH(true, float);
     else if (out_dtype == PH_OUT_F32) PH_CONV_LAUNCH(false, float);
@@ -152,8 +154,9 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     return 0;
 }
 
-extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_stride, const float* kbias,
-                          uint32_t* bits_out, void* logits_out, int out_dtype, int B, int N, int64_t HW, int prec,
+extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_stride,
+                          int64_t kern_batch_stride, const float* kbias, int64_t kbias_batch_stride, uint32_t* bits_out,
+                          void* logits_out, int out_dtype, int64_t out_batch_stride, int B, int N, int64_t HW, int prec,
                           void* stream) {
     PH_CHECK_ARG(planes && kern && kbias && B > 0 && N > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG((bits_out != nullptr) != (logits_out != nullptr), "exactly one of bits_out / logits_out");
@@ -165,9 +168,11 @@ extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t 
 #define PH_CONV_CASE(R)                                                                                         \
     case R:                                                                                                     \
         if (prec == PH_PREC_BF16)                                                                               \
-            launch_conv<1, R>(planes, kern, kern_plane_stride, kbias, bits_out, logits_out, out_dtype, B, N, HW, s); \
+            launch_conv<1, R>(planes, kern, kern_plane_stride, kern_batch_stride, kbias, kbias_batch_stride, bits_out,   \
+                              logits_out, out_dtype, out_batch_stride, B, N, HW, s); \
         else                                                                                                    \
-            launch_conv<2, R>(planes, kern, kern_plane_stride, kbias, bits_out, logits_out, out_dtype, B, N, HW, s); \
+            launch_conv<2, R>(planes, kern, kern_plane_stride, kern_batch_stride, kbias, kbias_batch_stride, bits_out,   \
+                              logits_out, out_dtype, out_batch_stride, B, N, HW, s); \
         break;
     switch (nrt) {
         PH_CONV_CASE(1) PH_CONV_CASE(2) PH_CONV_CASE(3) PH_CONV_CASE(4)

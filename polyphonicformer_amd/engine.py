@@ -115,14 +115,26 @@ def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=
 
 
 def dynconv(planes, kern, kbias, branch, N, HW, prec, bits_out=None, logits_out=None, out_dtype=_lib.PH_OUT_F32):
-    """kern [P,2,B,Npad,256], kbias [2,B,Npad]; `branch` selects mask (0) or depth (1)."""
+    """per-frame dynamic kernels: kern [P,2,B,Npad,256], kbias [2,B,Npad]; `branch` = mask (0) / depth (1)."""
     B, Npad = kern.shape[2], kern.shape[3]
     lib = _lib.load()
     kptr = C.c_void_p(kern.data_ptr() + branch * B * Npad * 256 * 2)
     bptr = C.c_void_p(kbias.data_ptr() + branch * B * Npad * 4)
-    _lib.check(lib.ph_dynconv(_lib.ptr(planes), kptr, 2 * B * Npad * 256, bptr, _lib.ptr(bits_out),
-                              _lib.ptr(logits_out), out_dtype, B, N, HW, prec, _lib.stream_ptr()), "ph_dynconv")
+    _lib.check(lib.ph_dynconv(_lib.ptr(planes), kptr, 2 * B * Npad * 256, Npad * 256, bptr, Npad, _lib.ptr(bits_out),
+                              _lib.ptr(logits_out), out_dtype, N * HW, B, N, HW, prec, _lib.stream_ptr()), "ph_dynconv")
     return bits_out if bits_out is not None else logits_out
+
+
+def static_conv(planes, wplanes, bias, N, HW, prec, logits_out, out_rows):
+    """the same 1x1 conv weights for every frame: wplanes [P,Npad,256] bf16 planes, bias fp32 [Npad];
+    writes fp32 logits into rows [0, N) of each frame of `logits_out` ([B, out_rows, H, W] view)."""
+    B = planes.shape[1]
+    Npad = wplanes.shape[1]
+    lib = _lib.load()
+    _lib.check(lib.ph_dynconv(_lib.ptr(planes), _lib.ptr(wplanes), Npad * 256, 0, _lib.ptr(bias), 0, None,
+                              _lib.ptr(logits_out), _lib.PH_OUT_F32, out_rows * HW, B, N, HW, prec, _lib.stream_ptr()),
+               "ph_dynconv(static)")
+    return logits_out
 
 
 def upsample2x(src, out=None):
@@ -216,6 +228,14 @@ class DecodePlan:
         self.ingest()
         self.stages()
 
+    def run_from_planes(self, xp, dp, bits, k0, q0):
+        """same, starting from feature planes / mask bits another kernel already produced
+        (KernelHead hand-off): no ingest pass.  `bits` is consumed (overwritten by the stages)."""
+        self.xp, self.dp, self.bits = xp, dp, bits
+        self.k0.copy_(k0.reshape(self.B, self.N, 256))
+        self.q0.copy_(q0.reshape(self.B, self.N, 256))
+        self.stages()
+
     def capture(self):
         """record `run` into a HIP graph (replay with `replay`)"""
         s = torch.cuda.Stream()
@@ -236,3 +256,114 @@ class DecodePlan:
         last = self.stage_out[-1]
         return dict(obj=last["obj"], dobj=last["dobj"], cls=last["cls"], mask=self.mask, depth=self.depth,
                     mask_up=self.mask_up, depth_up=self.depth_up)
+
+
+# ---- KernelHead (a1) ---------------------------------------------------------------------------------
+def _planes_of(w64, P):
+    """float64 [..] -> int16 [P, ...] bf16 hi(/lo) planes"""
+    w = w64.to(torch.float32)
+    hi = w.to(torch.bfloat16)
+    out = [hi.view(torch.int16)]
+    if P == 2:
+        out.append((w - hi.float()).to(torch.bfloat16).view(torch.int16))
+    return torch.stack(out, 0).contiguous()
+
+
+def _pad_rows32(w):
+    r = (-w.shape[0]) % 32
+    return torch.cat([w, w.new_zeros((r,) + tuple(w.shape[1:]))], 0) if r else w
+
+
+class KernelHeadPack:
+    """device-resident packed parameters of KernelHead's post-neck part (kernel_head.py:142-211)"""
+
+    def __init__(self, sd, prec, device, groups):
+        P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+        g = lambda k: sd[k].detach().to("cpu", torch.float64)
+        convs = torch.stack([g(f"{n}_convs.0.conv.weight").reshape(256, 256) for n in ("loc", "seg", "depth")], 0)
+        self.wplanes = _planes_of(convs, P).to(device)                       # [P,3,256,256]
+        self.gn = torch.stack([torch.stack([g(f"{n}_convs.0.gn.weight"), g(f"{n}_convs.0.gn.bias")], 0)
+                               for n in ("loc", "seg", "depth")], 0).float().contiguous().to(device)   # [3,2,256]
+        w_init = g("init_kernels.weight").reshape(-1, 256)
+        w_seg = g("conv_seg.weight").reshape(-1, 256)
+        w_dd = g("conv_direct_depth.weight").reshape(1, 256)
+        self.n_init, self.n_seg = w_init.shape[0], w_seg.shape[0]
+        self.init_planes = _planes_of(_pad_rows32(w_init), P).to(device)
+        self.seg_planes = _planes_of(_pad_rows32(w_seg), P).to(device)
+        self.dd_planes = _planes_of(_pad_rows32(w_dd), P).to(device)
+        z = lambda n: torch.zeros(n, dtype=torch.float32)
+        self.init_bias = z(self.init_planes.shape[1]).to(device)
+        sb = z(self.seg_planes.shape[1]); sb[:self.n_seg] = g("conv_seg.bias").float()
+        self.seg_bias = sb.to(device)
+        db = z(32); db[0] = float(g("conv_direct_depth.bias")[0])
+        self.dd_bias = db.to(device)
+        self.w_init_f32 = w_init.float().contiguous().to(device)
+        self.w_seg_f32 = w_seg.float().contiguous().to(device)
+        self.w_dd_f32 = sd["conv_direct_depth.weight"].detach().float().contiguous().to(device)   # [1,256,1,1]
+        self.prec, self.groups = prec, groups
+
+
+class KernelHeadPlan:
+    """buffers + launch sequence of KernelHead's post-neck part for one (B, H, W)."""
+
+    def __init__(self, pack, B, H, W, num_thing_classes, num_classes, cat_stuff, device, want_f32=True, nsplit=None):
+        self.pack, self.B, self.H, self.W, self.HW = pack, B, H, W, H * W
+        self.n_thing_cls, self.n_cls, self.cat_stuff = num_thing_classes, num_classes, cat_stuff
+        self.Nq = pack.n_init
+        self.n_stuff = (num_classes - num_thing_classes) if cat_stuff else 0
+        self.N = self.Nq + self.n_stuff
+        prec = pack.prec
+        P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+        HWp = hw_padded(self.HW)
+        dev = torch.device(device)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.f = [e((B, 256, H, W), torch.float32) for _ in range(3)]
+        self.loc_p, self.sem_p = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
+        self.xp, self.dp = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
+        self.x_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
+        self.dfe_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
+        self.mask_preds = e((B, self.N, H, W), torch.float32)
+        self.seg_preds = e((B, pack.n_seg, H, W), torch.float32)
+        self.depth_pred = e((B, 1, H, W), torch.float32)
+        self.bits = e((B, n_padded(self.N), HWp // 32), torch.int32)
+        self.bits_th = e((B, n_padded(self.Nq), HWp // 32), torch.int32)
+        self.nsplit = nsplit or default_nsplit(B, self.HW)
+        self.partial = e((B, self.nsplit, n_padded(self.Nq), 512), torch.float32)
+        self.proposal = e((B, self.N, 256), torch.float32)
+        self.ws = e((_lib.load().ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
+
+    def set_inputs(self, feats):
+        for dst, src in zip(self.f, feats):
+            dst.copy_(src)
+
+    def run(self):
+        lib, pk, s = _lib.load(), self.pack, _lib.stream_ptr
+        B, HW, prec = self.B, self.HW, pk.prec
+        _lib.check(lib.ph_khead_conv_gn(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
+                                        _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(self.loc_p), _lib.ptr(self.sem_p),
+                                        _lib.ptr(self.xp), _lib.ptr(self.dp), _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32),
+                                        _lib.ptr(self.ws), self.ws.numel(), B, HW, prec, s()), "ph_khead_conv_gn")
+        # init_kernels(loc) -> thing mask logits (rows [0, Nq) of mask_preds)           kernel_head.py:256
+        static_conv(self.loc_p, pk.init_planes, pk.init_bias, self.Nq, HW, prec, self.mask_preds, self.N)
+        # conv_seg(sem) -> seg_preds                                                     :295
+        static_conv(self.sem_p, pk.seg_planes, pk.seg_bias, pk.n_seg, HW, prec, self.seg_preds, pk.n_seg)
+        # conv_direct_depth(dfe) -> depth_pred                                           :285
+        static_conv(self.dp, pk.dd_planes, pk.dd_bias, 1, HW, prec, self.depth_pred, 1)
+        if self.n_stuff:                                                               # :329-331 (device copy)
+            self.mask_preds[:, self.Nq:].copy_(self.seg_preds[:, self.n_thing_cls:self.n_cls])
+        # object features: binarise the THING logits, pool x (:314-320), add to the kernels (:324-326)
+        _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
+        th = self.mask_preds[:, :self.Nq]
+        # thing rows are the first Nq rows of every frame: bits_th = bits rows [0, Npad_th) when the paddings agree,
+        # otherwise binarise the slice separately
+        if n_padded(self.Nq) == n_padded(self.N) and self.n_stuff == 0:
+            bits_th = self.bits
+        else:
+            th_c = th.contiguous()
+            _lib.check(lib.ph_binarize(_lib.ptr(th_c), _lib.ptr(self.bits_th), B, self.Nq, HW, s()), "ph_binarize")
+            bits_th = self.bits_th
+        pool(self.xp, None, bits_th, self.Nq, HW, prec, self.nsplit, out=self.partial)
+        stuff = pk.w_seg_f32[self.n_thing_cls:self.n_cls] if self.n_stuff else None
+        _lib.check(lib.ph_khead_proposals(_lib.ptr(self.partial), self.nsplit, _lib.ptr(pk.w_init_f32),
+                                          _lib.ptr(stuff.contiguous()) if stuff is not None else None,
+                                          _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")

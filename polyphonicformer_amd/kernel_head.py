@@ -1,0 +1,154 @@
+"""KernelHead -- drop-in for polyphonic/kernel_head.py:11-347,700-706 (inference side).
+Same registry name, constructor kwargs, attribute and state_dict names.  Everything after
+`localization_fpn(img)` (kernel_head.py:243) runs in libpolyhead."""
+import torch
+import torch.nn as nn
+
+from . import _lib, engine as E
+from .bricks import ConvModuleParams, bias_init_with_prob
+from .registry import NECKS, build_loss, build_neck, register_everywhere
+
+
+class KernelHead(nn.Module):
+
+    def __init__(self, num_proposals=100, num_classes=133, num_thing_classes=80, num_stuff_classes=53,
+                 in_channels=256, out_channels=256, num_heads=8, num_cls_fcs=1, num_seg_convs=1, num_loc_convs=1,
+                 att_dropout=False, localization_fpn=None, conv_kernel_size=1, norm_cfg=dict(type='GN', num_groups=32),
+                 semantic_fpn=True, train_cfg=None, xavier_init_kernel=False, kernel_init_std=0.01, use_binary=False,
+                 proposal_feats_with_obj=False, loss_mask=None, loss_seg=None, loss_cls=None, loss_dice=None,
+                 loss_rank=None, loss_depth=None, feat_downsample_stride=1, feat_refine_stride=1, feat_refine=True,
+                 conv_normal_init=False, mask_out_stride=4, hard_target=False, ignore_label=255, cat_stuff_mask=False,
+                 with_depth=True, num_depth_convs=1, semantic_out_cfg=None, loss_semantic_seg=None, **kwargs):
+        super().__init__()
+        unsupported = []
+        if in_channels != 256 or out_channels != 256: unsupported.append("channels != 256")
+        if conv_kernel_size != 1: unsupported.append("conv_kernel_size != 1")
+        if num_seg_convs != 1 or num_loc_convs != 1 or num_depth_convs != 1: unsupported.append("num_*_convs != 1")
+        if not semantic_fpn or not with_depth: unsupported.append("semantic_fpn / with_depth off")
+        if feat_downsample_stride > 1 and feat_refine: unsupported.append("feat_refine (3x3 downsample convs)")
+        if not (use_binary and proposal_feats_with_obj): unsupported.append("use_binary / proposal_feats_with_obj off")
+        if semantic_out_cfg: unsupported.append("semantic_out_cfg")
+        if norm_cfg.get('type') != 'GN' or 256 % norm_cfg.get('num_groups', 32): unsupported.append("norm_cfg")
+        if unsupported:
+            raise NotImplementedError("libpolyhead implements the shipped KernelHead configuration "
+                                      "(configs/_base_/models/polyphonic_former.py:30-97); got: " + ", ".join(unsupported))
+        self.num_proposals, self.num_cls_fcs, self.train_cfg = num_proposals, num_cls_fcs, train_cfg
+        self.in_channels, self.out_channels, self.num_classes = in_channels, out_channels, num_classes
+        self.proposal_feats_with_obj, self.sampling = proposal_feats_with_obj, False
+        if localization_fpn is None:
+            self.localization_fpn = None
+        elif isinstance(localization_fpn, nn.Module):
+            self.localization_fpn = localization_fpn
+        elif localization_fpn.get('type') in NECKS:
+            self.localization_fpn = build_neck(localization_fpn)
+        else:
+            # the neck (SemanticFPNWrapper) is the step BEFORE the hot path: when it is not
+            # registered, `simple_test_rpn` expects its three output maps as `img`
+            self.localization_fpn = None
+        self.semantic_fpn, self.norm_cfg, self.num_heads, self.att_dropout = semantic_fpn, norm_cfg, num_heads, att_dropout
+        self.mask_out_stride, self.hard_target, self.conv_kernel_size = mask_out_stride, hard_target, conv_kernel_size
+        self.xavier_init_kernel, self.kernel_init_std = xavier_init_kernel, kernel_init_std
+        self.feat_downsample_stride, self.feat_refine_stride = feat_downsample_stride, feat_refine_stride
+        self.conv_normal_init, self.feat_refine = conv_normal_init, feat_refine
+        self.num_loc_convs, self.num_seg_convs, self.use_binary = num_loc_convs, num_seg_convs, use_binary
+        self.num_thing_classes, self.num_stuff_classes = num_thing_classes, num_stuff_classes
+        self.ignore_label, self.cat_stuff_mask = ignore_label, cat_stuff_mask
+        self.with_depth, self.num_depth_convs, self.semantic_out_cfg = with_depth, num_depth_convs, semantic_out_cfg
+        bl = lambda c: build_loss(c) if c is not None else None
+        self.loss_mask, self.loss_dice, self.loss_seg, self.loss_cls = bl(loss_mask), bl(loss_dice), bl(loss_seg), bl(loss_cls)
+        self.loss_rank, self.loss_depth, self.loss_semantic_seg = bl(loss_rank), bl(loss_depth), bl(loss_semantic_seg)
+        if self.loss_seg is None:
+            raise ValueError("loss_seg is required when semantic_fpn=True (kernel_head.py:152)")
+        # layers (kernel_head.py:142-211)
+        self.init_kernels = nn.Conv2d(out_channels, num_proposals, 1, padding=0, bias=False)
+        self.conv_seg = nn.Conv2d(out_channels, num_classes if self.loss_seg.use_sigmoid else num_classes + 1, 1)
+        self.loc_convs = nn.ModuleList([ConvModuleParams(in_channels, out_channels, 1, norm_cfg=norm_cfg)])
+        self.seg_convs = nn.ModuleList([ConvModuleParams(in_channels, out_channels, 1, norm_cfg=norm_cfg)])
+        self.depth_convs = nn.ModuleList([ConvModuleParams(in_channels, out_channels, 1, norm_cfg=norm_cfg)])
+        self.conv_direct_depth = nn.Conv2d(out_channels, 1, 1)
+        self.semantic_aspp = None
+        self.precision = "fp32"
+        self.emit_fp32_features = True     # the reference API returns x_feats / depth_feats as fp32 NCHW tensors
+        self._pack, self._plans = None, {}
+
+    def init_weights(self):
+        """kernel_head.py:213-238"""
+        if self.localization_fpn is not None and hasattr(self.localization_fpn, "init_weights"):
+            self.localization_fpn.init_weights()
+        if self.feat_downsample_stride > 1 and self.conv_normal_init:
+            for conv in [self.loc_convs, self.seg_convs]:
+                for m in conv.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.normal_(m.weight, 0, 0.01)
+        if self.loss_seg.use_sigmoid:
+            nn.init.normal_(self.conv_seg.weight, 0, 0.01)
+            nn.init.constant_(self.conv_seg.bias, bias_init_with_prob(0.01))
+        else:
+            nn.init.normal_(self.conv_seg.weight, 0, 0.01)
+        if self.xavier_init_kernel:
+            nn.init.xavier_uniform_(self.init_kernels.weight)
+        else:
+            nn.init.normal_(self.init_kernels.weight, 0, self.kernel_init_std)
+
+    def set_precision(self, precision):
+        assert precision in ("fp32", "split", "bf16")
+        self.precision = precision
+        self._pack, self._plans = None, {}
+        return self
+
+    def _get_pack(self, device):
+        prec = E.PREC[self.precision]
+        own = {k: v for k, v in self.state_dict().items() if not k.startswith("localization_fpn.")}
+        ver = tuple(p._version for p in self.parameters())
+        if self._pack is None or self._pack[0] != (prec, str(device), ver):
+            self._pack = ((prec, str(device), ver),
+                          E.KernelHeadPack(own, prec, device, self.norm_cfg.get('num_groups', 32)))
+            self._plans = {}
+        return self._pack[1]
+
+    def _decode_init_proposals(self, img, img_metas, train_tracking=False):
+        """kernel_head.py:240-347 (eval).  `img`: the FPN tuple when `localization_fpn` is a module,
+        otherwise the three post-neck maps [B,256,H,W]."""
+        if self.training:
+            raise NotImplementedError("training is outside the implemented hot path")
+        feats = self.localization_fpn(img) if self.localization_fpn is not None else list(img)
+        if not isinstance(feats, (list, tuple)) or len(feats) != 3:
+            raise NotImplementedError("with_depth needs the neck's three maps (kernel_head.py:272-276)")
+        E._require_gpu(feats[0], "localization feats")
+        B, C, H, W = feats[0].shape
+        dev = feats[0].device
+        pack = self._get_pack(dev)
+        cat_stuff = self.cat_stuff_mask and not self.training
+        key = (B, H, W, cat_stuff, self.emit_fp32_features)
+        plan = self._plans.get(key)
+        if plan is None:
+            self._plans = {key: E.KernelHeadPlan(pack, B, H, W, self.num_thing_classes, self.num_classes, cat_stuff, dev,
+                                                 want_f32=self.emit_fp32_features)}
+            plan = self._plans[key]
+        plan.set_inputs([f.float() for f in feats])
+        plan.run()
+        N = plan.N
+        proposal_feats = plan.proposal.reshape(B, N, 256, 1, 1)
+        depth_proposal = pack.w_dd_f32[None].expand(B, N if cat_stuff else 1, 256, 1, 1)     # stride-0 view (:286-289,336)
+        x_feats, depth_feats = plan.x_f32, plan.dfe_f32
+        if x_feats is not None:
+            # hand the bf16 planes / mask bits to KernelUpdateIterHead so that it can skip its ingest pass
+            x_feats._ph_handoff = dict(xp=plan.xp, dp=plan.dp, bits=plan.bits, prec=pack.prec, mask_preds=plan.mask_preds,
+                                       depth_feats=depth_feats)
+        return (proposal_feats, x_feats, plan.mask_preds, None, plan.seg_preds, depth_feats, depth_proposal,
+                plan.depth_pred, None)
+
+    def simple_test_rpn(self, img, img_metas, train_tracking=False):
+        """kernel_head.py:700-706"""
+        return self._decode_init_proposals(img, img_metas, train_tracking)
+
+    def forward_dummy(self, img, img_metas):
+        return self._decode_init_proposals(img, img_metas)
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError("training (kernel_head.py:349-698) is outside the implemented hot path")
+
+    loss = forward_train
+
+
+register_everywhere(KernelHead)

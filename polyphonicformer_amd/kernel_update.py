@@ -93,8 +93,15 @@ class KernelUpdateIterHead(nn.Module):
         if not self.mask_head[-1].loss_cls.use_sigmoid:
             raise NotImplementedError("libpolyhead: sigmoid classification only (the shipped config)")
         plan = self._plan(B, N, H, W, x.device)
-        plan.set_inputs(x, depth_feats, proposal_feats, depth_proposal, mask_preds)
-        plan.run()
+        ho = getattr(x, "_ph_handoff", None)
+        if (ho is not None and ho["prec"] == plan.prec and ho["mask_preds"] is mask_preds
+                and ho["depth_feats"] is depth_feats and tuple(ho["xp"].shape) == tuple(plan.xp.shape)
+                and tuple(ho["bits"].shape) == tuple(plan.bits.shape)):
+            # inputs come straight from this package's KernelHead: its bf16 planes and mask bits are reused
+            plan.run_from_planes(ho["xp"], ho["dp"], ho["bits"], proposal_feats, depth_proposal)
+        else:
+            plan.set_inputs(x, depth_feats, proposal_feats, depth_proposal, mask_preds)
+            plan.run()
         return plan.outputs()
 
     def simple_test_mask_preds(self, x, proposal_feats, mask_preds, cls_score, img_metas, depth_preds=None,
