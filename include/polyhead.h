@@ -163,6 +163,24 @@ int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[
                        const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
                        int B, int n_thing_queries, int n_stuff, void* stream);
 
+/* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
+ * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.
+ * activate: act_mask[k] = sigmoid(mask_up[q_idx[k]]), act_depth[k] = depth_act(depth_up[q_idx[k]]),
+ *           act_depth0 = depth_act(depth_init_up); logits fp32 or bf16 ([N][sh][sw]), outputs fp32.
+ * argmax  : ids[px] = first argmax_k scores[k] * rescale(act_mask[k])(px); counts[0][k] = #{ids == k},
+ *           counts[1][k] = #{rescale(act_mask[k]) >= 0.5} (counts zeroed by the call).
+ * paste   : pan = newid[ids]; depth_final = newid[ids] > 0 ? rescale(act_depth[ids]) : rescale(act_depth0).
+ * from_probs != 0: act_* are already full-resolution [K][Ho][Wo] maps (no resampling) -- the integer
+ * semantics in isolation. The accept loop between argmax and paste (:500-533) is host logic. */
+int ph_panoptic_activate(const void* mask_up, const void* depth_up, int dtype, const float* depth_init_up,
+                         const int32_t* q_idx, int K, int h2, int w2, int depth_mode /*0 sigmoid, 1 monodepth*/,
+                         float* act_mask, float* act_depth, float* act_depth0, void* stream);
+int ph_panoptic_argmax(const float* act_mask, const float* scores, int K, const int32_t* geom, int from_probs,
+                       int32_t* ids, int32_t* counts /*[2][K]*/, void* stream);
+int ph_panoptic_paste(const int32_t* ids, const int32_t* newid, const float* act_depth, const float* act_depth0,
+                      const int32_t* geom, int from_probs, int32_t* pan, float* depth_basic, float* depth_final,
+                      void* stream);
+
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);
 int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);

@@ -42,6 +42,9 @@ SIGNATURES = {
     "ph_khead_conv_gn": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ph_panoptic_argmax": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32), _I, _P, _P, _P]),
+    "ph_panoptic_paste": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _I, _P, _P, _P, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_trread": (C.c_int, [_P, _P, _P]),

@@ -1,0 +1,208 @@
+// A16-A18 -- panoptic merge (polyphonic/kernel_update.py:421-535, kernel_update_head.py:593-626).
+//
+// The reference materialises ~N full-resolution fp32 probability and depth maps (1.3 GB at
+// 1024x2048, N=153) and then runs a host loop with three device syncs per segment.  Here:
+//   k_pan_activate : sigmoid / depth_act of the K selected stride-4 logit maps (gathered by query
+//                    index), once, at stride 4 (K*h2*w2 values).
+//   k_pan_argmax   : per OUTPUT pixel, bilinear(->batch_input_shape) . crop . bilinear(->ori_shape)
+//                    of every selected map on the fly, running first-index argmax of score*prob
+//                    (torch.argmax tie rule), integer histograms area[k] = #{ids == k} and
+//                    orig[k] = #{prob_k >= 0.5} (LDS histogram + integer atomics: exact, order free).
+//   host           : the accept loop over <= K segments on the two histograms (one D2H copy).
+//   k_pan_paste    : pan = new_id[ids], depth_final = accepted ? depth_k : depth_init.
+// Integer work (ids, areas, thresholds, pasted ids) is bit-exact given the same probability values;
+// `from_probs` mode takes materialised full-resolution maps so that tests can prove exactly that.
+// Bilinear index/weight arithmetic follows ATen (area_pixel_compute_source_index, align_corners =
+// False): src = scale*(dst+0.5)-0.5 clamped at 0, scale = in/out in fp32.
+#include "ph_common.h"
+
+struct PanGeom {
+    int sh, sw;     // source (stride-4) map size
+    int Hb, Wb;     // batch_input_shape
+    int h, w;       // img_shape (crop of the batch-resolution map)
+    int Ho, Wo;     // ori_shape
+};
+
+struct Tap { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Tap make_tap(int dst, int in_size, int out_size) {
+    const float scale = (float)in_size / (float)out_size;
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = fmaxf(s, 0.f);
+    Tap t;
+    t.i0 = (int)s;
+    if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+    t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+    t.l1 = fminf(fmaxf(s - (float)t.i0, 0.f), 1.f);
+    t.l0 = 1.f - t.l1;
+    return t;
+}
+
+// value of the batch-resolution map at integer (y, x): bilinear of the source map
+__device__ __forceinline__ float sample_mid(const float* __restrict__ src, const PanGeom& G, int y, int x) {
+    const Tap ty = make_tap(y, G.sh, G.Hb), tx = make_tap(x, G.sw, G.Wb);
+    const float* r0 = src + (int64_t)ty.i0 * G.sw;
+    const float* r1 = src + (int64_t)ty.i1 * G.sw;
+    return ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
+}
+
+struct OutTaps { Tap ty, tx; bool identity; };
+
+__device__ __forceinline__ OutTaps make_out_taps(const PanGeom& G, int y, int x) {
+    OutTaps o;
+    o.identity = (G.h == G.Ho && G.w == G.Wo);
+    if (!o.identity) { o.ty = make_tap(y, G.h, G.Ho); o.tx = make_tap(x, G.w, G.Wo); }
+    else { o.ty.i0 = y; o.tx.i0 = x; }
+    return o;
+}
+
+__device__ __forceinline__ float sample_out(const float* __restrict__ src, const PanGeom& G, const OutTaps& o) {
+    if (o.identity) return sample_mid(src, G, o.ty.i0, o.tx.i0);
+    const float a = sample_mid(src, G, o.ty.i0, o.tx.i0), b = sample_mid(src, G, o.ty.i0, o.tx.i1);
+    const float c = sample_mid(src, G, o.ty.i1, o.tx.i0), d = sample_mid(src, G, o.ty.i1, o.tx.i1);
+    return o.ty.l0 * (o.tx.l0 * a + o.tx.l1 * b) + o.ty.l1 * (o.tx.l0 * c + o.tx.l1 * d);
+}
+
+__device__ __forceinline__ float ld_logit(const float* p) { return *p; }
+__device__ __forceinline__ float ld_logit(const uint16_t* p) { return bf2f(*p); }
+
+__device__ __forceinline__ float sigmoid_exact(float z) { return (float)(1.0 / (1.0 + exp(-(double)z))); }
+
+// depth_act (funcs/depth_utils.py): mode 0 'sigmoid' -> s*(80-0.01)+0.01 ; mode 1 'monodepth'
+__device__ __forceinline__ float depth_act_dev(float z, int mode) {
+    const float s = sigmoid_exact(z);
+    if (mode == 0) return __fadd_rn(__fmul_rn(s, 79.99f), 0.01f);   // disp * (max - min) + min, two roundings like torch
+    const float min_disp = 1.0f / 80.0f, max_disp = 1.0f / 0.01f;
+    return 1.0f / (min_disp + (max_disp - min_disp) * s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pan_activate(const T* __restrict__ mask_up, const T* __restrict__ depth_up,
+                                                      const float* __restrict__ depth_init, const int* __restrict__ qidx,
+                                                      int K, int64_t hw, int depth_mode, float* __restrict__ act_mask,
+                                                      float* __restrict__ act_depth, float* __restrict__ act_depth0) {
+    const int64_t total = (int64_t)(K + 1) * hw;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / hw);
+        const int64_t p = idx - (int64_t)k * hw;
+        if (k < K) {
+            const int64_t q = qidx[k];
+            act_mask[idx] = sigmoid_exact(ld_logit(mask_up + q * hw + p));
+            act_depth[idx] = depth_act_dev(ld_logit(depth_up + q * hw + p), depth_mode);
+        } else {
+            act_depth0[p] = depth_act_dev(depth_init[p], depth_mode);
+        }
+    }
+}
+
+template <bool FROM_PROBS>
+__global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ act_mask, const float* __restrict__ scores,
+                                                    int K, PanGeom G, int* __restrict__ ids, int* __restrict__ counts) {
+    extern __shared__ int hist[];   // [2][K]
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int64_t npx = (int64_t)G.Ho * G.Wo;
+    const int64_t src_hw = FROM_PROBS ? npx : (int64_t)G.sh * G.sw;
+    for (int64_t px = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; px < npx; px += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(px / G.Wo), x = (int)(px - (int64_t)y * G.Wo);
+        OutTaps o;
+        if (!FROM_PROBS) o = make_out_taps(G, y, x);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const float p = FROM_PROBS ? act_mask[(int64_t)k * src_hw + px] : sample_out(act_mask + (int64_t)k * src_hw, G, o);
+            if (p >= 0.5f) atomicAdd(&hist[K + k], 1);          // original_area  (kernel_update.py:508)
+            const float v = scores[k] * p;                       // cur_prob_masks (:492)
+            if (v > best) { best = v; bi = k; }                  // argmax(0): first maximal index (:494)
+        }
+        ids[px] = bi;
+        atomicAdd(&hist[bi], 1);                                 // mask_area      (:506-507)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x)
+        if (hist[i]) atomicAdd(&counts[i], hist[i]);
+}
+
+template <bool FROM_PROBS>
+__global__ __launch_bounds__(256) void k_pan_paste(const int* __restrict__ ids, const int* __restrict__ newid,
+                                                   const float* __restrict__ act_depth, const float* __restrict__ act_depth0,
+                                                   PanGeom G, int* __restrict__ pan, float* __restrict__ depth_basic,
+                                                   float* __restrict__ depth_final) {
+    const int64_t npx = (int64_t)G.Ho * G.Wo;
+    const int64_t src_hw = FROM_PROBS ? npx : (int64_t)G.sh * G.sw;
+    for (int64_t px = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; px < npx; px += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(px / G.Wo), x = (int)(px - (int64_t)y * G.Wo);
+        OutTaps o;
+        if (!FROM_PROBS) o = make_out_taps(G, y, x);
+        const int k = ids[px];
+        const int nid = newid[k];
+        const float d0 = FROM_PROBS ? act_depth0[px] : sample_out(act_depth0, G, o);
+        float df = d0;
+        if (nid > 0) df = FROM_PROBS ? act_depth[(int64_t)k * src_hw + px] : sample_out(act_depth + (int64_t)k * src_hw, G, o);
+        pan[px] = nid;                                           // panoptic_seg[mask] = id   (:515)
+        depth_basic[px] = d0;                                    // depth_basic = depth_init  (:445-446)
+        depth_final[px] = df;                                    // depth_all[mask] = total_depth[k][mask]  (:517)
+    }
+}
+
+static int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+extern "C" int ph_panoptic_activate(const void* mask_up, const void* depth_up, int dtype, const float* depth_init_up,
+                                    const int32_t* q_idx, int K, int h2, int w2, int depth_mode, float* act_mask,
+                                    float* act_depth, float* act_depth0, void* stream) {
+    PH_CHECK_ARG(mask_up && depth_up && depth_init_up && q_idx && act_mask && act_depth && act_depth0, "null pointer");
+    PH_CHECK_ARG(K > 0 && h2 > 0 && w2 > 0 && (depth_mode == 0 || depth_mode == 1), "bad size / mode");
+    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16, "bad dtype");
+    const int64_t hw = (int64_t)h2 * w2;
+    const int grid = grid_for((int64_t)(K + 1) * hw);
+    if (dtype == PH_OUT_F32)
+        hipLaunchKernelGGL(k_pan_activate<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)mask_up,
+                           (const float*)depth_up, depth_init_up, q_idx, K, hw, depth_mode, act_mask, act_depth, act_depth0);
+    else
+        hipLaunchKernelGGL(k_pan_activate<uint16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)mask_up,
+                           (const uint16_t*)depth_up, depth_init_up, q_idx, K, hw, depth_mode, act_mask, act_depth, act_depth0);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+static int fill_geom(PanGeom& G, const int32_t* geom, int from_probs) {
+    G.sh = geom[0]; G.sw = geom[1]; G.Hb = geom[2]; G.Wb = geom[3]; G.h = geom[4]; G.w = geom[5]; G.Ho = geom[6]; G.Wo = geom[7];
+    if (G.Ho <= 0 || G.Wo <= 0) return -1;
+    if (!from_probs && (G.sh <= 0 || G.sw <= 0 || G.h <= 0 || G.w <= 0 || G.h > G.Hb || G.w > G.Wb)) return -1;
+    return 0;
+}
+
+extern "C" int ph_panoptic_argmax(const float* act_mask, const float* scores, int K, const int32_t* geom, int from_probs,
+                                  int32_t* ids, int32_t* counts, void* stream) {
+    PH_CHECK_ARG(act_mask && scores && geom && ids && counts && K > 0 && K <= 4096, "bad pointer or K");
+    PanGeom G;
+    PH_CHECK_ARG(fill_geom(G, geom, from_probs) == 0, "bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, (size_t)2 * K * sizeof(int32_t), s) != hipSuccess) {
+        ph_set_error("ph_panoptic_argmax: memset failed");
+        return PH_ELAUNCH;
+    }
+    const int grid = grid_for((int64_t)G.Ho * G.Wo);
+    const size_t lds = (size_t)2 * K * sizeof(int);
+    if (from_probs) hipLaunchKernelGGL(k_pan_argmax<true>, dim3(grid), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
+    else hipLaunchKernelGGL(k_pan_argmax<false>, dim3(grid), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_panoptic_paste(const int32_t* ids, const int32_t* newid, const float* act_depth, const float* act_depth0,
+                                 const int32_t* geom, int from_probs, int32_t* pan, float* depth_basic, float* depth_final,
+                                 void* stream) {
+    PH_CHECK_ARG(ids && newid && act_depth && act_depth0 && geom && pan && depth_basic && depth_final, "null pointer");
+    PanGeom G;
+    PH_CHECK_ARG(fill_geom(G, geom, from_probs) == 0, "bad geometry");
+    const int grid = grid_for((int64_t)G.Ho * G.Wo);
+    hipStream_t s = (hipStream_t)stream;
+    if (from_probs) hipLaunchKernelGGL(k_pan_paste<true>, dim3(grid), dim3(256), 0, s, ids, newid, act_depth, act_depth0, G, pan, depth_basic, depth_final);
+    else hipLaunchKernelGGL(k_pan_paste<false>, dim3(grid), dim3(256), 0, s, ids, newid, act_depth, act_depth0, G, pan, depth_basic, depth_final);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

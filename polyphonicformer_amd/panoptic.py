@@ -1,0 +1,115 @@
+"""Panoptic merge -- KernelUpdateIterHead.get_panoptic / merge_stuff_thing_stuff_joint
+(polyphonic/kernel_update.py:421-535) on libpolyhead's merge kernels.
+
+Host logic here (segment selection, the accept loop over <= max_per_img + num_stuff segments) mirrors
+the reference's Python; the per-pixel work (activation, two-step bilinear rescale, first-index
+argmax, area histograms, id / depth paste) is one activate + one argmax + one paste kernel and a
+single 2K-int D2H copy instead of ~3 syncs per segment."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEPTH_MODES = {"sigmoid": 0, "monodepth": 1}
+
+
+def select_segments(cls_scores, num_proposals, num_thing_classes, max_per_img):
+    """kernel_update.py:428-434 (top-k thing (query, class) pairs) and :448-459 (stuff diagonal,
+    sorted by score).  cls_scores: CPU fp32 [N, L] (post-sigmoid).  Returns query index, label, score
+    of the K candidate segments, things first (the order `total_*` are concatenated in, :487-489)."""
+    thing = cls_scores[:num_proposals][:, :num_thing_classes]
+    tscore, tidx = thing.flatten(0, 1).topk(max_per_img, sorted=True)
+    tq = torch.div(tidx, num_thing_classes, rounding_mode="floor")
+    tl = tidx % num_thing_classes
+    sscore = cls_scores[num_proposals:][:, num_thing_classes:].diag()
+    sscore, sind = torch.sort(sscore, descending=True)
+    return (torch.cat([tq, sind + num_proposals]), torch.cat([tl, sind + num_thing_classes]),
+            torch.cat([tscore, sscore]))
+
+
+def accept_loop(scores, labels, area, orig, num_thing_classes, instance_score_thr, overlap_thr):
+    """kernel_update.py:497-533 on the two per-segment pixel histograms.  Returns (newid[K], segments_info)."""
+    K = len(scores)
+    newid = np.zeros(K, dtype=np.int32)
+    info, seg = [], 0
+    for k in torch.argsort(-scores).tolist():                                # :497 (same call, same tie order)
+        cls = int(labels[k])
+        isthing = cls < num_thing_classes
+        if isthing and float(scores[k]) < instance_score_thr:                # :503
+            continue
+        mask_area, original_area = int(area[k]), int(orig[k])
+        if mask_area > 0 and original_area > 0:                              # :510
+            if mask_area / original_area < overlap_thr:                      # :511
+                continue
+            seg += 1
+            newid[k] = seg
+            if isthing:
+                info.append({'id': seg, 'isthing': isthing, 'score': float(scores[k]), 'category_id': cls,
+                             'instance_id': k})
+            else:
+                info.append({'id': seg, 'isthing': isthing, 'category_id': cls, 'area': mask_area})
+    return newid, info
+
+
+def _geom(src_hw, img_meta):
+    h, w = img_meta['img_shape'][:2]
+    Hb, Wb = img_meta['batch_input_shape']
+    Ho, Wo = img_meta['ori_shape'][:2]
+    return (C.c_int32 * 8)(src_hw[0], src_hw[1], Hb, Wb, h, w, Ho, Wo), (Ho, Wo)
+
+
+def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, num_thing_classes,
+                 instance_score_thr, overlap_thr, from_probs=False):
+    """argmax -> accept loop -> paste on already activated maps (device fp32)."""
+    lib, dev = _lib.load(), act_mask.device
+    K = act_mask.shape[0]
+    Ho, Wo = out_hw
+    ids = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
+    counts = torch.empty((2, K), dtype=torch.int32, device=dev)
+    sc = scores.to(dev, torch.float32).contiguous()
+    _lib.check(lib.ph_panoptic_argmax(_lib.ptr(act_mask), _lib.ptr(sc), K, geom, 1 if from_probs else 0, _lib.ptr(ids),
+                                      _lib.ptr(counts), _lib.stream_ptr()), "ph_panoptic_argmax")
+    cnt = counts.cpu().numpy()                                               # the one sync of the merge
+    newid, info = accept_loop(scores, labels, cnt[0], cnt[1], num_thing_classes, instance_score_thr, overlap_thr)
+    nid = torch.from_numpy(newid).to(dev)
+    pan = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
+    d_basic = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
+    d_final = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
+    _lib.check(lib.ph_panoptic_paste(_lib.ptr(ids), _lib.ptr(nid), _lib.ptr(act_depth), _lib.ptr(act_depth0), geom,
+                                     1 if from_probs else 0, _lib.ptr(pan), _lib.ptr(d_basic), _lib.ptr(d_final),
+                                     _lib.stream_ptr()), "ph_panoptic_paste")
+    return pan.cpu().numpy(), info, d_basic.cpu().numpy(), d_final.cpu().numpy()
+
+
+def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
+    """kernel_update.py:421-469 for one image.  cls_scores [N, L] (post-sigmoid), mask_preds /
+    depth_preds [N, 2H, 2W] logits (fp32 or bf16), depth_init [1, 2H, 2W] fp32 logits; all on the GPU.
+    Returns (None, None, (panoptic_seg int32 ndarray, segments_info), depth_basic, depth_final)."""
+    if not head.merge_joint:
+        raise NotImplementedError               # as the reference (:467-468)
+    lib, dev = _lib.load(), mask_preds.device
+    cfg = head.test_cfg
+    merge_cfg = cfg.merge_stuff_thing
+    q, labels, scores = select_segments(cls_scores.detach().float().cpu(), head.num_proposals,
+                                        head.num_thing_classes, cfg.max_per_img)
+    K = len(q)
+    N, h2, w2 = mask_preds.shape
+    mask_preds, depth_preds = mask_preds.contiguous(), depth_preds.contiguous()
+    if mask_preds.dtype != depth_preds.dtype or mask_preds.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.PolyheadError("mask/depth logits must both be fp32 or both bf16")
+    dt = _lib.PH_OUT_F32 if mask_preds.dtype == torch.float32 else _lib.PH_OUT_BF16
+    d0 = depth_init.reshape(h2, w2).float().contiguous()
+    qd = q.to(torch.int32).to(dev)
+    act_mask = torch.empty((K, h2, w2), dtype=torch.float32, device=dev)
+    act_depth = torch.empty((K, h2, w2), dtype=torch.float32, device=dev)
+    act_d0 = torch.empty((h2, w2), dtype=torch.float32, device=dev)
+    mode = DEPTH_MODES[head.mask_head[-1].depth_act_mode]
+    _lib.check(lib.ph_panoptic_activate(_lib.ptr(mask_preds), _lib.ptr(depth_preds), dt, _lib.ptr(d0), _lib.ptr(qd), K, h2, w2,
+                                        mode, _lib.ptr(act_mask), _lib.ptr(act_depth), _lib.ptr(act_d0), _lib.stream_ptr()),
+               "ph_panoptic_activate")
+    geom, out_hw = _geom((h2, w2), img_meta)
+    pan, info, d_basic, d_final = merge_device(act_mask, act_depth, act_d0, scores, labels, geom, out_hw,
+                                               head.num_thing_classes, merge_cfg.instance_score_thr, merge_cfg.overlap_thr)
+    return None, None, (pan, info), d_basic, d_final

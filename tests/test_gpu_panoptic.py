@@ -1,0 +1,116 @@
+"""GPU: panoptic merge (a7).  Integer work is checked BIT-EXACT:
+  * `from_probs`: the merge kernels on materialised full-resolution probability / depth maps against the
+    oracle's merge on the very same maps (ids, areas, accept decisions, pasted ids and depths).
+  * fused path (logits -> ids with on-the-fly sigmoid + two-step bilinear): against the reference's own
+    golden id maps.  The float resampling is this library's arithmetic (the reference's differs between its
+    own CPU and CUDA back ends at the ulp level), so a per-pixel mismatch budget of 1e-4 is allowed and the
+    observed count is printed; segment lists must agree exactly."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import poly_oracle as O
+from polyphonicformer_amd import panoptic as Pn
+from polyphonicformer_amd.registry import ConfigDict
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+CFG = Hh.FULL
+
+
+class _Head:
+    """the attributes get_panoptic reads from KernelUpdateIterHead"""
+    merge_joint, num_proposals, num_thing_classes = True, CFG["Nq"], CFG["n_thing"]
+    test_cfg = ConfigDict(max_per_img=CFG["Nq"], merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))
+    mask_head = [type("S", (), {"depth_act_mode": "sigmoid"})()]
+
+
+def _case(z, c):
+    h, w, bh, bw, oh, ow = [int(v) for v in z[f"{c}_meta"]]
+    return (torch.from_numpy(z[f"{c}_cls"]), torch.from_numpy(z[f"{c}_mask_up"]), torch.from_numpy(z[f"{c}_depth_up"]),
+            torch.from_numpy(z[f"{c}_depth_init_up"]), Hh.img_meta(h, w, pad_to=(bh, bw), ori=(oh, ow)))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_merge_from_probs_bit_exact(gpu, case):
+    z = Hh.load_golden("merge.npz")
+    cls, m_up, d_up, d0_up, meta = _case(z, case)
+    q, lab, sc = O.select_segments(cls, CFG["Nq"], CFG["n_thing"], CFG["Nq"])
+    q2, lab2, sc2 = Pn.select_segments(cls, CFG["Nq"], CFG["n_thing"], CFG["Nq"])
+    assert torch.equal(q, q2) and torch.equal(lab, lab2) and torch.equal(sc, sc2)
+    P = O.rescale(m_up[q].sigmoid(), meta)
+    D = O.rescale(O.depth_act(d_up, "sigmoid"), meta)[q]
+    D0 = O.rescale(O.depth_act(d0_up, "sigmoid"), meta)[0]
+    pan_ref, info_ref, dfin_ref = O.merge_from_probs(P, D, sc, lab, D0, CFG["n_thing"])
+    Ho, Wo = P.shape[-2:]
+    geom = (Pn.C.c_int32 * 8)(0, 0, 0, 0, 0, 0, Ho, Wo)
+    pan, info, d_basic, d_final = Pn.merge_device(P.to(gpu).contiguous(), D.to(gpu).contiguous(), D0.to(gpu).contiguous(),
+                                                  sc, lab, geom, (Ho, Wo), CFG["n_thing"], 0.3, 0.6, from_probs=True)
+    assert pan.dtype == np.int32 and np.array_equal(pan, pan_ref)
+    assert info == info_ref
+    assert np.array_equal(d_final, dfin_ref.numpy()) and np.array_equal(d_basic, D0.numpy())
+    # and the oracle on these maps reproduces the reference's golden id map
+    assert np.array_equal(pan_ref, z[f"{case}_pan"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_get_panoptic_fused_vs_reference_golden(gpu, case, dtype):
+    z = Hh.load_golden("merge.npz")
+    cls, m_up, d_up, d0_up, meta = _case(z, case)
+    if dtype == torch.bfloat16:      # bf16 logits (benchmark output dtype): the golden must be recomputed on them
+        m_up, d_up = m_up.to(dtype), d_up.to(dtype)
+        pan_ref, info_ref, dbas_ref, dfin_ref = O.get_panoptic(cls, m_up.float(), d_up.float(), d0_up, meta, CFG["Nq"],
+                                                               CFG["n_thing"], CFG["Nq"])
+    else:
+        pan_ref, info_ref = z[f"{case}_pan"], json.loads(bytes(z[f"{case}_info"]).decode())
+        dbas_ref, dfin_ref = z[f"{case}_depth_basic"], z[f"{case}_depth_final"]
+    out = Pn.get_panoptic(_Head, cls.to(gpu), m_up.to(gpu), d_up.to(gpu), d0_up.to(gpu), meta)
+    assert out[0] is None and out[1] is None
+    pan, info = out[2]
+    bad = int((pan != pan_ref).sum())
+    print(f"fused merge case {case} {dtype}: {bad} of {pan.size} pixels differ from the reference id map")
+    assert pan.dtype == np.int32 and pan.shape == pan_ref.shape
+    assert bad <= max(1, int(1e-4 * pan.size))
+    assert [(s["id"], s["isthing"], s["category_id"], s.get("instance_id")) for s in info] == \
+           [(s["id"], s["isthing"], s["category_id"], s.get("instance_id")) for s in info_ref]
+    for a, b in zip(info, info_ref):
+        if not a["isthing"]:
+            assert abs(a["area"] - b["area"]) <= max(2, bad)
+    assert Hh.rel_err(out[3], dbas_ref) < 1e-5
+    same = pan == pan_ref
+    assert np.abs(out[4] - dfin_ref)[same].max() < 1e-3 * np.abs(dfin_ref).max()
+
+
+def test_simple_test_whole_path_golden(gpu):
+    """KernelHead.simple_test_rpn -> KernelUpdateIterHead.simple_test exactly as Polyphonic.simple_test
+    (polyphonic_former.py:145-161) against the reference's golden panoptic outputs."""
+    from test_gpu_parity import _full_weights, _iter_head, _kernel_head
+    z = Hh.load_golden("full_panoptic.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    B, H, W = m["B"], m["H"], m["W"]
+    weights = _full_weights()
+    kh, ih = _kernel_head(weights, "fp32"), _iter_head(weights, m["cfg"]["S"], precision="fp32")
+    feats = [f.to(gpu) for f in Hh.neck_inputs(m["nseed"], B, 256, H, W)]
+    metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
+    (pf, xf, mp, cs, seg, df, dp, dpr, aspp) = kh.simple_test_rpn(feats, metas)
+    res = ih.simple_test(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp, imgs_whwh=None,
+                         aspp_semantic=aspp, rescale=True)
+    assert len(res) == B
+    for b in range(B):
+        assert res[b][0] is None and res[b][1] is None
+        pan, info = res[b][2]
+        assert pan.dtype == np.int32 and np.array_equal(pan, z[f"pan{b}"])
+        ref_info = json.loads(bytes(z[f"info{b}"]).decode())
+        assert [(s["id"], s["category_id"]) for s in info] == [(s["id"], s["category_id"]) for s in ref_info]
+        assert Hh.rel_err(res[b][3], z[f"depth_basic{b}"]) < 1e-3
+        assert Hh.rel_err(res[b][4], z[f"depth_final{b}"]) < 1e-3
+    # second geometry: padded batch shape + different ori_shape
+    h, w, bh, bw, oh, ow = [int(v) for v in z["geo2_meta"]]
+    meta2 = Hh.img_meta(h, w, pad_to=(bh, bw), ori=(oh, ow))
+    (pf, xf, mp, cs, seg, df, dp, dpr, aspp) = kh.simple_test_rpn([f[:1] for f in feats], [meta2])
+    res2 = ih.simple_test(xf, pf, mp, cs, [meta2], depth_preds=dpr, depth_feats=df, depth_proposal=dp)
+    assert np.array_equal(res2[0][2][0], z["pan_geo2"])

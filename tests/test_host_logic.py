@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the package (no GPU, no compute calls into the library):
+the C-ABI library loads and exports every symbol include/polyhead.h declares, the registry /
+state_dict contract, weight packing round trips, and the merge accept loop."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import poly_oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    from polyphonicformer_amd import _lib
+    from polyphonicformer_amd.build import build_library
+    build_library()
+    hdr = open(os.path.join(Hh.REPO, "include", "polyhead.h")).read()
+    declared = set(re.findall(r"\b(ph_[a-z0-9_]+)\s*\(", hdr)) - {"ph_hw_padded", "ph_n_padded"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ph_version.restype = ctypes.c_int
+    assert lib.ph_version() == 100
+    assert ctypes.sizeof(_lib.StageLayout) == 8 * (2 * 13 + 2 * 30) + 8 + 4 + 4
+
+
+def test_no_cpu_fallback():
+    from polyphonicformer_amd import _lib, engine as E
+    with pytest.raises(_lib.PolyheadError):
+        E.ingest(torch.zeros(1, 256, 4, 4), _lib.PH_PREC_BF16)
+    with pytest.raises(_lib.PolyheadError):
+        E.upsample2x(torch.zeros(1, 1, 4, 4))
+
+
+def _heads():
+    from polyphonicformer_amd.registry import HEADS, TRANSFORMER_LAYER
+    import polyphonicformer_amd.kernel_head, polyphonicformer_amd.kernel_update  # noqa: F401,E401
+    import polyphonicformer_amd.kernel_update_head, polyphonicformer_amd.kernel_updator  # noqa: F401,E401
+    import bench
+    S = 3
+    ih = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=S, assign_stages=S, stage_loss_weights=[1] * S,
+                          num_proposals=100, num_thing_classes=8, num_stuff_classes=11, do_panoptic=True,
+                          mask_head=bench.stage_cfg(19, 8, 11, 2048), test_cfg=dict(max_per_img=100),
+                          some_future_kwarg=1))                      # **kwargs tolerated like the reference
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8,
+                          num_stuff_classes=11, cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), test_cfg=None, train_cfg=None,
+                          localization_fpn=dict(type="SemanticFPNWrapper", in_channels=256)))
+    assert "KernelUpdator" in TRANSFORMER_LAYER and "KernelUpdateHead" in HEADS
+    return ih, kh
+
+
+def test_state_dict_keys_match_the_reference():
+    ih, kh = _heads()
+    with open(Hh.GOLDEN + "/full_state_keys.json") as f:
+        ref = json.load(f)
+    got = {"roi_head." + k: list(v.shape) for k, v in ih.state_dict().items()}
+    got.update({"rpn_head." + k: list(v.shape) for k, v in kh.state_dict().items()})
+    assert got == ref
+    assert kh.num_proposals == 100 and ih.mask_head[0].mask_upsample_stride == 2
+    assert ih.mask_head[0].num_classes == 19 and ih.mask_head[0].loss_cls.use_sigmoid
+
+
+def test_unsupported_configs_fail_loudly():
+    from polyphonicformer_amd.registry import HEADS
+    import bench
+    cfg = bench.stage_cfg(19, 8, 11, 2048)
+    cfg["conv_kernel_size"] = 3
+    with pytest.raises(NotImplementedError):
+        HEADS.build(cfg)
+    ih, kh = _heads()
+    with pytest.raises(NotImplementedError):
+        ih.forward_train()
+    with pytest.raises(NotImplementedError):
+        ih.aug_test(None, None, None)
+
+
+def test_feat_transform_cfg_is_not_mutated():
+    from polyphonicformer_amd.registry import HEADS
+    import bench
+    cfg = bench.stage_cfg(19, 8, 11, 2048)
+    cfg["feat_transform_cfg"]["kernel_size"] = 1
+    HEADS.build(cfg)
+    assert cfg["feat_transform_cfg"]["kernel_size"] == 1      # the reference pops it (kernel_update_head.py:125)
+
+
+def test_pack_fragments_round_trip_and_folding():
+    from polyphonicformer_amd import _lib
+    from polyphonicformer_amd.pack import pack_b_fragments, pack_stage, unpack_b_fragments
+    w = torch.randn(48, 64, dtype=torch.float64)
+    assert torch.equal(unpack_b_fragments(pack_b_fragments(w), 48, 64), w)
+    with open(Hh.GOLDEN + "/full_state_keys.json") as f:
+        sd = Hh.seeded_fill(json.load(f), 1234)
+    pre = "roi_head.mask_head.1."
+    wb, wf, lay = pack_stage(sd, pre, 19, _lib.PH_PREC_SPLIT)
+    assert wb.shape[0] == 2 and wb.dtype == torch.int16 and lay.ffn_dim == 2048 and lay.num_classes == 19
+    # folded dynamic_layer: (pooled x) W'^T + cnt v == dynamic_layer(pooled(feat_transform(x)))
+    off = lay.w[0][_lib.W_IDX["DYN"]]
+    flat = sum(wb[p, off:off + 512 * 256].view(torch.bfloat16).double() for p in range(2))
+    Wf = unpack_b_fragments(flat, 512, 256)
+    Wx = sd[pre + "feat_transform.conv.weight"].reshape(256, 256).double()
+    Wd = sd[pre + "kernel_update_conv.dynamic_layer.weight"].double()
+    assert (Wf - Wd @ Wx).abs().max() < 2e-5 * (Wd @ Wx).abs().max()
+    v = wf[lay.v[0][_lib.V_IDX["DYN_CNT"]]:][:512].double()
+    assert torch.allclose(v, Wd @ sd[pre + "feat_transform.conv.bias"].double(), atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_accept_loop_matches_reference_segments(case):
+    """host logic of the merge on histograms computed from the oracle's maps -> the reference's segments_info"""
+    from polyphonicformer_amd import panoptic as Pn
+    z = Hh.load_golden("merge.npz")
+    cfg = Hh.FULL
+    h, w, bh, bw, oh, ow = [int(v) for v in z[f"{case}_meta"]]
+    meta = Hh.img_meta(h, w, pad_to=(bh, bw), ori=(oh, ow))
+    cls = torch.from_numpy(z[f"{case}_cls"])
+    q, lab, sc = Pn.select_segments(cls, cfg["Nq"], cfg["n_thing"], cfg["Nq"])
+    P = O.rescale(torch.from_numpy(z[f"{case}_mask_up"])[q].sigmoid(), meta)
+    ids = (sc.view(-1, 1, 1) * P).argmax(0)
+    area = torch.bincount(ids.flatten(), minlength=len(q)).numpy()
+    orig = (P >= 0.5).flatten(1).sum(1).numpy()
+    newid, info = Pn.accept_loop(sc, lab, area, orig, cfg["n_thing"], 0.3, 0.6)
+    ref = json.loads(bytes(z[f"{case}_info"]).decode())
+    assert len(info) == len(ref)
+    for a, b in zip(info, ref):
+        assert a["id"] == b["id"] and a["category_id"] == b["category_id"] and a["isthing"] == b["isthing"]
+    pan = torch.from_numpy(newid)[ids].numpy().astype(np.int32)
+    assert np.array_equal(pan, z[f"{case}_pan"])
