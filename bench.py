@@ -206,10 +206,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from polyphonicformer_amd.dist import barrier_and_max
+    dt = barrier_and_max(dt, dev)                    # MAX over ranks
     fps = world * B * args.steps / dt
 
     if rank == 0:

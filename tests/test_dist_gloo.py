@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the N>1 path (frame sharding, the one track-record all-gather, the bench's
+max-over-ranks timing) is correct by construction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from polyphonicformer_amd import dist as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _frame_records(fid):
+    g = torch.Generator().manual_seed(1000 + fid)
+    n = int(torch.randint(0, 100, (1,), generator=g))
+    return torch.rand(n, 5, generator=g), torch.randint(0, 8, (n,), generator=g), torch.randn(n, 256, generator=g)
+
+
+def _worker(rank, world, port, nframes, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = D.shard_frames(nframes, rank, world)
+    per = -(-nframes // world)
+    recs, cnts = [], []
+    for f in mine:
+        r, n = D.pack_track_records(*_frame_records(f))
+        recs.append(r)
+        cnts.append(n)
+    allrec = D.allgather_track_records(mine, recs, cnts, per)
+    ok = [t[0] for t in allrec] == list(range(nframes))
+    for fid, bb, lab, emb in allrec:
+        b0, l0, e0 = _frame_records(fid)
+        ok &= torch.equal(bb, b0) and torch.equal(lab, l0) and torch.equal(emb, e0)   # bit-exact payload
+    mx = D.barrier_and_max(float(rank + 1), torch.device("cpu"))
+    q.put((rank, ok, mx, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nframes", [7, 8])
+def test_allgather_track_records_world2(nframes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, nframes, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert all(r[2] == 2.0 for r in res)                      # max over ranks
+    assert sorted(res[0][3] + res[1][3]) == list(range(nframes))   # a partition of the frames
+
+
+def test_shard_frames_partitions():
+    for n in (1, 5, 16, 17):
+        for w in (1, 2, 4, 8):
+            parts = [D.shard_frames(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_single_process_gather_is_identity():
+    r, n = D.pack_track_records(*_frame_records(3))
+    out = D.allgather_track_records([3], [r], [n], 1)
+    assert out[0][0] == 3 and torch.equal(out[0][3], _frame_records(3)[2])
