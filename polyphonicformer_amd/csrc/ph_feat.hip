@@ -7,13 +7,11 @@
 template <int P>
 __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, uint16_t* __restrict__ planes,
                                                 int64_t rows, int64_t HW, int64_t HWp) {
-    const int64_t per_row = HWp / 8;
-    const int64_t total = rows * per_row;
     const int64_t plane_stride = rows * HWp;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / per_row;
-        const int64_t px = (idx - row * per_row) * 8;
+    const int64_t row = blockIdx.y;
+    const int per_row = (int)(HWp / 8);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_row; i += gridDim.x * blockDim.x) {
+        const int64_t px = (int64_t)i * 8;
         float v[8];
         const float* s = src + row * HW + px;
         if (px + 8 <= HW && ((HW & 3) == 0)) {
@@ -41,12 +39,14 @@ extern "C" int ph_ingest_features(const float* src, uint16_t* planes, int B, int
     PH_CHECK_ARG(src && planes && B > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
     const int64_t HWp = ph_hw_padded(HW), rows = (int64_t)B * PH_C;
-    const int64_t total = rows * (HWp / 8);
-    int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    PH_CHECK_ARG(rows <= 65535, "B * 256 must be <= 65535");
+    int gx = (int)((HWp / 8 + 255) / 256);
+    if (gx > 8) gx = 8;                          // 8 x 256 threads x 32 B in flight per row
+    const dim3 grid(gx, (unsigned)rows);
     if (prec == PH_PREC_BF16)
-        hipLaunchKernelGGL(k_ingest<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
+        hipLaunchKernelGGL(k_ingest<1>, grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
     else
-        hipLaunchKernelGGL(k_ingest<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
+        hipLaunchKernelGGL(k_ingest<2>, grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -56,19 +56,33 @@ extern "C" int ph_ingest_features(const float* src, uint16_t* planes, int B, int
 // with __ballot (lane = pixel).  Rows >= N and pixels >= HW come out 0.
 __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logits, uint32_t* __restrict__ bits,
                                                   int B, int N, int Npad, int64_t HW, int64_t HWp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t w64_per_row = HWp / 64;
-    const int64_t total = (int64_t)B * Npad * w64_per_row;
-    for (int64_t t = wave; t < total; t += nwaves) {
-        const int64_t row = t / w64_per_row;          // b*Npad + n
-        const int64_t px = (t - row * w64_per_row) * 64 + lane;
-        const int b = (int)(row / Npad), n = (int)(row - (int64_t)b * Npad);
-        float v = -1.f;
-        if (n < N && px < HW) v = logits[((int64_t)b * N + n) * HW + px];
-        const unsigned long long m = __ballot(v > 0.f);
-        if (lane == 0) *(uint2*)(bits + row * (HWp / 32) + (px >> 5)) = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    // one row (b, n) per blockIdx.y; each lane tests 4 consecutive pixels (16-byte load); a wave covers
+    // 256 px = 8 words; the 8 lanes of a word OR their nibbles together with three xor-shuffles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y;
+    const int b = row / Npad, n = row - b * Npad;
+    const bool live = n < N;
+    const float* src = logits + ((int64_t)b * N + n) * HW;
+    uint32_t* dst = bits + (int64_t)row * (HWp / 32);
+    const bool vec_ok = (HW & 3) == 0;
+    for (int c = blockIdx.x * 4 + wave; (int64_t)c * 256 < HWp; c += gridDim.x * 4) {
+        const int64_t px = (int64_t)c * 256 + lane * 4;
+        float v[4] = {-1.f, -1.f, -1.f, -1.f};
+        if (live && px < HW) {
+            if (vec_ok && px + 4 <= HW) {
+                const float4 q = *(const float4*)(src + px);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = src[px + e];
+            }
+        }
+        const uint32_t nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+        uint32_t word = nib << (4 * (lane & 7));
+        word |= __shfl_xor(word, 1);
+        word |= __shfl_xor(word, 2);
+        word |= __shfl_xor(word, 4);
+        if ((lane & 7) == 0 && (int64_t)c * 256 + (lane >> 3) * 32 < HWp) dst[c * 8 + (lane >> 3)] = word;
     }
 }
 
@@ -76,10 +90,10 @@ extern "C" int ph_binarize(const float* logits, uint32_t* bits, int B, int N, in
     PH_CHECK_ARG(logits && bits && B > 0 && N > 0 && HW > 0, "bad pointer or size");
     const int Npad = ph_n_padded(N);
     const int64_t HWp = ph_hw_padded(HW);
-    const int64_t waves = (int64_t)B * Npad * (HWp / 64);
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_binarize, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, logits, bits, B, N, Npad, HW, HWp);
+    PH_CHECK_ARG((int64_t)B * Npad <= 65535, "B * Npad must be <= 65535");
+    int gx = (int)((HWp + 1023) / 1024);          // 4 waves x 256 px per block step
+    if (gx > 8) gx = 8;
+    hipLaunchKernelGGL(k_binarize, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, logits, bits, B, N, Npad, HW, HWp);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -95,50 +109,93 @@ template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v)
 template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_from_f32<uint16_t>(uint16_t* p, float v) { *p = (uint16_t)f2bf(v); }
 
-template <typename T>
+// One thread = 4 source columns x 1 source row -> an 8-column x 2-row output patch (16 B bf16 / 32 B fp32
+// stores per row).  Needs the 3x6 source neighbourhood; the overlap between threads is served by L1/L2, so
+// HBM sees the source once and the destination once (5 * planes*H*W elements: the algorithmic traffic).
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T* __restrict__ dst, int64_t planes,
                                                     int H, int W) {
-    const int W2 = 2 * W, H2 = 2 * H;
-    const int64_t total = planes * H2 * (int64_t)W;   // one thread = 2 horizontally adjacent outputs
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int xo = (int)(idx % W);
-        const int64_t t = idx / W;
-        const int yo = (int)(t % H2);
-        const int64_t p = t / H2;
-        const float sy = fmaxf((yo + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int y0 = (int)sy;
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
-        const float hy1 = sy - y0, hy0 = 1.f - hy1;
-        const T* r0 = src + (p * H + y0) * W;
-        const T* r1 = src + (p * H + y1) * W;
-        const int xm = xo > 0 ? xo - 1 : 0, xp = xo < W - 1 ? xo + 1 : xo;
-        const float a_m = ld_as_f32(r0 + xm), a_c = ld_as_f32(r0 + xo), a_p = ld_as_f32(r0 + xp);
-        const float b_m = ld_as_f32(r1 + xm), b_c = ld_as_f32(r1 + xo), b_p = ld_as_f32(r1 + xp);
-        // output column 2*xo   : src x = xo - 0.25 -> (x0 = xo-1, l1 = 0.75) except at xo = 0 (clamped: x0 = 0, l1 = 0)
-        // output column 2*xo+1 : src x = xo + 0.25 -> (x0 = xo,   l1 = 0.25), x1 clamped at the border
-        float e, o;
-        if (xo > 0) e = hy0 * (0.25f * a_m + 0.75f * a_c) + hy1 * (0.25f * b_m + 0.75f * b_c);
-        else e = hy0 * (1.f * a_c + 0.f * a_p) + hy1 * (1.f * b_c + 0.f * b_p);
-        o = hy0 * (0.75f * a_c + 0.25f * a_p) + hy1 * (0.75f * b_c + 0.25f * b_p);
-        T* d = dst + (p * H2 + yo) * W2 + 2 * xo;
-        st_from_f32(d, e);
-        st_from_f32(d + 1, o);
+    const int W2 = 2 * W;
+    const unsigned segs = (W + 3) / 4;
+    const unsigned total = (unsigned)(planes * H) * segs;            // checked < 2^31 by the launcher
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned t = idx / segs;                                // = p*H + y
+        const int j = (int)(idx - t * segs);
+        const int64_t p = t / (unsigned)H;
+        const int y = (int)(t - (unsigned)p * (unsigned)H);
+        const int x0 = 4 * j;
+        const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : y;
+        const int rows[3] = {ym, y, yp};
+        float h[3][8];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const T* row = src + (p * H + rows[r]) * W;
+            float v[6];
+            v[0] = ld_as_f32(row + (x0 > 0 ? x0 - 1 : 0));
+            if (VEC) {
+                if (sizeof(T) == 2) {
+                    const uint2 q = *(const uint2*)(row + x0);
+                    v[1] = bf2f(q.x & 0xFFFF); v[2] = bf2f(q.x >> 16); v[3] = bf2f(q.y & 0xFFFF); v[4] = bf2f(q.y >> 16);
+                } else {
+                    const float4 q = *(const float4*)(row + x0);
+                    v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w;
+                }
+                v[5] = ld_as_f32(row + (x0 + 4 < W ? x0 + 4 : W - 1));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) v[1 + c] = ld_as_f32(row + (x0 + c < W ? x0 + c : W - 1));
+            }
+            // output column 2x   : src = x - 0.25 -> (x-1, x) weights (0.25, 0.75); x = 0: clamped, weights (1, 0)
+            // output column 2x+1 : src = x + 0.25 -> (x, x+1 clamped) weights (0.75, 0.25)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool first = (x0 + c == 0);
+                h[r][2 * c] = first ? (1.f * v[1] + 0.f * v[2]) : (0.25f * v[c] + 0.75f * v[c + 1]);
+                h[r][2 * c + 1] = 0.75f * v[c + 1] + 0.25f * v[c + 2];
+            }
+        }
+        float o[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[0][e] = (y > 0) ? (0.25f * h[0][e] + 0.75f * h[1][e]) : (1.f * h[1][e] + 0.f * h[2][e]);
+            o[1][e] = 0.75f * h[1][e] + 0.25f * h[2][e];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            T* d = dst + (p * 2 * H + 2 * y + r) * W2 + 2 * x0;
+            if (VEC) {
+                if (sizeof(T) == 2) {
+                    *(uint4*)d = make_uint4(pack2(f2bf(o[r][0]), f2bf(o[r][1])), pack2(f2bf(o[r][2]), f2bf(o[r][3])),
+                                            pack2(f2bf(o[r][4]), f2bf(o[r][5])), pack2(f2bf(o[r][6]), f2bf(o[r][7])));
+                } else {
+                    *(float4*)d = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+                    *(float4*)((float*)d + 4) = make_float4(o[r][4], o[r][5], o[r][6], o[r][7]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (2 * x0 + e < W2) st_from_f32(d + e, o[r][e]);
+            }
+        }
     }
 }
 
 extern "C" int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes, int H, int W, void* stream) {
     PH_CHECK_ARG(src && dst && planes > 0 && H > 0 && W > 0, "bad pointer or size");
     PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16, "dtype must be PH_OUT_F32 or PH_OUT_BF16");
-    const int64_t total = planes * 2 * H * (int64_t)W;
+    const int64_t total = planes * H * (int64_t)((W + 3) / 4);
+    PH_CHECK_ARG(total < (1ll << 31), "planes * H * W / 4 must be < 2^31");
     int64_t blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    if (dtype == PH_OUT_F32)
-        hipLaunchKernelGGL(k_upsample2x<float>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)src, (float*)dst, planes, H, W);
-    else
-        hipLaunchKernelGGL(k_upsample2x<uint16_t>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+    if (blocks > 65536) blocks = 65536;
+    const bool vec = (W % 4) == 0;      // rows then start 8-byte (bf16) / 16-byte (fp32) aligned
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PH_OUT_F32) {
+        if (vec) hipLaunchKernelGGL((k_upsample2x<float, true>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
+        else hipLaunchKernelGGL((k_upsample2x<float, false>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+        else hipLaunchKernelGGL((k_upsample2x<uint16_t, false>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+    }
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
