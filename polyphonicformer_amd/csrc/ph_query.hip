@@ -20,7 +20,12 @@
 constexpr int LDA = 264;   // LDS row stride (elements) of a [rows][256] bf16 activation buffer
 constexpr float LN_EPS = 1e-5f;
 
-template <int NRT> struct Tile { f32x4_t v[NRT][4]; };
+constexpr int NW = 8;             // waves per workgroup
+constexpr int CT = 2;             // 16-column tiles per wave: NW * CT * 16 = 256 columns
+constexpr int WCOLS = CT * 16;
+constexpr int NTHREADS = NW * 64;
+
+template <int NRT> struct Tile { f32x4_t v[NRT][CT]; };
 
 struct QArgs {
     const float* partial; const uint32_t* bits; const float* k_in; const float* q_in;
@@ -33,19 +38,29 @@ struct QArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int NRT> __device__ __forceinline__ void tile_zero(f32x4_t (&a)[NRT][4]) {
+template <int NRT> __device__ __forceinline__ void tile_zero(f32x4_t (&a)[NRT][CT]) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) a[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct) a[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc[rt][ct] += A(LDS, [NRT*16 rows][K]) x W(col tiles ct0.., k-steps wks0..wks0+NKS-1)
+// acc[rt][ct] += A(LDS, [NRT*16 rows][K]) x W(col tiles ct0.., k-steps wks0..wks0+NKS-1).
+// All weight fragments of the call are requested up front (NKS*NCT 16-byte loads per lane in flight):
+// with one or two waves per SIMD nothing else hides the L2 latency of this stream.
 template <int PA, int NRT, int NCT, int NKS>
 __device__ __forceinline__ void gemm_tile(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int a_plane,
                                           const uint16_t* __restrict__ W, int64_t w_plane, int ct0, int ks_total,
                                           int wks0, int lane) {
     const int i = lane & 15, g = lane >> 4;
+    uint4 b[PA][NKS][NCT];
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                b[p][ks][ct] = *(const uint4*)(W + p * w_plane + ((int64_t)(ct0 + ct) * ks_total + wks0 + ks) * 512 + lane * 8);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         uint4 a[PA][NRT];
@@ -55,29 +70,24 @@ __device__ __forceinline__ void gemm_tile(f32x4_t (&acc)[NRT][NCT], const uint16
             for (int rt = 0; rt < NRT; ++rt)
                 a[p][rt] = *(const uint4*)(A + p * a_plane + (rt * 16 + i) * LDA + ks * 32 + g * 8);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            uint4 b[PA];
-#pragma unroll
-            for (int p = 0; p < PA; ++p)
-                b[p] = *(const uint4*)(W + p * w_plane + ((int64_t)(ct0 + ct) * ks_total + wks0 + ks) * 512 + lane * 8);
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                acc[rt][ct] = mfma16(a[0][rt], b[0], acc[rt][ct]);
+                acc[rt][ct] = mfma16(a[0][rt], b[0][ks][ct], acc[rt][ct]);
                 if (PA == 2) {
-                    acc[rt][ct] = mfma16(a[0][rt], b[PA - 1], acc[rt][ct]);
-                    acc[rt][ct] = mfma16(a[PA - 1][rt], b[0], acc[rt][ct]);
+                    acc[rt][ct] = mfma16(a[0][rt], b[PA - 1][ks][ct], acc[rt][ct]);
+                    acc[rt][ct] = mfma16(a[PA - 1][rt], b[0][ks][ct], acc[rt][ct]);
                 }
             }
-        }
     }
 }
 
-// t[row][col] += bias[col]   (col = 64*wave + 16*ct + (lane&15))
+// t[row][col] += bias[col]   (col = WCOLS*wave + 16*ct + (lane&15))
 template <int NRT>
 __device__ __forceinline__ void tile_add_bias(Tile<NRT>& t, const float* __restrict__ bias, int wave, int lane) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const float bv = bias[wave * 64 + ct * 16 + (lane & 15)];
+    for (int ct = 0; ct < CT; ++ct) {
+        const float bv = bias[wave * WCOLS + ct * 16 + (lane & 15)];
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -92,10 +102,10 @@ __device__ __forceinline__ void tile_to_lds(const Tile<NRT>& t, uint16_t* dst, i
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int off = (rt * 16 + g * 4 + r) * LDA + wave * 64 + ct * 16 + i;
+                const int off = (rt * 16 + g * 4 + r) * LDA + wave * WCOLS + ct * 16 + i;
                 if (PA == 1) dst[off] = (uint16_t)f2bf(t.v[rt][ct][r]);
                 else {
                     uint32_t hi, lo;
@@ -107,7 +117,7 @@ __device__ __forceinline__ void tile_to_lds(const Tile<NRT>& t, uint16_t* dst, i
 }
 
 // LayerNorm over the 256 columns of NT tiles at once (two-pass: mean, then centred variance).
-// red: float [2][NT][4 waves][NRT*16]
+// red: float [2][NT][NW waves][NRT*16]
 template <int NRT, int NT>
 __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const (&gam)[NT], const float* const (&bet)[NT],
                                          float* red, int wave, int lane) {
@@ -120,9 +130,11 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = t[n].v[rt][0][r] + t[n].v[rt][1][r] + t[n].v[rt][2][r] + t[n].v[rt][3][r];
+                float s = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) s += t[n].v[rt][ct][r];
                 s = wave_group16_sum(s);
-                if (i == 0) red[((0 * NT + n) * 4 + wave) * ROWS + rt * 16 + g * 4 + r] = s;
+                if (i == 0) red[((0 * NT + n) * NW + wave) * ROWS + rt * 16 + g * 4 + r] = s;
             }
     __syncthreads();
 #pragma unroll
@@ -131,36 +143,42 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* p = red + (0 * NT + n) * 4 * ROWS + rt * 16 + g * 4 + r;
-                mean[n][rt][r] = (p[0] + p[ROWS] + p[2 * ROWS] + p[3 * ROWS]) * (1.f / 256.f);
+                const float* p = red + (0 * NT + n) * NW * ROWS + rt * 16 + g * 4 + r;
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += p[w * ROWS];
+                mean[n][rt][r] = tot * (1.f / 256.f);
                 float s = 0.f;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
+                for (int ct = 0; ct < CT; ++ct) {
                     const float d = t[n].v[rt][ct][r] - mean[n][rt][r];
                     t[n].v[rt][ct][r] = d;
                     s += d * d;
                 }
                 s = wave_group16_sum(s);
-                if (i == 0) red[((1 * NT + n) * 4 + wave) * ROWS + rt * 16 + g * 4 + r] = s;
+                if (i == 0) red[((1 * NT + n) * NW + wave) * ROWS + rt * 16 + g * 4 + r] = s;
             }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        float gm[4], bt[4];
+        float gm[CT], bt[CT];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            gm[ct] = gam[n][wave * 64 + ct * 16 + i];
-            bt[ct] = bet[n][wave * 64 + ct * 16 + i];
+        for (int ct = 0; ct < CT; ++ct) {
+            gm[ct] = gam[n][wave * WCOLS + ct * 16 + i];
+            bt[ct] = bet[n][wave * WCOLS + ct * 16 + i];
         }
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* p = red + (1 * NT + n) * 4 * ROWS + rt * 16 + g * 4 + r;
-                const float var = (p[0] + p[ROWS] + p[2 * ROWS] + p[3 * ROWS]) * (1.f / 256.f);
+                const float* p = red + (1 * NT + n) * NW * ROWS + rt * 16 + g * 4 + r;
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += p[w * ROWS];
+                const float var = tot * (1.f / 256.f);
                 const float rstd = 1.f / sqrtf(var + LN_EPS);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) t[n].v[rt][ct][r] = t[n].v[rt][ct][r] * rstd * gm[ct] + bt[ct];
+                for (int ct = 0; ct < CT; ++ct) t[n].v[rt][ct][r] = t[n].v[rt][ct][r] * rstd * gm[ct] + bt[ct];
             }
     }
 }
@@ -171,7 +189,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 //  k_query_pre
 // ================================================================================================
 template <int PA, int NRT>
-__global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
+__global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     constexpr int ROWS = NRT * 16;
     constexpr int PLANE = ROWS * LDA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
     uint16_t* actB = actA + PA * PLANE;           // kernel k (or q + k)
     uint16_t* actG = actB + PA * PLANE;           // g, then f, then o1
     float* red = (float*)(actG + PA * PLANE);     // [2][2][4][ROWS]
-    float* cnt = red + 2 * 2 * 4 * ROWS;          // [ROWS]
+    float* cnt = red + 2 * 2 * NW * ROWS;          // [ROWS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -193,17 +211,17 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
 
     // ---- step 0: reduce pooling partials (fixed order), pixel counts, kernel rows -> LDS ----------
     {
-        const int r = tid >> 3, cb = (tid & 7) * 32;   // 8 threads per row, 32 columns each
+        const int r = tid >> 4, cb = (tid & 15) * 16;   // 16 threads per row, 16 columns each
         for (int rr = r; rr < ROWS; rr += 32) {
             const int row = row0 + rr;
-            float u[32], kv[32];
+            float u[16], kv[16];
 #pragma unroll
-            for (int e = 0; e < 32; ++e) { u[e] = 0.f; kv[e] = 0.f; }
+            for (int e = 0; e < 16; ++e) { u[e] = 0.f; kv[e] = 0.f; }
             if (row < Npad) {
                 for (int s = 0; s < a.nsplit; ++s) {
                     const float* p = a.partial + (((int64_t)b * a.nsplit + s) * Npad + row) * 512 + br * 256 + cb;
 #pragma unroll
-                    for (int e = 0; e < 32; e += 4) {
+                    for (int e = 0; e < 16; e += 4) {
                         const float4 v = *(const float4*)(p + e);
                         u[e] += v.x; u[e + 1] += v.y; u[e + 2] += v.z; u[e + 3] += v.w;
                     }
@@ -212,21 +230,21 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
             if (row < N) {
                 const float* kp = a.k_in + ((int64_t)b * N + row) * 256 + cb;
 #pragma unroll
-                for (int e = 0; e < 32; e += 4) {
+                for (int e = 0; e < 16; e += 4) {
                     const float4 v = *(const float4*)(kp + e);
                     kv[e] = v.x; kv[e + 1] = v.y; kv[e + 2] = v.z; kv[e + 3] = v.w;
                 }
                 if (br == 1) {   // depth_proposal + proposal_feat   (kernel_update_head.py:250)
                     const float* qp = a.q_in + ((int64_t)b * N + row) * 256 + cb;
 #pragma unroll
-                    for (int e = 0; e < 32; e += 4) {
+                    for (int e = 0; e < 16; e += 4) {
                         const float4 v = *(const float4*)(qp + e);
                         kv[e] += v.x; kv[e + 1] += v.y; kv[e + 2] += v.z; kv[e + 3] += v.w;
                     }
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 32; e += 2) {
+            for (int e = 0; e < 16; e += 2) {
                 uint32_t h0, l0, h1, l1;
                 f2bf_split(u[e], h0, l0); f2bf_split(u[e + 1], h1, l1);
                 *(uint32_t*)(actA + rr * LDA + cb + e) = pack2(h0, h1);
@@ -239,10 +257,10 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
             int c = 0;
             if (row < Npad) {
                 const uint32_t* bw = a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32);
-                for (int w = (tid & 7); w < a.HWp / 32; w += 8) c += __popc(bw[w]);
+                for (int w = (tid & 15); w < a.HWp / 32; w += 16) c += __popc(bw[w]);
             }
-            c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4);
-            if ((tid & 7) == 0) cnt[rr] = (float)c;
+            c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+            if ((tid & 15) == 0) cnt[rr] = (float)c;
         }
     }
     __syncthreads();
@@ -250,17 +268,17 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
     // ---- step 1: P = dynamic_layer(u), I = input_layer(k)   (kernel_updator.py:58-67) ------------
     Tile<NRT> Pin, Iin, PI[2];   // PI[0] = P_out, PI[1] = I_out
     tile_zero(Pin.v); tile_zero(Iin.v); tile_zero(PI[0].v); tile_zero(PI[1].v);
-    gemm_tile<PA, NRT, 4, 8>(Pin.v, actA, PLANE, wb + WO[PH_W_DYN], wpl, wave * 4, 8, 0, lane);
-    gemm_tile<PA, NRT, 4, 8>(PI[0].v, actA, PLANE, wb + WO[PH_W_DYN], wpl, 16 + wave * 4, 8, 0, lane);
-    gemm_tile<PA, NRT, 4, 8>(Iin.v, actB, PLANE, wb + WO[PH_W_INP], wpl, wave * 4, 8, 0, lane);
-    gemm_tile<PA, NRT, 4, 8>(PI[1].v, actB, PLANE, wb + WO[PH_W_INP], wpl, 16 + wave * 4, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(Pin.v, actA, PLANE, wb + WO[PH_W_DYN], wpl, wave * CT, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(PI[0].v, actA, PLANE, wb + WO[PH_W_DYN], wpl, 16 + wave * CT, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(Iin.v, actB, PLANE, wb + WO[PH_W_INP], wpl, wave * CT, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(PI[1].v, actB, PLANE, wb + WO[PH_W_INP], wpl, 16 + wave * CT, 8, 0, lane);
     {
         const float* vc = wf + VO[PH_V_DYN_CNT];
         const float* bd = wf + VO[PH_V_DYN_B];
         const float* bi = wf + VO[PH_V_INP_B];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int col = wave * 64 + ct * 16 + i;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = wave * WCOLS + ct * 16 + i;
             const float vc0 = vc[col], vc1 = vc[256 + col], bd0 = bd[col], bd1 = bd[256 + col];
             const float bi0 = bi[col], bi1 = bi[256 + col];
 #pragma unroll
@@ -287,8 +305,8 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
     // ---- step 2: gates (kernel_updator.py:73-77), features (:86-87) --------------------------------
     Tile<NRT> G[2];   // G[0] = input_gate, G[1] = update_gate
     tile_zero(G[0].v); tile_zero(G[1].v);
-    gemm_tile<PA, NRT, 4, 8>(G[0].v, actG, PLANE, wb + WO[PH_W_IG], wpl, wave * 4, 8, 0, lane);
-    gemm_tile<PA, NRT, 4, 8>(G[1].v, actG, PLANE, wb + WO[PH_W_UG], wpl, wave * 4, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(G[0].v, actG, PLANE, wb + WO[PH_W_IG], wpl, wave * CT, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(G[1].v, actG, PLANE, wb + WO[PH_W_UG], wpl, wave * CT, 8, 0, lane);
     tile_add_bias(G[0], wf + VO[PH_V_IG_B], wave, lane);
     tile_add_bias(G[1], wf + VO[PH_V_UG_B], wave, lane);
     {
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 G[0].v[rt][ct][r] = sigmoidf_(G[1].v[rt][ct][r]) * PI[0].v[rt][ct][r] +
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
     // ---- step 3: fc_layer + fc_norm + ReLU (kernel_updator.py:89-91) -------------------------------
     Tile<NRT> O[1];
     tile_zero(O[0].v);
-    gemm_tile<PA, NRT, 4, 8>(O[0].v, actG, PLANE, wb + WO[PH_W_FC], wpl, wave * 4, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(O[0].v, actG, PLANE, wb + WO[PH_W_FC], wpl, wave * CT, 8, 0, lane);
     tile_add_bias(O[0], wf + VO[PH_V_FC_B], wave, lane);
     {
         const float* const gm[1] = {wf + VO[PH_V_LN_FC_G]};
@@ -322,12 +340,12 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = fmaxf(O[0].v[rt][ct][r], 0.f);
                 O[0].v[rt][ct][r] = v;
-                o1[(rt * 16 + g * 4 + r) * 256 + wave * 64 + ct * 16 + i] = v;   // residual for the post kernel
+                o1[(rt * 16 + g * 4 + r) * 256 + wave * WCOLS + ct * 16 + i] = v;   // residual for the post kernel
             }
     tile_to_lds<PA, NRT>(O[0], actG, PLANE, wave, lane);
     __syncthreads();
@@ -340,11 +358,11 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
     for (int part = 0; part < 3; ++part) {
         Tile<NRT> T;
         tile_zero(T.v);
-        gemm_tile<PA, NRT, 4, 8>(T.v, actG, PLANE, wb + WO[PH_W_QKV], wpl, part * 16 + wave * 4, 8, 0, lane);
+        gemm_tile<PA, NRT, CT, 8>(T.v, actG, PLANE, wb + WO[PH_W_QKV], wpl, part * 16 + wave * CT, 8, 0, lane);
         const float* bias = wf + VO[PH_V_QKV_B] + part * 256;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int col = wave * 64 + ct * 16 + i;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = wave * WCOLS + ct * 16 + i;
             const float bv = bias[col];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
@@ -376,13 +394,13 @@ __global__ __launch_bounds__(256) void k_query_pre(const QArgs a) {
 //  k_query_post
 // ================================================================================================
 template <int PA, int NRT>
-__global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
+__global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     constexpr int ROWS = NRT * 16;
     constexpr int PLANE = ROWS * LDA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* actA = (uint16_t*)smem;                       // [PA][ROWS][LDA]
     float* red = (float*)(actA + PA * PLANE);               // [2][2][4][ROWS]
-    uint16_t* region = (uint16_t*)(red + 2 * 2 * 4 * ROWS); // attention P buffers, then FFN h buffers, then head buffers
+    uint16_t* region = (uint16_t*)(red + 2 * 2 * NW * ROWS); // attention P buffers, then FFN h buffers, then head buffers
     const int Npad = a.Npad, N = a.N;
     const int LDP = Npad + 8;                               // row stride of a per-wave P buffer
 
@@ -400,13 +418,12 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     const uint16_t* Kb = a.Kp + ((int64_t)b * 2 + br) * Npad * 256;
     const uint16_t* Vb = a.Vt + ((int64_t)b * 2 + br) * 256 * Npad;
 
-    // ---- attention: wave w owns heads 2w, 2w+1 for this block's ROWS query rows -------------------
+    // ---- attention: wave w owns head w for this block's ROWS query rows ---------------------------
     Tile<NRT> At[1];
     uint16_t* Pb = region + wave * (PA * ROWS * LDP);
     const int pplane = ROWS * LDP;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int h = wave * 2 + hh;
+    {
+        const int h = wave;
         uint4 qf[PA][NRT];
 #pragma unroll
         for (int p = 0; p < PA; ++p)
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sm[rt][r] = 1.f / wave_group16_sum(sm[rt][r]);
-        __syncthreads();   // P of this head visible (uniform trip count: every wave runs 2 heads)
+        __syncthreads();   // P visible (per-wave buffers; the barrier orders this wave's LDS writes before its reads)
         // PV: out[rows][32 d] = P[rows][keys] x V[keys][d]
         f32x4_t o[NRT][2];
 #pragma unroll
@@ -497,8 +514,7 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) At[0].v[rt][hh * 2 + ct][r] = o[rt][ct][r] * sm[rt][r];
-        __syncthreads();   // P buffer free for the next head
+                for (int r = 0; r < 4; ++r) At[0].v[rt][ct][r] = o[rt][ct][r] * sm[rt][r];
     }
     tile_to_lds<PA, NRT>(At[0], actA, PLANE, wave, lane);
     __syncthreads();
@@ -506,16 +522,16 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     // ---- out_proj + identity + attention_norm (kernel_update_head.py:259-260) ----------------------
     Tile<NRT> O2[1];
     tile_zero(O2[0].v);
-    gemm_tile<PA, NRT, 4, 8>(O2[0].v, actA, PLANE, wb + WO[PH_W_OUT], wpl, wave * 4, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(O2[0].v, actA, PLANE, wb + WO[PH_W_OUT], wpl, wave * CT, 8, 0, lane);
     tile_add_bias(O2[0], wf + VO[PH_V_OUT_B], wave, lane);
     {
         const float* o1 = a.o1 + (((int64_t)b * 2 + br) * Npad + row0) * 256;
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) O2[0].v[rt][ct][r] += o1[(rt * 16 + g * 4 + r) * 256 + wave * 64 + ct * 16 + i];
+                for (int r = 0; r < 4; ++r) O2[0].v[rt][ct][r] += o1[(rt * 16 + g * 4 + r) * 256 + wave * WCOLS + ct * 16 + i];
         const float* const gm[1] = {wf + VO[PH_V_LN_ATT_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_ATT_B]};
         ln_tiles<NRT, 1>(O2, gm, bt, red, wave, lane);   // includes barriers: actA readers are done
@@ -531,11 +547,11 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         Tile<NRT> Hc;
         tile_zero(Hc.v);
-        gemm_tile<PA, NRT, 4, 8>(Hc.v, actA, PLANE, wb + WO[PH_W_FFN1], wpl, c * 16 + wave * 4, 8, 0, lane);
+        gemm_tile<PA, NRT, CT, 8>(Hc.v, actA, PLANE, wb + WO[PH_W_FFN1], wpl, c * 16 + wave * CT, 8, 0, lane);
         const float* b1 = wf + VO[PH_V_FFN1_B] + c * 256;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const float bv = b1[wave * 64 + ct * 16 + i];
+        for (int ct = 0; ct < CT; ++ct) {
+            const float bv = b1[wave * WCOLS + ct * 16 + i];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -543,14 +559,14 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
         }
         tile_to_lds<PA, NRT>(Hc, hbuf[c & 1], PLANE, wave, lane);
         __syncthreads();
-        gemm_tile<PA, NRT, 4, 8>(O3[0].v, hbuf[c & 1], PLANE, wb + WO[PH_W_FFN2], wpl, wave * 4, a.lay.ffn_dim / 32, c * 8,
+        gemm_tile<PA, NRT, CT, 8>(O3[0].v, hbuf[c & 1], PLANE, wb + WO[PH_W_FFN2], wpl, wave * CT, a.lay.ffn_dim / 32, c * 8,
                                  lane);
     }
     tile_add_bias(O3[0], wf + VO[PH_V_FFN2_B], wave, lane);
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) O3[0].v[rt][ct] += O2[0].v[rt][ct];
+        for (int ct = 0; ct < CT; ++ct) O3[0].v[rt][ct] += O2[0].v[rt][ct];
     {
         const float* const gm[1] = {wf + VO[PH_V_LN_FFN_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_FFN_B]};
@@ -561,11 +577,11 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rr = rt * 16 + g * 4 + r;
-                    if (row0 + rr < N) out[rr * 256 + wave * 64 + ct * 16 + i] = O3[0].v[rt][ct][r];
+                    if (row0 + rr < N) out[rr * 256 + wave * WCOLS + ct * 16 + i] = O3[0].v[rt][ct][r];
                 }
     }
     tile_to_lds<PA, NRT>(O3[0], actA, PLANE, wave, lane);   // ln_tiles' barriers: FFN readers of actA are done
@@ -576,10 +592,10 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     uint16_t* bufC = region + PA * PLANE;      // cls_fcs activation (mask branch)
     Tile<NRT> Hd[2];
     tile_zero(Hd[0].v);
-    gemm_tile<PA, NRT, 4, 8>(Hd[0].v, actA, PLANE, wb + WO[PH_W_H0A], wpl, wave * 4, 8, 0, lane);
+    gemm_tile<PA, NRT, CT, 8>(Hd[0].v, actA, PLANE, wb + WO[PH_W_H0A], wpl, wave * CT, 8, 0, lane);
     if (br == 0) {
         tile_zero(Hd[1].v);
-        gemm_tile<PA, NRT, 4, 8>(Hd[1].v, actA, PLANE, wb + WO[PH_W_H0B], wpl, wave * 4, 8, 0, lane);
+        gemm_tile<PA, NRT, CT, 8>(Hd[1].v, actA, PLANE, wb + WO[PH_W_H0B], wpl, wave * CT, 8, 0, lane);
         const float* const gm[2] = {wf + VO[PH_V_LN_H0A_G], wf + VO[PH_V_LN_H0B_G]};
         const float* const bt[2] = {wf + VO[PH_V_LN_H0A_B], wf + VO[PH_V_LN_H0B_B]};
         ln_tiles<NRT, 2>(Hd, gm, bt, red, wave, lane);
@@ -588,7 +604,7 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Hd[n].v[rt][ct][r] = fmaxf(Hd[n].v[rt][ct][r], 0.f);   // ReLU (:167,180)
         tile_to_lds<PA, NRT>(Hd[0], bufC, PLANE, wave, lane);
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     if (br == 0) {   // fc_cls  (:285)
         const int L = a.lay.num_classes, nct = (L + 15) / 16;
         const float* bc = wf + VO[PH_V_CLS_B];
-        for (int ct = wave; ct < nct; ct += 4) {
+        for (int ct = wave; ct < nct; ct += NW) {
             f32x4_t acc[NRT][1];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) acc[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -629,13 +645,13 @@ __global__ __launch_bounds__(256) void k_query_post(const QArgs a) {
     {   // fc_mask / fc_depth folded with feat_transform / feat_depth_transform -> conv kernel + bias
         Tile<NRT> Kt;
         tile_zero(Kt.v);
-        gemm_tile<PA, NRT, 4, 8>(Kt.v, bufM, PLANE, wb + WO[PH_W_KERN], wpl, wave * 4, 8, 0, lane);
+        gemm_tile<PA, NRT, CT, 8>(Kt.v, bufM, PLANE, wb + WO[PH_W_KERN], wpl, wave * CT, 8, 0, lane);
         const float* bk = wf + VO[PH_V_KERN_B];
         const int64_t kplane = (int64_t)2 * a.B * Npad * 256;
         uint16_t* kd = a.kern + (((int64_t)br * a.B + b) * Npad + row0) * 256;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int col = wave * 64 + ct * 16 + i;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = wave * WCOLS + ct * 16 + i;
             const float bv = bk[col];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
@@ -681,9 +697,9 @@ extern "C" size_t ph_query_workspace_bytes(int B, int N, int prec) {
 template <int PA, int NRT>
 static void launch_query(const QArgs& a, int phases, hipStream_t s) {
     constexpr int ROWS = NRT * 16, PLANE = ROWS * LDA;
-    const size_t red = 2 * 2 * 4 * ROWS * sizeof(float);
+    const size_t red = 2 * 2 * NW * ROWS * sizeof(float);
     const size_t lds_pre = (size_t)3 * PA * PLANE * 2 + red + ROWS * sizeof(float);
-    size_t region = (size_t)4 * PA * ROWS * (a.Npad + 8) * 2;        // attention P buffers
+    size_t region = (size_t)NW * PA * ROWS * (a.Npad + 8) * 2;       // attention P buffers
     if (region < (size_t)2 * PA * PLANE * 2) region = (size_t)2 * PA * PLANE * 2;
     const size_t lds_post = (size_t)PA * PLANE * 2 + red + region;
     static bool once = false;
@@ -693,8 +709,8 @@ static void launch_query(const QArgs& a, int phases, hipStream_t s) {
         once = true;
     }
     const dim3 grid(a.Npad / ROWS, 2, a.B);
-    if (phases & 1) hipLaunchKernelGGL((k_query_pre<PA, NRT>), grid, dim3(256), lds_pre, s, a);
-    if (phases & 2) hipLaunchKernelGGL((k_query_post<PA, NRT>), grid, dim3(256), lds_post, s, a);
+    if (phases & 1) hipLaunchKernelGGL((k_query_pre<PA, NRT>), grid, dim3(NTHREADS), lds_pre, s, a);
+    if (phases & 2) hipLaunchKernelGGL((k_query_post<PA, NRT>), grid, dim3(NTHREADS), lds_post, s, a);
 }
 
 extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits, const float* k_in, const float* q_in,
