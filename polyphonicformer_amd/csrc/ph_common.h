@@ -33,10 +33,14 @@ void ph_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- bf16 bit helpers (round to nearest even; inputs are finite in this code base) ----------
-__device__ __forceinline__ uint32_t f2bf(float x) {
-    uint32_t u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
+// gfx950 has a hardware round-to-nearest-even conversion (v_cvt_pk_bf16_f32); the compiler selects
+// it for fp32 -> __bf16 conversions.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x); }
+// two conversions in one instruction: low half = a, high half = b
+__device__ __forceinline__ uint32_t f2bf_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
 // x ~= hi + lo, |x - hi - lo| <= 2^-17 |x|

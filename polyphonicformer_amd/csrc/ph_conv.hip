@@ -9,6 +9,8 @@
 // (32 x 256 kernel slice = 64 VGPRs per plane) in registers across `tiles_per_wg` pixel tiles.
 // Non-final stages emit only the mask bits the next pooling pass consumes (__ballot -> 1 bit/px),
 // the final stage writes the logits.  Roofline: HBM.
+#include <stdlib.h>
+
 #include "ph_common.h"
 
 constexpr int CONV_T = 64;            // pixels per tile: one 128-byte line per channel row
@@ -173,9 +175,12 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
                        int64_t HW, hipStream_t s) {
     const int64_t HWp = ph_hw_padded(HW);
     const int ntiles = (int)(HWp / CONV_T);
-    int tpw = (int)(((int64_t)ntiles * B + 1023) / 1024);
+    // at most one resident generation of workgroups (2 per CU = 512), evenly split over the frames: no tail
+    int gx = 512 / B;
+    if (gx < 1) gx = 1;
+    int tpw = (ntiles + gx - 1) / gx;
     if (tpw < 1) tpw = 1;
-    if (tpw > 16) tpw = 16;
+    if (const char* e = getenv("PH_CONV_TPW")) tpw = atoi(e);   // tuning knob
     const dim3 grid((ntiles + tpw - 1) / tpw, B), block(NRT * 64);
     size_t lds = (size_t)2 * PA * 256 * CONV_T * sizeof(uint16_t);
     if (!bits_out && PA == 1) lds += (size_t)NRT * 32 * (out_dtype == PH_OUT_F32 ? EP_LD<float>() * 4 : EP_LD<uint16_t>() * 2);

@@ -109,29 +109,36 @@ template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v)
 template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_from_f32<uint16_t>(uint16_t* p, float v) { *p = (uint16_t)f2bf(v); }
 
-// One thread = 4 source columns x 1 source row -> an 8-column x 2-row output patch (16 B bf16 / 32 B fp32
-// stores per row).  Needs the 3x6 source neighbourhood; the overlap between threads is served by L1/L2, so
-// HBM sees the source once and the destination once (5 * planes*H*W elements: the algorithmic traffic).
+// One thread = 4 source columns x 2 source rows -> an 8-column x 4-row output patch (16 B bf16 / 32 B fp32
+// stores per row).  It needs the 4 x 6 source neighbourhood: the 4 rows are loaded once (vector loads), the
+// two edge columns come from the neighbouring lanes by cross-lane shuffles (a real load only at wave / row
+// boundaries), so HBM sees the source once and the destination once (5 * planes*H*W elements).
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T* __restrict__ dst, int64_t planes,
                                                     int H, int W) {
     const int W2 = 2 * W;
-    const unsigned segs = (W + 3) / 4;
-    const unsigned total = (unsigned)(planes * H) * segs;            // checked < 2^31 by the launcher
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned t = idx / segs;                                // = p*H + y
-        const int j = (int)(idx - t * segs);
-        const int64_t p = t / (unsigned)H;
-        const int y = (int)(t - (unsigned)p * (unsigned)H);
+    const unsigned segs = (W + 3) / 4, hp = (H + 1) / 2;
+    const unsigned total = (unsigned)planes * hp * segs;             // checked < 2^31 by the launcher
+    const unsigned nthreads = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (unsigned base = blockIdx.x * blockDim.x; base < total; base += nthreads) {
+        const unsigned idx = base + threadIdx.x;
+        const bool live = idx < total;
+        const unsigned t = (live ? idx : total - 1) / segs;          // = p*hp + pair
+        const int j = (int)((live ? idx : total - 1) - t * segs);
+        const int64_t p = t / hp;
+        const int y = 2 * (int)(t - (unsigned)p * hp);               // first source row of the pair
         const int x0 = 4 * j;
-        const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : y;
-        const int rows[3] = {ym, y, yp};
-        float h[3][8];
+        int rows[4];
+        rows[0] = y > 0 ? y - 1 : 0;
+        rows[1] = y;
+        rows[2] = y + 1 < H ? y + 1 : H - 1;
+        rows[3] = y + 2 < H ? y + 2 : H - 1;
+        float h[4][8];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 4; ++r) {
             const T* row = src + (p * H + rows[r]) * W;
             float v[6];
-            v[0] = ld_as_f32(row + (x0 > 0 ? x0 - 1 : 0));
             if (VEC) {
                 if (sizeof(T) == 2) {
                     const uint2 q = *(const uint2*)(row + x0);
@@ -140,11 +147,19 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
                     const float4 q = *(const float4*)(row + x0);
                     v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w;
                 }
-                v[5] = ld_as_f32(row + (x0 + 4 < W ? x0 + 4 : W - 1));
             } else {
 #pragma unroll
-                for (int c = 0; c < 5; ++c) v[1 + c] = ld_as_f32(row + (x0 + c < W ? x0 + c : W - 1));
+                for (int c = 0; c < 4; ++c) v[1 + c] = ld_as_f32(row + (x0 + c < W ? x0 + c : W - 1));
             }
+            // edge columns x0-1 and x0+4 from the neighbouring lanes (same source row when j-1 / j+1 exist
+            // in this wave), otherwise clamp or load
+            const float from_left = __shfl_up(v[4], 1), from_right = __shfl_down(v[1], 1);
+            if (j == 0) v[0] = v[1];
+            else if (lane > 0) v[0] = from_left;
+            else v[0] = ld_as_f32(row + x0 - 1);
+            if (x0 + 4 >= W) v[5] = VEC ? v[4] : ld_as_f32(row + W - 1);
+            else if (lane < 63) v[5] = from_right;
+            else v[5] = ld_as_f32(row + x0 + 4);
             // output column 2x   : src = x - 0.25 -> (x-1, x) weights (0.25, 0.75); x = 0: clamped, weights (1, 0)
             // output column 2x+1 : src = x + 0.25 -> (x, x+1 clamped) weights (0.75, 0.25)
 #pragma unroll
@@ -154,27 +169,32 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
                 h[r][2 * c + 1] = 0.75f * v[c + 1] + 0.25f * v[c + 2];
             }
         }
-        float o[2][8];
+        if (!live) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o[0][e] = (y > 0) ? (0.25f * h[0][e] + 0.75f * h[1][e]) : (1.f * h[1][e] + 0.f * h[2][e]);
-            o[1][e] = 0.75f * h[1][e] + 0.25f * h[2][e];
-        }
+        for (int r = 0; r < 4; ++r) {
+            // output row 2*y + r: even -> source rows (s-1, s) weights (.25,.75) [row 0: (1,0)], odd -> (s, s+1) (.75,.25)
+            const int yo = 2 * y + r;
+            if (yo >= 2 * H) break;
+            const int ia = (r + 1) >> 1, ib = ia + 1;            // r=0:(0,1) r=1:(1,2) r=2:(1,2) r=3:(2,3)
+            const bool even = (r & 1) == 0;
+            float o[8];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            T* d = dst + (p * 2 * H + 2 * y + r) * W2 + 2 * x0;
+            for (int e = 0; e < 8; ++e) {
+                if (even) o[e] = (yo > 0) ? (0.25f * h[ia][e] + 0.75f * h[ib][e]) : (1.f * h[ib][e] + 0.f * h[ib + 1 < 4 ? ib + 1 : 3][e]);
+                else o[e] = 0.75f * h[ia][e] + 0.25f * h[ib][e];
+            }
+            T* d = dst + (p * 2 * H + yo) * W2 + 2 * x0;
             if (VEC) {
                 if (sizeof(T) == 2) {
-                    *(uint4*)d = make_uint4(pack2(f2bf(o[r][0]), f2bf(o[r][1])), pack2(f2bf(o[r][2]), f2bf(o[r][3])),
-                                            pack2(f2bf(o[r][4]), f2bf(o[r][5])), pack2(f2bf(o[r][6]), f2bf(o[r][7])));
+                    *(uint4*)d = make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7]));
                 } else {
-                    *(float4*)d = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
-                    *(float4*)((float*)d + 4) = make_float4(o[r][4], o[r][5], o[r][6], o[r][7]);
+                    *(float4*)d = make_float4(o[0], o[1], o[2], o[3]);
+                    *(float4*)((float*)d + 4) = make_float4(o[4], o[5], o[6], o[7]);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (2 * x0 + e < W2) st_from_f32(d + e, o[r][e]);
+                    if (2 * x0 + e < W2) st_from_f32(d + e, o[e]);
             }
         }
     }
@@ -183,10 +203,10 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
 extern "C" int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes, int H, int W, void* stream) {
     PH_CHECK_ARG(src && dst && planes > 0 && H > 0 && W > 0, "bad pointer or size");
     PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16, "dtype must be PH_OUT_F32 or PH_OUT_BF16");
-    const int64_t total = planes * H * (int64_t)((W + 3) / 4);
-    PH_CHECK_ARG(total < (1ll << 31), "planes * H * W / 4 must be < 2^31");
+    const int64_t total = planes * ((H + 1) / 2) * (int64_t)((W + 3) / 4);
+    PH_CHECK_ARG(total < (1ll << 31), "planes * H * W / 8 must be < 2^31");
     int64_t blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
+
     const bool vec = (W % 4) == 0;      // rows then start 8-byte (bf16) / 16-byte (fp32) aligned
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PH_OUT_F32) {
