@@ -184,6 +184,7 @@ int ph_panoptic_paste(const int32_t* ids, const int32_t* newid, const float* act
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);
 int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);
+int ph_selftest_readbw(const void* p, int64_t bytes, int blocks, void* out /*4 B*/, void* stream);   /* streaming-read yardstick */
 int ph_selftest_trread(const uint16_t* src /*[16][16]*/, uint16_t* out /*[64][4]*/, void* stream);
 
 #ifdef __cplusplus

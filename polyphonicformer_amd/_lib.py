@@ -47,6 +47,7 @@ SIGNATURES = {
     "ph_panoptic_paste": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _I, _P, _P, _P, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
+    "ph_selftest_readbw": (C.c_int, [_P, _L, _I, _P, _P]),
     "ph_selftest_trread": (C.c_int, [_P, _P, _P]),
 }
 

@@ -3,17 +3,21 @@
 // NT GEMM with M = Npad query rows, N = 256 channels per map, K = HW pixels, split-K over
 // `nsplit` pixel ranges.  One workgroup = (pixel range, 128-channel group, frame); its 4 waves own
 // 32 channels each (one 32x32x16 MFMA column tile) and ALL query rows:
-//   B operand (features): straight from HBM into VGPRs -- lane (channel j, half g) loads 64
-//     contiguous pixels (8 x 16 B); MFMA step t consumes its t-th 16-byte piece, so k-slot
-//     (g, e) of step t <-> pixel 128*chunk + 64*g + 8*t + e.  Every feature byte is read once.
-//   A operand (mask bits -> {0,1} bf16): expanded ONCE per workgroup per 128-pixel chunk into an
-//     LDS tile [Npad][128 px] (row stride 272 B: conflict-free ds_read_b128) and shared by the 4
-//     waves; {0,1} is exact in bf16, so in split precision only the feature operand has two planes.
+//   B operand (features): the [128 ch][64 px] tile goes HBM -> LDS by LDS-DMA in whole 128-byte lines
+//     (global_load_lds_dwordx4, double buffered, XOR-swizzled on the source side) and is read back as
+//     fragments with ds_read_b128: lane (channel j, half g), step t <-> pixel 64*chunk + 32*g + 8*t + e
+//     (the k-slot <-> pixel map is a free permutation as long as A agrees).  Every feature byte is read
+//     from HBM exactly once; fragment-shaped loads straight from HBM (16 B per lane at a 64 KB stride)
+//     measured 3.4 TB/s, whole-line DMA removes the 8x request amplification at the L1/TA.
+//   A operand (mask bits -> {0,1} bf16): the chunk's mask words also arrive by LDS-DMA (2 words per query
+//     row); an A fragment is ONE ds_read_b128 from a 256-entry byte -> 8 x bf16 lookup table in LDS, so no
+//     expanded mask tile exists at all (36 KiB of LDS per workgroup -> 4 workgroups per CU, 64 KiB of HBM
+//     loads in flight per CU).  {0,1} is exact in bf16, so split precision only doubles the feature operand.
 // Roofline: HBM: 2*256*HWp*2 B of features per frame vs 2*Npad*512*HWp flop.
 #include "ph_common.h"
 
-constexpr int POOL_CHUNK = 128;                 // pixels per LDS mask tile
-constexpr int POOL_LDA = POOL_CHUNK + 8;        // bf16 elements per LDS row (272 B)
+constexpr int POOL_CHUNK = 64;                  // pixels per step: one 128-byte line per channel row
+constexpr int POOL_FT = 128 * POOL_CHUNK;       // elements of one feature tile [128 ch][64 px]
 
 __device__ __forceinline__ uint4 expand8(uint32_t byte) {
     // 8 mask bits -> 8 bf16 {0, 1.0}
@@ -26,26 +30,38 @@ __device__ __forceinline__ uint4 expand8(uint32_t byte) {
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// LDS image of a feature tile: [128 channel rows][8 x 16-byte pieces], rows contiguous (written by LDS-DMA).
+// Piece index XOR ((row >> 1) & 7) -- applied on the DMA *source* address and by the readers -- makes the
+// ds_read_b128 of 16 consecutive channel rows at one piece index hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int pool_swz(int row) { return (row >> 1) & 7; }
+
 template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/>
-__global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
+__global__ __launch_bounds__(256, (NRT <= 5 ? 4 : 2)) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
                                               const uint32_t* __restrict__ bits, float* __restrict__ partial,
                                               int B, int64_t HWp, int nsplit) {
     constexpr int Npad = NRT * 32;
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [Npad][POOL_LDA]
+    constexpr int NBI = (Npad * 2 + 63) / 64;                         // DMA instructions for the mask words of a chunk
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    // [2][PA][128][64] feature tiles | lut[256] (16 B each) | [2][NBI*64] mask words
+    uint4* lut = (uint4*)(lds + 2 * PA * POOL_FT);
+    uint32_t* lbits = (uint32_t*)(lut + 256);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
     const int map = cg >> 1;
-    const int ch = (cg & 1) * 128 + wave * 32 + (lane & 31);
+    const int ch0 = (cg & 1) * 128;                                  // first channel of this workgroup
     const int g = lane >> 5;
     const uint16_t* feat = (map == 0 ? xplanes : dplanes);
     const int64_t plane_stride = (int64_t)B * PH_C * HWp;
-    const uint16_t* frow = feat + ((int64_t)b * PH_C + ch) * HWp;
+    const uint16_t* fbase = feat + ((int64_t)b * PH_C + ch0) * HWp;
     const int64_t words_per_row = HWp / 32;
     const uint32_t* brow = bits + (int64_t)b * Npad * words_per_row;
 
     const int nchunks = (int)(HWp / POOL_CHUNK);
     const int c0 = (int)((int64_t)split * nchunks / nsplit), c1 = (int)((int64_t)(split + 1) * nchunks / nsplit);
+
+    lut[tid] = expand8((uint32_t)tid);                               // byte -> A fragment (8 x {0,1} bf16)
 
     f32x16_t acc[NRT];
 #pragma unroll
@@ -53,40 +69,60 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xplan
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
+    // LDS-DMA of chunk c: features = 16 wave-instructions of 1 KiB (8 channel rows x 128 B) per plane, mask
+    // words = NBI instructions of 64 x 4 B (row = l>>1, word = l&1).  Nothing in the loop is a VGPR load, so the
+    // only vector-memory wait is the vmcnt(0) in front of the barrier.
+    auto issue_chunk = [&](int c, int buf) {
+        for (int j = wave; j < 16 * PA; j += 4) {
+            const int p = j >> 4, jj = j & 15;
+            const int row = jj * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ pool_swz(row);
+            const uint16_t* src = fbase + p * plane_stride + (int64_t)row * HWp + (int64_t)c * POOL_CHUNK + q * 8;
+            uint16_t* dst = lds + (buf * PA + p) * POOL_FT + jj * 512;          // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, 0);
+        }
+        for (int j = wave; j < NBI; j += 4) {
+            int row = j * 32 + (lane >> 1);
+            if (row > Npad - 1) row = Npad - 1;                                    // tail lanes re-read the last row
+            const uint32_t* src = brow + (int64_t)row * words_per_row + c * 2 + (lane & 1);
+            uint32_t* dst = lbits + buf * (NBI * 64) + j * 64;                    // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 4, 0, 0);
+        }
+    };
+
+    if (c0 < c1) issue_chunk(c0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
     for (int c = c0; c < c1; ++c) {
-        // (1) feature fragments for this chunk: 8 x 16 B per lane per plane, issued first
-        uint4 xf[PA][8];
+        const int cur = (c - c0) & 1;
+        if (c + 1 < c1) issue_chunk(c + 1, cur ^ 1);          // DMA overlaps the MFMA phase below
+        const uint16_t* ft = lds + cur * PA * POOL_FT;
+        const uint32_t* wb = lbits + cur * (NBI * 64);
+        // B fragments: this lane's channel row, 4 k-steps of 8 pixels in its 32-pixel half
+        const int frow = wave * 32 + (lane & 31);
+        uint4 xf[PA][4];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const uint16_t* s = frow + p * plane_stride + (int64_t)c * POOL_CHUNK + g * 64;
+        for (int p = 0; p < PA; ++p)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) xf[p][t] = *(const uint4*)(s + t * 8);
-        }
-        // (2) expand this chunk's mask words into the LDS A tile (all 256 threads)
-        for (int wi = tid; wi < Npad * 4; wi += 256) {
-            const int row = wi >> 2, wq = wi & 3;
-            const uint32_t w = brow[row * words_per_row + c * 4 + wq];
-            uint16_t* d = lds + row * POOL_LDA + wq * 32;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *(uint4*)(d + q * 8) = expand8((w >> (8 * q)) & 0xFFu);
-        }
-        __syncthreads();
-        // (3) MFMA: every row tile against the 8 k-steps of this chunk
+            for (int t = 0; t < 4; ++t)
+                xf[p][t] = *(const uint4*)(ft + p * POOL_FT + frow * POOL_CHUNK + (((g * 4 + t) ^ pool_swz(frow)) * 8));
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
-            const uint16_t* arow = lds + (rt * 32 + (lane & 31)) * POOL_LDA + g * 64;
+            const uint32_t w = wb[(rt * 32 + (lane & 31)) * 2 + g];   // 32 mask bits: this lane's row, its 32-pixel half
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const uint4 a = *(const uint4*)(arow + t * 8);
+            for (int t = 0; t < 4; ++t) {
+                const uint4 a = lut[(w >> (8 * t)) & 0xFFu];
 #pragma unroll
                 for (int p = 0; p < PA; ++p) acc[rt] = mfma32(a, xf[p][t], acc[rt]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c+1 have landed
         __syncthreads();
     }
 
     // epilogue: partial[b][split][row][map*256 + ch]
-    float* out = partial + (((int64_t)b * nsplit + split) * Npad) * 512 + map * 256 + ch;
+    float* out = partial + (((int64_t)b * nsplit + split) * Npad) * 512 + map * 256 + ch0 + wave * 32 + (lane & 31);
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -99,7 +135,7 @@ __global__ __launch_bounds__(256) void k_pool(const uint16_t* __restrict__ xplan
 template <int PA, int NRT>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
                         int nsplit, hipStream_t s) {
-    const size_t lds = (size_t)NRT * 32 * POOL_LDA * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)2 * ((NRT * 64 + 63) / 64) * 64 * 4;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

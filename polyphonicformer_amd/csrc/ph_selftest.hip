@@ -35,6 +35,31 @@ __global__ void k_selftest_trread(const uint16_t* src, uint16_t* out) {
     out[l * 4 + 3] = v.y >> 16;
 }
 
+// pure streaming read: the achievable HBM read bandwidth on this box (the yardstick for the read-dominated
+// pooling / conv kernels).  16 B per lane, UNROLL independent loads in flight per lane.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_selftest_readbw(const uint4* __restrict__ p, int64_t n16, uint32_t* out) {
+    uint32_t acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9E3779B9u) out[0] = acc;      // practically never: keeps the loads alive
+}
+
+extern "C" int ph_selftest_readbw(const void* p, int64_t bytes, int blocks, void* out, void* stream) {
+    hipLaunchKernelGGL(k_selftest_readbw<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)p, bytes / 16,
+                       (uint32_t*)out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
 extern "C" int ph_selftest_mfma16(const uint16_t* a, const uint16_t* bt, float* d, void* stream) {
     hipLaunchKernelGGL(k_selftest_mfma16, dim3(1), dim3(64), 0, (hipStream_t)stream, a, bt, d);
     PH_CHECK_LAUNCH();

@@ -45,8 +45,13 @@ class StagePack:
 
 
 def default_nsplit(B, HW):
+    """pixel ranges per frame for the split-K pooling: 4*B*nsplit workgroups should fill the chip's resident
+    slots (2 workgroups per CU x 256 CUs) without a partial second generation"""
+    import os
+    if os.environ.get("PH_POOL_NSPLIT"):
+        return int(os.environ["PH_POOL_NSPLIT"])
     nchunks = hw_padded(HW) // 128
-    ns = max(1, -(-768 // (4 * B)))
+    ns = max(1, 512 // (4 * B))
     return int(min(ns, 32, max(1, nchunks)))
 
 
