@@ -13,6 +13,11 @@
 //     row); an A fragment is ONE ds_read_b128 from a 256-entry byte -> 8 x bf16 lookup table in LDS, so no
 //     expanded mask tile exists at all (36 KiB of LDS per workgroup -> 4 workgroups per CU, 64 KiB of HBM
 //     loads in flight per CU).  {0,1} is exact in bf16, so split precision only doubles the feature operand.
+// Measured alternatives at cfg2, B = 24 (805 MB per launch): fragment-shaped 16-byte loads straight from HBM
+// into VGPRs (128-byte lane stride, shared expanded mask tile) 3.4 TB/s; 32 B per lane at a 64 KB lane stride with a
+// 3-deep register ring and no barriers 2.1 TB/s (request amplification at the L1/TA dominates); this whole-line
+// DMA version 3.7 TB/s against a 5.2-5.7 TB/s pure-read yardstick (ph_selftest_readbw).  It is latency bound:
+// 70 % of wave cycles wait on vmcnt/barrier with 64 KiB of loads in flight per CU (profiles/r01).
 // Roofline: HBM: 2*256*HWp*2 B of features per frame vs 2*Npad*512*HWp flop.
 #include "ph_common.h"
 

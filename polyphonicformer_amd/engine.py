@@ -372,3 +372,58 @@ class KernelHeadPlan:
         _lib.check(lib.ph_khead_proposals(_lib.ptr(self.partial), self.nsplit, _lib.ptr(pk.w_init_f32),
                                           _lib.ptr(stuff.contiguous()) if stuff is not None else None,
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
+
+
+class DualDecodePlan:
+    """Two half-batches on two HIP streams, skewed by one phase: the query kernels of a stage are a short,
+    latency-bound chain on ~1 workgroup per CU, the pooling / conv / upsample kernels are HBM-bound; running
+    half B's HBM phases underneath half A's query phase (and vice versa) fills both.  Frames are independent,
+    so the split changes nothing numerically.  Captured as ONE HIP graph with fork/join edges."""
+
+    def __init__(self, packs, B, N, H, W, prec, out_dtype=torch.float32, device="cuda:0"):
+        assert B >= 2
+        self.B = B
+        self.halves = [DecodePlan(packs, B // 2, N, H, W, prec, out_dtype, device),
+                       DecodePlan(packs, B - B // 2, N, H, W, prec, out_dtype, device)]
+        self.graph = None
+
+    def set_inputs(self, x, dfe, k0, q0, m0):
+        h = self.B // 2
+        self.halves[0].set_inputs(x[:h], dfe[:h], k0[:h], q0[:h], m0[:h])
+        self.halves[1].set_inputs(x[h:], dfe[h:], k0[h:], q0[h:], m0[h:])
+
+    def _issue(self, sa, sb):
+        cur = torch.cuda.current_stream()
+        a, b = self.halves
+        sa.wait_stream(cur)
+        with torch.cuda.stream(sa):
+            a.ingest()
+            skew = torch.cuda.Event()
+            skew.record(sa)
+            a.stages()
+        with torch.cuda.stream(sb):
+            sb.wait_event(skew)              # B starts once A's ingest is done: from then on they run a phase apart
+            b.ingest()
+            b.stages()
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+
+    def run(self):
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        self._issue(*self._streams)
+
+    def capture(self):
+        self.run()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._issue(*self._streams)
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+
+    def outputs(self):
+        o = [h.outputs() for h in self.halves]
+        return {k: torch.cat([o[0][k], o[1][k]], 0) for k in o[0]}
