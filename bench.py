@@ -127,6 +127,49 @@ def algorithmic_bytes(plan, kernel):
     return None
 
 
+def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
+    """secondary number (reported next to the headline): KernelHead post-neck (a1) + the S-stage decode (a6)
+    with the bf16-plane / mask-bit hand-off (no ingest pass), one stream, HIP graph."""
+    from polyphonicformer_amd.registry import HEADS
+    from polyphonicformer_amd import engine as E
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    L = wl["n_thing"] + wl["n_stuff"]
+    torch.manual_seed(1)
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=wl["Nq"], num_classes=L, num_thing_classes=wl["n_thing"],
+                          num_stuff_classes=wl["n_stuff"], cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True)))
+    kh.init_weights()
+    kh.eval().to(dev)
+    kh.set_precision(precision)
+    kh.emit_fp32_features = False
+    N, H, W = wl["Nq"] + wl["n_stuff"], wl["H"], wl["W"]
+    kplan = E.KernelHeadPlan(kh._get_pack(dev), B, H, W, wl["n_thing"], L, True, dev, want_f32=False)
+    g = torch.Generator().manual_seed(3)
+    kplan.set_inputs([torch.randn(B, 256, H, W, generator=g).relu().to(dev) for _ in range(3)])
+    dplan = E.DecodePlan([h.stage_pack(dev, precision) for h in head.mask_head], B, N, H, W, E.PREC[precision], out_dtype, dev)
+    q0 = kh._get_pack(dev).w_dd_f32.reshape(1, 1, 256).expand(B, N, 256)
+
+    def run():
+        kplan.run()
+        dplan.run_from_planes(kplan.xp, kplan.dp, kplan.bits, kplan.proposal, q0)
+
+    def run_a1():
+        kplan.run()
+
+    run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    t_all = time_op(graph.replay, steps)
+    t_a1 = time_op(run_a1, steps)
+    return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
+            "a1_only_ms_per_step": round(t_a1, 4),
+            "note": "KernelHead post-neck (3 x conv1x1+GN+ReLU two-pass, static 1x1 convs, object pooling) + 3-stage decode, "
+                    "bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
+
+
 def cpu_baseline(wl, head, budget_s=20.0):
     """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample"""
     from oracle import poly_oracle as O
@@ -164,6 +207,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = two half-batches on two skewed HIP streams (engine.DualDecodePlan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-head", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,6 +298,11 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
+        if world == 1 and not args.no_kernel_head:
+            try:
+                res["with_kernel_head"] = kernel_head_leg(wl, head, args.precision, out_dtype, dev)
+            except Exception as e:          # secondary leg: never lose the headline line
+                res["with_kernel_head"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         print(json.dumps(res))

@@ -33,27 +33,35 @@ struct KHArgs {
     int64_t HW, HWp;
 };
 
-template <int PA>
-__device__ __forceinline__ void kh_stage_tile(const float* __restrict__ src, int64_t HW, int64_t px0, uint16_t* lds,
-                                              int tid) {
-    // tile [256 c][64 px] fp32 -> bf16 plane(s) in LDS; 16 threads per channel row, 4 px each
+// tile [256 c][64 px] fp32: 16 threads per channel row, 4 px each, 8 rows-of-threads per pass.
+// Split in two so that the HBM loads of the NEXT tile are in flight during the MFMA phase of the current one.
+__device__ __forceinline__ void kh_load_tile(float (&v)[8][4], const float* __restrict__ src, int64_t HW, int64_t px0, int tid) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int idx = tid + q * KH_THREADS;
         const int row = idx >> 4, p4 = (idx & 15) * 4;
         const int64_t px = px0 + p4;
         const float* s = src + (int64_t)row * HW + px;
-        float v[4];
         if (px + 4 <= HW && ((HW & 3) == 0)) {
             const float4 t = *(const float4*)s;
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (px + e < HW) ? s[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[q][e] = (px + e < HW) ? s[e] : 0.f;
         }
+    }
+}
+
+template <int PA>
+__device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* lds, int tid) {
+    // fp32 -> bf16 plane(s) in LDS
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = tid + q * KH_THREADS;
+        const int row = idx >> 4, p4 = (idx & 15) * 4;
         uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f2bf_split(v[e], hi[e], lo[e]);
+        for (int e = 0; e < 4; ++e) f2bf_split(v[q][e], hi[e], lo[e]);
         *(uint2*)(lds + row * KH_LDT + p4) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
         if (PA == 2) *(uint2*)(lds + 256 * KH_LDT + row * KH_LDT + p4) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
     }
@@ -110,10 +118,13 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    float stg[8][4];
+    if (t0 < t1) kh_load_tile(stg, src, a.HW, (int64_t)t0 * KH_T, tid);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();
-        kh_stage_tile<PA>(src, a.HW, (int64_t)t * KH_T, lds, tid);
+        kh_store_tile<PA>(stg, lds, tid);
         __syncthreads();
+        if (t + 1 < t1) kh_load_tile(stg, src, a.HW, (int64_t)(t + 1) * KH_T, tid);   // in flight during the MFMAs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
@@ -164,62 +175,126 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
 }
 
 // ---- pass 2: normalise + ReLU, write planes (and fp32), optional sum of two maps ----------------
+constexpr int KH_PLD = KH_T + 8;    // row stride (elements) of a per-wave [32 ch][64 px] store patch
+
+// bf16 patch [32 ch][64 px] of this wave -> planes: 8 lanes x 16 B per channel row = whole 128-byte lines
+__device__ __forceinline__ void kh_flush_patch(const uint16_t* patch, uint16_t* dst_plane, int64_t row0_off, int64_t HWp,
+                                               int lane) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rl = it * 8 + (lane >> 3), piece = lane & 7;
+        const uint4 v = *(const uint4*)(patch + rl * KH_PLD + piece * 8);
+        *(uint4*)(dst_plane + row0_off + (int64_t)rl * HWp + piece * 8) = v;
+    }
+}
+
 template <int PA, int NMAP>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* patches = lds + PA * 256 * KH_LDT;                     // [8 waves][32][KH_PLD] (one plane at a time)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    uint16_t* patch = patches + wave * (32 * KH_PLD);
     const int b = blockIdx.y;
     const int cpg = 256 / a.groups;
     const int64_t oplane = (int64_t)a.B * 256 * a.HWp;
-    float scale[NMAP][16], shift[NMAP][16];
+    // per-channel affine of the normalisation (rstd*gamma, beta - mean*rstd*gamma) in LDS: 64 registers saved
+    float2* ss = (float2*)(patches + 8 * 32 * KH_PLD);               // [NMAP][256]
+    for (int i = tid; i < NMAP * 256; i += KH_THREADS) {
+        const int m = i >> 8, ch = i & 255;
+        const float* st = a.stats[m] + ((int64_t)b * a.groups + ch / cpg) * 2;
+        const float mean = st[0], rstd = st[1];
+        ss[i] = make_float2(rstd * a.gamma[m][ch], a.beta[m][ch] - mean * rstd * a.gamma[m][ch]);
+    }
+    __syncthreads();
+    constexpr bool HOIST = (PA == 1 && NMAP == 1);   // a single map: its weights stay in registers across tiles
+    uint4 af[HOIST ? NMAP : 1][PA][16];
+    if (HOIST) {
 #pragma unroll
-    for (int m = 0; m < NMAP; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const float* st = a.stats[m] + ((int64_t)b * a.groups + ch / cpg) * 2;
-            const float mean = st[0], rstd = st[1];
-            scale[m][r] = rstd * a.gamma[m][ch];
-            shift[m][r] = a.beta[m][ch] - mean * rstd * a.gamma[m][ch];
-        }
-    uint4 af[PA][16];
-    if (NMAP == 1) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+        for (int m = 0; m < NMAP; ++m) kh_load_a<PA>(af[m], a.w[m], a.w_plane, wave, lane);
+    }
     const int ntiles = (int)(a.HWp / KH_T);
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
+    float stg[8][4];
+    if (t0 < t1) kh_load_tile(stg, a.f[0] + (int64_t)b * 256 * a.HW, a.HW, (int64_t)t0 * KH_T, tid);
     for (int t = t0; t < t1; ++t) {
+        const int64_t px0 = (int64_t)t * KH_T;
+        const int64_t row0 = ((int64_t)b * 256 + wave * 32) * a.HWp + px0;       // this wave's first channel row, tile start
         float keep[2][16];
 #pragma unroll
         for (int m = 0; m < NMAP; ++m) {
             __syncthreads();
-            kh_stage_tile<PA>(a.f[m] + (int64_t)b * 256 * a.HW, a.HW, (int64_t)t * KH_T, lds, tid);
+            kh_store_tile<PA>(stg, lds, tid);
             __syncthreads();
-            if (NMAP == 2) kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
+            // next (tile, map) in flight during this one's MFMAs and stores
+            if (m + 1 < NMAP) kh_load_tile(stg, a.f[m + 1] + (int64_t)b * 256 * a.HW, a.HW, px0, tid);
+            else if (t + 1 < t1) kh_load_tile(stg, a.f[0] + (int64_t)b * 256 * a.HW, a.HW, px0 + KH_T, tid);
+            if (!HOIST) kh_load_a<PA>(af[0], a.w[m], a.w_plane, wave, lane);
+            float vals[2][16];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
-                const int64_t px = (int64_t)t * KH_T + ct * 32 + (lane & 31);
+                const f32x16_t acc = kh_gemm<PA>(af[HOIST ? m : 0], lds, ct, lane);
+                const int64_t px = px0 + ct * 32 + (lane & 31);
                 const bool inside = px < a.HW;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    float v = fmaxf(acc[r] * scale[m][r] + shift[m][r], 0.f);
-                    if (!inside) v = 0.f;
-                    uint32_t hi, lo;
-                    f2bf_split(v, hi, lo);
-                    const int64_t o = ((int64_t)b * 256 + ch) * a.HWp + px;
-                    a.planes[m][o] = (uint16_t)hi;
-                    if (PA == 2) a.planes[m][o + oplane] = (uint16_t)lo;
-                    if (a.f32[m] && inside) a.f32[m][((int64_t)b * 256 + ch) * a.HW + px] = v;
-                    if (NMAP == 2) {
-                        if (m == 0) keep[ct][r] = v;
-                        else {
-                            const float sum = keep[ct][r] + v;      // x_feats = semantic_feats + loc_feats (:303)
-                            f2bf_split(sum, hi, lo);
-                            a.sum_planes[o] = (uint16_t)hi;
-                            if (PA == 2) a.sum_planes[o + oplane] = (uint16_t)lo;
-                            if (a.f32_sum && inside) a.f32_sum[((int64_t)b * 256 + ch) * a.HW + px] = sum;
+                    const float2 af2 = ss[m * 256 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+                    float v = fmaxf(acc[r] * af2.x + af2.y, 0.f);
+                    if (!inside) v = 0.f;                                    // planes are zero padded
+                    vals[ct][r] = v;
+                    if (a.f32[m] && inside) {
+                        const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        a.f32[m][((int64_t)b * 256 + ch) * a.HW + px] = v;
+                    }
+                }
+            }
+            // map m through the store patch, one bf16 plane at a time
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                        uint32_t hi, lo;
+                        f2bf_split(vals[ct][r], hi, lo);
+                        patch[rl * KH_PLD + ct * 32 + (lane & 31)] = (uint16_t)(p == 0 ? hi : lo);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                kh_flush_patch(patch, a.planes[m] + p * oplane, row0, a.HWp, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (NMAP == 2) {
+                if (m == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) keep[ct][r] = vals[ct][r];
+                } else {
+                    // x_feats = semantic_feats + loc_feats   (kernel_head.py:303)
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const int64_t px = px0 + ct * 32 + (lane & 31);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+                                const float sum = keep[ct][r] + vals[ct][r];
+                                uint32_t hi, lo;
+                                f2bf_split(sum, hi, lo);
+                                patch[rl * KH_PLD + ct * 32 + (lane & 31)] = (uint16_t)(p == 0 ? hi : lo);
+                                if (p == 0 && a.f32_sum && px < a.HW)
+                                    a.f32_sum[((int64_t)b * 256 + wave * 32 + rl) * a.HW + px] = sum;
+                            }
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        kh_flush_patch(patch, a.sum_planes + p * oplane, row0, a.HWp, lane);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
@@ -281,6 +356,7 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
     float* stats = partial + (size_t)3 * B * nwg * 256 * 2;
     const float* fm[3] = {f0, f1, f2};
     const size_t lds = (size_t)PA * 256 * KH_LDT * sizeof(uint16_t);
+    const size_t lds_apply = lds + (size_t)8 * 32 * KH_PLD * sizeof(uint16_t) + 2 * 256 * sizeof(float2);
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)k_khead_stats<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -314,14 +390,14 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
         a.f32[m] = nullptr;
     }
     a.planes[0] = loc_planes; a.planes[1] = sem_planes; a.sum_planes = x_planes; a.f32_sum = x_f32;
-    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 2>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_khead_apply<2, 2>), grid, block, lds, s, a);
+    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 2>), grid, block, lds_apply, s, a);
+    else hipLaunchKernelGGL((k_khead_apply<2, 2>), grid, block, lds_apply, s, a);
     a.f[0] = f2; a.w[0] = wplanes + (size_t)2 * 256 * 256;
     a.gamma[0] = gn_affine + 2 * 512; a.beta[0] = gn_affine + 2 * 512 + 256;
     a.stats[0] = stats + (size_t)2 * B * groups * 2;
     a.planes[0] = dfe_planes; a.f32[0] = dfe_f32; a.sum_planes = nullptr; a.f32_sum = nullptr;
-    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_khead_apply<2, 1>), grid, block, lds, s, a);
+    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 1>), grid, block, lds_apply, s, a);
+    else hipLaunchKernelGGL((k_khead_apply<2, 1>), grid, block, lds_apply, s, a);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
