@@ -98,7 +98,7 @@ def kernel_breakdown(plan, iters=10):
     t["dynconv_logits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.prec,
                                                     logits_out=p.mask, out_dtype=p.out_code), iters)
     t["upsample2x"] = time_op(lambda: E.upsample2x(p.mask, out=p.mask_up), iters)
-    counts = dict(ingest=2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
+    counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
                   dynconv_logits=2, upsample2x=2)
     return t, counts
 
@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--frames", type=int, default=48, help="frames per step per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
+                         "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = two half-batches on two skewed HIP streams (engine.DualDecodePlan)")
@@ -231,7 +234,10 @@ def main():
     N = wl["Nq"] + wl["n_stuff"]
     plan = head._plan(B, N, wl["H"], wl["W"], dev)      # single-stream plan (also used for the per-kernel timings)
     inp = synth_inputs(wl, B, seed=1234 + rank)         # each rank: its own frames
+    in_dt = args.input_dtype if args.input_dtype != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
+    if in_dt == "bf16":
+        gin[0], gin[1] = gin[0].to(torch.bfloat16), gin[1].to(torch.bfloat16)
     plan.set_inputs(*gin)
     runner = plan
     if args.streams == 2:
@@ -288,7 +294,8 @@ def main():
             "config": {"workload": f"{args.workload}: KernelUpdateIterHead.simple_test_mask_preds, "
                                    f"{wl['H'] * 8}x{wl['W'] * 8}, stride-8 {wl['H']}x{wl['W']}, N={N}, S={wl['S']}, "
                                    f"L={wl['n_thing'] + wl['n_stuff']}, random-init weights",
-                       "frames_per_step_per_gpu": B, "hip_graph": not args.no_graph, "streams": args.streams, "output_dtype": str(out_dtype),
+                       "frames_per_step_per_gpu": B, "hip_graph": not args.no_graph, "streams": args.streams,
+                       "feature_input_dtype": in_dt, "mask_logit_input_dtype": "fp32", "output_dtype": str(out_dtype),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
@@ -298,6 +305,18 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
+        if world == 1 and in_dt == "bf16" and not args.no_kernel_head:
+            # the same step when the features arrive as fp32 NCHW (the reference's dtype) and go through the ingest kernel
+            try:
+                gin32 = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
+                runner.set_inputs(*gin32)
+                if not args.no_graph:
+                    runner.capture()
+                t32 = time_op(step, 10)
+                res["fp32_feature_inputs"] = {"value": round(B / (t32 * 1e-3), 2), "unit": "frames/s", "ms_per_step": round(t32, 4),
+                                              "note": "same step + 2 ingest launches (fp32 NCHW -> bf16 planes) inside the timed region"}
+            except Exception as e:
+                res["fp32_feature_inputs"] = {"error": repr(e)}
         if world == 1 and not args.no_kernel_head:
             try:
                 res["with_kernel_head"] = kernel_head_leg(wl, head, args.precision, out_dtype, dev)

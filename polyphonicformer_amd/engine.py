@@ -199,15 +199,26 @@ class DecodePlan:
         return _lib.PH_OUT_F32 if self.out_dtype == torch.float32 else _lib.PH_OUT_BF16
 
     def set_inputs(self, x, dfe, k0, q0, m0):
-        self.x.copy_(x)
-        self.dfe.copy_(dfe)
+        """x / dfe: fp32 NCHW (converted to bf16 planes by the ingest kernel inside `run`), or -- bf16 precision
+        only -- bf16 NCHW tensors, which ARE the plane format when H*W is a multiple of 128: they are adopted
+        as they are and no ingest pass runs."""
+        self.feat_is_bf16 = (x.dtype == torch.bfloat16 and dfe.dtype == torch.bfloat16)
+        if self.feat_is_bf16:
+            if self.prec != _lib.PH_PREC_BF16 or self.HW % 128:
+                raise _lib.PolyheadError("bf16 feature inputs need precision 'bf16' and H*W % 128 == 0")
+            self.xp.view(torch.bfloat16).reshape(self.B, 256, self.H, self.W).copy_(x)
+            self.dp.view(torch.bfloat16).reshape(self.B, 256, self.H, self.W).copy_(dfe)
+        else:
+            self.x.copy_(x)
+            self.dfe.copy_(dfe)
         self.k0.copy_(k0.reshape(self.B, self.N, 256))
         self.q0.copy_(q0.reshape(self.B, self.N, 256))   # materialises the stride-0 expand view
         self.m0.copy_(m0)
 
     def ingest(self):
-        ingest(self.x, self.prec, out=self.xp)
-        ingest(self.dfe, self.prec, out=self.dp)
+        if not getattr(self, "feat_is_bf16", False):
+            ingest(self.x, self.prec, out=self.xp)
+            ingest(self.dfe, self.prec, out=self.dp)
         binarize(self.m0, out=self.bits)
 
     def stages(self):

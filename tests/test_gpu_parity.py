@@ -245,3 +245,21 @@ def test_whole_path_a1_a6(gpu, weights):
     assert Hh.rel_err(obj.cpu().reshape(B, -1, 256), ref["obj"]) < tol
     assert Hh.rel_err(cls.cpu(), ref["cls"]) < tol
     assert Hh.rel_err(mask_up.cpu(), ref["mask_up"]) < tol
+
+
+def test_bf16_feature_inputs_skip_ingest(gpu, weights):
+    """bf16 NCHW feature tensors are the plane format: same result as fp32 inputs rounded by the ingest kernel"""
+    B, N, H, W, S = 1, 111, 8, 16, 2
+    inp = {k: v.to(gpu) for k, v in Hh.iter_inputs(77, B, N, 256, H, W).items()}
+    head = _iter_head(weights, S, precision="bf16")
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    a = head.simple_test_mask_preds(inp["x"], inp["k0"], inp["m0"], None, metas, depth_feats=inp["dfe"], depth_proposal=inp["q0"])
+    a = [t.clone() for t in a]
+    b = head.simple_test_mask_preds(inp["x"].to(torch.bfloat16), inp["k0"], inp["m0"], None, metas,
+                                    depth_feats=inp["dfe"].to(torch.bfloat16), depth_proposal=inp["q0"])
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+    head.set_precision("fp32")
+    with pytest.raises(_lib.PolyheadError):
+        head.simple_test_mask_preds(inp["x"].to(torch.bfloat16), inp["k0"], inp["m0"], None, metas,
+                                    depth_feats=inp["dfe"].to(torch.bfloat16), depth_proposal=inp["q0"])
