@@ -170,6 +170,25 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
                     "bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
 
 
+def panoptic_leg(wl, head, plan, dev):
+    """get_panoptic (a7, SURVEY 8d: reported separately) on ONE frame of the step's outputs; host wall time,
+    including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
+    from polyphonicformer_amd import panoptic as Pn
+    from polyphonicformer_amd.registry import ConfigDict
+    head.test_cfg = ConfigDict(max_per_img=wl["Nq"], merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))
+    o = plan.outputs()
+    H, W = wl["H"], wl["W"]
+    meta = dict(img_shape=(H * 8, W * 8, 3), ori_shape=(H * 8, W * 8, 3), batch_input_shape=(H * 8, W * 8))
+    d0 = torch.randn(1, 2 * H, 2 * W, device=dev)
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = Pn.get_panoptic(head, o["cls"][0], o["mask_up"][0], o["depth_up"][0], d0, meta)
+        ts.append((time.perf_counter() - t) * 1e3)
+    return {"ms_per_frame": round(min(ts[1:]), 3), "segments": len(r[2][1]), "output": f"int32 {H * 8}x{W * 8} id map + 2 fp32 depth maps on the host"}
+
+
 def cpu_baseline(wl, head, budget_s=20.0):
     """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample"""
     from oracle import poly_oracle as O
@@ -322,6 +341,11 @@ def main():
                 res["with_kernel_head"] = kernel_head_leg(wl, head, args.precision, out_dtype, dev)
             except Exception as e:          # secondary leg: never lose the headline line
                 res["with_kernel_head"] = {"error": repr(e)}
+        if world == 1 and not args.no_kernel_head:
+            try:
+                res["panoptic_merge"] = panoptic_leg(wl, head, kplan, dev)
+            except Exception as e:
+                res["panoptic_merge"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         print(json.dumps(res))

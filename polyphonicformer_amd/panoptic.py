@@ -71,16 +71,26 @@ def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, 
     sc = scores.to(dev, torch.float32).contiguous()
     _lib.check(lib.ph_panoptic_argmax(_lib.ptr(act_mask), _lib.ptr(sc), K, geom, 1 if from_probs else 0, _lib.ptr(ids),
                                       _lib.ptr(counts), _lib.stream_ptr()), "ph_panoptic_argmax")
-    cnt = counts.cpu().numpy()                                               # the one sync of the merge
+    cnt_h = torch.empty((2, K), dtype=torch.int32, pin_memory=True)
+    cnt_h.copy_(counts, non_blocking=True)
+    torch.cuda.current_stream().synchronize()                                # the one mid-merge sync (2K ints)
+    cnt = cnt_h.numpy()
     newid, info = accept_loop(scores, labels, cnt[0], cnt[1], num_thing_classes, instance_score_thr, overlap_thr)
-    nid = torch.from_numpy(newid).to(dev)
+    nid = torch.from_numpy(newid).pin_memory().to(dev, non_blocking=True)
     pan = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
     d_basic = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
     d_final = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
     _lib.check(lib.ph_panoptic_paste(_lib.ptr(ids), _lib.ptr(nid), _lib.ptr(act_depth), _lib.ptr(act_depth0), geom,
                                      1 if from_probs else 0, _lib.ptr(pan), _lib.ptr(d_basic), _lib.ptr(d_final),
                                      _lib.stream_ptr()), "ph_panoptic_paste")
-    return pan.cpu().numpy(), info, d_basic.cpu().numpy(), d_final.cpu().numpy()
+    # results go to pinned host memory (torch's caching host allocator) with async copies and ONE final sync
+    outs = []
+    for t in (pan, d_basic, d_final):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    torch.cuda.current_stream().synchronize()
+    return outs[0].numpy(), info, outs[1].numpy(), outs[2].numpy()
 
 
 def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
