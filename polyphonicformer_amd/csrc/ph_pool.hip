@@ -23,6 +23,24 @@
 
 constexpr int POOL_CHUNK = 64;                  // pixels per step: one 128-byte line per channel row
 constexpr int POOL_FT = 128 * POOL_CHUNK;       // elements of one feature tile [128 ch][64 px]
+constexpr int POOL_NBUF = 4;                    // LDS ring depth: NBUF-1 chunks of DMA in flight while one is consumed
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// LDS reads hidden from the compiler: hipcc waits vmcnt(0) before ANY DS read while an LDS-DMA that may alias it
+// is in flight (SIInsertWaitcnts), which would drain the ring every chunk.  These reads are ordered by hand:
+// counted vmcnt + raw s_barrier before the first read of a chunk, counted lgkmcnt before the first use.
+__device__ __forceinline__ u32x4_t lds_read128_asm(uint32_t byte_addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_read32_asm(uint32_t byte_addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(PH_LDS const void*)p; }
 
 __device__ __forceinline__ uint4 expand8(uint32_t byte) {
     // 8 mask bits -> 8 bf16 {0, 1.0}
@@ -41,14 +59,16 @@ __device__ __forceinline__ uint4 expand8(uint32_t byte) {
 __device__ __forceinline__ int pool_swz(int row) { return (row >> 1) & 7; }
 
 template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/>
-__global__ __launch_bounds__(256, (NRT <= 5 ? 4 : 2)) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
+__global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
                                               const uint32_t* __restrict__ bits, float* __restrict__ partial,
                                               int B, int64_t HWp, int nsplit) {
     constexpr int Npad = NRT * 32;
     constexpr int NBI = (Npad * 2 + 63) / 64;                         // DMA instructions for the mask words of a chunk
+    constexpr int NBW = (NBI + 3) / 4;                                // ... issued per wave
+    constexpr int PER_CHUNK = 4 * PA + NBW;                           // vector-memory instructions per wave per chunk
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    // [2][PA][128][64] feature tiles | lut[256] (16 B each) | [2][NBI*64] mask words
-    uint4* lut = (uint4*)(lds + 2 * PA * POOL_FT);
+    // [NBUF][PA][128][64] feature tiles | lut[256] (16 B each) | [NBUF][NBI*64] mask words
+    uint4* lut = (uint4*)(lds + POOL_NBUF * PA * POOL_FT);
     uint32_t* lbits = (uint32_t*)(lut + 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -86,7 +106,12 @@ __global__ __launch_bounds__(256, (NRT <= 5 ? 4 : 2)) void k_pool(const uint16_t
             uint16_t* dst = lds + (buf * PA + p) * POOL_FT + jj * 512;          // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, 0);
         }
-        for (int j = wave; j < NBI; j += 4) {
+        // every wave issues the same number of mask-word instructions (a wave past the end repeats the last one:
+        // the duplicate rewrites identical bytes), so ONE compile-time vmcnt covers a whole chunk for every wave
+#pragma unroll
+        for (int k = 0; k < NBW; ++k) {
+            int j = wave + 4 * k;
+            if (j > NBI - 1) j = NBI - 1;
             int row = j * 32 + (lane >> 1);
             if (row > Npad - 1) row = Npad - 1;                                    // tail lanes re-read the last row
             const uint32_t* src = brow + (int64_t)row * words_per_row + c * 2 + (lane & 1);
@@ -95,35 +120,63 @@ __global__ __launch_bounds__(256, (NRT <= 5 ? 4 : 2)) void k_pool(const uint16_t
         }
     };
 
-    if (c0 < c1) issue_chunk(c0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < POOL_NBUF - 1; ++d)
+        if (c0 + d < c1) issue_chunk(c0 + d, d);
+    __syncthreads();                                       // LUT visible (this barrier also drains the prologue DMA)
 
+    const uint32_t lut_addr = lds_addr(lut);
+    const int frow = wave * 32 + (lane & 31);
+    int cur = 0;
     for (int c = c0; c < c1; ++c) {
-        const int cur = (c - c0) & 1;
-        if (c + 1 < c1) issue_chunk(c + 1, cur ^ 1);          // DMA overlaps the MFMA phase below
-        const uint16_t* ft = lds + cur * PA * POOL_FT;
-        const uint32_t* wb = lbits + cur * (NBI * 64);
-        // B fragments: this lane's channel row, 4 k-steps of 8 pixels in its 32-pixel half
-        const int frow = wave * 32 + (lane & 31);
-        uint4 xf[PA][4];
+        // chunk c must have landed; the up to NBUF-2 younger chunks stay in flight ACROSS the barrier:
+        // counted vmcnt + RAW s_barrier (__syncthreads would drain the DMA queue with vmcnt(0))
+        const int younger = (c1 - 1 - c) < (POOL_NBUF - 2) ? (c1 - 1 - c) : (POOL_NBUF - 2);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_CHUNK) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave is past compute(c-1): its buffer, (cur + NBUF-1) % NBUF, is free for chunk c + NBUF-1
+        int nb = cur + POOL_NBUF - 1;
+        if (nb >= POOL_NBUF) nb -= POOL_NBUF;
+        if (c + POOL_NBUF - 1 < c1) issue_chunk(c + POOL_NBUF - 1, nb);
+        const uint32_t ft = lds_addr(lds + cur * PA * POOL_FT);
+        const uint32_t wb = lds_addr(lbits + cur * (NBI * 64));
+        // B fragments (this lane's channel row, 4 k-steps of 8 pixels in its 32-pixel half) and the mask words
+        u32x4_t xf[PA][4];
 #pragma unroll
         for (int p = 0; p < PA; ++p)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                xf[p][t] = *(const uint4*)(ft + p * POOL_FT + frow * POOL_CHUNK + (((g * 4 + t) ^ pool_swz(frow)) * 8));
+                xf[p][t] = lds_read128_asm(ft + 2 * (p * POOL_FT + frow * POOL_CHUNK + (((g * 4 + t) ^ pool_swz(frow)) * 8)));
+        uint32_t w[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) w[rt] = lds_read32_asm(wb + 4 * ((rt * 32 + (lane & 31)) * 2 + g));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // A fragments from the lookup table, one row tile ahead of the MFMAs (LDS returns in order: lgkmcnt(4))
+        u32x4_t a[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[0][t] = lds_read128_asm(lut_addr + (((w[0] >> (8 * t)) & 0xFFu) << 4));
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
-            const uint32_t w = wb[(rt * 32 + (lane & 31)) * 2 + g];   // 32 mask bits: this lane's row, its 32-pixel half
+            if (rt + 1 < NRT) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint4 a = lut[(w >> (8 * t)) & 0xFFu];
-#pragma unroll
-                for (int p = 0; p < PA; ++p) acc[rt] = mfma32(a, xf[p][t], acc[rt]);
+                for (int t = 0; t < 4; ++t) a[(rt + 1) & 1][t] = lds_read128_asm(lut_addr + (((w[rt + 1] >> (8 * t)) & 0xFFu) << 4));
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+                    acc[rt] = mfma32(__builtin_bit_cast(uint4, a[rt & 1][t]), __builtin_bit_cast(uint4, xf[p][t]), acc[rt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c+1 have landed
-        __syncthreads();
+        cur = cur + 1 == POOL_NBUF ? 0 : cur + 1;
     }
 
     // epilogue: partial[b][split][row][map*256 + ch]
@@ -140,7 +193,7 @@ __global__ __launch_bounds__(256, (NRT <= 5 ? 4 : 2)) void k_pool(const uint16_t
 template <int PA, int NRT>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
                         int nsplit, hipStream_t s) {
-    const size_t lds = (size_t)2 * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)2 * ((NRT * 64 + 63) / 64) * 64 * 4;
+    const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
