@@ -239,12 +239,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("PH_DIST_BACKEND", "nccl")        # "gloo": lets 2 ranks share ONE GPU (path test only)
+    if world > 1 and backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     B = args.frames
@@ -284,7 +291,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     from polyphonicformer_amd.dist import barrier_and_max
-    dt = barrier_and_max(dt, dev)                    # MAX over ranks
+    dt = barrier_and_max(dt, dev if (world == 1 or backend == "nccl") else torch.device("cpu"))   # MAX over ranks
     fps = world * B * args.steps / dt
 
     if rank == 0:
