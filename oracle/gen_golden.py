@@ -188,9 +188,35 @@ def merge_fixture(ns, tag="merge"):
     np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
 
 
+def tracker_fixture():
+    """the reference's QuasiDenseEmbedTracker replayed over synthetic clips (configs/polyphonic_video/
+    poly_r50_cityscapes_1x.py:51-64 settings) -> golden integer ids per frame"""
+    Tr = R.load_reference_tracker()
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5,
+               memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3,
+               nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+    out = {"cfg_json": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
+    for seed in (1, 2, 3):
+        tr = Tr(**cfg)
+        cnt = 1
+        for f, bb, lab, emb in Hh.tracker_records(seed):
+            if bb.shape[0] == 0:
+                continue
+            obb, olab, ids = tr.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
+            cnt += 1
+            ids = ids + 1
+            ids[ids == -1] = 0
+            out[f"s{seed}_f{f}_ids"] = ids.numpy().astype(np.int64)
+            out[f"s{seed}_f{f}_bboxes"] = obb.numpy().astype(np.float32)
+            out[f"s{seed}_f{f}_labels"] = olab.numpy().astype(np.int64)
+        print(f"[tracker seed {seed}] tracklets created: {tr.num_tracklets}")
+    np.savez_compressed(os.path.join(OUT, "tracker.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load_reference()
+    tracker_fixture()
     merge_fixture(ns)
     run_family(ns, Hh.MINI, "mini", B=2, H=6, W=10, store_all=True)
     shapes = run_family(ns, Hh.FULL, "full", B=2, H=8, W=16, store_all=False)

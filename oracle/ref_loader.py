@@ -336,6 +336,38 @@ def load_reference():
     return ns
 
 
+def load_reference_tracker():
+    """the reference's QuasiDenseEmbedTracker class (needs only mmdet.core.bbox_overlaps and a TRACKERS registry)"""
+    load_reference()
+    core = sys.modules["mmdet.core"]
+    if not hasattr(core, "bbox_overlaps"):
+        def bbox_overlaps(b1, b2, mode="iou", is_aligned=False, eps=1e-6):
+            # mmdet/core/bbox/iou_calculators/iou2d_calculator.py semantics for mode='iou', is_aligned=False
+            area1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+            area2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+            if b1.shape[0] == 0 or b2.shape[0] == 0:
+                return b1.new_zeros((b1.shape[0], b2.shape[0]))
+            lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+            rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+            wh = (rb - lt).clamp(min=0)
+            overlap = wh[..., 0] * wh[..., 1]
+            union = torch.max(area1[:, None] + area2[None, :] - overlap, overlap.new_tensor([eps]))
+            return overlap / union
+        core.bbox_overlaps = bbox_overlaps
+    for name in ("polyphonic.video", "polyphonic.video.qdtrack", "polyphonic.video.qdtrack.trackers"):
+        if name not in sys.modules:
+            _mod(name)
+    b = _mod("polyphonic.video.qdtrack.builder")
+    b.TRACKERS = Registry("trackers")
+    spec = importlib.util.spec_from_file_location(
+        "polyphonic.video.qdtrack.trackers.quasi_dense_embed_tracker",
+        os.path.join(REF_ROOT, "polyphonic/video/qdtrack/trackers/quasi_dense_embed_tracker.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    return m.QuasiDenseEmbedTracker
+
+
 def stage_cfg(C=256, F=2048, heads=8, L=19, n_thing=8, n_stuff=11):
     """`mask_head` dict with the shipped config's structure (configs/_base_/models/
     polyphonic_former.py:111-165) at parametric width."""

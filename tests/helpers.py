@@ -75,3 +75,22 @@ def rel_err(a, b):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def tracker_records(seed, nframes=12, nobj=14):
+    """a synthetic clip: objects drift, appear and disappear; embeddings = identity vector + noise"""
+    g = torch.Generator().manual_seed(seed)
+    ident = torch.randn(nobj, 256, generator=g) * 0.5
+    pos = torch.rand(nobj, 2, generator=g) * torch.tensor([1800.0, 800.0])
+    size = 40 + torch.rand(nobj, 2, generator=g) * 200
+    cls = torch.randint(0, 8, (nobj,), generator=g)
+    recs = []
+    for f in range(nframes):
+        alive = torch.rand(nobj, generator=g) < 0.8
+        pos = pos + torch.randn(nobj, 2, generator=g) * 8
+        idx = alive.nonzero().squeeze(1)
+        idx = idx[torch.randperm(len(idx), generator=g)]
+        bb = torch.cat([pos[idx], pos[idx] + size[idx], 0.2 + 0.8 * torch.rand(len(idx), 1, generator=g)], 1)
+        emb = ident[idx] + 0.15 * torch.randn(len(idx), 256, generator=g)
+        recs.append((f, bb, cls[idx].clone(), emb))
+    return recs

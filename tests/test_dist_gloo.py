@@ -63,6 +63,42 @@ def test_allgather_track_records_world2(nframes):
     assert sorted(res[0][3] + res[1][3]) == list(range(nframes))   # a partition of the frames
 
 
+def _track_worker(rank, world, port, q):
+    import json
+    import numpy as np
+    import helpers as Hh
+    from polyphonicformer_amd import video as V
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = Hh.tracker_records(1)
+    mine = D.shard_frames(len(recs), rank, world)
+    per = -(-len(recs) // world)
+    packed = [D.pack_track_records(recs[f][1], recs[f][2], recs[f][3]) for f in mine]
+    allrec = D.allgather_track_records(mine, [p[0] for p in packed], [p[1] for p in packed], per)
+    z = Hh.load_golden("tracker.npz")
+    ids = V.replay_tracking(allrec, json.loads(bytes(z["cfg_json"]).decode()))
+    ok = all(np.array_equal(ids[f].numpy(), z[f"s1_f{f}_ids"]) for f in range(len(recs)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_video_tracking_matches_reference_ids():
+    """cfg4's exchange: frames sharded over 2 ranks, one all-gather of the records, replay in frame order on every
+    rank -> the reference tracker's integer ids, bit for bit"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_track_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+
+
 def test_shard_frames_partitions():
     for n in (1, 5, 16, 17):
         for w in (1, 2, 4, 8):

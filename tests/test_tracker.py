@@ -1,0 +1,57 @@
+"""CPU: the tracker drop-in (host logic of the video association step) reproduces the integer
+track ids of the REFERENCE's QuasiDenseEmbedTracker bit-for-bit on synthetic clips (golden: tests/golden/tracker.npz,
+written by oracle/gen_golden.py from the reference class itself), also when the frames come back from an all-gather in
+arbitrary order."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from polyphonicformer_amd import video as V
+from polyphonicformer_amd import dist as D
+
+
+def _cfg(z):
+    return json.loads(bytes(z["cfg_json"]).decode())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tracker_ids_match_reference(seed):
+    z = Hh.load_golden("tracker.npz")
+    tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **_cfg(z)))
+    cnt = 1
+    for f, bb, lab, emb in Hh.tracker_records(seed):
+        if bb.shape[0] == 0:
+            continue
+        obb, olab, ids = tr.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
+        cnt += 1
+        ids = ids + 1
+        ids[ids == -1] = 0
+        assert np.array_equal(ids.numpy(), z[f"s{seed}_f{f}_ids"]), f
+        assert np.array_equal(olab.numpy(), z[f"s{seed}_f{f}_labels"])
+        assert np.array_equal(obb.numpy(), z[f"s{seed}_f{f}_bboxes"])
+
+
+def test_replay_is_order_independent_and_matches_reference():
+    z = Hh.load_golden("tracker.npz")
+    recs = Hh.tracker_records(2)
+    shuffled = [recs[i] for i in torch.randperm(len(recs), generator=torch.Generator().manual_seed(0)).tolist()]
+    out = V.replay_tracking(shuffled, _cfg(z))
+    for f, bb, lab, emb in recs:
+        assert np.array_equal(out[f].numpy(), z[f"s2_f{f}_ids"])
+
+
+def test_pack_unpack_records_are_lossless():
+    for f, bb, lab, emb in Hh.tracker_records(3)[:4]:
+        rec, n = D.pack_track_records(bb, lab, emb)
+        b2, l2, e2 = D.unpack_track_records(rec, n)
+        assert torch.equal(b2, bb) and torch.equal(l2, lab) and torch.equal(e2, emb)
+
+
+def test_bbox_overlaps_edge_cases():
+    a = torch.tensor([[0., 0., 10., 10.], [5., 5., 5., 5.]])
+    iou = V.bbox_overlaps(a, a)
+    assert iou[0, 0] == 1.0 and iou[1, 1] == 0.0 and iou[0, 1] == 0.0
+    assert V.bbox_overlaps(a[:0], a).shape == (0, 2)
