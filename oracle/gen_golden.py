@@ -213,9 +213,29 @@ def tracker_fixture():
     np.savez_compressed(os.path.join(OUT, "tracker.npz"), **out)
 
 
+def video_fixture():
+    """mask -> box helpers and the track embedding head of the reference on a crafted frame (video.npz)"""
+    V = R.load_reference_track_head()
+    pan, info, feats, roi_feats = Hh.video_case()
+    masks = torch.stack([torch.from_numpy(pan == s["id"]).float() for s in info])
+    stat = V.batch_mask2boxlist([masks])[0]                      # polyphonic_former_video.py:413
+    rois = V.bboxlist2roi([stat]).clamp(min=0.0)                  # :414-415
+    ext = torch.tensor(V.tensor_mask2box(masks))                  # :386-389
+    head = V.Head(num_convs=4, num_fcs=1, embed_channels=256, norm_cfg=dict(type="GN", num_groups=32))
+    sd = Hh.seeded_fill(Hh.TRACK_HEAD_SHAPES, 4321)
+    head.load_state_dict({k[len("track_head."):]: v for k, v in sd.items()})
+    head.eval()
+    assert {"track_head." + k: tuple(v.shape) for k, v in head.state_dict().items()} == Hh.TRACK_HEAD_SHAPES
+    emb = head(roi_feats)
+    np.savez_compressed(os.path.join(OUT, "video.npz"), stat_boxes=np_(stat), rois=np_(rois), extent_boxes=np_(ext),
+                        embeds=np_(emb))
+    print("[video] segments:", len(info), "embed norm:", float(emb.norm(dim=1).mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load_reference()
+    video_fixture()
     tracker_fixture()
     merge_fixture(ns)
     run_family(ns, Hh.MINI, "mini", B=2, H=6, W=10, store_all=True)

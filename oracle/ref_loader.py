@@ -368,6 +368,33 @@ def load_reference_tracker():
     return m.QuasiDenseEmbedTracker
 
 
+def load_reference_track_head():
+    """QuasiDenseMaskEmbedHeadGTMask + the mask->box helpers of polyphonic/video/utils.py"""
+    ns = load_reference()
+    for n in ("MultiPosCrossEntropyLoss", "L2Loss"):
+        ns.MODELS.register_module(name=n, module=type(n, (_Loss,), {}))
+    for name in ("polyphonic.video", "polyphonic.video.qdtrack", "polyphonic.video.qdtrack.track"):
+        if name not in sys.modules:
+            _mod(name)
+
+    def load(modname, relpath):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, relpath))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        parent, _, child = modname.rpartition(".")
+        setattr(sys.modules[parent], child, m)
+        spec.loader.exec_module(m)
+        return m
+
+    sim = load("polyphonic.video.qdtrack.track.similarity", "polyphonic/video/qdtrack/track/similarity.py")
+    sys.modules["polyphonic.video.qdtrack.track"].cal_similarity = sim.cal_similarity
+    vu = load("polyphonic.video.utils", "polyphonic/video/utils.py")
+    th = load("polyphonic.video.track_heads", "polyphonic/video/track_heads.py")
+    return types.SimpleNamespace(Head=th.QuasiDenseMaskEmbedHeadGTMask, batch_mask2boxlist=vu.batch_mask2boxlist,
+                                 bboxlist2roi=vu.bboxlist2roi,
+                                 tensor_mask2box=sys.modules["polyphonic.funcs.utils"].tensor_mask2box)
+
+
 def stage_cfg(C=256, F=2048, heads=8, L=19, n_thing=8, n_stuff=11):
     """`mask_head` dict with the shipped config's structure (configs/_base_/models/
     polyphonic_former.py:111-165) at parametric width."""

@@ -94,3 +94,33 @@ def tracker_records(seed, nframes=12, nobj=14):
         emb = ident[idx] + 0.15 * torch.randn(len(idx), 256, generator=g)
         recs.append((f, bb, cls[idx].clone(), emb))
     return recs
+
+
+def video_case(seed=11, H=96, W=160, nseg=9):
+    """a crafted panoptic id map with `nseg` thing blobs (ids 1..nseg) + per-segment labels/scores, 4 FPN levels of
+    random features for a (8H x 8W... here H x W image) and random RoI features -- inputs of the association step"""
+    g = torch.Generator().manual_seed(seed)
+    pan = np.zeros((H, W), dtype=np.int32)
+    ys, xs = np.mgrid[0:H, 0:W]
+    info = []
+    for s in range(1, nseg + 1):
+        cy, cx = float(torch.rand(1, generator=g)) * H, float(torch.rand(1, generator=g)) * W
+        ry, rx = 3 + float(torch.rand(1, generator=g)) * H / 5, 3 + float(torch.rand(1, generator=g)) * W / 5
+        m = ((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2 < 1
+        if m.sum() == 0:
+            m[int(min(cy, H - 1)), int(min(cx, W - 1))] = True
+        pan[m] = s
+    for s in range(1, nseg + 1):
+        if (pan == s).any():
+            info.append(dict(id=s, isthing=True, category_id=int(torch.randint(0, 8, (1,), generator=g)),
+                             score=float(0.3 + 0.7 * torch.rand(1, generator=g)), instance_id=s - 1))
+    feats = [torch.randn(1, 256, max(H // st, 1), max(W // st, 1), generator=g) for st in (4, 8, 16, 32)]
+    roi_feats = torch.randn(len(info), 256, 7, 7, generator=g)
+    return pan, info, feats, roi_feats
+
+
+TRACK_HEAD_SHAPES = {**{f"track_head.convs.{i}.conv.weight": (256, 256, 3, 3) for i in range(4)},
+                     **{f"track_head.convs.{i}.gn.weight": (256,) for i in range(4)},
+                     **{f"track_head.convs.{i}.gn.bias": (256,) for i in range(4)},
+                     "track_head.fcs.0.weight": (1024, 12544), "track_head.fcs.0.bias": (1024,),
+                     "track_head.fc_embed.weight": (256, 1024), "track_head.fc_embed.bias": (256,)}

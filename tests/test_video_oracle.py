@@ -1,0 +1,45 @@
+"""CPU: the video-association oracle (oracle/video_oracle.py) against the reference's own helpers / track head
+(tests/golden/video.npz) and, for RoIAlign (mmcv op, not runnable here), analytic properties."""
+import numpy as np
+import torch
+
+import helpers as Hh
+from oracle import video_oracle as VO
+
+torch.set_grad_enabled(False)
+
+
+def test_boxes_and_embed_head_match_reference():
+    z = Hh.load_golden("video.npz")
+    pan, info, feats, roi_feats = Hh.video_case()
+    masks = torch.stack([torch.from_numpy(pan == s["id"]) for s in info])
+    stat = VO.mask_stat_boxes(masks)
+    assert np.allclose(stat.numpy(), z["stat_boxes"], rtol=0, atol=1e-4)
+    rois = torch.cat([torch.zeros(len(stat), 1), stat], 1).clamp(min=0.0)
+    assert np.allclose(rois.numpy(), z["rois"], atol=1e-4)
+    assert np.array_equal(VO.mask_extent_boxes(masks).numpy(), z["extent_boxes"])
+    sd = Hh.seeded_fill(Hh.TRACK_HEAD_SHAPES, 4321)
+    emb = VO.track_embed_head(sd, roi_feats)
+    assert Hh.rel_err(emb, z["embeds"]) < 1e-5
+
+
+def test_roi_align_analytic_properties():
+    # constant field -> constant; affine field f = a*x + b*y + c -> value at the bin centre (interior RoIs)
+    H, W = 40, 64
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    const = torch.full((1, 2, H, W), 3.5)
+    aff = (0.25 * xs + 0.5 * ys + 1.0)[None, None].repeat(1, 2, 1, 1)
+    rois = torch.tensor([[0, 40.0, 24.0, 120.0, 88.0], [0, 16.5, 8.25, 77.0, 40.0]])
+    s = 0.25
+    out = VO.roi_align(const, rois, s)
+    assert torch.allclose(out, torch.full_like(out, 3.5))
+    out = VO.roi_align(aff, rois, s)
+    for i, r in enumerate(rois):
+        x1, y1, x2, y2 = [float(v) * s - 0.5 for v in r[1:]]
+        bw, bh = (x2 - x1) / 7, (y2 - y1) / 7
+        for ph in range(7):
+            for pw in range(7):
+                cx, cy = x1 + (pw + 0.5) * bw, y1 + (ph + 0.5) * bh
+                assert abs(float(out[i, 0, ph, pw]) - (0.25 * cx + 0.5 * cy + 1.0)) < 1e-4
+    lv = VO.map_roi_levels(torch.tensor([[0, 0, 0, 50., 50.], [0, 0, 0, 120., 120.], [0, 0, 0, 300., 300.], [0, 0, 0, 2000., 900.]]))
+    assert lv.tolist() == [0, 1, 2, 3]
