@@ -181,6 +181,30 @@ int ph_panoptic_paste(const int32_t* ids, const int32_t* newid, const float* act
                       const int32_t* geom, int from_probs, int32_t* pan, float* depth_basic, float* depth_final,
                       void* stream);
 
+/* ---- device side of the video association step (polyphonic_former_video.py:359-396) ----------
+ * ph_segment_boxes : int32 panoptic id map [H][W], segment ids 1..nseg -> rois [nseg][5] = (0, x1, y1, x2, y2)
+ *                    (centre +- 2 * mean |deviation| per axis, clamped at 0: polyphonic/video/utils.py:39-83,
+ *                    polyphonic_former_video.py:413-415) and tight extent boxes [nseg][4] (funcs/utils.py:4-22).
+ * ph_roi_align_fpn : mmdet SingleRoIExtractor (level = floor(log2(sqrt(area)/56 + 1e-6))) + mmcv RoIAlign(7,
+ *                    sampling_ratio 2, avg, aligned) over `nlev` fp32 maps [1][256][H_l][W_l] (feats = host array of
+ *                    device pointers, hw = {H_0, W_0, H_1, ...}, scales = 1/stride) -> channels-last bf16 planes
+ *                    [P][n][49][256] (+ optional fp32 [n][256][7][7]).
+ * ph_gemm_rows     : Y[M][N] = act(X[M][K] W^T + b), X bf16 planes [P][M][K], W packed B fragments (plane stride
+ *                    given), Y fp32 and/or bf16 planes; the track head's conv3x3-as-GEMM, fc and fc_embed
+ *                    (polyphonic/video/track_heads.py:92-102).
+ * ph_im2col7       : channels-last [P][n][49][256] -> 3x3/pad-1 patches [P][n*49][2304], K order (tap, channel).
+ * ph_gn_relu_cl    : per-RoI GroupNorm + ReLU of fp32 [n*49][256] -> channels-last bf16 planes. */
+size_t ph_segment_boxes_workspace_bytes(int nseg);
+int ph_segment_boxes(const int32_t* pan, int H, int W, int nseg, float* rois, float* ext_boxes,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int ph_roi_align_fpn(const float* const* feats, const int32_t* hw, const float* scales, int nlev, const float* rois,
+                     int n, float finest_scale, uint16_t* out_cl, float* out_f32 /* nullable */, int prec, void* stream);
+int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, const float* bias /* nullable */, int relu,
+                 float* Yf /* nullable */, uint16_t* Yp /* nullable */, int M, int N, int K, int prec, void* stream);
+int ph_im2col7(const uint16_t* in, uint16_t* out, int n, int prec, void* stream);
+int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int groups, float eps, uint16_t* out, int n,
+                  int prec, void* stream);
+
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);
 int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);

@@ -45,6 +45,13 @@ SIGNATURES = {
     "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ph_panoptic_argmax": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32), _I, _P, _P, _P]),
     "ph_panoptic_paste": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _I, _P, _P, _P, _P]),
+    "ph_segment_boxes_workspace_bytes": (C.c_size_t, [_I]),
+    "ph_segment_boxes": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "ph_roi_align_fpn": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_float), _I, _P, _I, C.c_float,
+                                   _P, _P, _I, _P]),
+    "ph_gemm_rows": (C.c_int, [_P, _P, _L, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "ph_im2col7": (C.c_int, [_P, _P, _I, _I, _P]),
+    "ph_gn_relu_cl": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _I, _I, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_readbw": (C.c_int, [_P, _L, _I, _P, _P]),

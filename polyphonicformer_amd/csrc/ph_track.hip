@@ -1,0 +1,290 @@
+// SURVEY.md 8f row N1 -- device side of the video association step (polyphonic_former_video.py:359-396):
+//   ph_segment_boxes : panoptic id map -> per thing segment the RoI box (centre +- 2 * mean |deviation|,
+//                      polyphonic/video/utils.py:39-83) and the tight extent box (funcs/utils.py:4-22)
+//   ph_roi_align_fpn : SingleRoIExtractor (FPN level by sqrt(area)) + mmcv RoIAlign(7, sampling_ratio 2, avg, aligned)
+//   ph_gemm_rows     : Y = act(X W^T + b) on bf16 MFMA with packed weight fragments (conv3x3-as-GEMM, fc, fc_embed)
+//   ph_im2col7 / ph_gn_relu_cl : 3x3 patches of the 7x7 RoI maps / per-sample GroupNorm(32) + ReLU, channels-last
+// The tensors are tiny (<= 100 RoIs): these kernels are latency bound and written for simplicity, not roofline.
+#include "ph_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// segment statistics.  st [nseg][3] = count, sum_row, sum_col ; emin [nseg][2] = min_r, min_c ; emax [nseg][2] = max_r, max_c
+__global__ __launch_bounds__(256) void k_seg_stats(const int* __restrict__ pan, int H, int W, int nseg,
+                                                   unsigned long long* __restrict__ st, int* __restrict__ emin, int* __restrict__ emax) {
+    const int64_t npx = (int64_t)H * W;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int id = pan[p];
+        if (id < 1 || id > nseg) continue;
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W), s = id - 1;
+        atomicAdd(&st[s * 3 + 0], 1ull);
+        atomicAdd(&st[s * 3 + 1], (unsigned long long)r);
+        atomicAdd(&st[s * 3 + 2], (unsigned long long)c);
+        atomicMin(&emin[s * 2 + 0], r);
+        atomicMin(&emin[s * 2 + 1], c);
+        atomicMax(&emax[s * 2 + 0], r);
+        atomicMax(&emax[s * 2 + 1], c);
+    }
+}
+// dev [nseg][2] (double): sum |row - mean_row|, sum |col - mean_col| with the fp32 means the reference uses
+__global__ __launch_bounds__(256) void k_seg_absdev(const int* __restrict__ pan, int H, int W, int nseg,
+                                                    const unsigned long long* __restrict__ st, double* __restrict__ dev) {
+    const int64_t npx = (int64_t)H * W;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int id = pan[p];
+        if (id < 1 || id > nseg) continue;
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W), s = id - 1;
+        const double n = (double)st[s * 3];
+        const float mr = (float)((double)st[s * 3 + 1] / n), mc = (float)((double)st[s * 3 + 2] / n);
+        atomicAdd(&dev[s * 2 + 0], (double)fabsf((float)r - mr));
+        atomicAdd(&dev[s * 2 + 1], (double)fabsf((float)c - mc));
+    }
+}
+// rois [nseg][5] = (0, x1, y1, x2, y2) clamped at 0 ; ext_boxes [nseg][4] xyxy
+__global__ void k_seg_boxes(const unsigned long long* __restrict__ st, const int* __restrict__ emin, const int* __restrict__ emax,
+                            const double* __restrict__ dev,
+                            int nseg, float* __restrict__ rois, float* __restrict__ ext_boxes) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const double n = (double)st[s * 3];
+    if (n == 0) {          // empty mask: [0,0,0,0] (video/utils.py:75) and (-1,-1,10,10) (funcs/utils.py:19)
+        for (int k = 0; k < 5; ++k) rois[s * 5 + k] = 0.f;
+        ext_boxes[s * 4 + 0] = -1.f; ext_boxes[s * 4 + 1] = -1.f; ext_boxes[s * 4 + 2] = 10.f; ext_boxes[s * 4 + 3] = 10.f;
+        return;
+    }
+    const float mr = (float)((double)st[s * 3 + 1] / n), mc = (float)((double)st[s * 3 + 2] / n);
+    const float dr = fmaxf((float)(dev[s * 2] / n), 1.f), dc = fmaxf((float)(dev[s * 2 + 1] / n), 1.f);
+    rois[s * 5 + 0] = 0.f;
+    rois[s * 5 + 1] = fmaxf(mc - dc * 2.f, 0.f);
+    rois[s * 5 + 2] = fmaxf(mr - dr * 2.f, 0.f);
+    rois[s * 5 + 3] = fmaxf(mc + dc * 2.f, 0.f);
+    rois[s * 5 + 4] = fmaxf(mr + dr * 2.f, 0.f);
+    ext_boxes[s * 4 + 0] = (float)emin[s * 2 + 1];      // x1 = min col
+    ext_boxes[s * 4 + 1] = (float)emin[s * 2 + 0];      // y1 = min row
+    ext_boxes[s * 4 + 2] = (float)emax[s * 2 + 1];
+    ext_boxes[s * 4 + 3] = (float)emax[s * 2 + 0];
+}
+
+extern "C" size_t ph_segment_boxes_workspace_bytes(int nseg) {
+    return (size_t)nseg * (3 * sizeof(unsigned long long) + 4 * sizeof(int) + 2 * sizeof(double));
+}
+
+extern "C" int ph_segment_boxes(const int32_t* pan, int H, int W, int nseg, float* rois, float* ext_boxes, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    PH_CHECK_ARG(pan && rois && ext_boxes && workspace && H > 0 && W > 0 && nseg > 0, "bad pointer or size");
+    PH_CHECK_ARG(workspace_bytes >= ph_segment_boxes_workspace_bytes(nseg), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* st = (unsigned long long*)workspace;
+    double* dev = (double*)(st + 3 * nseg);
+    int* emin = (int*)(dev + 2 * nseg);
+    int* emax = emin + 2 * nseg;
+    (void)hipMemsetAsync(st, 0, (size_t)nseg * (3 * 8 + 2 * 8), s);
+    (void)hipMemsetAsync(emin, 0x7f, (size_t)nseg * 2 * sizeof(int), s);      // 0x7f7f7f7f > any coordinate
+    (void)hipMemsetAsync(emax, 0, (size_t)nseg * 2 * sizeof(int), s);
+    const int64_t npx = (int64_t)H * W;
+    int grid = (int)((npx + 255) / 256 < 2048 ? (npx + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_seg_stats, dim3(grid), dim3(256), 0, s, pan, H, W, nseg, st, emin, emax);
+    hipLaunchKernelGGL(k_seg_absdev, dim3(grid), dim3(256), 0, s, pan, H, W, nseg, st, dev);
+    hipLaunchKernelGGL(k_seg_boxes, dim3((nseg + 63) / 64), dim3(64), 0, s, st, emin, emax, dev, nseg, rois, ext_boxes);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoIAlign over an FPN.  out_cl: bf16 planes [P][n][49][256] (channels last, what the track head consumes);
+// out_f32 (optional): [n][256][7][7] like the reference's roi_feats.
+struct FpnArgs { const float* feat[4]; int H[4], W[4]; float scale[4]; int nlev; };
+
+__device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H, int W, float y, float x) {
+    if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) return 0.f;
+    y = fmaxf(y, 0.f); x = fmaxf(x, 0.f);
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * hx * f[yl * W + xl] + hy * lx * f[yl * W + xh] + ly * hx * f[yh * W + xl] + ly * lx * f[yh * W + xh];
+}
+
+template <int PA>
+__global__ __launch_bounds__(256) void k_roi_align_fpn(FpnArgs a, const float* __restrict__ rois, int n, float finest,
+                                                        uint16_t* __restrict__ out_cl, float* __restrict__ out_f32) {
+    const int roi = blockIdx.x, c = threadIdx.x;                 // one block per RoI, one thread per channel
+    const float* r = rois + roi * 5;
+    const float sc = sqrtf((r[3] - r[1]) * (r[4] - r[2]));
+    int lv = (int)floorf(log2f(sc / finest + 1e-6f));
+    lv = lv < 0 ? 0 : (lv > a.nlev - 1 ? a.nlev - 1 : lv);
+    const float s = a.scale[lv];
+    const int H = a.H[lv], W = a.W[lv];
+    const float* f = a.feat[lv] + (int64_t)c * H * W;
+    const float x1 = r[1] * s - 0.5f, y1 = r[2] * s - 0.5f, x2 = r[3] * s - 0.5f, y2 = r[4] * s - 0.5f;
+    const float bw = (x2 - x1) / 7.f, bh = (y2 - y1) / 7.f;
+    const int64_t plane = (int64_t)n * 49 * 256;
+    for (int ph = 0; ph < 7; ++ph)
+        for (int pw = 0; pw < 7; ++pw) {
+            float acc = 0.f;
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                const float yy = y1 + ph * bh + (iy + 0.5f) * bh / 2.f;
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) acc += roi_bilinear(f, H, W, yy, x1 + pw * bw + (ix + 0.5f) * bw / 2.f);
+            }
+            const float v = acc / 4.f;
+            uint32_t hi, lo;
+            f2bf_split(v, hi, lo);
+            const int64_t o = ((int64_t)roi * 49 + ph * 7 + pw) * 256 + c;
+            out_cl[o] = (uint16_t)hi;
+            if (PA == 2) out_cl[o + plane] = (uint16_t)lo;
+            if (out_f32) out_f32[((int64_t)roi * 256 + c) * 49 + ph * 7 + pw] = v;
+        }
+}
+
+extern "C" int ph_roi_align_fpn(const float* const* feats, const int32_t* hw /*[nlev][2]*/, const float* scales, int nlev,
+                                const float* rois, int n, float finest_scale, uint16_t* out_cl, float* out_f32, int prec,
+                                void* stream) {
+    PH_CHECK_ARG(feats && hw && scales && rois && out_cl && nlev >= 1 && nlev <= 4 && n > 0, "bad pointer or size");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    FpnArgs a;
+    a.nlev = nlev;
+    for (int l = 0; l < nlev; ++l) { a.feat[l] = feats[l]; a.H[l] = hw[2 * l]; a.W[l] = hw[2 * l + 1]; a.scale[l] = scales[l]; }
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_roi_align_fpn<1>, dim3(n), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
+    else hipLaunchKernelGGL(k_roi_align_fpn<2>, dim3(n), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic row GEMM: Y[M][N] = act(X[M][K] W^T + b).  X: bf16 planes [PA][M][K] row major; W: packed B fragments
+// (pack.pack_b_fragments, [N/16][K/32] blocks); Y: fp32 [M][N] and/or bf16 planes [PA][M][N].
+template <int PA>
+__global__ __launch_bounds__(256) void k_gemm_rows(const uint16_t* __restrict__ X, int64_t x_plane, const uint16_t* __restrict__ Wp,
+                                                   int64_t w_plane, const float* __restrict__ bias, int relu,
+                                                   float* __restrict__ Yf, uint16_t* __restrict__ Yp, int64_t y_plane,
+                                                   int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 32, ct = blockIdx.y * 4 + wave;
+    if (ct * 16 >= N) return;
+    const int KS = K / 32;
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const uint16_t* wb = Wp + ((int64_t)ct * KS) * 512 + lane * 8;
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 a[PA][2], b[PA];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            b[p] = *(const uint4*)(wb + p * w_plane + (int64_t)ks * 512);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = row0 + rt * 16 + i;
+                a[p][rt] = row < M ? *(const uint4*)(X + p * x_plane + (int64_t)row * K + ks * 32 + g * 8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            acc[rt] = mfma16(a[0][rt], b[0], acc[rt]);
+            if (PA == 2) { acc[rt] = mfma16(a[0][rt], b[PA - 1], acc[rt]); acc[rt] = mfma16(a[PA - 1][rt], b[0], acc[rt]); }
+        }
+    }
+    const int col = ct * 16 + i;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + rt * 16 + g * 4 + r;
+            if (row >= M) continue;
+            float v = acc[rt][r] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            if (Yf) Yf[(int64_t)row * N + col] = v;
+            if (Yp) {
+                uint32_t hi, lo;
+                f2bf_split(v, hi, lo);
+                Yp[(int64_t)row * N + col] = (uint16_t)hi;
+                if (PA == 2) Yp[(int64_t)row * N + col + y_plane] = (uint16_t)lo;
+            }
+        }
+}
+
+extern "C" int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, const float* bias, int relu,
+                            float* Yf, uint16_t* Yp, int M, int N, int K, int prec, void* stream) {
+    PH_CHECK_ARG(X && Wp && (Yf || Yp) && M > 0 && N > 0 && K > 0, "bad pointer or size");
+    PH_CHECK_ARG(N % 16 == 0 && K % 32 == 0, "N % 16 == 0 and K % 32 == 0 required");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    const dim3 grid((M + 31) / 32, (N / 16 + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gemm_rows<1>, grid, dim3(256), 0, s, X, (int64_t)M * K, Wp, w_plane_elems, bias, relu, Yf, Yp, (int64_t)M * N, M, N, K);
+    else hipLaunchKernelGGL(k_gemm_rows<2>, grid, dim3(256), 0, s, X, (int64_t)M * K, Wp, w_plane_elems, bias, relu, Yf, Yp, (int64_t)M * N, M, N, K);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 (pad 1) patches of 7x7 channels-last maps: in [P][n][49][256] -> out [P][n*49][9*256], K order (tap, channel)
+__global__ __launch_bounds__(256) void k_im2col7(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int n, int P) {
+    const int64_t chunks = (int64_t)P * n * 49 * 9 * 32;               // 16-byte chunks (8 channels)
+    const int64_t in_plane = (int64_t)n * 49 * 256, out_plane = (int64_t)n * 49 * 2304;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx & 31);
+        int64_t t = idx >> 5;
+        const int tap = (int)(t % 9); t /= 9;
+        const int pos = (int)(t % 49); t /= 49;
+        const int s = (int)(t % n);
+        const int p = (int)(t / n);
+        const int y = pos / 7 + tap / 3 - 1, x = pos % 7 + tap % 3 - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y >= 0 && y < 7 && x >= 0 && x < 7) v = *(const uint4*)(in + p * in_plane + ((int64_t)s * 49 + y * 7 + x) * 256 + c8 * 8);
+        *(uint4*)(out + p * out_plane + ((int64_t)s * 49 + pos) * 2304 + tap * 256 + c8 * 8) = v;
+    }
+}
+
+// per-sample GroupNorm (groups of 256/groups channels over the 49 positions) + ReLU on fp32 [n*49][256] -> bf16 planes
+template <int PA>
+__global__ __launch_bounds__(256) void k_gn_relu_cl(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int groups, float eps, uint16_t* __restrict__ out, int n) {
+    __shared__ float red[2][256];
+    const int s = blockIdx.x, c = threadIdx.x, cpg = 256 / groups;
+    float v[49];
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 49; ++p) { v[p] = y[((int64_t)s * 49 + p) * 256 + c]; sum += v[p]; }
+    red[0][c] = sum;
+    __syncthreads();
+    float gs = 0.f;
+    for (int j = 0; j < cpg; ++j) gs += red[0][(c / cpg) * cpg + j];
+    const float mean = gs / (float)(cpg * 49);
+    float sq = 0.f;
+#pragma unroll
+    for (int p = 0; p < 49; ++p) { const float d = v[p] - mean; sq += d * d; }
+    red[1][c] = sq;
+    __syncthreads();
+    float gq = 0.f;
+    for (int j = 0; j < cpg; ++j) gq += red[1][(c / cpg) * cpg + j];
+    const float rstd = 1.f / sqrtf(gq / (float)(cpg * 49) + eps);
+    const float ga = gamma[c], be = beta[c];
+    const int64_t plane = (int64_t)n * 49 * 256;
+#pragma unroll
+    for (int p = 0; p < 49; ++p) {
+        const float o = fmaxf((v[p] - mean) * rstd * ga + be, 0.f);
+        uint32_t hi, lo;
+        f2bf_split(o, hi, lo);
+        const int64_t idx = ((int64_t)s * 49 + p) * 256 + c;
+        out[idx] = (uint16_t)hi;
+        if (PA == 2) out[idx + plane] = (uint16_t)lo;
+    }
+}
+
+extern "C" int ph_im2col7(const uint16_t* in, uint16_t* out, int n, int prec, void* stream) {
+    PH_CHECK_ARG(in && out && n > 0, "bad pointer or size");
+    const int P = prec == PH_PREC_SPLIT ? 2 : 1;
+    const int64_t chunks = (int64_t)P * n * 49 * 9 * 32;
+    int grid = (int)((chunks + 255) / 256 < 4096 ? (chunks + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_im2col7, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, n, P);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int groups, float eps, uint16_t* out, int n,
+                             int prec, void* stream) {
+    PH_CHECK_ARG(y && gamma && beta && out && n > 0 && groups > 0 && 256 % groups == 0, "bad pointer or size");
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_relu_cl<1>, dim3(n), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, groups, eps, out, n);
+    else hipLaunchKernelGGL(k_gn_relu_cl<2>, dim3(n), dim3(256), 0, (hipStream_t)stream, y, gamma, beta, groups, eps, out, n);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
