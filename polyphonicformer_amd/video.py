@@ -169,3 +169,90 @@ def replay_tracking(records, tracker_cfg=None, tracker=None):
             ids = torch.zeros((0,), dtype=torch.long)
         out[fid] = ids
     return out
+
+
+# ---- the per-frame association step of PolyphonicVideo.simple_test (polyphonic_former_video.py:359-405) ----------
+INSTANCE_DIVISOR = 10000       # datasets/cityscapes_dvps.py (max_ins): pred_pan = sem * 10000 + track_id
+
+
+def things_for_tracking(panoptic_seg, segments_info):
+    """get_things_id_for_tracking (:421-434): segment ids, labels and scores of the thing segments, in segment order"""
+    seg_ids, idxs, labels, score = [], [], [], []
+    for s in segments_info:
+        if s['isthing']:
+            seg_ids.append(s['id'])
+            idxs.append(s['instance_id'])
+            labels.append(s['category_id'])
+            score.append(s['score'])
+    return seg_ids, idxs, labels, score
+
+
+def semantic_map(panoptic_seg, segments_info, num_thing_classes, num_stuff_classes):
+    """get_semantic_seg (:436-440) as one table lookup; void = num_thing + num_stuff (uint8 like the reference)"""
+    import numpy as np
+    lut = np.full(int(panoptic_seg.max()) + 1, num_thing_classes + num_stuff_classes, dtype=np.uint8)
+    for s in segments_info:
+        lut[s['id']] = s['category_id']
+    return lut[panoptic_seg]
+
+
+def track_id_map(panoptic_seg, seg_ids, ids):
+    """generate_track_id_maps (:442-451): float64 map, 0 = no track (the masks are `panoptic_seg == segment id`)"""
+    import numpy as np
+    lut = np.zeros(int(panoptic_seg.max()) + 1, dtype=np.float64)
+    for sid, tid in zip(seg_ids, ids):
+        lut[sid] = float(tid)
+    return lut[panoptic_seg]
+
+
+def wire_record(result):
+    """datasets/cityscapes_dvps.py:325-338 (pre_eval): what is saved per frame for DVPQ evaluation"""
+    import numpy as np
+    pan = result['sem'].astype(np.int64) * INSTANCE_DIVISOR + result['track'].astype(np.int64)
+    return {"panseg": pan.astype(np.uint32), "depth": result['depth'].astype(np.float32)}
+
+
+class VideoAssociator:
+    """What PolyphonicVideo.simple_test does after `roi_head.simple_test` (:359-405), for one video stream:
+    boxes from the id map -> FPN RoIAlign -> track embeddings (libpolyhead) -> tracker -> sem / track / depth maps.
+    `records_only=True` returns the (bboxes, labels, embeds) record instead of matching, for the sharded mode where
+    the records are all-gathered and replayed in frame order (`dist.allgather_track_records`, `replay_tracking`)."""
+
+    def __init__(self, track_head, tracker_cfg, num_thing_classes, num_stuff_classes, strides=(4, 8, 16, 32)):
+        self.track_head, self.tracker_cfg = track_head, dict(tracker_cfg)
+        self.num_thing_classes, self.num_stuff_classes, self.strides = num_thing_classes, num_stuff_classes, strides
+        self.init_tracker()
+
+    def init_tracker(self):
+        """polyphonic_former_video.py:59-61"""
+        self.tracker = QuasiDenseEmbedTracker(**self.tracker_cfg)
+        self.cnt = 1
+
+    def record(self, fpn_feats, panoptic_seg, segments_info):
+        from . import track_head as T, engine as E
+        seg_ids, idxs, labels, score = things_for_tracking(panoptic_seg, segments_info)
+        if not seg_ids:
+            return seg_ids, None
+        dev = fpn_feats[0].device
+        rois_all, ext_all = T.segment_boxes(torch.from_numpy(panoptic_seg).to(dev), int(max(s['id'] for s in segments_info)))
+        sel = torch.tensor([i - 1 for i in seg_ids], device=dev)
+        prec = E.PREC[self.track_head.precision]
+        embeds = self.track_head.forward_planes(T.roi_extract(fpn_feats, rois_all[sel].contiguous(), prec, self.strides))
+        bboxes = torch.cat([ext_all[sel], torch.tensor(score, device=dev, dtype=torch.float32)[:, None]], 1)
+        return seg_ids, (bboxes.cpu(), torch.tensor(labels, dtype=torch.int64), embeds.cpu())
+
+    def step(self, fpn_feats, panoptic_seg, segments_info, depth_final, records_only=False):
+        seg_ids, rec = self.record(fpn_feats, panoptic_seg, segments_info)
+        if records_only:
+            return seg_ids, rec
+        ids = []
+        if rec is not None:
+            # NB the reference sorts detections by score inside `match`; ids come back in that order (:142-145) and are
+            # painted onto the masks in segment order (:403) -- mirrored as is
+            _, _, ids = self.tracker.match(bboxes=rec[0], labels=rec[1], track_feats=rec[2], frame_id=self.cnt)
+            self.cnt += 1
+            ids = ids + 1
+            ids[ids == -1] = 0
+            ids = ids.tolist()
+        return [{"sem": semantic_map(panoptic_seg, segments_info, self.num_thing_classes, self.num_stuff_classes),
+                 "track": track_id_map(panoptic_seg, seg_ids, ids), "depth": depth_final}]

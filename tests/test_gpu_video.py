@@ -81,3 +81,37 @@ def test_association_chain_vs_oracle(gpu):
         ia = a.match(bb, lab, emb.cpu(), f)[2]
         ib = b.match(torch.cat([VO.mask_extent_boxes(masks), bb[:, 4:]], 1), lab, emb_ref, f)[2]
         assert torch.equal(ia, ib)
+
+
+def test_two_frame_clip_association(gpu):
+    """BASELINE config 3: a 2-frame clip through the association step (VideoAssociator.step) -- the second frame is the
+    first one shifted by a few pixels, so every object must keep its track id; checked against the oracle chain."""
+    from polyphonicformer_amd import video as V
+    sd = Hh.seeded_fill(Hh.TRACK_HEAD_SHAPES, 4321)
+    head = HEADS.build(dict(type="QuasiDenseMaskEmbedHeadGTMask", norm_cfg=dict(type="GN", num_groups=32)))
+    head.load_state_dict({k[len("track_head."):]: v for k, v in sd.items()})
+    head.to(gpu).eval()
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+               match_metric="bisoftmax")
+    assoc = V.VideoAssociator(head, cfg, 8, 11)
+    pan0, info, feats, _ = Hh.video_case(seed=21, H=192, W=320, nseg=8)
+    pan1 = np.roll(pan0, (2, 3), axis=(0, 1))
+    feats1 = [torch.roll(f, (1, 1), dims=(2, 3)) if i == 0 else f for i, f in enumerate(feats)]
+    ref_tr = V.QuasiDenseEmbedTracker(**cfg)
+    outs, ref_ids = [], []
+    for fi, (pan, ff) in enumerate(((pan0, feats), (pan1, feats1))):
+        depth = np.full(pan.shape, 1.5, dtype=np.float32)
+        outs.append(assoc.step([f.to(gpu) for f in ff], pan, info, depth)[0])
+        masks = torch.stack([torch.from_numpy(pan == s["id"]) for s in info])
+        rois = torch.cat([torch.zeros(len(info), 1), VO.mask_stat_boxes(masks)], 1).clamp(min=0)
+        emb = VO.track_embed_head(sd, VO.roi_extract(ff, rois))
+        bb = torch.cat([VO.mask_extent_boxes(masks), torch.tensor([[s["score"]] for s in info])], 1)
+        ids = ref_tr.match(bb, torch.tensor([s["category_id"] for s in info]), emb, fi + 1)[2] + 1
+        ids[ids == -1] = 0
+        ref_ids.append(ids.tolist())
+    for fi, pan in enumerate((pan0, pan1)):
+        want = V.track_id_map(pan, [s["id"] for s in info], ref_ids[fi])
+        assert np.array_equal(outs[fi]["track"], want)
+        assert outs[fi]["sem"].dtype == np.uint8 and outs[fi]["depth"].dtype == np.float32
+    assert V.wire_record(outs[1])["panseg"].dtype == np.uint32

@@ -55,3 +55,25 @@ def test_bbox_overlaps_edge_cases():
     iou = V.bbox_overlaps(a, a)
     assert iou[0, 0] == 1.0 and iou[1, 1] == 0.0 and iou[0, 1] == 0.0
     assert V.bbox_overlaps(a[:0], a).shape == (0, 2)
+
+
+def test_sem_track_maps_and_wire_format():
+    """get_semantic_seg / generate_track_id_maps (polyphonic_former_video.py:436-451) and the pre_eval record
+    (datasets/cityscapes_dvps.py:325-338) against their direct per-segment formulation"""
+    pan, info, _, _ = Hh.video_case(seed=5)
+    info[1] = dict(id=info[1]["id"], isthing=False, category_id=12, area=3)         # a stuff segment
+    seg_ids, idxs, labels, score = V.things_for_tracking(pan, info)
+    assert info[1]["id"] not in seg_ids and len(seg_ids) == len(info) - 1
+    ids = list(range(5, 5 + len(seg_ids)))
+    ids[2] = 0
+    sem_ref = np.ones(pan.shape, dtype=np.uint8) * 8 + 11
+    for s in info:
+        sem_ref[pan == s["id"]] = s["category_id"]
+    trk_ref = np.zeros(pan.shape)
+    for sid, t in zip(seg_ids, ids):
+        trk_ref[pan == sid] = t
+    sem, trk = V.semantic_map(pan, info, 8, 11), V.track_id_map(pan, seg_ids, ids)
+    assert sem.dtype == np.uint8 and np.array_equal(sem, sem_ref) and np.array_equal(trk, trk_ref)
+    rec = V.wire_record({"sem": sem, "track": trk, "depth": np.ones(pan.shape, dtype=np.float64)})
+    assert rec["panseg"].dtype == np.uint32 and rec["depth"].dtype == np.float32
+    assert np.array_equal(rec["panseg"], sem_ref.astype(np.int64) * 10000 + trk_ref.astype(np.int64))
