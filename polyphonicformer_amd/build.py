@@ -47,7 +47,7 @@ def build_library(force=False, verbose=False):
 
     def cc(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + os.environ.get("PH_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")

@@ -72,17 +72,29 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint16_t* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// 16-lane butterflies on the DPP crossbar (no LDS traffic): quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror.  Every lane of a 16-lane row ends with the same value, and the pairing
+// (hence the fp result) is that of an xor-1/2/4/8 butterfly.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_group16_sum(float t) {
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
-    t += __shfl_xor(t, 8);
+    t += dpp_mov<0xB1>(t);
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0x141>(t);
+    t += dpp_mov<0x140>(t);
     return t;
 }
 __device__ __forceinline__ float wave_group16_max(float t) {
-    t = fmaxf(t, __shfl_xor(t, 1));
-    t = fmaxf(t, __shfl_xor(t, 2));
-    t = fmaxf(t, __shfl_xor(t, 4));
-    t = fmaxf(t, __shfl_xor(t, 8));
+    t = fmaxf(t, dpp_mov<0xB1>(t));
+    t = fmaxf(t, dpp_mov<0x4E>(t));
+    t = fmaxf(t, dpp_mov<0x141>(t));
+    t = fmaxf(t, dpp_mov<0x140>(t));
     return t;
 }
+// 1 ulp hardware transcendentals (v_exp_f32 / v_rcp_f32 / v_rsq_f32): ~2e-7 relative, far inside both
+// precision modes' budgets, and an order of magnitude fewer VALU slots than the IEEE-exact library forms.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.f + fast_exp(-x)); }

@@ -7,14 +7,15 @@
 //                  LN, FFN (chunked over the hidden dim, never materialised) + residual + LN, then
 //                  cls / mask-kernel / depth-kernel heads with feat_transform folded in.
 //
-// Decomposition: one workgroup (4 waves) = (ROWS query rows, branch, frame).  The [ROWS x 256] state
-// lives in REGISTERS in MFMA C-fragment form (a "Tile": wave w owns columns 64w..64w+63 as four
-// 16-column tiles); LayerNorm statistics are reduced with 16-lane butterflies + one tiny LDS
-// exchange across the 4 waves.  Activations feeding the next GEMM are written to LDS as bf16
+// Decomposition: one workgroup (8 waves) = (ROWS query rows, branch, frame).  The [ROWS x 256] state
+// lives in REGISTERS in MFMA C-fragment form (a "Tile": wave w owns columns 32w..32w+31 as two
+// 16-column tiles); LayerNorm statistics are reduced with 16-lane DPP butterflies + one tiny LDS
+// exchange across the 8 waves.  Activations feeding the next GEMM are written to LDS as bf16
 // (one plane, or hi/lo planes in split precision) and read back as A fragments (ds_read_b128,
 // row stride 528 B = conflict free).  Weights stream from L2 as pre-packed B fragments: one
 // contiguous 1 KiB block per (16-column tile, 32-deep k-step), see DESIGN.md 3.4.
-// These kernels are latency/L2-stream bound, not HBM bound.
+// These kernels are bound by the L2 -> CU weight stream (every workgroup reads the stage's 4 MB of
+// weights for its 32 rows: ~2 us per 128 KiB call measured, ~15 TB/s aggregate), not by HBM.
 #include "ph_common.h"
 
 constexpr int LDA = 264;   // LDS row stride (elements) of a [rows][256] bf16 activation buffer
@@ -26,6 +27,7 @@ constexpr int WCOLS = CT * 16;
 constexpr int NTHREADS = NW * 64;
 
 template <int NRT> struct Tile { f32x4_t v[NRT][CT]; };
+
 
 struct QArgs {
     const float* partial; const uint32_t* bits; const float* k_in; const float* q_in;
@@ -45,22 +47,42 @@ template <int NRT> __device__ __forceinline__ void tile_zero(f32x4_t (&a)[NRT][C
         for (int ct = 0; ct < CT; ++ct) a[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc[rt][ct] += A(LDS, [NRT*16 rows][K]) x W(col tiles ct0.., k-steps wks0..wks0+NKS-1).
-// All weight fragments of the call are requested up front (NKS*NCT 16-byte loads per lane in flight):
-// with one or two waves per SIMD nothing else hides the L2 latency of this stream.
-template <int PA, int NRT, int NCT, int NKS>
-__device__ __forceinline__ void gemm_tile(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int a_plane,
-                                          const uint16_t* __restrict__ W, int64_t w_plane, int ct0, int ks_total,
-                                          int wks0, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    uint4 b[PA][NKS][NCT];
+// One GEMM call of a wave = acc[rt][ct] += A(LDS, [NRT*16 rows][NKS*32]) x W(col tiles ct0.., k-steps wks0..).
+// A call's weight fragments (NKS*NCT 16-byte loads per lane, 16 KiB per wave) are requested as ONE batch.
+// k_query_post (single-plane precision) requests them one call AHEAD: `w_issue` for call k+1 is placed
+// before `w_use` of call k, so the L2 round trip and the 128 KiB-per-workgroup transfer through the CU's L1
+// overlap the MFMAs, LayerNorms and barriers of the previous call.  With the two bf16 planes of the fp32
+// mode two fragment sets do not fit the register file; there `w_issue` is a no-op and `w_use` loads on
+// demand.  k_query_pre keeps up to four [ROWS x 256] fp32 tiles live next to the fragments: a second set
+// in flight spills (measured: 52 us on-demand vs 60-65 us pipelined), so it uses `w_run` throughout and
+// leaves the hoisting inside its barrier-free regions to the scheduler.
+struct WRef { const uint16_t* W; int ct0, ks_total, wks0; };
+template <int PA, int NKS, int NCT> struct WFrag { uint4 b[PA][NKS][NCT]; };
+
+template <int PA, int NKS, int NCT>
+__device__ __forceinline__ void w_load(WFrag<PA, NKS, NCT>& f, const WRef& r, int64_t w_plane, int lane) {
 #pragma unroll
     for (int p = 0; p < PA; ++p)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                b[p][ks][ct] = *(const uint4*)(W + p * w_plane + ((int64_t)(ct0 + ct) * ks_total + wks0 + ks) * 512 + lane * 8);
+                f.b[p][ks][ct] = *(const uint4*)(r.W + p * w_plane + ((int64_t)(r.ct0 + ct) * r.ks_total + r.wks0 + ks) * 512 + lane * 8);
+}
+
+template <int PA, int NKS, int NCT>
+__device__ __forceinline__ void w_issue(WFrag<PA, NKS, NCT>& f, const WRef& r, int64_t w_plane, int lane) {
+    if constexpr (PA == 1) {
+        w_load(f, r, w_plane, lane);
+        //SB
+    }
+}
+
+// the MFMA loop over fragments that have been requested already
+template <int PA, int NRT, int NCT, int NKS>
+__device__ __forceinline__ void w_use_loaded(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int a_plane,
+                                             const WFrag<PA, NKS, NCT>& f, int lane) {
+    const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         uint4 a[PA][NRT];
@@ -73,13 +95,28 @@ __device__ __forceinline__ void gemm_tile(f32x4_t (&acc)[NRT][NCT], const uint16
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                acc[rt][ct] = mfma16(a[0][rt], b[0][ks][ct], acc[rt][ct]);
+                acc[rt][ct] = mfma16(a[0][rt], f.b[0][ks][ct], acc[rt][ct]);
                 if (PA == 2) {
-                    acc[rt][ct] = mfma16(a[0][rt], b[PA - 1][ks][ct], acc[rt][ct]);
-                    acc[rt][ct] = mfma16(a[PA - 1][rt], b[0][ks][ct], acc[rt][ct]);
+                    acc[rt][ct] = mfma16(a[0][rt], f.b[PA - 1][ks][ct], acc[rt][ct]);
+                    acc[rt][ct] = mfma16(a[PA - 1][rt], f.b[0][ks][ct], acc[rt][ct]);
                 }
             }
     }
+}
+
+template <int PA, int NRT, int NCT, int NKS>
+__device__ __forceinline__ void w_use(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int a_plane, WFrag<PA, NKS, NCT>& f,
+                                      const WRef& r, int64_t w_plane, int lane) {
+    if constexpr (PA != 1) w_load(f, r, w_plane, lane);
+    w_use_loaded<PA, NRT, NCT, NKS>(acc, A, a_plane, f, lane);
+}
+
+// load-on-demand flavour (the scheduler may still hoist the loads inside a barrier-free region)
+template <int PA, int NRT, int NCT, int NKS>
+__device__ __forceinline__ void w_run(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int a_plane, WFrag<PA, NKS, NCT>& f,
+                                      const WRef& r, int64_t w_plane, int lane) {
+    w_load(f, r, w_plane, lane);
+    w_use_loaded<PA, NRT, NCT, NKS>(acc, A, a_plane, f, lane);
 }
 
 // t[row][col] += bias[col]   (col = WCOLS*wave + 16*ct + (lane&15))
@@ -140,7 +177,10 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
+        for (int rt = 0; rt < NRT; ++rt) {
+            // bound the scheduler's hoisting of the 8-reads-per-row LDS gathers: all NT*NRT groups at once
+            // cost 128 VGPRs next to a prefetched weight set
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* p = red + (0 * NT + n) * NW * ROWS + rt * 16 + g * 4 + r;
@@ -158,6 +198,7 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
                 s = wave_group16_sum(s);
                 if (i == 0) red[((1 * NT + n) * NW + wave) * ROWS + rt * 16 + g * 4 + r] = s;
             }
+        }
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -168,7 +209,8 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
             bt[ct] = bet[n][wave * WCOLS + ct * 16 + i];
         }
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
+        for (int rt = 0; rt < NRT; ++rt) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* p = red + (1 * NT + n) * NW * ROWS + rt * 16 + g * 4 + r;
@@ -176,18 +218,53 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
 #pragma unroll
                 for (int w = 0; w < NW; ++w) tot += p[w * ROWS];
                 const float var = tot * (1.f / 256.f);
-                const float rstd = 1.f / sqrtf(var + LN_EPS);
+                const float rstd = fast_rsqrt(var + LN_EPS);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) t[n].v[rt][ct][r] = t[n].v[rt][ct][r] * rstd * gm[ct] + bt[ct];
             }
+        }
     }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ================================================================================================
 //  k_query_pre
 // ================================================================================================
+// in-projection epilogue: + bias, q scaled by head_dim^-0.5, bf16 plane(s) to the workspace
+template <int PA, int NRT, int PART>
+__device__ __forceinline__ void store_qkv(const Tile<NRT>& T, const QArgs& a, const float* bias, int64_t qk_base,
+                                          int64_t qk_plane, int64_t vt_base, int wave, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * WCOLS + ct * 16 + i;
+        const float bv = bias[col];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = T.v[rt][ct][r] + bv;
+                if (PART == 0) v *= 0.17677669529663687f;   // q * head_dim^-0.5
+                if (PA == 2) f2bf_split(v, hi[r], lo[r]);
+                else hi[r] = f2bf(v);
+            }
+            if (PART < 2) {
+                uint16_t* dst = (PART == 0 ? a.Qp : a.Kp) + qk_base + (rt * 16 + g * 4) * 256 + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dst[r * 256] = (uint16_t)hi[r];
+                    if (PA == 2) dst[qk_plane + r * 256] = (uint16_t)lo[r];
+                }
+            } else {   // V transposed: [feature][query row], 4 consecutive rows per lane
+                uint16_t* dst = a.Vt + vt_base + (int64_t)col * a.Npad + rt * 16 + g * 4;
+                *(uint2*)dst = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
+                if (PA == 2) *(uint2*)(dst + qk_plane) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+            }
+        }
+    }
+}
+
 template <int PA, int NRT>
 __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     constexpr int ROWS = NRT * 16;
@@ -199,7 +276,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     float* red = (float*)(actG + PA * PLANE);     // [2][2][4][ROWS]
     float* cnt = red + 2 * 2 * NW * ROWS;          // [ROWS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight / bias addresses live in SGPRs
     const int i = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * ROWS, br = blockIdx.y, b = blockIdx.z;
     const int N = a.N, Npad = a.Npad;
@@ -209,22 +287,52 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     const int64_t* WO = a.lay.w[br];
     const int64_t* VO = a.lay.v[br];
 
+    // the ten GEMM calls of this kernel
+    const WRef c_dyn0{wb + WO[PH_W_DYN], wave * CT, 8, 0}, c_dyn1{wb + WO[PH_W_DYN], 16 + wave * CT, 8, 0};
+    const WRef c_inp0{wb + WO[PH_W_INP], wave * CT, 8, 0}, c_inp1{wb + WO[PH_W_INP], 16 + wave * CT, 8, 0};
+    const WRef c_ig{wb + WO[PH_W_IG], wave * CT, 8, 0}, c_ug{wb + WO[PH_W_UG], wave * CT, 8, 0};
+    const WRef c_fc{wb + WO[PH_W_FC], wave * CT, 8, 0};
+    const WRef c_q{wb + WO[PH_W_QKV], wave * CT, 8, 0}, c_k{wb + WO[PH_W_QKV], 16 + wave * CT, 8, 0},
+        c_v{wb + WO[PH_W_QKV], 32 + wave * CT, 8, 0};
+    WFrag<PA, 8, CT> fa, fb;
+
     // ---- step 0: reduce pooling partials (fixed order), pixel counts, kernel rows -> LDS ----------
     {
         const int r = tid >> 4, cb = (tid & 15) * 16;   // 16 threads per row, 16 columns each
-        for (int rr = r; rr < ROWS; rr += 32) {
+        for (int rr = r; rr < ROWS; rr += NTHREADS / 16) {
             const int row = row0 + rr;
             float u[16], kv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) { u[e] = 0.f; kv[e] = 0.f; }
+            // pixel count of this row's mask (multiplies the folded feat_transform bias): 16 lanes x uint4,
+            // eight independent loads per round trip
+            int c = 0;
             if (row < Npad) {
-                for (int s = 0; s < a.nsplit; ++s) {
-                    const float* p = a.partial + (((int64_t)b * a.nsplit + s) * Npad + row) * 512 + br * 256 + cb;
+                const uint4* bw = (const uint4*)(a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32));
+                const int nq = (int)(a.HWp / 128);        // HWp is a multiple of 128 pixels = 4 words
+                for (int w0 = tid & 15; w0 < nq; w0 += 128) {
+                    uint4 q[8];
 #pragma unroll
-                    for (int e = 0; e < 16; e += 4) {
-                        const float4 v = *(const float4*)(p + e);
-                        u[e] += v.x; u[e + 1] += v.y; u[e + 2] += v.z; u[e + 3] += v.w;
+                    for (int j = 0; j < 8; ++j) q[j] = w0 + 16 * j < nq ? bw[w0 + 16 * j] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) c += __popc(q[j].x) + __popc(q[j].y) + __popc(q[j].z) + __popc(q[j].w);
+                }
+                // split-K partial sums, ascending split order (deterministic), four splits per round trip
+                for (int s0 = 0; s0 < a.nsplit; s0 += 4) {
+                    float4 v[4][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* p = a.partial + (((int64_t)b * a.nsplit + s0 + j) * Npad + row) * 512 + br * 256 + cb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[j][e] = s0 + j < a.nsplit ? *(const float4*)(p + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            u[4 * e] += v[j][e].x; u[4 * e + 1] += v[j][e].y; u[4 * e + 2] += v[j][e].z; u[4 * e + 3] += v[j][e].w;
+                        }
                 }
             }
             if (row < N) {
@@ -253,48 +361,53 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
                 *(uint32_t*)(actB + rr * LDA + cb + e) = pack2(h0, h1);
                 if (PA == 2) *(uint32_t*)(actB + PLANE + rr * LDA + cb + e) = pack2(l0, l1);
             }
-            // pixel count of this row's mask (multiplies the folded feat_transform bias)
-            int c = 0;
-            if (row < Npad) {
-                const uint32_t* bw = a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32);
-                for (int w = (tid & 15); w < a.HWp / 32; w += 16) c += __popc(bw[w]);
-            }
-            c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+            c = (int)wave_group16_sum((float)c);          // exact: counts < 2^24
             if ((tid & 15) == 0) cnt[rr] = (float)c;
         }
     }
     __syncthreads();
 
     // ---- step 1: P = dynamic_layer(u), I = input_layer(k)   (kernel_updator.py:58-67) ------------
-    Tile<NRT> Pin, Iin, PI[2];   // PI[0] = P_out, PI[1] = I_out
-    tile_zero(Pin.v); tile_zero(Iin.v); tile_zero(PI[0].v); tile_zero(PI[1].v);
-    gemm_tile<PA, NRT, CT, 8>(Pin.v, actA, PLANE, wb + WO[PH_W_DYN], wpl, wave * CT, 8, 0, lane);
-    gemm_tile<PA, NRT, CT, 8>(PI[0].v, actA, PLANE, wb + WO[PH_W_DYN], wpl, 16 + wave * CT, 8, 0, lane);
-    gemm_tile<PA, NRT, CT, 8>(Iin.v, actB, PLANE, wb + WO[PH_W_INP], wpl, wave * CT, 8, 0, lane);
-    gemm_tile<PA, NRT, CT, 8>(PI[1].v, actB, PLANE, wb + WO[PH_W_INP], wpl, 16 + wave * CT, 8, 0, lane);
+    Tile<NRT> PI[2];   // PI[0] = P_out, PI[1] = I_out
+    const float* vc = wf + VO[PH_V_DYN_CNT];
+    const float* bd = wf + VO[PH_V_DYN_B];
+    const float* bi = wf + VO[PH_V_INP_B];
     {
-        const float* vc = wf + VO[PH_V_DYN_CNT];
-        const float* bd = wf + VO[PH_V_DYN_B];
-        const float* bi = wf + VO[PH_V_INP_B];
+        Tile<NRT> Pin, Iin;
+        tile_zero(Pin.v); tile_zero(Iin.v);
+        w_run<PA, NRT, CT, 8>(Pin.v, actA, PLANE, fa, c_dyn0, wpl, lane);
+        w_run<PA, NRT, CT, 8>(Iin.v, actB, PLANE, fb, c_inp0, wpl, lane);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int col = wave * WCOLS + ct * 16 + i;
-            const float vc0 = vc[col], vc1 = vc[256 + col], bd0 = bd[col], bd1 = bd[256 + col];
-            const float bi0 = bi[col], bi1 = bi[256 + col];
+            const float vc0 = vc[col], bd0 = bd[col], bi0 = bi[col];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float cn = cnt[rt * 16 + g * 4 + r];
                     const float pin = Pin.v[rt][ct][r] + cn * vc0 + bd0;
-                    PI[0].v[rt][ct][r] += cn * vc1 + bd1;
                     const float iin = Iin.v[rt][ct][r] + bi0;
-                    PI[1].v[rt][ct][r] += bi1;
                     Pin.v[rt][ct][r] = iin * pin;   // gate_feats = input_in * param_in   (:69)
                 }
         }
+        tile_to_lds<PA, NRT>(Pin, actG, PLANE, wave, lane);
     }
-    tile_to_lds<PA, NRT>(Pin, actG, PLANE, wave, lane);
+    tile_zero(PI[0].v); tile_zero(PI[1].v);
+    w_run<PA, NRT, CT, 8>(PI[0].v, actA, PLANE, fa, c_dyn1, wpl, lane);
+    w_run<PA, NRT, CT, 8>(PI[1].v, actB, PLANE, fb, c_inp1, wpl, lane);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * WCOLS + ct * 16 + i;
+        const float vc1 = vc[256 + col], bd1 = bd[256 + col], bi1 = bi[256 + col];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                PI[0].v[rt][ct][r] += cnt[rt * 16 + g * 4 + r] * vc1 + bd1;
+                PI[1].v[rt][ct][r] += bi1;
+            }
+    }
     {
         const float* const gm[2] = {wf + VO[PH_V_LN_PO_G], wf + VO[PH_V_LN_IO_G]};
         const float* const bt[2] = {wf + VO[PH_V_LN_PO_B], wf + VO[PH_V_LN_IO_B]};
@@ -305,8 +418,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     // ---- step 2: gates (kernel_updator.py:73-77), features (:86-87) --------------------------------
     Tile<NRT> G[2];   // G[0] = input_gate, G[1] = update_gate
     tile_zero(G[0].v); tile_zero(G[1].v);
-    gemm_tile<PA, NRT, CT, 8>(G[0].v, actG, PLANE, wb + WO[PH_W_IG], wpl, wave * CT, 8, 0, lane);
-    gemm_tile<PA, NRT, CT, 8>(G[1].v, actG, PLANE, wb + WO[PH_W_UG], wpl, wave * CT, 8, 0, lane);
+    w_run<PA, NRT, CT, 8>(G[0].v, actG, PLANE, fa, c_ig, wpl, lane);
+    w_run<PA, NRT, CT, 8>(G[1].v, actG, PLANE, fb, c_ug, wpl, lane);
     tile_add_bias(G[0], wf + VO[PH_V_IG_B], wave, lane);
     tile_add_bias(G[1], wf + VO[PH_V_UG_B], wave, lane);
     {
@@ -320,8 +433,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                G[0].v[rt][ct][r] = sigmoidf_(G[1].v[rt][ct][r]) * PI[0].v[rt][ct][r] +
-                                    sigmoidf_(G[0].v[rt][ct][r]) * PI[1].v[rt][ct][r];
+                G[0].v[rt][ct][r] = fast_sigmoid(G[1].v[rt][ct][r]) * PI[0].v[rt][ct][r] +
+                                    fast_sigmoid(G[0].v[rt][ct][r]) * PI[1].v[rt][ct][r];
     // ln_tiles ended with a barrier after every wave's last read of actG in the gate GEMMs
     tile_to_lds<PA, NRT>(G[0], actG, PLANE, wave, lane);
     __syncthreads();
@@ -329,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     // ---- step 3: fc_layer + fc_norm + ReLU (kernel_updator.py:89-91) -------------------------------
     Tile<NRT> O[1];
     tile_zero(O[0].v);
-    gemm_tile<PA, NRT, CT, 8>(O[0].v, actG, PLANE, wb + WO[PH_W_FC], wpl, wave * CT, 8, 0, lane);
+    w_run<PA, NRT, CT, 8>(O[0].v, actG, PLANE, fa, c_fc, wpl, lane);
     tile_add_bias(O[0], wf + VO[PH_V_FC_B], wave, lane);
     {
         const float* const gm[1] = {wf + VO[PH_V_LN_FC_G]};
@@ -354,45 +467,26 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre(const QArgs a) {
     const int64_t qk_base = (((int64_t)b * 2 + br) * Npad + row0) * 256;
     const int64_t qk_plane = (int64_t)a.B * 2 * Npad * 256;
     const int64_t vt_base = ((int64_t)b * 2 + br) * 256 * Npad + row0;
-#pragma unroll
-    for (int part = 0; part < 3; ++part) {
+    const float* qkv_bias = wf + VO[PH_V_QKV_B];
+    {
         Tile<NRT> T;
         tile_zero(T.v);
-        gemm_tile<PA, NRT, CT, 8>(T.v, actG, PLANE, wb + WO[PH_W_QKV], wpl, part * 16 + wave * CT, 8, 0, lane);
-        const float* bias = wf + VO[PH_V_QKV_B] + part * 256;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int col = wave * WCOLS + ct * 16 + i;
-            const float bv = bias[col];
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                uint32_t hi[4], lo[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = T.v[rt][ct][r] + bv;
-                    if (part == 0) v *= 0.17677669529663687f;   // q * head_dim^-0.5
-                    f2bf_split(v, hi[r], lo[r]);
-                }
-                if (part < 2) {
-                    uint16_t* dst = (part == 0 ? a.Qp : a.Kp) + qk_base + (rt * 16 + g * 4) * 256 + col;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[r * 256] = (uint16_t)hi[r];
-                        if (PA == 2) dst[qk_plane + r * 256] = (uint16_t)lo[r];
-                    }
-                } else {   // V transposed: [feature][query row], 4 consecutive rows per lane
-                    uint16_t* dst = a.Vt + vt_base + (int64_t)col * Npad + rt * 16 + g * 4;
-                    *(uint2*)dst = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
-                    if (PA == 2) *(uint2*)(dst + qk_plane) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
-                }
-            }
-        }
+        w_run<PA, NRT, CT, 8>(T.v, actG, PLANE, fb, c_q, wpl, lane);
+        store_qkv<PA, NRT, 0>(T, a, qkv_bias, qk_base, qk_plane, vt_base, wave, lane);
+        tile_zero(T.v);
+        w_run<PA, NRT, CT, 8>(T.v, actG, PLANE, fa, c_k, wpl, lane);
+        store_qkv<PA, NRT, 1>(T, a, qkv_bias + 256, qk_base, qk_plane, vt_base, wave, lane);
+        tile_zero(T.v);
+        w_run<PA, NRT, CT, 8>(T.v, actG, PLANE, fb, c_v, wpl, lane);
+        store_qkv<PA, NRT, 2>(T, a, qkv_bias + 512, qk_base, qk_plane, vt_base, wave, lane);
     }
 }
 
 // ================================================================================================
 //  k_query_post
 // ================================================================================================
+constexpr int MAXKT = 16;   // N <= 256 queries -> at most 16 key tiles / 8 key k-steps per head
+
 template <int PA, int NRT>
 __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     constexpr int ROWS = NRT * 16;
@@ -404,7 +498,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     const int Npad = a.Npad, N = a.N;
     const int LDP = Npad + 8;                               // row stride of a per-wave P buffer
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight / bias addresses live in SGPRs
     const int i = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * ROWS, br = blockIdx.y, b = blockIdx.z;
     const uint16_t* wb = a.wb;
@@ -418,36 +513,61 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     const uint16_t* Kb = a.Kp + ((int64_t)b * 2 + br) * Npad * 256;
     const uint16_t* Vb = a.Vt + ((int64_t)b * 2 + br) * 256 * Npad;
 
+    WFrag<PA, 8, CT> fa, fb;
+    const WRef c_out{wb + WO[PH_W_OUT], wave * CT, 8, 0};
+    const int ffn_ks = a.lay.ffn_dim / 32;
     // ---- attention: wave w owns head w for this block's ROWS query rows ---------------------------
     Tile<NRT> At[1];
     uint16_t* Pb = region + wave * (PA * ROWS * LDP);
     const int pplane = ROWS * LDP;
     {
         const int h = wave;
+        const int nkt = Npad / 16;
         uint4 qf[PA][NRT];
 #pragma unroll
         for (int p = 0; p < PA; ++p)
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
                 qf[p][rt] = *(const uint4*)(Qb + p * qk_plane + (rt * 16 + i) * 256 + h * 32 + g * 8);
+        // single-plane precision: the head's whole K and V^T slices (<= 16 + 16 fragments) are requested
+        // up front and reused by both softmax passes; split precision loads them where they are used.
+        constexpr int NPRE = PA == 1 ? MAXKT : 1;
+        uint4 kpre[NPRE], vpre[NPRE];
+        if constexpr (PA == 1) {
+#pragma unroll
+            for (int kt = 0; kt < MAXKT; ++kt)
+                if (kt < nkt) kpre[kt] = *(const uint4*)(Kb + (kt * 16 + i) * 256 + h * 32 + g * 8);
+#pragma unroll
+            for (int ks = 0; ks < MAXKT / 2; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    if (2 * ks < nkt) vpre[ks * 2 + ct] = *(const uint4*)(Vb + (int64_t)(h * 32 + ct * 16 + i) * Npad + ks * 32 + g * 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float mx[NRT][4], sm[NRT][4];
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { mx[rt][r] = -INFINITY; sm[rt][r] = 0.f; }
         // pass 1: row maxima
-        for (int kt = 0; kt < Npad / 16; ++kt) {
-            uint4 kf[PA];
 #pragma unroll
-            for (int p = 0; p < PA; ++p) kf[p] = *(const uint4*)(Kb + p * qk_plane + (kt * 16 + i) * 256 + h * 32 + g * 8);
-            const bool valid = kt * 16 + i < N;
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                uint4 kf[PA];
+                if constexpr (PA == 1) kf[0] = kpre[kt];
+                else {
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-                s = mfma16(qf[0][rt], kf[0], s);
-                if (PA == 2) { s = mfma16(qf[0][rt], kf[PA - 1], s); s = mfma16(qf[PA - 1][rt], kf[0], s); }
+                    for (int p = 0; p < PA; ++p) kf[p] = *(const uint4*)(Kb + p * qk_plane + (kt * 16 + i) * 256 + h * 32 + g * 8);
+                }
+                const bool valid = kt * 16 + i < N;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx[rt][r] = fmaxf(mx[rt][r], valid ? s[r] : -INFINITY);
+                for (int rt = 0; rt < NRT; ++rt) {
+                    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+                    s = mfma16(qf[0][rt], kf[0], s);
+                    if (PA == 2) { s = mfma16(qf[0][rt], kf[PA - 1], s); s = mfma16(qf[PA - 1][rt], kf[0], s); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx[rt][r] = fmaxf(mx[rt][r], valid ? s[r] : -INFINITY);
+                }
             }
         }
 #pragma unroll
@@ -455,56 +575,71 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx[rt][r] = wave_group16_max(mx[rt][r]);
         // pass 2: p = exp(s - max) -> LDS (bf16 planes), row sums
-        for (int kt = 0; kt < Npad / 16; ++kt) {
-            uint4 kf[PA];
 #pragma unroll
-            for (int p = 0; p < PA; ++p) kf[p] = *(const uint4*)(Kb + p * qk_plane + (kt * 16 + i) * 256 + h * 32 + g * 8);
-            const bool valid = kt * 16 + i < N;
+        for (int kt = 0; kt < MAXKT; ++kt) {
+            if (kt < nkt) {
+                uint4 kf[PA];
+                if constexpr (PA == 1) kf[0] = kpre[kt];
+                else {
 #pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) {
-                f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-                s = mfma16(qf[0][rt], kf[0], s);
-                if (PA == 2) { s = mfma16(qf[0][rt], kf[PA - 1], s); s = mfma16(qf[PA - 1][rt], kf[0], s); }
+                    for (int p = 0; p < PA; ++p) kf[p] = *(const uint4*)(Kb + p * qk_plane + (kt * 16 + i) * 256 + h * 32 + g * 8);
+                }
+                const bool valid = kt * 16 + i < N;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = valid ? expf(s[r] - mx[rt][r]) : 0.f;
-                    sm[rt][r] += pv;
-                    uint32_t hi, lo;
-                    f2bf_split(pv, hi, lo);
-                    const int off = (rt * 16 + g * 4 + r) * LDP + kt * 16 + i;
-                    Pb[off] = (uint16_t)hi;
-                    if (PA == 2) Pb[pplane + off] = (uint16_t)lo;
+                for (int rt = 0; rt < NRT; ++rt) {
+                    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+                    s = mfma16(qf[0][rt], kf[0], s);
+                    if (PA == 2) { s = mfma16(qf[0][rt], kf[PA - 1], s); s = mfma16(qf[PA - 1][rt], kf[0], s); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = valid ? fast_exp(s[r] - mx[rt][r]) : 0.f;
+                        sm[rt][r] += pv;
+                        const int off = (rt * 16 + g * 4 + r) * LDP + kt * 16 + i;
+                        if (PA == 2) {
+                            uint32_t hi, lo;
+                            f2bf_split(pv, hi, lo);
+                            Pb[off] = (uint16_t)hi;
+                            Pb[pplane + off] = (uint16_t)lo;
+                        } else Pb[off] = (uint16_t)f2bf(pv);
+                    }
                 }
             }
         }
+        w_issue(fa, c_out, wpl, lane);
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm[rt][r] = 1.f / wave_group16_sum(sm[rt][r]);
-        __syncthreads();   // P visible (per-wave buffers; the barrier orders this wave's LDS writes before its reads)
+            for (int r = 0; r < 4; ++r) sm[rt][r] = fast_rcp(wave_group16_sum(sm[rt][r]));
+        // The P buffer is private to this wave and LDS operations of one wave complete in order: no barrier.
         // PV: out[rows][32 d] = P[rows][keys] x V[keys][d]
         f32x4_t o[NRT][2];
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) { o[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; o[rt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-        for (int ks = 0; ks < Npad / 32; ++ks) {
-            uint4 pf[PA][NRT];
 #pragma unroll
-            for (int p = 0; p < PA; ++p)
-#pragma unroll
-                for (int rt = 0; rt < NRT; ++rt)
-                    pf[p][rt] = *(const uint4*)(Pb + p * pplane + (rt * 16 + i) * LDP + ks * 32 + g * 8);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                uint4 vf[PA];
+        for (int ks = 0; ks < MAXKT / 2; ++ks) {
+            if (2 * ks < nkt) {
+                uint4 pf[PA][NRT];
 #pragma unroll
                 for (int p = 0; p < PA; ++p)
-                    vf[p] = *(const uint4*)(Vb + p * qk_plane + (int64_t)(h * 32 + ct * 16 + i) * Npad + ks * 32 + g * 8);
 #pragma unroll
-                for (int rt = 0; rt < NRT; ++rt) {
-                    o[rt][ct] = mfma16(pf[0][rt], vf[0], o[rt][ct]);
-                    if (PA == 2) {
-                        o[rt][ct] = mfma16(pf[0][rt], vf[PA - 1], o[rt][ct]);
-                        o[rt][ct] = mfma16(pf[PA - 1][rt], vf[0], o[rt][ct]);
+                    for (int rt = 0; rt < NRT; ++rt)
+                        pf[p][rt] = *(const uint4*)(Pb + p * pplane + (rt * 16 + i) * LDP + ks * 32 + g * 8);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    uint4 vf[PA];
+                    if constexpr (PA == 1) vf[0] = vpre[ks * 2 + ct];
+                    else {
+#pragma unroll
+                        for (int p = 0; p < PA; ++p)
+                            vf[p] = *(const uint4*)(Vb + p * qk_plane + (int64_t)(h * 32 + ct * 16 + i) * Npad + ks * 32 + g * 8);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) {
+                        o[rt][ct] = mfma16(pf[0][rt], vf[0], o[rt][ct]);
+                        if (PA == 2) {
+                            o[rt][ct] = mfma16(pf[0][rt], vf[PA - 1], o[rt][ct]);
+                            o[rt][ct] = mfma16(pf[PA - 1][rt], vf[0], o[rt][ct]);
+                        }
                     }
                 }
             }
@@ -517,13 +652,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
                 for (int r = 0; r < 4; ++r) At[0].v[rt][ct][r] = o[rt][ct][r] * sm[rt][r];
     }
     tile_to_lds<PA, NRT>(At[0], actA, PLANE, wave, lane);
-    __syncthreads();
-
-    // ---- out_proj + identity + attention_norm (kernel_update_head.py:259-260) ----------------------
-    Tile<NRT> O2[1];
-    tile_zero(O2[0].v);
-    gemm_tile<PA, NRT, CT, 8>(O2[0].v, actA, PLANE, wb + WO[PH_W_OUT], wpl, wave * CT, 8, 0, lane);
-    tile_add_bias(O2[0], wf + VO[PH_V_OUT_B], wave, lane);
+    // residual of the attention block (written by the pre kernel): requested before the barrier
+    float res[NRT][CT][4];
     {
         const float* o1 = a.o1 + (((int64_t)b * 2 + br) * Npad + row0) * 256;
 #pragma unroll
@@ -531,7 +661,23 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) O2[0].v[rt][ct][r] += o1[(rt * 16 + g * 4 + r) * 256 + wave * WCOLS + ct * 16 + i];
+                for (int r = 0; r < 4; ++r) res[rt][ct][r] = o1[(rt * 16 + g * 4 + r) * 256 + wave * WCOLS + ct * 16 + i];
+    }
+    __syncthreads();   // also: every wave is done with its P buffer before `region` is reused below
+
+    // ---- out_proj + identity + attention_norm (kernel_update_head.py:259-260) ----------------------
+    Tile<NRT> O2[1];
+    tile_zero(O2[0].v);
+    w_issue(fb, WRef{wb + WO[PH_W_FFN1], wave * CT, 8, 0}, wpl, lane);
+    w_use<PA, NRT, CT, 8>(O2[0].v, actA, PLANE, fa, c_out, wpl, lane);
+    tile_add_bias(O2[0], wf + VO[PH_V_OUT_B], wave, lane);
+    {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) O2[0].v[rt][ct][r] += res[rt][ct][r];
         const float* const gm[1] = {wf + VO[PH_V_LN_ATT_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_ATT_B]};
         ln_tiles<NRT, 1>(O2, gm, bt, red, wave, lane);   // includes barriers: actA readers are done
@@ -540,14 +686,19 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     __syncthreads();
 
     // ---- FFN (mmcv FFN: x + W2 relu(W1 x + b1) + b2) + ffn_norm (kernel_update_head.py:270-272) ----
+    // software pipeline over the 2 * nchunk calls: fb = W1 chunk c (in flight on entry), fa = W2 chunk c
     uint16_t* hbuf[2] = {region, region + PA * PLANE};
     Tile<NRT> O3[1];
     tile_zero(O3[0].v);
     const int nchunk = a.lay.ffn_dim / 256;
+    const WRef c_h0a{wb + WO[PH_W_H0A], wave * CT, 8, 0};
     for (int c = 0; c < nchunk; ++c) {
+        const WRef w1{wb + WO[PH_W_FFN1], c * 16 + wave * CT, 8, 0};
+        const WRef w2{wb + WO[PH_W_FFN2], wave * CT, ffn_ks, c * 8};
         Tile<NRT> Hc;
         tile_zero(Hc.v);
-        gemm_tile<PA, NRT, CT, 8>(Hc.v, actA, PLANE, wb + WO[PH_W_FFN1], wpl, c * 16 + wave * CT, 8, 0, lane);
+        w_issue(fa, w2, wpl, lane);
+        w_use<PA, NRT, CT, 8>(Hc.v, actA, PLANE, fb, w1, wpl, lane);
         const float* b1 = wf + VO[PH_V_FFN1_B] + c * 256;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -559,8 +710,10 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
         }
         tile_to_lds<PA, NRT>(Hc, hbuf[c & 1], PLANE, wave, lane);
         __syncthreads();
-        gemm_tile<PA, NRT, CT, 8>(O3[0].v, hbuf[c & 1], PLANE, wb + WO[PH_W_FFN2], wpl, wave * CT, a.lay.ffn_dim / 32, c * 8,
-                                 lane);
+        // next W1 chunk, or -- after the last chunk -- the first head GEMM
+        const WRef nxt = c + 1 < nchunk ? WRef{wb + WO[PH_W_FFN1], (c + 1) * 16 + wave * CT, 8, 0} : c_h0a;
+        w_issue(fb, nxt, wpl, lane);
+        w_use<PA, NRT, CT, 8>(O3[0].v, hbuf[c & 1], PLANE, fa, w2, wpl, lane);
     }
     tile_add_bias(O3[0], wf + VO[PH_V_FFN2_B], wave, lane);
 #pragma unroll
@@ -590,12 +743,16 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     // ---- heads (kernel_update_head.py:274-288) ----------------------------------------------------
     uint16_t* bufM = region;                   // mask_fcs / depth_regs activation
     uint16_t* bufC = region + PA * PLANE;      // cls_fcs activation (mask branch)
+    const WRef c_kern{wb + WO[PH_W_KERN], wave * CT, 8, 0};
     Tile<NRT> Hd[2];
     tile_zero(Hd[0].v);
-    gemm_tile<PA, NRT, CT, 8>(Hd[0].v, actA, PLANE, wb + WO[PH_W_H0A], wpl, wave * CT, 8, 0, lane);
     if (br == 0) {
+        const WRef c_h0b{wb + WO[PH_W_H0B], wave * CT, 8, 0};
+        w_issue(fa, c_h0b, wpl, lane);
+        w_use<PA, NRT, CT, 8>(Hd[0].v, actA, PLANE, fb, c_h0a, wpl, lane);
         tile_zero(Hd[1].v);
-        gemm_tile<PA, NRT, CT, 8>(Hd[1].v, actA, PLANE, wb + WO[PH_W_H0B], wpl, wave * CT, 8, 0, lane);
+        w_issue(fb, c_kern, wpl, lane);
+        w_use<PA, NRT, CT, 8>(Hd[1].v, actA, PLANE, fa, c_h0b, wpl, lane);
         const float* const gm[2] = {wf + VO[PH_V_LN_H0A_G], wf + VO[PH_V_LN_H0B_G]};
         const float* const bt[2] = {wf + VO[PH_V_LN_H0A_B], wf + VO[PH_V_LN_H0B_B]};
         ln_tiles<NRT, 2>(Hd, gm, bt, red, wave, lane);
@@ -610,6 +767,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
         tile_to_lds<PA, NRT>(Hd[0], bufC, PLANE, wave, lane);
         tile_to_lds<PA, NRT>(Hd[1], bufM, PLANE, wave, lane);
     } else {
+        w_use<PA, NRT, CT, 8>(Hd[0].v, actA, PLANE, fb, c_h0a, wpl, lane);
+        w_issue(fb, c_kern, wpl, lane);
         Tile<NRT> D[1] = {Hd[0]};
         const float* const gm[1] = {wf + VO[PH_V_LN_H0A_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_H0A_B]};
@@ -618,6 +777,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
     }
     __syncthreads();
 
+    WFrag<PA, 8, 1> f1;
     if (br == 0) {   // fc_cls  (:285)
         const int L = a.lay.num_classes, nct = (L + 15) / 16;
         const float* bc = wf + VO[PH_V_CLS_B];
@@ -625,7 +785,9 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
             f32x4_t acc[NRT][1];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) acc[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            gemm_tile<PA, NRT, 1, 8>(acc, bufC, PLANE, wb + WO[PH_W_CLS], wpl, ct, 8, 0, lane);
+            const WRef c_cls{wb + WO[PH_W_CLS], ct, 8, 0};
+            w_load(f1, c_cls, wpl, lane);
+            w_use_loaded<PA, NRT, 1, 8>(acc, bufC, PLANE, f1, lane);
             const int col = ct * 16 + i;
             if (col < L) {
                 const float bv = bc[col];
@@ -636,16 +798,17 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
                         const int row = row0 + rt * 16 + g * 4 + r;
                         if (row < N) {
                             const float z = acc[rt][0][r] + bv;
-                            a.cls[((int64_t)b * N + row) * L + col] = a.cls_sigmoid ? sigmoidf_(z) : z;
+                            a.cls[((int64_t)b * N + row) * L + col] = a.cls_sigmoid ? fast_sigmoid(z) : z;
                         }
                     }
             }
         }
     }
     {   // fc_mask / fc_depth folded with feat_transform / feat_depth_transform -> conv kernel + bias
+        if (wave == 0) w_load(f1, WRef{wb + WO[PH_W_KERN], 16, 8, 0}, wpl, lane);   // column 256: kernel . transform bias
         Tile<NRT> Kt;
         tile_zero(Kt.v);
-        gemm_tile<PA, NRT, CT, 8>(Kt.v, bufM, PLANE, wb + WO[PH_W_KERN], wpl, wave * CT, 8, 0, lane);
+        w_use<PA, NRT, CT, 8>(Kt.v, bufM, PLANE, fb, c_kern, wpl, lane);
         const float* bk = wf + VO[PH_V_KERN_B];
         const int64_t kplane = (int64_t)2 * a.B * Npad * 256;
         uint16_t* kd = a.kern + (((int64_t)br * a.B + b) * Npad + row0) * 256;
@@ -664,11 +827,11 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
                     if (PA == 2) kd[kplane + off] = (uint16_t)lo;
                 }
         }
-        if (wave == 0) {   // column 256 of the folded matrix: kernel . transform bias
+        if (wave == 0) {
             f32x4_t acc[NRT][1];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) acc[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            gemm_tile<PA, NRT, 1, 8>(acc, bufM, PLANE, wb + WO[PH_W_KERN], wpl, 16, 8, 0, lane);
+            w_use_loaded<PA, NRT, 1, 8>(acc, bufM, PLANE, f1, lane);
             if (i == 0) {
                 const float bv = bk[256];
 #pragma unroll
