@@ -15,6 +15,32 @@
 
 constexpr int CONV_T = 64;            // pixels per tile: one 128-byte line per channel row
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// ---- LDS accesses of the tile loop, hidden from the compiler -------------------------------------------
+// hipcc waits vmcnt(0) before any DS access it can see while an LDS-DMA that may alias it is in flight
+// (SIInsertWaitcnts), which would drain the ring every tile.  Ordering is done by hand: counted vmcnt + raw
+// s_barrier before the first read of a tile, counted lgkmcnt before the first use of a read.
+template <int OFF> __device__ __forceinline__ u32x2_t lds_tr16_asm(uint32_t byte_addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ u32x4_t lds_read128_asm(uint32_t byte_addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ void lds_write_asm(uint32_t byte_addr, float v, float*) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_write_asm(uint32_t byte_addr, float v, uint16_t*) {
+    const uint32_t h = f2bf(v);
+    asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(byte_addr), "v"(h), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(PH_LDS const void*)p; }
+
 __device__ __forceinline__ void st_out(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_out(uint16_t* p, float v) { *p = (uint16_t)f2bf(v); }
 
@@ -25,148 +51,301 @@ __device__ __forceinline__ void st_out(uint16_t* p, float v) { *p = (uint16_t)f2
 // the 4 rows x 2 half-tiles a 32-lane read touches then cover 8 distinct 32-byte bank windows.
 __device__ __forceinline__ int conv_swz(int row) { return ((row >> 1) & 1) << 2; }
 
-// row stride (elements) of the per-wave epilogue patch: 64 px + 16 bytes of padding
-template <typename OutT> __device__ __host__ constexpr int EP_LD() { return CONV_T + 16 / (int)sizeof(OutT); }
+
+// ---- MFMA phase of one 32-pixel half: 16 k-steps, B fragments by transposing reads, KB k-steps per batch, the
+// reads of batch i+1 in flight while the MFMAs of batch i run.  Compile-time recursion (immediate offsets).
+template <int PA, int KB, int BI, int K = 0, int P = 0>
+__device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PA][KB][2]) {
+    if constexpr (K < KB) {
+        constexpr int OFF = P * (256 * CONV_T * 2) + (BI * KB + K) * 2048;     // plane, k-step (16 rows x 128 B)
+        dst[P][K][0] = lds_tr16_asm<OFF>(fa);
+        dst[P][K][1] = lds_tr16_asm<OFF + 4 * CONV_T * 2>(fa);                 // 4 rows below
+        if constexpr (P + 1 < PA) conv_read_batch<PA, KB, BI, K, P + 1>(fa, dst);
+        else conv_read_batch<PA, KB, BI, K + 1, 0>(fa, dst);
+    }
+}
+
+template <int PA, int KB, int BI>
+__device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][16], u32x2_t (&bq)[2][PA][KB][2], f32x16_t& acc) {
+    constexpr int NBATCH = 16 / KB;
+    if constexpr (BI < NBATCH) {
+        if constexpr (BI + 1 < NBATCH) {
+            conv_read_batch<PA, KB, BI + 1>(fa, bq[(BI + 1) & 1]);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PA * KB) : "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            uint4 bf[PA];
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+                bf[p] = make_uint4(bq[BI & 1][p][k][0].x, bq[BI & 1][p][k][0].y, bq[BI & 1][p][k][1].x, bq[BI & 1][p][k][1].y);
+            acc = mfma32(af[0][BI * KB + k], bf[0], acc);
+            if (PA == 2) {
+                acc = mfma32(af[0][BI * KB + k], bf[PA - 1], acc);
+                acc = mfma32(af[PA - 1][BI * KB + k], bf[0], acc);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        conv_batches<PA, KB, BI + 1>(fa, af, bq, acc);
+    }
+}
+
+template <int R = 0> __device__ __forceinline__ void conv_bias_get(uint32_t addr, float (&bias)[16]) {
+    if constexpr (R < 16) {
+        constexpr int rr = (R & 3) + 8 * (R >> 2);
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bias[R]) : "v"(addr), "n"(rr * 4));
+        conv_bias_get<R + 1>(addr, bias);
+    }
+}
+
+// patch writes of the 16 C-layout registers of a lane (rows rr + 4g), immediate row offsets
+template <typename OutT, int LD, int R = 0>
+__device__ __forceinline__ void conv_patch_put(uint32_t wa, const f32x16_t& acc, const float (&bias)[16]) {
+    if constexpr (R < 16) {
+        constexpr int rr = (R & 3) + 8 * (R >> 2);
+        lds_write_asm<rr * LD * (int)sizeof(OutT)>(wa, acc[R] + bias[R], (OutT*)nullptr);
+        conv_patch_put<OutT, LD, R + 1>(wa, acc, bias);
+    }
+}
+
+constexpr int conv_dma_waves(int nw, int pieces) {
+    int d = nw < pieces ? nw : pieces;
+    while (pieces % d) --d;
+    return d;
+}
+
+// Compile-time geometry of one instantiation.  A workgroup has 2 waves per 32-row block of queries (one per
+// 32-pixel half of the tile) and owns the whole LDS of its CU: a ring of NBUF tile buffers, NBUF-1 tiles of DMA
+// in flight while one is consumed (96 KiB at cfg2), plus -- logits output, single-plane precision -- a per-wave
+// transposition patch.
+template <int PA, int NRT, bool BITS, typename OutT> struct ConvCfg {
+    // 32-pixel halves per wave: one (two waves per row block) while that keeps <= 3 waves per SIMD (168 VGPRs for
+    // the 64-VGPR A operand + fragments); two for wide N and for split precision (A operand = 128 VGPRs)
+    static constexpr int HPW = (PA == 1 && NRT <= 6) ? 1 : 2;
+    static constexpr int NW = 2 * NRT / HPW;
+    static constexpr int TILE = 256 * CONV_T;                                  // elements per plane per buffer
+    static constexpr int TILEB = PA * TILE * 2;                                // bytes per ring stage
+    static constexpr int PATCH_LD = 32 + 16 / (int)sizeof(OutT);               // elements: 32 px + 16 B padding
+    static constexpr bool PATCH = !BITS && PA == 1;
+    static constexpr int PATCHB = PATCH ? NW * 32 * PATCH_LD * (int)sizeof(OutT) : 0;
+    static constexpr int LDS_MAX = 160 * 1024;
+    static constexpr int NDW = conv_dma_waves(NW, 32 * PA);                    // waves that issue DMA
+    static constexpr int DPW = 32 * PA / NDW;                                  // ... instructions each per tile
+    static constexpr int KBB = NW * 32 * 4;                                    // per-wave copy of its 32 biases
+    static constexpr int NBUF = 4 * TILEB + PATCHB + KBB <= LDS_MAX ? 4 : (3 * TILEB + PATCHB + KBB <= LDS_MAX ? 3 : 2);
+    static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
+};
 
 template <int PA, int NRT, bool BITS, typename OutT>
-__global__ __launch_bounds__(NRT * 64) void k_dynconv(const uint16_t* __restrict__ planes,
-                                                      const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
-                                                      int64_t kern_batch_stride, const float* __restrict__ kbias,
-                                                      int64_t kbias_batch_stride, uint32_t* __restrict__ bits_out,
-                                                      OutT* __restrict__ logits_out, int64_t out_batch_stride, int B,
-                                                      int N, int64_t HW, int64_t HWp, int tiles_per_wg) {
-    constexpr int Npad = NRT * 32;
-    constexpr int TILE = 256 * CONV_T;                               // elements per plane per buffer
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [2 buffers][PA][256][64]
+__global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
+                                                          const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
+                                                          int64_t kern_batch_stride, const float* __restrict__ kbias,
+                                                          int64_t kbias_batch_stride, uint32_t* __restrict__ bits_out,
+                                                          OutT* __restrict__ logits_out, int64_t out_batch_stride, int B,
+                                                          int N, int64_t HW, int64_t HWp) {
+    using C = ConvCfg<PA, NRT, BITS, OutT>;
+    constexpr int Npad = NRT * 32, TILE = C::TILE, NBUF = C::NBUF;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][PA][256][64] | patch[NW][32][PATCH_LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int rt = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave % NRT, half0 = (wave / NRT) * C::HPW;       // 32-row block, first 32-pixel half of the tile
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
     const int64_t fplane = (int64_t)B * PH_C * HWp;
-    const uint16_t* fbase = planes + (int64_t)b * PH_C * HWp;
 
-    // A operand: this wave's 32 kernel rows, all 16 k-steps
-    uint4 af[PA][16];
+    // this workgroup's share of the B * ntiles tiles: one contiguous range (may span frames).  Measured
+    // alternative: teams of workgroups interleaving the tiles of one frame (adjacent 128-byte pieces of a channel
+    // row read at the same time, whole DRAM pages) -- 7 % slower, the extra A-operand reloads cost more than the
+    // page locality gives.
+    const int ntiles = (int)(HWp / CONV_T);
+    const int64_t total64 = (int64_t)B * ntiles;
+    const int tg0 = (int)(total64 * blockIdx.x / gridDim.x), tg1 = (int)(total64 * (blockIdx.x + 1) / gridDim.x);
+    if (tg0 >= tg1) return;
+
+    // LDS-DMA of tile (b, t) into ring buffer `buf`: 32 wave-instructions of 1 KiB (8 rows x 128 B) per plane.
+    // Address = wave-uniform base (SGPRs) + ONE per-lane byte offset: row-in-piece * HWp + swizzled 16-byte piece
+    // (the swizzle needs bit 1 of the row, which is bit 1 of lane >> 3 whatever the piece).
+    const uint32_t dma_lane_off = 2u * (uint32_t)((lane >> 3) * HWp + (((lane & 7) ^ conv_swz(lane >> 3)) * 8));
+    auto issue_tile = [&](int b, int t, int buf) {
+        if (wave < C::NDW) {
+#pragma unroll
+            for (int k = 0; k < C::DPW; ++k) {
+                const int j = wave + C::NDW * k;
+                const int p = j >> 5, jj = j & 31;
+                const uint16_t* ubase = planes + p * fplane + ((int64_t)b * PH_C + jj * 8) * HWp + (int64_t)t * CONV_T;
+                const char* src = (const char*)ubase + dma_lane_off;
+                uint16_t* dst = lds + (buf * PA + p) * TILE + jj * 512;          // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (PH_LDS void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    int ib = tg0 / ntiles, it = tg0 - ib * ntiles, ti = tg0;        // next tile to request
+    auto issue_next = [&](int buf) {
+        issue_tile(ib, it, buf);
+        ++ti;
+        if (++it == ntiles) { it = 0; ++ib; }
+    };
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (ti < tg1) issue_next(d);
+
+    // B-fragment read address of this lane inside a tile (bytes): row (ks = 0) = g*8 + (i16 >> 2); the swizzle
+    // depends on bit 1 of the row = bit 3 of i16 only, so every k-step is an immediate offset of ks * 2 KiB
+    const int row0 = g * 8 + (i16 >> 2);
+    uint32_t frag_off[C::HPW];
+#pragma unroll
+    for (int h = 0; h < C::HPW; ++h)
+        frag_off[h] = 2u * (uint32_t)(row0 * CONV_T + ((((half0 + h) * 4 + gi * 2) ^ conv_swz(row0)) * 8) + (i16 & 3) * 4);
+    const uint32_t lds0 = lds_addr(lds);
+    const uint32_t patch_addr = lds0 + NBUF * C::TILEB + wave * (32 * C::PATCH_LD * (int)sizeof(OutT));
+    // this wave's 32 biases live in LDS (a select between two wave-uniform array elements is turned into an
+    // indexed scratch access by the optimiser, and scratch traffic shares vmcnt with the DMA ring)
+    float* kb_lds = (float*)((unsigned char*)lds + NBUF * C::TILEB + C::PATCHB) + wave * 32;
+    const uint32_t kb_addr = lds_addr(kb_lds) + 16 * g;
+
+    uint4 af[PA][16];      // A operand: this wave's 32 kernel rows, all 16 k-steps
+
+    // results of the previous tile, written out one iteration late (after the next barrier) so that the
+    // vector-memory queue in front of each counted wait is [stores(t-1), DMA(t+1) .. DMA(t+NBUF-1)]
+    int pend = 0, pend_b = 0, pend_t = 0, pend_h = 0;     // 0 none, 1 bits word(s), 2 patch of half half0 + pend_h
+    uint32_t pend_word[C::HPW] = {};
+    constexpr int PER16 = 16 / (int)sizeof(OutT);                // elements per 16-byte store
+    constexpr int LPR = 32 / PER16;                              // lanes per row: 4 (bf16) / 8 (fp32)
+    constexpr int RPI = 64 / LPR;                                // rows per store instruction
+    // per-lane parts of the output addresses (bytes), one VGPR each; everything else is wave-uniform
+    const uint32_t bits_lane_off = 4u * (uint32_t)((lane & 31) * (HWp / 32));
+    const uint32_t patch_lane_off = (uint32_t)sizeof(OutT) * (uint32_t)((lane / LPR) * HW + (lane % LPR) * PER16);
+    const uint32_t slow_lane_off = (uint32_t)sizeof(OutT) * (uint32_t)((4 * g) * HW + (lane & 31));
+    auto flush = [&]() {
+        if (BITS) {
+            if (pend == 1 && lane < 32) {
+                const uint32_t* ub = bits_out + ((int64_t)pend_b * Npad + rt * 32) * (HWp / 32) + pend_t * 2 + half0;
+                uint32_t* w = (uint32_t*)((char*)ub + bits_lane_off);
+#pragma unroll
+                for (int h = 0; h < C::HPW; ++h) w[h] = pend_word[h];
+            }
+        } else if (C::PATCH) {
+            if (pend == 2) {
+                u32x4_t v[32 / RPI];
+#pragma unroll
+                for (int k = 0; k < 32 / RPI; ++k)
+                    v[k] = lds_read128_asm(patch_addr + ((k * RPI + lane / LPR) * C::PATCH_LD + (lane % LPR) * PER16) * (int)sizeof(OutT));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const OutT* ub = logits_out + (int64_t)pend_b * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)pend_t * CONV_T + (half0 + pend_h) * 32;
+#pragma unroll
+                for (int k = 0; k < 32 / RPI; ++k) {
+                    const int row = rt * 32 + k * RPI + lane / LPR;
+                    if (row < N) *(u32x4_t*)((char*)(ub + (int64_t)(k * RPI) * HW) + patch_lane_off) = v[k];
+                }
+            }
+        }
+        pend = 0;
+    };
+
+    int b = tg0 / ntiles, t = tg0 - b * ntiles, cur = 0;
+    for (int tg = tg0; tg < tg1; ++b, t = 0) {      // one pass per frame this workgroup's range touches
+    int seg_end = tg + (ntiles - t);
+    if (seg_end > tg1) seg_end = tg1;
+    // The A operand of the frame: ordinary VGPR loads OUTSIDE the tile loop (inside it they would be a
+    // loop-carried phi and the compiler would wait vmcnt(0) on them every tile).  The compiler-visible
+    // s_waitcnt retires them in its scoreboard; it also drains the ring, once per frame.
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const uint16_t* kr = kern + p * kern_plane_stride + (int64_t)b * kern_batch_stride + (rt * 32 + (lane & 31)) * PH_C + g * 8;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) af[p][ks] = *(const uint4*)(kr + ks * 16);
     }
-    const float* kbp = kbias + (int64_t)b * kbias_batch_stride + rt * 32 + 4 * g;
-
-    const int ntiles = (int)(HWp / CONV_T);
-    const int t0 = blockIdx.x * tiles_per_wg;
-    const int t1 = (t0 + tiles_per_wg < ntiles) ? t0 + tiles_per_wg : ntiles;
-
-    // LDS-DMA of tile t into buffer `buf`: 32 wave-instructions of 1 KiB (8 rows x 128 B) per plane
-    auto issue_tile = [&](int t, int buf) {
-        for (int j = rt; j < 32 * PA; j += NRT) {
-            const int p = j >> 5, jj = j & 31;
-            const int row = jj * 8 + (lane >> 3);
-            const int q = (lane & 7) ^ conv_swz(row);
-            const uint16_t* src = fbase + p * fplane + (int64_t)row * HWp + (int64_t)t * CONV_T + q * 8;
-            uint16_t* dst = lds + (buf * PA + p) * TILE + jj * 512;          // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (PH_LDS void*)dst, 16, 0, 0);
+    if (lane < 32) kb_lds[lane] = kbias[(int64_t)b * kbias_batch_stride + rt * 32 + lane];
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+    for (; tg < seg_end; ++tg, ++t) {
+        {
+            // tile tg must have landed; up to NBUF-2 younger tiles stay in flight across the barrier
+            const int younger = (tg1 - 1 - tg) < (NBUF - 2) ? (tg1 - 1 - tg) : (NBUF - 2);
+            if (NBUF >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::DPW) : "memory");
+            else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    };
-    if (t0 < t1) issue_tile(t0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = t0; t < t1; ++t) {
-        const int cur = (t - t0) & 1;
-        if (t + 1 < t1) issue_tile(t + 1, cur ^ 1);      // DMA overlaps the MFMA phase below
-        const uint16_t* tile = lds + cur * PA * TILE;
-        f32x16_t acc[CONV_T / 32];
-#pragma unroll
-        for (int ct = 0; ct < CONV_T / 32; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                uint4 bf[PA];
-                const int row = ks * 16 + g * 8 + (i16 >> 2);
-                const int off = row * CONV_T + (((ct * 4 + gi * 2) ^ conv_swz(row)) * 8) + (i16 & 3) * 4;
-#pragma unroll
-                for (int p = 0; p < PA; ++p) {
-                    const uint2 lo = lds_read_tr16(tile + p * TILE + off);
-                    const uint2 hi = lds_read_tr16(tile + p * TILE + off + 4 * CONV_T);
-                    bf[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-                acc[ct] = mfma32(af[0][ks], bf[0], acc[ct]);
-                if (PA == 2) {
-                    acc[ct] = mfma32(af[0][ks], bf[PA - 1], acc[ct]);
-                    acc[ct] = mfma32(af[PA - 1][ks], bf[0], acc[ct]);
-                }
-            }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        flush();
+        // every wave is past compute(tg-1): its buffer is free for tile tg + NBUF-1
+        if (ti < tg1) {
+            int nb = cur + NBUF - 1;
+            if (nb >= NBUF) nb -= NBUF;
+            issue_next(nb);
         }
-        const int64_t px0 = (int64_t)t * CONV_T;
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int h = 0; h < C::HPW; ++h) {
+        // ---- MFMA phase: 16 k-steps, B fragments by transposing reads, KB k-steps per batch, one batch ahead
+        const uint32_t fa = lds0 + cur * C::TILEB + frag_off[h];
+        const int half = half0 + h;
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        constexpr int KB = 2;                        // 4 * PA reads per batch (lgkmcnt counts to 15)
+        u32x2_t bq[2][PA][KB][2];
+        conv_read_batch<PA, KB, 0>(fa, bq[0]);
+        conv_batches<PA, KB, 0>(fa, af, bq, acc);
+
+        // ---- epilogue of tile (b, t), 32-pixel half `half`
+        const int64_t px = (int64_t)t * CONV_T + half * 32 + (lane & 31);
+        float bias[16];
+        conv_bias_get(kb_addr, bias);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         if (BITS) {
+            uint32_t word = 0;
 #pragma unroll
-            for (int ct = 0; ct < CONV_T / 32; ++ct) {
-                const int64_t px = px0 + ct * 32 + (lane & 31);
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const int row = rt * 32 + rr + 4 * g;
+                const unsigned long long m = __ballot(acc[r] + bias[r] > 0.f && px < HW && row < N);
+                // lanes 0..31 voted for row rr, lanes 32..63 for the row 4 below; lane l keeps the word of row l
+                word = lane == rr ? (uint32_t)m : word;
+                word = lane == rr + 4 ? (uint32_t)(m >> 32) : word;
+            }
+            pend_word[h] = word; pend = 1; pend_b = b; pend_t = t;
+        } else {
+            const bool fast = C::PATCH && (HW % PER16 == 0) && ((int64_t)(t + 1) * CONV_T <= HW);
+            if (fast) {
+                // transpose the [32 rows][32 px] result through the per-wave LDS patch so that every lane stores
+                // 16 contiguous bytes of one row
+                if (C::HPW > 1) flush();   // the one patch still holds the previous half: write it out first
+                const uint32_t wa = patch_addr + ((4 * g) * C::PATCH_LD + (lane & 31)) * (int)sizeof(OutT);
+                conv_patch_put<OutT, C::PATCH_LD>(wa, acc, bias);
+                pend = 2; pend_b = b; pend_t = t; pend_h = h;
+            } else {
+                const OutT* ub = logits_out + (int64_t)b * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)t * CONV_T + half * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
                     const int row = rt * 32 + rr + 4 * g;
-                    const float v = acc[ct][r] + kbp[rr];
-                    const unsigned long long m = __ballot(v > 0.f && px < HW && row < N);
-                    // lanes 0..31 -> row with g = 0, lanes 32..63 -> the row 4 below
-                    if (lane == 0) {
-                        uint32_t* w = bits_out + ((int64_t)b * Npad + rt * 32 + rr) * (HWp / 32) + (px >> 5);
-                        w[0] = (uint32_t)m;
-                        w[4 * (HWp / 32)] = (uint32_t)(m >> 32);
-                    }
-                }
-            }
-        } else {
-            constexpr int PER16 = 16 / (int)sizeof(OutT);                    // elements per 16-byte store
-            // (split precision keeps both LDS buffers at 64 KiB each: no room for the patch, scalar stores)
-            const bool fast = (PA == 1) && (HW % PER16 == 0) && (px0 + CONV_T <= HW);
-            if (fast) {
-                // transpose the [32 rows][64 px] result through a per-wave LDS patch so that every lane stores
-                // 16 contiguous bytes of one row (whole 128 / 256-byte row segments per instruction group)
-                OutT* ep = (OutT*)(lds + 2 * PA * TILE) + rt * (32 * EP_LD<OutT>());
-#pragma unroll
-                for (int ct = 0; ct < CONV_T / 32; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = (r & 3) + 8 * (r >> 2);
-                        st_out(ep + (rr + 4 * g) * EP_LD<OutT>() + ct * 32 + (lane & 31), acc[ct][r] + kbp[rr]);
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                constexpr int LPR = CONV_T / PER16;                          // lanes per row: 8 (bf16) / 16 (fp32)
-                constexpr int RPI = 64 / LPR;                                // rows per iteration
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int rl = it * RPI + lane / LPR, piece = lane % LPR;
-                    const int row = rt * 32 + rl;
-                    const uint4 v = *(const uint4*)(ep + rl * EP_LD<OutT>() + piece * PER16);
-                    if (row < N)
-                        *(uint4*)(logits_out + (int64_t)b * out_batch_stride + (int64_t)row * HW + px0 + piece * PER16) = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-#pragma unroll
-                for (int ct = 0; ct < CONV_T / 32; ++ct) {
-                    const int64_t px = px0 + ct * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = (r & 3) + 8 * (r >> 2);
-                        const int row = rt * 32 + rr + 4 * g;
-                        if (row < N && px < HW)
-                            st_out(logits_out + (int64_t)b * out_batch_stride + (int64_t)row * HW + px, acc[ct][r] + kbp[rr]);
-                    }
+                    if (row < N && px < HW) st_out((OutT*)((char*)(ub + (int64_t)rr * HW) + slow_lane_off), acc[r] + bias[r]);
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile t+1 have landed
-        __syncthreads();                                    // ... and everybody's; tile t's readers are done
+        }
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
+    }
+    flush();
+}
+
+static int conv_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
 }
 
 template <int PA, int NRT>
@@ -174,26 +353,24 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
                        int64_t bbs, uint32_t* bits_out, void* logits_out, int out_dtype, int64_t obs, int B, int N,
                        int64_t HW, hipStream_t s) {
     const int64_t HWp = ph_hw_padded(HW);
-    const int ntiles = (int)(HWp / CONV_T);
-    // at most one resident generation of workgroups (2 per CU = 512), evenly split over the frames: no tail
-    int gx = 512 / B;
-    if (gx < 1) gx = 1;
-    int tpw = (ntiles + gx - 1) / gx;
-    if (tpw < 1) tpw = 1;
-    if (const char* e = getenv("PH_CONV_TPW")) tpw = atoi(e);   // tuning knob
-    const dim3 grid((ntiles + tpw - 1) / tpw, B), block(NRT * 64);
-    size_t lds = (size_t)2 * PA * 256 * CONV_T * sizeof(uint16_t);
-    if (!bits_out && PA == 1) lds += (size_t)NRT * 32 * (out_dtype == PH_OUT_F32 ? EP_LD<float>() * 4 : EP_LD<uint16_t>() * 2);
+    const int64_t total = (int64_t)B * (HWp / CONV_T);
+    // one persistent workgroup per CU (it owns the CU's LDS), tiles split evenly: no tail generation
+    int wgs = conv_num_cus();
+    if (const char* e = getenv("PH_CONV_WGS")) wgs = atoi(e);   // tuning knob
+    if (wgs > total) wgs = (int)total;
+    if (wgs < 1) wgs = 1;
+    const dim3 grid(wgs), block(ConvCfg<PA, NRT, true, float>::NW * 64);
 #define PH_CONV_LAUNCH(BITS, T)                                                                                      \
     do {                                                                                                             \
+        constexpr int lds = ConvCfg<PA, NRT, BITS, T>::LDSB;                                                         \
         static bool once = false;                                                                                    \
         if (!once) {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)k_dynconv<PA, NRT, BITS, T>,                                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
             once = true;                                                                                             \
         }                                                                                                            \
         hipLaunchKernelGGL((k_dynconv<PA, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
-                           bits_out, (T*)logits_out, obs, B, N, HW, HWp, tpw);                                       \
+                           bits_out, (T*)logits_out, obs, B, N, HW, HWp);                                            \
     } while (0)
     if (bits_out) PH_CONV_LAUNCH(true, float);
     else if (out_dtype == PH_OUT_F32) PH_CONV_LAUNCH(false, float);
