@@ -66,7 +66,8 @@ __device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PA][
 }
 
 template <int PA, int KB, int BI>
-__device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][16], u32x2_t (&bq)[2][PA][KB][2], f32x16_t& acc) {
+__device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][16], u32x2_t (&bq)[2][PA][KB][2], f32x16_t& acc,
+                                             const float (&bias)[16]) {
     constexpr int NBATCH = 16 / KB;
     if constexpr (BI < NBATCH) {
         if constexpr (BI + 1 < NBATCH) {
@@ -76,6 +77,10 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BI == 0) {   // the accumulator starts from the bias
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+        }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             uint4 bf[PA];
@@ -89,25 +94,33 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        conv_batches<PA, KB, BI + 1>(fa, af, bq, acc);
+        conv_batches<PA, KB, BI + 1>(fa, af, bq, acc, bias);
     }
 }
 
-template <int R = 0> __device__ __forceinline__ void conv_bias_get(uint32_t addr, float (&bias)[16]) {
-    if constexpr (R < 16) {
-        constexpr int rr = (R & 3) + 8 * (R >> 2);
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bias[R]) : "v"(addr), "n"(rr * 4));
-        conv_bias_get<R + 1>(addr, bias);
-    }
+// The 16 biases of a lane's C-layout rows (rr + 4g, rr = (r & 3) + 8 (r >> 2)) from the wave's LDS copy.  Reads AND
+// their wait are ONE asm statement: the values are later copied into the accumulator tuple by compiler-generated
+// moves, which must never run ahead of a hand-placed s_waitcnt.
+__device__ __forceinline__ void conv_bias_get(uint32_t addr, float (&b)[16]) {
+    asm volatile(
+        "ds_read_b32 %0, %16\n ds_read_b32 %1, %16 offset:4\n ds_read_b32 %2, %16 offset:8\n ds_read_b32 %3, %16 offset:12\n"
+        "ds_read_b32 %4, %16 offset:32\n ds_read_b32 %5, %16 offset:36\n ds_read_b32 %6, %16 offset:40\n ds_read_b32 %7, %16 offset:44\n"
+        "ds_read_b32 %8, %16 offset:64\n ds_read_b32 %9, %16 offset:68\n ds_read_b32 %10, %16 offset:72\n ds_read_b32 %11, %16 offset:76\n"
+        "ds_read_b32 %12, %16 offset:96\n ds_read_b32 %13, %16 offset:100\n ds_read_b32 %14, %16 offset:104\n ds_read_b32 %15, %16 offset:108\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7]), "=&v"(b[8]),
+          "=&v"(b[9]), "=&v"(b[10]), "=&v"(b[11]), "=&v"(b[12]), "=&v"(b[13]), "=&v"(b[14]), "=&v"(b[15])
+        : "v"(addr)
+        : "memory");
 }
 
 // patch writes of the 16 C-layout registers of a lane (rows rr + 4g), immediate row offsets
 template <typename OutT, int LD, int R = 0>
-__device__ __forceinline__ void conv_patch_put(uint32_t wa, const f32x16_t& acc, const float (&bias)[16]) {
+__device__ __forceinline__ void conv_patch_put(uint32_t wa, const f32x16_t& acc) {
     if constexpr (R < 16) {
         constexpr int rr = (R & 3) + 8 * (R >> 2);
-        lds_write_asm<rr * LD * (int)sizeof(OutT)>(wa, acc[R] + bias[R], (OutT*)nullptr);
-        conv_patch_put<OutT, LD, R + 1>(wa, acc, bias);
+        lds_write_asm<rr * LD * (int)sizeof(OutT)>(wa, acc[R], (OutT*)nullptr);
+        conv_patch_put<OutT, LD, R + 1>(wa, acc);
     }
 }
 
@@ -263,6 +276,8 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
     if (lane < 32) kb_lds[lane] = kbias[(int64_t)b * kbias_batch_stride + rt * 32 + lane];
     __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
     for (; tg < seg_end; ++tg, ++t) {
+        float bias[16];
+        conv_bias_get(kb_addr, bias);   // its LDS round trip overlaps the wait for the tile
         {
             // tile tg must have landed; up to NBUF-2 younger tiles stay in flight across the barrier
             const int younger = (tg1 - 1 - tg) < (NBUF - 2) ? (tg1 - 1 - tg) : (NBUF - 2);
@@ -287,31 +302,30 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
         const uint32_t fa = lds0 + cur * C::TILEB + frag_off[h];
         const int half = half0 + h;
         f32x16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         constexpr int KB = 2;                        // 4 * PA reads per batch (lgkmcnt counts to 15)
         u32x2_t bq[2][PA][KB][2];
         conv_read_batch<PA, KB, 0>(fa, bq[0]);
-        conv_batches<PA, KB, 0>(fa, af, bq, acc);
+        conv_batches<PA, KB, 0>(fa, af, bq, acc, bias);
 
         // ---- epilogue of tile (b, t), 32-pixel half `half`
-        const int64_t px = (int64_t)t * CONV_T + half * 32 + (lane & 31);
-        float bias[16];
-        conv_bias_get(kb_addr, bias);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        const int px_base = t * CONV_T + half * 32;
+        const int64_t px = (int64_t)px_base + (lane & 31);
         if (BITS) {
-            uint32_t word = 0;
+            // sign bits of the 32 rows: ballot -> SGPR pair (lanes 0..31 voted for row rr, lanes 32..63 for the row
+            // 4 below) -> lane rr / rr + 4 of `word` by v_writelane; pixels past HW and rows past N are cleared
+            const int64_t left = HW - px_base;
+            const uint32_t pxmask = left >= 32 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+            int word = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                const int row = rt * 32 + rr + 4 * g;
-                const unsigned long long m = __ballot(acc[r] + bias[r] > 0.f && px < HW && row < N);
-                // lanes 0..31 voted for row rr, lanes 32..63 for the row 4 below; lane l keeps the word of row l
-                word = lane == rr ? (uint32_t)m : word;
-                word = lane == rr + 4 ? (uint32_t)(m >> 32) : word;
+                const unsigned long long m = __ballot(acc[r] > 0.f);
+                const uint32_t lo = (uint32_t)m & pxmask, hi = (uint32_t)(m >> 32) & pxmask;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(lo), "n"(rr));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(hi), "n"(rr + 4));
             }
-            pend_word[h] = word; pend = 1; pend_b = b; pend_t = t;
+            if (rt * 32 + lane >= N) word = 0;
+            pend_word[h] = (uint32_t)word; pend = 1; pend_b = b; pend_t = t;
         } else {
             const bool fast = C::PATCH && (HW % PER16 == 0) && ((int64_t)(t + 1) * CONV_T <= HW);
             if (fast) {
@@ -319,7 +333,10 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
                 // 16 contiguous bytes of one row
                 if (C::HPW > 1) flush();   // the one patch still holds the previous half: write it out first
                 const uint32_t wa = patch_addr + ((4 * g) * C::PATCH_LD + (lane & 31)) * (int)sizeof(OutT);
-                conv_patch_put<OutT, C::PATCH_LD>(wa, acc, bias);
+                // MFMA result -> LDS write hazard: the compiler pads it with wait states for instructions it knows,
+                // not for inline asm (fp32 output feeds the accumulator registers to ds_write directly)
+                asm volatile("s_nop 15\n s_nop 7" ::: "memory");
+                conv_patch_put<OutT, C::PATCH_LD>(wa, acc);
                 pend = 2; pend_b = b; pend_t = t; pend_h = h;
             } else {
                 const OutT* ub = logits_out + (int64_t)b * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)t * CONV_T + half * 32;
@@ -327,7 +344,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
                     const int row = rt * 32 + rr + 4 * g;
-                    if (row < N && px < HW) st_out((OutT*)((char*)(ub + (int64_t)rr * HW) + slow_lane_off), acc[r] + bias[r]);
+                    if (row < N && px < HW) st_out((OutT*)((char*)(ub + (int64_t)rr * HW) + slow_lane_off), acc[r]);
                 }
             }
         }
