@@ -182,25 +182,31 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
     // Address = wave-uniform base (SGPRs) + ONE per-lane byte offset: row-in-piece * HWp + swizzled 16-byte piece
     // (the swizzle needs bit 1 of the row, which is bit 1 of lane >> 3 whatever the piece).
     const uint32_t dma_lane_off = 2u * (uint32_t)((lane >> 3) * HWp + (((lane & 7) ^ conv_swz(lane >> 3)) * 8));
-    auto issue_tile = [&](int b, int t, int buf) {
+    // Instruction slots are the scarce resource of this loop (a wave issues at most one instruction every 4
+    // cycles, three waves share a SIMD): tile addresses are running wave-uniform pointers (+128 B per tile, one
+    // jump per frame) plus per-piece constants computed once.
+    int64_t piece_off[C::DPW];                                   // bytes from the tile's first row to this wave's pieces
+    uint32_t piece_lds[C::DPW];                                  // ... and inside a ring buffer
+#pragma unroll
+    for (int k = 0; k < C::DPW; ++k) {
+        const int j = wave + C::NDW * k;
+        const int p = j >> 5, jj = j & 31;
+        piece_off[k] = 2 * (p * fplane + (int64_t)(jj * 8) * HWp);
+        piece_lds[k] = 2u * (uint32_t)(p * TILE + jj * 512);
+    }
+    const int64_t frame_jump = 2 * ((int64_t)PH_C * HWp - (int64_t)ntiles * CONV_T);   // bytes, after the last tile's +128
+    int it = tg0 % ntiles, ti = tg0;                                                    // next tile to request
+    const char* iptr = (const char*)planes + 2 * ((int64_t)(tg0 / ntiles) * PH_C * HWp + (int64_t)it * CONV_T);
+    auto issue_next = [&](int buf) {
         if (wave < C::NDW) {
 #pragma unroll
-            for (int k = 0; k < C::DPW; ++k) {
-                const int j = wave + C::NDW * k;
-                const int p = j >> 5, jj = j & 31;
-                const uint16_t* ubase = planes + p * fplane + ((int64_t)b * PH_C + jj * 8) * HWp + (int64_t)t * CONV_T;
-                const char* src = (const char*)ubase + dma_lane_off;
-                uint16_t* dst = lds + (buf * PA + p) * TILE + jj * 512;          // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (PH_LDS void*)dst, 16, 0, 0);
-            }
+            for (int k = 0; k < C::DPW; ++k)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(iptr + piece_off[k] + dma_lane_off),
+                                                 (PH_LDS void*)((PH_LDS char*)lds + buf * C::TILEB + piece_lds[k]), 16, 0, 0);
         }
-    };
-    int ib = tg0 / ntiles, it = tg0 - ib * ntiles, ti = tg0;        // next tile to request
-    auto issue_next = [&](int buf) {
-        issue_tile(ib, it, buf);
         ++ti;
-        if (++it == ntiles) { it = 0; ++ib; }
+        iptr += 2 * CONV_T;
+        if (++it == ntiles) { it = 0; iptr += frame_jump; }
     };
 #pragma unroll
     for (int d = 0; d < NBUF - 1; ++d)
@@ -224,7 +230,8 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
 
     // results of the previous tile, written out one iteration late (after the next barrier) so that the
     // vector-memory queue in front of each counted wait is [stores(t-1), DMA(t+1) .. DMA(t+NBUF-1)]
-    int pend = 0, pend_b = 0, pend_t = 0, pend_h = 0;     // 0 none, 1 bits word(s), 2 patch of half half0 + pend_h
+    int pend = 0, pend_h = 0;                             // 0 none, 1 bits word(s), 2 patch of half half0 + pend_h
+    char* pend_ptr = nullptr;                             // wave-uniform output address of the pending tile
     uint32_t pend_word[C::HPW] = {};
     constexpr int PER16 = 16 / (int)sizeof(OutT);                // elements per 16-byte store
     constexpr int LPR = 32 / PER16;                              // lanes per row: 4 (bf16) / 8 (fp32)
@@ -233,11 +240,11 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
     const uint32_t bits_lane_off = 4u * (uint32_t)((lane & 31) * (HWp / 32));
     const uint32_t patch_lane_off = (uint32_t)sizeof(OutT) * (uint32_t)((lane / LPR) * HW + (lane % LPR) * PER16);
     const uint32_t slow_lane_off = (uint32_t)sizeof(OutT) * (uint32_t)((4 * g) * HW + (lane & 31));
+    const int64_t rpi_bytes = (int64_t)RPI * HW * (int)sizeof(OutT);
     auto flush = [&]() {
         if (BITS) {
             if (pend == 1 && lane < 32) {
-                const uint32_t* ub = bits_out + ((int64_t)pend_b * Npad + rt * 32) * (HWp / 32) + pend_t * 2 + half0;
-                uint32_t* w = (uint32_t*)((char*)ub + bits_lane_off);
+                uint32_t* w = (uint32_t*)(pend_ptr + bits_lane_off);
 #pragma unroll
                 for (int h = 0; h < C::HPW; ++h) w[h] = pend_word[h];
             }
@@ -249,17 +256,27 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
                     v[k] = lds_read128_asm(patch_addr + ((k * RPI + lane / LPR) * C::PATCH_LD + (lane % LPR) * PER16) * (int)sizeof(OutT));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                const OutT* ub = logits_out + (int64_t)pend_b * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)pend_t * CONV_T + (half0 + pend_h) * 32;
+                char* ub = pend_ptr + pend_h * (32 * (int)sizeof(OutT));
 #pragma unroll
                 for (int k = 0; k < 32 / RPI; ++k) {
                     const int row = rt * 32 + k * RPI + lane / LPR;
-                    if (row < N) *(u32x4_t*)((char*)(ub + (int64_t)(k * RPI) * HW) + patch_lane_off) = v[k];
+                    if (row < N) *(u32x4_t*)(ub + k * rpi_bytes + patch_lane_off) = v[k];
                 }
             }
         }
         pend = 0;
     };
 
+    // output address of the tile being computed (wave-uniform, running): mask words / logits of rows rt*32.., half0
+    const int64_t out_step = BITS ? 2 * 4 : CONV_T * (int)sizeof(OutT);
+    const int64_t out_jump = BITS ? 4 * ((int64_t)Npad * (HWp / 32) - (int64_t)ntiles * 2)
+                                  : (int64_t)sizeof(OutT) * (out_batch_stride - (int64_t)ntiles * CONV_T);
+    char* optr;
+    {
+        const int b0 = tg0 / ntiles, t0 = tg0 - b0 * ntiles;
+        if (BITS) optr = (char*)(bits_out + ((int64_t)b0 * Npad + rt * 32) * (HWp / 32) + t0 * 2 + half0);
+        else optr = (char*)(logits_out + (int64_t)b0 * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)t0 * CONV_T + half0 * 32);
+    }
     int b = tg0 / ntiles, t = tg0 - b * ntiles, cur = 0;
     for (int tg = tg0; tg < tg1; ++b, t = 0) {      // one pass per frame this workgroup's range touches
     int seg_end = tg + (ntiles - t);
@@ -302,11 +319,10 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
         const uint32_t fa = lds0 + cur * C::TILEB + frag_off[h];
         const int half = half0 + h;
         f32x16_t acc;
-        constexpr int KB = 2;                        // 4 * PA reads per batch (lgkmcnt counts to 15)
+        constexpr int KB = 2;                        // 4 * PA reads per batch (KB = 4 measured 7 % slower)
         u32x2_t bq[2][PA][KB][2];
         conv_read_batch<PA, KB, 0>(fa, bq[0]);
         conv_batches<PA, KB, 0>(fa, af, bq, acc, bias);
-
         // ---- epilogue of tile (b, t), 32-pixel half `half`
         const int px_base = t * CONV_T + half * 32;
         const int64_t px = (int64_t)px_base + (lane & 31);
@@ -316,16 +332,31 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
             const int64_t left = HW - px_base;
             const uint32_t pxmask = left >= 32 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
             int word = 0;
+            if (pxmask == 0xFFFFFFFFu) {
+                // all 16 compares first: a v_writelane that reads the SGPR a v_cmp wrote in the previous slot gets
+                // stale data (observed; the documented hazard names only the lane-select operand)
+                unsigned long long m[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                const unsigned long long m = __ballot(acc[r] > 0.f);
-                const uint32_t lo = (uint32_t)m & pxmask, hi = (uint32_t)(m >> 32) & pxmask;
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(lo), "n"(rr));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(hi), "n"(rr + 4));
+                for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] > 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)m[r]), "n"(rr));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((uint32_t)(m[r] >> 32)), "n"(rr + 4));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    const unsigned long long m = __ballot(acc[r] > 0.f);
+                    const uint32_t lo = (uint32_t)m & pxmask, hi = (uint32_t)(m >> 32) & pxmask;
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(lo), "n"(rr));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(hi), "n"(rr + 4));
+                }
             }
             if (rt * 32 + lane >= N) word = 0;
-            pend_word[h] = (uint32_t)word; pend = 1; pend_b = b; pend_t = t;
+            pend_word[h] = (uint32_t)word; pend = 1; pend_ptr = optr;
         } else {
             const bool fast = C::PATCH && (HW % PER16 == 0) && ((int64_t)(t + 1) * CONV_T <= HW);
             if (fast) {
@@ -337,9 +368,9 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
                 // not for inline asm (fp32 output feeds the accumulator registers to ds_write directly)
                 asm volatile("s_nop 15\n s_nop 7" ::: "memory");
                 conv_patch_put<OutT, C::PATCH_LD>(wa, acc);
-                pend = 2; pend_b = b; pend_t = t; pend_h = h;
+                pend = 2; pend_ptr = optr; pend_h = h;
             } else {
-                const OutT* ub = logits_out + (int64_t)b * out_batch_stride + (int64_t)(rt * 32) * HW + (int64_t)t * CONV_T + half * 32;
+                const OutT* ub = (const OutT*)optr + h * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
@@ -350,7 +381,9 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
         }
         }
         cur = cur + 1 == NBUF ? 0 : cur + 1;
+        optr += out_step;
     }
+    if (t == ntiles) optr += out_jump;   // next frame
     }
     flush();
 }
