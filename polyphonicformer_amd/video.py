@@ -206,10 +206,9 @@ def track_id_map(panoptic_seg, seg_ids, ids):
 
 
 def wire_record(result):
-    """datasets/cityscapes_dvps.py:325-338 (pre_eval): what is saved per frame for DVPQ evaluation"""
-    import numpy as np
-    pan = result['sem'].astype(np.int64) * INSTANCE_DIVISOR + result['track'].astype(np.int64)
-    return {"panseg": pan.astype(np.uint32), "depth": result['depth'].astype(np.float32)}
+    """datasets/cityscapes_dvps.py:325-338 (pre_eval): what is saved per frame for DVPQ evaluation (see dvps_eval.py)"""
+    from .dvps_eval import wire_record as _w
+    return _w(result)
 
 
 class VideoAssociator:

@@ -124,3 +124,39 @@ TRACK_HEAD_SHAPES = {**{f"track_head.convs.{i}.conv.weight": (256, 256, 3, 3) fo
                      **{f"track_head.convs.{i}.gn.bias": (256,) for i in range(4)},
                      "track_head.fcs.0.weight": (1024, 12544), "track_head.fcs.0.bias": (1024,),
                      "track_head.fc_embed.weight": (256, 1024), "track_head.fc_embed.bias": (256,)}
+
+
+def dvps_clip(seed, nseq=2, nframes=5, H=32, W=64, num_classes=19, num_things=8):
+    """synthetic DVPS evaluation data: per frame gt (sem, instance, depth) and a perturbed prediction
+    (sem, track id, depth) -- blobs that drift, label noise, an ignore region (class 255), depth holes"""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    frames = []
+    for s in range(nseq):
+        nobj = 6
+        cy, cx = rng.uniform(0, H, nobj), rng.uniform(0, W, nobj)
+        ry, rx = rng.uniform(3, H / 3, nobj), rng.uniform(3, W / 4, nobj)
+        cls = rng.integers(0, num_things, nobj)
+        stuff = rng.integers(num_things, num_classes, 3)
+        for f in range(nframes):
+            cy = cy + rng.normal(0, 1.0, nobj)
+            cx = cx + rng.normal(0, 1.5, nobj)
+            sem = np.where(ys < H // 3, stuff[0], np.where(xs < W // 2, stuff[1], stuff[2])).astype(np.int64)
+            ins = np.zeros((H, W), dtype=np.int64)
+            psem, ptrk = sem.copy(), ins.copy()
+            for o in range(nobj):
+                m = ((ys - cy[o]) / ry[o]) ** 2 + ((xs - cx[o]) / rx[o]) ** 2 < 1
+                sem[m], ins[m] = cls[o], o + 1
+                mp = ((ys - cy[o] - rng.normal(0, 0.7)) / (ry[o] * rng.uniform(0.8, 1.2))) ** 2 + \
+                     ((xs - cx[o] - rng.normal(0, 0.7)) / rx[o]) ** 2 < 1
+                wrong = rng.random() < 0.15
+                psem[mp] = rng.integers(0, num_things) if wrong else cls[o]
+                ptrk[mp] = (o + 1) if rng.random() > 0.1 else o + 20
+            ign = (ys > H - 4) & (xs > W - 10)
+            sem[ign], ins[ign] = 255, 0
+            depth = (5 + 0.5 * ys + 0.1 * xs + rng.normal(0, 0.2, (H, W))).astype(np.float32)
+            depth[rng.random((H, W)) < 0.05] = 0.
+            pdepth = (np.maximum(depth, 1.0) * (1 + rng.normal(0, 0.08, (H, W)))).astype(np.float32)
+            frames.append(dict(seq=s + 3, img=f * 5, gt=dict(sem=sem, track=ins, depth=depth),
+                               pred=dict(sem=psem, track=ptrk, depth=pdepth)))
+    return frames
