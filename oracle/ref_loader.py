@@ -250,7 +250,11 @@ def load_reference():
     tr.build_transformer_layer = lambda cfg, default_args=None: TRANSFORMER_LAYER.build(cfg, default_args)
     tr.build_positional_encoding = lambda cfg, default_args=None: POSITIONAL_ENCODING.build(cfg, default_args)
     runner = _mod("mmcv.runner")
-    runner.BaseModule = nn.Module
+    class BaseModule(nn.Module):          # mmcv.runner.BaseModule: nn.Module + an ignored init_cfg
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    runner.BaseModule = BaseModule
 
     def force_fp32(apply_to=None, out_fp16=False):
         return lambda f: f
@@ -453,3 +457,33 @@ def build_kernel_head(ns, N_thing_q=100, C=256, n_thing=8, n_stuff=11, groups=32
     head.init_weights()
     head.eval()
     return head
+
+
+def load_reference_neck():
+    """SemanticFPNWrapper (polyphonic/funcs/semantic_fpn.py) + mmdet's SinePositionalEncoding
+    (mmdet/models/utils/positional_encoding.py, vendored in the reference tree)."""
+    ns = load_reference()
+    for name in ("mmdet.models.utils",):
+        if name not in sys.modules:
+            _mod(name)
+
+    def load(modname, relpath):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, relpath))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        parent, _, child = modname.rpartition(".")
+        setattr(sys.modules[parent], child, m)
+        spec.loader.exec_module(m)
+        return m
+
+    pe = load("mmdet.models.utils.positional_encoding", "mmdet/models/utils/positional_encoding.py")
+    sf = load("polyphonic.funcs.semantic_fpn", "polyphonic/funcs/semantic_fpn.py")
+    return types.SimpleNamespace(SemanticFPNWrapper=sf.SemanticFPNWrapper, SinePositionalEncoding=pe.SinePositionalEncoding)
+
+
+def neck_cfg(C=256, groups=32, num_feats=128):
+    """configs/_base_/models/polyphonic_former.py:78-96"""
+    return dict(in_channels=C, feat_channels=C, out_channels=C, start_level=0, end_level=3, upsample_times=2,
+                positional_encoding=dict(type="SinePositionalEncoding", num_feats=num_feats, normalize=True),
+                cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                norm_cfg=dict(type="GN", num_groups=groups, requires_grad=True))

@@ -160,3 +160,9 @@ def dvps_clip(seed, nseq=2, nframes=5, H=32, W=64, num_classes=19, num_things=8)
             frames.append(dict(seq=s + 3, img=f * 5, gt=dict(sem=sem, track=ins, depth=depth),
                                pred=dict(sem=psem, track=ptrk, depth=pdepth)))
     return frames
+
+
+def fpn_inputs(seed, B, C, H0, W0):
+    """4 FPN levels (strides 4, 8, 16, 32 of an 4*H0 x 4*W0 image) ~ N(0, 1)"""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, C, H0 >> i, W0 >> i, generator=g) for i in range(4)]
