@@ -170,6 +170,29 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
                     "bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
 
 
+def neck_leg(wl, precision, dev, B=8, steps=5):
+    """secondary number: SemanticFPNWrapper.forward, the step that produces the hot path's three input
+    maps, at the cfg2 FPN sizes (strides 4..32 of 1024x2048), fp32 NCHW levels resident in HBM"""
+    from polyphonicformer_amd.registry import NECKS
+    import polyphonicformer_amd.semantic_fpn  # noqa: F401
+    torch.manual_seed(2)
+    m = NECKS.build(dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0,
+                         end_level=3, upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                         cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                         norm_cfg=dict(type="GN", num_groups=32, requires_grad=True)))
+    m.init_weights()
+    m.eval().to(dev)
+    m.set_precision(precision)
+    H0, W0 = wl["H"] * 2, wl["W"] * 2
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(B, 256, H0 >> i, W0 >> i, generator=g).to(dev) for i in range(4)]
+    t = time_op(lambda: m(feats), steps)
+    flop = 2 * 256 * 256 * (9 * (4 * wl["H"] * wl["W"] + 2 * wl["H"] * wl["W"] // 4 + wl["H"] * wl["W"] // 16) + 3 * wl["H"] * wl["W"])
+    return {"frames_per_step": B, "frames_per_s": round(B / (t * 1e-3), 1), "ms_per_step": round(t, 4),
+            "mfma_TFLOPs": round(flop * B / (t * 1e-3) / 1e12, 1), "flop_per_frame": flop,
+            "note": "7 conv3x3 + GN + ReLU towers, x2 upsamples, level sum, conv_pred + 2 aux convs; channels-last implicit GEMM"}
+
+
 def panoptic_leg(wl, head, plan, dev):
     """get_panoptic (a7, SURVEY 8d: reported separately) on ONE frame of the step's outputs; host wall time,
     including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
@@ -230,6 +253,7 @@ def main():
                     help="2 = two half-batches on two skewed HIP streams (engine.DualDecodePlan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-head", action="store_true")
+    ap.add_argument("--no-neck", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -353,6 +377,11 @@ def main():
                 res["panoptic_merge"] = panoptic_leg(wl, head, kplan, dev)
             except Exception as e:
                 res["panoptic_merge"] = {"error": repr(e)}
+        if world == 1 and not args.no_neck:
+            try:
+                res["semantic_fpn_neck"] = neck_leg(wl, args.precision, dev)
+            except Exception as e:
+                res["semantic_fpn_neck"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         print(json.dumps(res))

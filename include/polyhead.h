@@ -34,6 +34,7 @@ extern "C" {
 enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWORKSPACE = -4 };
 enum { PH_PREC_BF16 = 1, PH_PREC_SPLIT = 3 };   /* number of bf16 MFMA products per logical product */
 enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1 };
+enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3 };   /* ph_gn_apply modes */
 
 #define PH_C 256          /* channels: in_channels == out_channels == feat_channels == 256 */
 #define PH_HEADS 8        /* num_heads (head dim 32) */
@@ -204,6 +205,27 @@ int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, c
 int ph_im2col7(const uint16_t* in, uint16_t* out, int n, int prec, void* stream);
 int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int groups, float eps, uint16_t* out, int n,
                   int prec, void* stream);
+
+/* ---- the step before the path, SemanticFPNWrapper.forward (polyphonic/funcs/semantic_fpn.py:198-235,
+ * configs/_base_/models/polyphonic_former.py:78-96).  Inside the neck every map is channels-last (NHWC):
+ * ph_nhwc_ingest : fp32 NCHW [B][256][HW] (+ add[256][HW], nullable: SinePositionalEncoding on level 3, :202-208)
+ *                  -> bf16 NHWC planes [P][B][HW][256].
+ * ph_conv_nhwc   : ConvModule's conv (no bias): KSxKS, pad KS/2, stride 1 or 2 (3x3) / 1 (1x1), 256 -> 256 channels;
+ *                  X bf16 NHWC planes, Wp = pack.pack_b32 fragments of W[n][tap * 256 + c], Y fp32 NHWC [B][Ho][Wo][256];
+ *                  partial = per-workgroup per-channel (sum, sum of squares) [B][nwg][256][2]
+ *                  (ph_conv_nhwc_partial_floats) for the GroupNorm that follows.
+ * ph_gn_finalize : partial -> stats [B][groups][2] = (mean, rstd), fp64 combine (also used by ph_khead_conv_gn).
+ * ph_gn_apply    : GroupNorm affine + ReLU on fp32 NHWC (stats == NULL: plain copy/convert), then per `mode`:
+ *                  bf16 NHWC planes | x2 bilinear (align_corners=False, nn.Upsample :131-134) bf16 NHWC planes |
+ *                  fp32 NHWC accumulate (the sum over levels, :221) | fp32 NCHW (what KernelHead takes). */
+int ph_nhwc_ingest(const float* src, const float* add /* nullable */, uint16_t* dst, int B, int64_t HW, int prec, void* stream);
+size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo);
+int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize, int stride,
+                 int B, int H, int W, int prec, void* stream);
+int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B, void* stream);
+int ph_gn_apply(const float* y, const float* stats /* nullable */, const float* gamma, const float* beta, int groups, int mode,
+                int accumulate, uint16_t* planes /* nullable */, float* outf /* nullable */, int B, int H, int W, int prec,
+                void* stream);
 
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);

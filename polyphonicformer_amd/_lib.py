@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
 PH_PREC_BF16, PH_PREC_SPLIT = 1, 3
 PH_OUT_F32, PH_OUT_BF16 = 0, 1
+PH_GN_TO_PLANES, PH_GN_UP2_PLANES, PH_GN_ACCUM, PH_GN_TO_NCHW = 0, 1, 2, 3
 
 W_NAMES = ["DYN", "INP", "IG", "UG", "FC", "QKV", "OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN"]
 V_NAMES = ["DYN_CNT", "DYN_B", "INP_B", "IG_B", "UG_B", "LN_IG_G", "LN_IG_B", "LN_UG_G", "LN_UG_B",
@@ -52,6 +53,11 @@ SIGNATURES = {
     "ph_gemm_rows": (C.c_int, [_P, _P, _L, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "ph_im2col7": (C.c_int, [_P, _P, _I, _I, _P]),
     "ph_gn_relu_cl": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _I, _I, _P]),
+    "ph_nhwc_ingest": (C.c_int, [_P, _P, _P, _I, _L, _I, _P]),
+    "ph_conv_nhwc_partial_floats": (C.c_size_t, [_I, _I, _I]),
+    "ph_conv_nhwc": (C.c_int, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ph_gn_finalize": (C.c_int, [_P, _P, _I, _I, _L, C.c_float, _I, _P]),
+    "ph_gn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_readbw": (C.c_int, [_P, _L, _I, _P, _P]),

@@ -174,6 +174,14 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ p
     }
 }
 
+extern "C" int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B,
+                              void* stream) {
+    PH_CHECK_ARG(partial && stats && nwg > 0 && groups > 0 && 256 % groups == 0 && HW > 0 && B > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, stats, nwg, groups, HW, eps);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
 // ---- pass 2: normalise + ReLU, write planes (and fp32), optional sum of two maps ----------------
 constexpr int KH_PLD = KH_T + 8;    // row stride (elements) of a per-wave [32 ch][64 px] store patch
 

@@ -1,0 +1,343 @@
+// SURVEY.md 8(f) row N3 -- the step before the hot path: SemanticFPNWrapper.forward
+// (polyphonic/funcs/semantic_fpn.py:198-235): per FPN level 3x3 conv + GroupNorm(32) + ReLU towers with x2
+// bilinear upsampling, sum of the levels, three 1x1 conv + GN + ReLU outputs.
+//
+// Layout: inside the neck every map is CHANNELS-LAST.  A 3x3 tap is then a pixel offset of whole 512-byte
+// channel vectors (no alignment problem for dx = +-1, which the [c][hw] plane format + transposing LDS reads
+// cannot express), the MFMA K dimension (tap, channel) is contiguous per pixel, and GroupNorm / ReLU /
+// upsample / sum are elementwise over the channel vector.
+//   k_nhwc_ingest : fp32 NCHW (+ optional positional encoding, level 3) -> bf16 NHWC plane(s)
+//   k_conv_nhwc   : implicit-GEMM KSxKS conv (stride 1 / 2, pad KS/2), bf16 NHWC in -> fp32 NHWC out
+//                   + per-workgroup per-channel (sum, sum of squares) for the GroupNorm that follows
+//   k_gn_apply    : (x - mean) * rstd * gamma + beta, ReLU, then one of: bf16 NHWC plane(s) | x2 bilinear
+//                   upsample to bf16 NHWC plane(s) | accumulate into the fp32 NHWC level sum | fp32 NCHW
+// GroupNorm statistics are finalised by k_gn_finalize (ph_khead.hip) from the conv kernel's partials.
+#include "ph_common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 NCHW [B][256][HW] (+ add[256][HW], nullable) -> bf16 NHWC planes [PA][B][HW][256]
+template <int PA>
+__global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ src, const float* __restrict__ add,
+                                                     uint16_t* __restrict__ dst, int B, int64_t HW) {
+    __shared__ float t[64][65];                       // [channel][pixel] tile
+    const int b = blockIdx.z, c0 = blockIdx.y * 64;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t p = p0 + tx;
+        float v = 0.f;
+        if (p < HW) {
+            v = src[((int64_t)b * 256 + c0 + c) * HW + p];
+            if (add) v += add[(int64_t)(c0 + c) * HW + p];
+        }
+        t[c][tx] = v;
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)B * HW * 256;
+    for (int p = ty; p < 64; p += 4) {
+        if (p0 + p >= HW) continue;
+        uint32_t hi, lo;
+        f2bf_split(t[tx][p], hi, lo);
+        const int64_t o = ((int64_t)b * HW + p0 + p) * 256 + c0 + tx;
+        dst[o] = (uint16_t)hi;
+        if (PA == 2) dst[o + plane] = (uint16_t)lo;
+    }
+}
+
+extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst, int B, int64_t HW, int prec, void* stream) {
+    PH_CHECK_ARG(src && dst && B > 0 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    const dim3 grid((unsigned)((HW + 63) / 64), 4, B);
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_nhwc_ingest<1>, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
+    else hipLaunchKernelGGL(k_nhwc_ingest<2>, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, M = output pixels, N = 256 output channels, K = KS*KS*256 ordered (tap, channel).
+// Workgroup (8 waves) = 2 output rows x 64 output pixels x all 256 channels; wave (wm, wn) owns output row wm and
+// channels 64 wn .. 64 wn + 63: two 32-pixel M tiles x two 32-channel N tiles of 32x32x16 MFMA = 64 accumulator
+// VGPRs.  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
+// time ([pixel][CH + 8] bf16: the 16-byte pad makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots);
+// an A fragment is one ds_read_b128 at a pixel offset given by the tap.  Weights are pre-packed B fragments
+// ([col tile][k-step] blocks of 1 KiB, pack.pack_b32) streamed from L2, one k-step ahead.
+// Roofline: MFMA (2*9*256*256 flop per output pixel); L2 weight stream = 1.18 MB per 128 output pixels.
+constexpr int CV_TW = 64, CV_TH = 2;
+
+template <int KS, int S> struct ConvGeo {
+    static constexpr int IR = (CV_TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;   // input patch rows / cols
+    static constexpr int CH = (S == 1) ? 64 : 32;                                  // channels per LDS stage
+    static constexpr int LDP = CH + 8;                                             // pixel stride (elements)
+    static constexpr int PLANE = IR * IC * LDP;                                    // elements per precision plane
+};
+
+template <int PA, int KS, int S>
+__global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ X, int64_t x_plane,
+                                                   const uint16_t* __restrict__ Wp, int64_t w_plane, float* __restrict__ Y,
+                                                   float* __restrict__ partial, int B, int H, int W, int Ho, int Wo) {
+    using G = ConvGeo<KS, S>;
+    constexpr int CH = G::CH, LDP = G::LDP, IR = G::IR, IC = G::IC, PAD = KS / 2;
+    constexpr int KSTEPS_TOTAL = KS * KS * 256 / 16;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
+    __shared__ float red[2][256][2];                                        // per output row: channel (sum, sumsq)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int b = blockIdx.z, oy0 = blockIdx.y * CV_TH, ox0 = blockIdx.x * CV_TW;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const int m = lane & 31, kg = lane >> 5;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][ct][r] = 0.f;
+
+    const uint16_t* xb = X + (int64_t)b * H * W * 256;
+    // this lane's B-fragment stream: column tiles 2 wn, 2 wn + 1
+    const uint16_t* wbase = Wp + ((int64_t)(wn * 2) * KSTEPS_TOTAL) * 512 + lane * 8;
+
+    for (int c0 = 0; c0 < 256; c0 += CH) {
+        __syncthreads();                                  // previous chunk's readers are done
+        // ---- stage the patch of channels [c0, c0 + CH): 16-byte pieces, zero outside the image
+        constexpr int PIECES = CH / 8;
+        for (int idx = tid; idx < IR * IC * PIECES; idx += 512) {
+            const int piece = idx % PIECES, pix = idx / PIECES;
+            const int r = pix / IC, x = pix - r * IC;
+            const int iy = iy0 + r, ix = ix0 + x;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (in) v = *(const uint4*)(xb + p * x_plane + ((int64_t)iy * W + ix) * 256 + c0 + piece * 8);
+                *(uint4*)(lds + p * G::PLANE + pix * LDP + piece * 8) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs of this chunk: taps x (CH / 16) k-steps, weights one k-step ahead
+        constexpr int NK = KS * KS * (CH / 16);
+        auto kstep_of = [&](int j) {                      // j-th k-step of the chunk -> global k-step index
+            const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
+            return tap * 16 + (c0 >> 4) + kk;             // (tap * 256 + c0 + kk * 16) / 16
+        };
+        uint4 bq[2][PA][2];
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                bq[0][p][ct] = *(const uint4*)(wbase + p * w_plane + ((int64_t)ct * KSTEPS_TOTAL + kstep_of(0)) * 512);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            if (j + 1 < NK) {
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        bq[(j + 1) & 1][p][ct] = *(const uint4*)(wbase + p * w_plane + ((int64_t)ct * KSTEPS_TOTAL + kstep_of(j + 1)) * 512);
+            }
+            const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
+            const int dy = tap / KS, dx = tap - dy * KS;
+            uint4 a[PA][2];
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int px = (mt * 32 + m) * S + dx, row = wm * S + dy;
+                    a[p][mt] = *(const uint4*)(lds + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
+                }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[mt][ct] = mfma32(a[0][mt], bq[j & 1][0][ct], acc[mt][ct]);
+                    if (PA == 2) {
+                        acc[mt][ct] = mfma32(a[0][mt], bq[j & 1][PA - 1][ct], acc[mt][ct]);
+                        acc[mt][ct] = mfma32(a[PA - 1][mt], bq[j & 1][0][ct], acc[mt][ct]);
+                    }
+                }
+        }
+    }
+
+    // ---- epilogue: fp32 NHWC store (32 lanes = 128 contiguous bytes of a pixel) + GroupNorm partial sums
+    const int oy = oy0 + wm;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;        // C layout: row = pixel, col = channel
+            const int ox = ox0 + px;
+            const bool ok = oy < Ho && ox < Wo;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float v = acc[mt][ct][r];
+                if (ok) {
+                    Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + wn * 64 + ct * 32 + m] = v;
+                    s1[ct] += v;
+                    s2[ct] += v * v;
+                }
+            }
+        }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float a1 = s1[ct] + __shfl_xor(s1[ct], 32), a2 = s2[ct] + __shfl_xor(s2[ct], 32);
+        if (kg == 0) {
+            red[wm][wn * 64 + ct * 32 + m][0] = a1;
+            red[wm][wn * 64 + ct * 32 + m][1] = a2;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
+        float* o = partial + (((int64_t)b * nwg + wg) * 256 + tid) * 2;
+        o[0] = red[0][tid][0] + red[1][tid][0];
+        o[1] = red[0][tid][1] + red[1][tid][1];
+    }
+}
+
+extern "C" size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo) {
+    return (size_t)B * ((Wo + CV_TW - 1) / CV_TW) * ((Ho + CV_TH - 1) / CV_TH) * 256 * 2;
+}
+
+extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize,
+                            int stride, int B, int H, int W, int prec, void* stream) {
+    PH_CHECK_ARG(X && Wp && Y && partial && B > 0 && H > 0 && W > 0, "bad pointer or size");
+    PH_CHECK_ARG((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "supported: 3x3 stride 1/2, 1x1 stride 1");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    const int pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const dim3 grid((Wo + CV_TW - 1) / CV_TW, (Ho + CV_TH - 1) / CV_TH, B);
+    const int64_t x_plane = (int64_t)B * H * W * 256;
+    hipStream_t s = (hipStream_t)stream;
+#define PH_CV(PA, KS, S)                                                                                                 \
+    do {                                                                                                                 \
+        const size_t lds = (size_t)PA * ConvGeo<KS, S>::PLANE * sizeof(uint16_t);                                        \
+        static bool once = false;                                                                                        \
+        if (!once) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)lds);                                                                         \
+            once = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
+                           B, H, W, Ho, Wo);                                                                             \
+    } while (0)
+    if (prec == PH_PREC_BF16) {
+        if (ksize == 1) PH_CV(1, 1, 1); else if (stride == 1) PH_CV(1, 3, 1); else PH_CV(1, 3, 2);
+    } else {
+        if (ksize == 1) PH_CV(2, 1, 1); else if (stride == 1) PH_CV(2, 3, 1); else PH_CV(2, 3, 2);
+    }
+#undef PH_CV
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm affine + ReLU on fp32 NHWC, elementwise over 4-channel vectors; `mode`:
+//   PH_GN_TO_PLANES   bf16 NHWC plane(s), same resolution
+//   PH_GN_UP2_PLANES  bf16 NHWC plane(s) at 2H x 2W, bilinear align_corners=False (F.interpolate / nn.Upsample)
+//   PH_GN_ACCUM       fp32 NHWC accumulator (+= when accumulate != 0, = otherwise)
+//   PH_GN_TO_NCHW     fp32 NCHW (the format KernelHead takes)
+// stats == nullptr: no normalisation, no ReLU (plain conversion of the level sum to planes).
+__device__ __forceinline__ float4 gn_relu4(float4 v, float4 sc, float4 sh, bool act) {
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (act) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    return o;
+}
+
+template <int PA>
+__device__ __forceinline__ void st_planes4(uint16_t* dst, int64_t plane, float4 o) {
+    uint32_t h[4], l[4];
+    f2bf_split(o.x, h[0], l[0]); f2bf_split(o.y, h[1], l[1]); f2bf_split(o.z, h[2], l[2]); f2bf_split(o.w, h[3], l[3]);
+    *(uint2*)dst = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+    if (PA == 2) *(uint2*)(dst + plane) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+}
+
+template <int PA>
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int groups,
+                                                  int mode, int accumulate, uint16_t* __restrict__ planes,
+                                                  float* __restrict__ outf, int B, int H, int W) {
+    const int b = blockIdx.z;
+    const int c4 = (threadIdx.x & 63) * 4;                       // 4 channels per thread, 64 threads per pixel
+    const int cpg = 256 / groups;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool act = stats != nullptr;
+    if (stats) {
+        float s_[4], h_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* st = stats + ((int64_t)b * groups + (c4 + e) / cpg) * 2;
+            const float g = st[1] * gamma[c4 + e];
+            s_[e] = g;
+            h_[e] = beta[c4 + e] - st[0] * g;
+        }
+        sc = make_float4(s_[0], s_[1], s_[2], s_[3]);
+        sh = make_float4(h_[0], h_[1], h_[2], h_[3]);
+    }
+    const float* yb = y + (int64_t)b * H * W * 256;
+    if (mode == PH_GN_UP2_PLANES) {
+        const int Ho = 2 * H, Wo = 2 * W;
+        const int64_t plane = (int64_t)B * Ho * Wo * 256;
+        for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < (int64_t)Ho * Wo; p += (int64_t)gridDim.x * 4) {
+            const int oy = (int)(p / Wo), ox = (int)(p - (int64_t)oy * Wo);
+            // source coordinate (o + 0.5) / 2 - 0.5, clamped at 0 (PyTorch area_pixel_compute_source_index)
+            float fy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+            const float ly = fy - y0, lx = fx - x0;
+            const float4 v00 = gn_relu4(*(const float4*)(yb + ((int64_t)y0 * W + x0) * 256 + c4), sc, sh, act);
+            const float4 v01 = gn_relu4(*(const float4*)(yb + ((int64_t)y0 * W + x1) * 256 + c4), sc, sh, act);
+            const float4 v10 = gn_relu4(*(const float4*)(yb + ((int64_t)y1 * W + x0) * 256 + c4), sc, sh, act);
+            const float4 v11 = gn_relu4(*(const float4*)(yb + ((int64_t)y1 * W + x1) * 256 + c4), sc, sh, act);
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+            float4 o;
+            o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+            o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+            o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+            o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+            st_planes4<PA>(planes + ((int64_t)b * Ho * Wo + p) * 256 + c4, plane, o);
+        }
+        return;
+    }
+    const int64_t HW = (int64_t)H * W, plane = (int64_t)B * HW * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < HW; p += (int64_t)gridDim.x * 4) {
+        const float4 o = gn_relu4(*(const float4*)(yb + p * 256 + c4), sc, sh, act);
+        if (mode == PH_GN_TO_PLANES) {
+            st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, o);
+        } else if (mode == PH_GN_ACCUM) {
+            float4* d = (float4*)(outf + ((int64_t)b * HW + p) * 256 + c4);
+            if (accumulate) {
+                const float4 t = *d;
+                *d = make_float4(t.x + o.x, t.y + o.y, t.z + o.z, t.w + o.w);
+            } else {
+                *d = o;
+            }
+        } else {   // PH_GN_TO_NCHW: strided 4-byte stores (the 64 threads of a pixel hit 64 channel rows; a block's
+                   // 4 consecutive pixels share each 16-byte piece) -- small maps, written once
+            float* d = outf + ((int64_t)b * 256 + c4) * HW + p;
+            d[0] = o.x; d[HW] = o.y; d[2 * HW] = o.z; d[3 * HW] = o.w;
+        }
+    }
+}
+
+extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamma, const float* beta, int groups, int mode,
+                           int accumulate, uint16_t* planes, float* outf, int B, int H, int W, int prec, void* stream) {
+    PH_CHECK_ARG(y && B > 0 && H > 0 && W > 0, "bad pointer or size");
+    PH_CHECK_ARG(!stats || (gamma && beta && groups > 0 && 256 % groups == 0), "stats need gamma, beta and a valid group count");
+    PH_CHECK_ARG(mode >= PH_GN_TO_PLANES && mode <= PH_GN_TO_NCHW, "bad mode");
+    PH_CHECK_ARG(((mode == PH_GN_TO_PLANES || mode == PH_GN_UP2_PLANES) && planes) || ((mode == PH_GN_ACCUM || mode == PH_GN_TO_NCHW) && outf),
+                 "output pointer missing for this mode");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    const int64_t npix = (int64_t)H * W * (mode == PH_GN_UP2_PLANES ? 4 : 1);
+    int gx = (int)((npix + 3) / 4 < 2048 ? (npix + 3) / 4 : 2048);
+    const dim3 grid(gx, 1, B);
+    if (!groups) groups = 1;
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_apply<1>, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
+    else hipLaunchKernelGGL(k_gn_apply<2>, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

@@ -385,6 +385,93 @@ class KernelHeadPlan:
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
 
 
+# ---- SemanticFPNWrapper (N3) -------------------------------------------------------------------------------
+def nhwc_ingest(x, add, prec, out):
+    B, Cc, H, W = x.shape
+    lib = _lib.load()
+    _lib.check(lib.ph_nhwc_ingest(_lib.ptr(x), _lib.ptr(add), _lib.ptr(out), B, H * W, prec, _lib.stream_ptr()), "ph_nhwc_ingest")
+    return out
+
+
+def conv_nhwc(xp, pk, y, partial, B, H, W, prec):
+    lib = _lib.load()
+    _lib.check(lib.ph_conv_nhwc(_lib.ptr(xp), _lib.ptr(pk["wp"]), pk["wp"].shape[1], _lib.ptr(y), _lib.ptr(partial), pk["k"],
+                                pk["s"], B, H, W, prec, _lib.stream_ptr()), "ph_conv_nhwc")
+
+
+def gn_finalize(partial, stats, nwg, groups, HW, B, eps=1e-5):
+    lib = _lib.load()
+    _lib.check(lib.ph_gn_finalize(_lib.ptr(partial), _lib.ptr(stats), nwg, groups, HW, eps, B, _lib.stream_ptr()), "ph_gn_finalize")
+
+
+def gn_apply(y, stats, pk, groups, mode, B, H, W, prec, planes=None, outf=None, accumulate=False):
+    lib = _lib.load()
+    _lib.check(lib.ph_gn_apply(_lib.ptr(y), _lib.ptr(stats), _lib.ptr(pk["gamma"]) if pk else None,
+                               _lib.ptr(pk["beta"]) if pk else None, groups, mode, 1 if accumulate else 0, _lib.ptr(planes),
+                               _lib.ptr(outf), B, H, W, prec, _lib.stream_ptr()), "ph_gn_apply")
+
+
+class NeckPlan:
+    """buffers + launch sequence of SemanticFPNWrapper.forward for one (B, level shapes): channels-last bf16 planes
+    between the convs, fp32 channels-last conv outputs, the fp32 level sum, three fp32 NCHW outputs"""
+
+    def __init__(self, B, shapes, prec, device):
+        self.B, self.shapes, self.prec = B, shapes, prec
+        P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+        dev = torch.device(device)
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        (h0, w0), (h1, w1) = shapes[0], shapes[1]
+        self.Ho, self.Wo = h1, w1                                  # stride-8 output size
+        if ((h0 + 1) // 2, (w0 + 1) // 2) != (h1, w1) or any(shapes[i + 1] != ((shapes[i][0] + 1) // 2, (shapes[i][1] + 1) // 2)
+                                                             for i in range(1, 3)):
+            raise _lib.PolyheadError(f"FPN level sizes {shapes} are not a stride-2 pyramid")
+        big = max(h * w for h, w in shapes)
+        self.xa = e((P, B, big, 256), torch.int16)                 # conv input planes (ping)
+        self.xb = e((P, B, self.Ho * self.Wo, 256), torch.int16)   # conv input planes (pong, <= output size)
+        self.y = e((B, self.Ho * self.Wo, 256), torch.float32)     # conv output (pre-norm)
+        self.sum = e((B, self.Ho * self.Wo, 256), torch.float32)   # sum over levels
+        lib = _lib.load()
+        self.partial = e((lib.ph_conv_nhwc_partial_floats(B, self.Ho, self.Wo),), torch.float32)
+        self.stats = e((B, 256, 2), torch.float32)
+        self.outs = [e((B, 256, self.Ho, self.Wo), torch.float32) for _ in range(3)]
+
+    def _conv_gn(self, xp, pk, H, W, groups):
+        """conv + stats; returns the conv output size"""
+        B, prec = self.B, self.prec
+        k, s = pk["k"], pk["s"]
+        Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        conv_nhwc(xp, pk, self.y, self.partial, B, H, W, prec)
+        nwg = ((Wo + 63) // 64) * ((Ho + 1) // 2)
+        gn_finalize(self.partial, self.stats, nwg, groups, Ho * Wo, B)
+        return Ho, Wo
+
+    def run(self, feats, pk, groups, posenc, pos_level):
+        B, prec = self.B, self.prec
+        first = True
+        for lvl in range(4):
+            H, W = self.shapes[lvl]
+            nhwc_ingest(feats[lvl], posenc if lvl == pos_level else None, prec, self.xa)
+            src = self.xa
+            convs = pk["levels"][lvl]
+            for j, c in enumerate(convs):
+                H, W = self._conv_gn(src, c, H, W, groups)
+                if j + 1 < len(convs):      # every non-final conv of levels 2 and 3 is followed by an x2 upsample
+                    dst = self.xb if src is self.xa else self.xa
+                    gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=dst)
+                    H, W, src = 2 * H, 2 * W, dst
+                else:
+                    if (H, W) != (self.Ho, self.Wo):
+                        raise _lib.PolyheadError("level does not end at the stride-8 size")
+                    gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_ACCUM, B, H, W, prec, outf=self.sum, accumulate=not first)
+                    first = False
+        # the level sum as conv input planes, then conv_pred / aux convs (1x1 + GN + ReLU) -> fp32 NCHW
+        gn_apply(self.sum, None, None, groups, _lib.PH_GN_TO_PLANES, B, self.Ho, self.Wo, prec, planes=self.xb)
+        for o, c in zip(self.outs, pk["outs"]):
+            self._conv_gn(self.xb, c, self.Ho, self.Wo, groups)
+            gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_TO_NCHW, B, self.Ho, self.Wo, prec, outf=o)
+        return self.outs[:len(pk["outs"])]
+
+
 class DualDecodePlan:
     """Two half-batches on two HIP streams, skewed by one phase: the query kernels of a stage are a short,
     latency-bound chain on ~1 workgroup per CU, the pooling / conv / upsample kernels are HBM-bound; running

@@ -42,8 +42,7 @@ class KernelHead(nn.Module):
         elif localization_fpn.get('type') in NECKS:
             self.localization_fpn = build_neck(localization_fpn)
         else:
-            # the neck (SemanticFPNWrapper) is the step BEFORE the hot path: when it is not
-            # registered, `simple_test_rpn` expects its three output maps as `img`
+            # an unknown neck type: `simple_test_rpn` then expects the neck's three output maps as `img`
             self.localization_fpn = None
         self.semantic_fpn, self.norm_cfg, self.num_heads, self.att_dropout = semantic_fpn, norm_cfg, num_heads, att_dropout
         self.mask_out_stride, self.hard_target, self.conv_kernel_size = mask_out_stride, hard_target, conv_kernel_size
@@ -94,6 +93,8 @@ class KernelHead(nn.Module):
         assert precision in ("fp32", "split", "bf16")
         self.precision = precision
         self._pack, self._plans = None, {}
+        if self.localization_fpn is not None and hasattr(self.localization_fpn, "set_precision"):
+            self.localization_fpn.set_precision("fp32" if precision == "split" else precision)
         return self
 
     def _get_pack(self, device):
@@ -152,3 +153,4 @@ class KernelHead(nn.Module):
 
 
 register_everywhere(KernelHead)
+from . import semantic_fpn  # noqa: E402,F401  registers 'SemanticFPNWrapper' (the localization_fpn)

@@ -40,6 +40,16 @@ def pack_b_fragments(w):
     return t.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)   # [ct][ks][g][j][e]
 
 
+def pack_b32(w):
+    """[Nout][K] (Nout % 32 == 0, K % 16 == 0) -> B fragments of the 32x32x16 MFMA, tile-major: one contiguous
+    1 KiB block per (32-column tile, 16-deep k-step); inside a block lane l = (column l & 31, k-group l >> 5)
+    holds 8 consecutive k (csrc/ph_neck.hip: k_conv_nhwc)."""
+    nout, k = w.shape
+    assert nout % 32 == 0 and k % 16 == 0, (nout, k)
+    t = w.reshape(nout // 32, 32, k // 16, 2, 8)        # [ct][n][ks][g][e]
+    return t.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)   # [ct][ks][g][n][e]
+
+
 def _pad_rows(w, mult=16):
     r = (-w.shape[0]) % mult
     if r:

@@ -1,0 +1,159 @@
+"""SURVEY.md 8(f) N3 on the device: channels-last conv / GroupNorm kernels against torch, and SemanticFPNWrapper
+against the reference's golden outputs and the oracle."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers as Hh
+from oracle import neck_oracle as NO
+from polyphonicformer_amd import _lib, engine as E
+from polyphonicformer_amd.pack import pack_b32
+from polyphonicformer_amd.registry import NECKS
+import polyphonicformer_amd.semantic_fpn as SF  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes_to_float(p):
+    """int16 bf16 planes [P, ...] -> float64 sum of planes"""
+    return sum((p[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(p.shape[0]))
+
+
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT])
+@pytest.mark.parametrize("k,s,H,W", [(3, 1, 6, 70), (3, 2, 9, 131), (1, 1, 5, 64), (3, 1, 2, 3)])
+def test_conv_nhwc(gpu, prec, k, s, H, W):
+    g = torch.Generator().manual_seed(7)
+    B, P = 2, (2 if prec == _lib.PH_PREC_SPLIT else 1)
+    x = torch.randn(B, 256, H, W, generator=g)
+    w = torch.randn(256, 256, k, k, generator=g) * 0.05
+    xp = torch.empty((P, B, H * W, 256), dtype=torch.int16, device=gpu)
+    E.nhwc_ingest(x.to(gpu), None, prec, xp)
+    xq = _planes_to_float(xp.cpu()).reshape(B, H, W, 256).permute(0, 3, 1, 2)             # what the kernel sees
+    w2 = w.double().permute(0, 2, 3, 1).reshape(256, -1)
+    wpl = E._planes_of(w2, P)
+    wq = _planes_to_float(wpl).reshape(256, k, k, 256).permute(0, 3, 1, 2)
+    wp = torch.stack([pack_b32(wpl[p]) for p in range(P)], 0).contiguous().to(gpu)
+    ref = F.conv2d(xq, wq, None, stride=s, padding=k // 2)                                  # float64
+    Ho, Wo = ref.shape[-2:]
+    y = torch.empty((B, Ho * Wo, 256), dtype=torch.float32, device=gpu)
+    lib = _lib.load()
+    partial = torch.zeros((lib.ph_conv_nhwc_partial_floats(B, Ho, Wo),), dtype=torch.float32, device=gpu)
+    E.conv_nhwc(xp, dict(wp=wp, k=k, s=s), y, partial, B, H, W, prec)
+    got = y.cpu().reshape(B, Ho, Wo, 256).permute(0, 3, 1, 2).double()
+    tol = 1e-5 if prec == _lib.PH_PREC_BF16 else 5e-5       # exact products of the bf16 operands / dropped lo*lo terms
+    assert Hh.rel_err(got, ref) < tol
+    nwg = ((Wo + 63) // 64) * ((Ho + 1) // 2)
+    pr = partial.cpu().reshape(B, nwg, 256, 2).double().sum(1)
+    assert Hh.rel_err(pr[..., 0], got.sum((2, 3))) < 1e-4 and Hh.rel_err(pr[..., 1], (got * got).sum((2, 3))) < 1e-4
+    stats = torch.empty((B, 32, 2), dtype=torch.float32, device=gpu)
+    E.gn_finalize(partial, stats, nwg, 32, Ho * Wo, B)
+    gm = got.reshape(B, 32, -1)
+    assert Hh.rel_err(stats.cpu()[..., 0], gm.mean(2)) < 1e-4
+    assert Hh.rel_err(stats.cpu()[..., 1], 1.0 / torch.sqrt(gm.var(2, unbiased=False) + 1e-5)) < 1e-4
+
+
+@pytest.mark.parametrize("H,W", [(5, 7), (8, 16)])
+def test_gn_apply_modes(gpu, H, W):
+    g = torch.Generator().manual_seed(9)
+    B, G = 2, 32
+    y = torch.randn(B, 256, H, W, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    ycl = y.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gm = y.reshape(B, G, -1)
+    stats = torch.stack([gm.mean(2), 1.0 / torch.sqrt(gm.var(2, unbiased=False) + 1e-5)], 2).contiguous().to(gpu)
+    pk = dict(gamma=gamma.to(gpu), beta=beta.to(gpu))
+    ref = F.group_norm(y, G, gamma, beta, 1e-5).relu()
+    prec = _lib.PH_PREC_SPLIT
+    pl = torch.empty((2, B, H * W, 256), dtype=torch.int16, device=gpu)
+    E.gn_apply(ycl, stats, pk, G, _lib.PH_GN_TO_PLANES, B, H, W, prec, planes=pl)
+    got = _planes_to_float(pl.cpu()).reshape(B, H, W, 256).permute(0, 3, 1, 2)
+    assert Hh.rel_err(got, ref) < 2e-5
+    up = torch.empty((2, B, 4 * H * W, 256), dtype=torch.int16, device=gpu)
+    E.gn_apply(ycl, stats, pk, G, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=up)
+    got = _planes_to_float(up.cpu()).reshape(B, 2 * H, 2 * W, 256).permute(0, 3, 1, 2)
+    assert Hh.rel_err(got, F.interpolate(ref, scale_factor=2, mode="bilinear", align_corners=False)) < 2e-5
+    acc = torch.full((B, H * W, 256), 1.5, dtype=torch.float32, device=gpu)
+    E.gn_apply(ycl, stats, pk, G, _lib.PH_GN_ACCUM, B, H, W, prec, outf=acc, accumulate=True)
+    assert Hh.rel_err(acc.cpu().reshape(B, H, W, 256).permute(0, 3, 1, 2), ref + 1.5) < 1e-6
+    E.gn_apply(ycl, stats, pk, G, _lib.PH_GN_ACCUM, B, H, W, prec, outf=acc, accumulate=False)
+    assert Hh.rel_err(acc.cpu().reshape(B, H, W, 256).permute(0, 3, 1, 2), ref) < 1e-6
+    nchw = torch.empty((B, 256, H, W), dtype=torch.float32, device=gpu)
+    E.gn_apply(ycl, stats, pk, G, _lib.PH_GN_TO_NCHW, B, H, W, prec, outf=nchw)
+    assert Hh.rel_err(nchw.cpu(), ref) < 1e-6
+    E.gn_apply(ycl, None, None, G, _lib.PH_GN_TO_PLANES, B, H, W, prec, planes=pl)        # plain conversion
+    assert Hh.rel_err(_planes_to_float(pl.cpu()).reshape(B, H, W, 256).permute(0, 3, 1, 2), y) < 2e-5
+
+
+def _neck(precision, gpu, sd):
+    cfg = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+               upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+               cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+               norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    m = NECKS.build(cfg)
+    m.load_state_dict(sd)
+    m.eval().to(gpu)
+    m.set_precision(precision)
+    return m
+
+
+def _state():
+    keys = json.load(open(os.path.join(Hh.GOLDEN, "neck_state_keys.json")))["full"]
+    return Hh.seeded_fill({k: tuple(v) for k, v in keys.items()}, 31)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_neck_vs_reference_golden(gpu, precision):
+    sd = _state()
+    m = _neck(precision, gpu, sd)
+    feats = Hh.fpn_inputs(seed=32, B=1, C=256, H0=16, W0=32)
+    outs = m([f.to(gpu) for f in feats])
+    g = Hh.load_golden("full_neck.npz")
+    tol = 1e-3 if precision == "fp32" else 3e-2
+    for name, o in zip(("out", "aux0", "aux1"), outs):
+        e = Hh.rel_err(o.cpu(), torch.from_numpy(g[name]))
+        assert e < tol, (name, e)
+
+
+def test_neck_vs_oracle_ragged_sizes(gpu):
+    """level sizes that are multiples of nothing (24x40 -> 12x20 -> 6x10 -> 3x5), two frames"""
+    sd = _state()
+    m = _neck("fp32", gpu, sd)
+    feats = Hh.fpn_inputs(seed=33, B=2, C=256, H0=24, W0=40)
+    outs = m([f.to(gpu) for f in feats])
+    ref = NO.semantic_fpn(sd, feats, groups=32, num_feats=128)
+    for o, r in zip(outs, ref):
+        assert tuple(o.shape) == tuple(r.shape) == (2, 256, 12, 20)
+        assert Hh.rel_err(o.cpu(), r) < 1e-3
+
+
+def test_kernel_head_with_its_neck(gpu):
+    """KernelHead built from the shipped config (localization_fpn = SemanticFPNWrapper) takes the FPN tuple, as
+    Polyphonic.simple_test hands it over (polyphonic_former.py:146-148): FPN levels -> neck -> post-neck, against
+    the two oracles chained"""
+    from oracle import poly_oracle as O
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    neck_cfg = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                    upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                    cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                    norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11,
+                          in_channels=256, out_channels=256, cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, conv_normal_init=True, proposal_feats_with_obj=True, kernel_init_std=1,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=neck_cfg))
+    sd = Hh.seeded_fill({k: tuple(v.shape) for k, v in kh.state_dict().items()}, 41)
+    kh.load_state_dict(sd)
+    kh.eval().to(gpu)
+    kh.set_precision("fp32")
+    feats = Hh.fpn_inputs(seed=42, B=1, C=256, H0=16, W0=24)
+    out = kh.simple_test_rpn(tuple(f.to(gpu) for f in feats), [Hh.img_meta(64, 96)])
+    nsd = {k[len("localization_fpn."):]: v for k, v in sd.items() if k.startswith("localization_fpn.")}
+    hsd = {k: v for k, v in sd.items() if not k.startswith("localization_fpn.")}
+    maps = NO.semantic_fpn(nsd, feats, groups=32, num_feats=128)
+    ref = O.kernel_head_post_neck(hsd, *maps, 8, 19, 32)
+    for name, t in (("x_feats", out[1]), ("seg_preds", out[4]), ("depth_feats", out[5]), ("depth_pred", out[7])):
+        assert Hh.rel_err(t.cpu(), ref[name]) < 1e-3, name
+    assert Hh.rel_err(out[2].cpu(), ref["mask_preds"]) < 1e-3

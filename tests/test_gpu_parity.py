@@ -174,7 +174,7 @@ def _kernel_head(sd, precision="fp32", n_thing=8, n_stuff=11, Nq=100):
                          feat_downsample_stride=2, feat_refine_stride=1, feat_refine=False, use_binary=True,
                          conv_normal_init=True, proposal_feats_with_obj=True, xavier_init_kernel=False, kernel_init_std=1,
                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True),
-                         localization_fpn=dict(type="SemanticFPNWrapper", in_channels=256)))
+                         localization_fpn=None))
     h.load_state_dict({k[len("rpn_head."):]: v for k, v in sd.items() if k.startswith("rpn_head.")})
     h.eval().to("cuda:0")
     h.set_precision(precision)
