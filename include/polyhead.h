@@ -217,12 +217,16 @@ int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int gro
  * ph_gn_finalize : partial -> stats [B][groups][2] = (mean, rstd), fp64 combine (also used by ph_khead_conv_gn).
  * ph_gn_apply    : GroupNorm affine + ReLU on fp32 NHWC (stats == NULL: plain copy/convert), then per `mode`:
  *                  bf16 NHWC planes | x2 bilinear (align_corners=False, nn.Upsample :131-134) bf16 NHWC planes |
- *                  fp32 NHWC accumulate (the sum over levels, :221) | fp32 NCHW (what KernelHead takes). */
+ *                  fp32 NHWC accumulate | fp32 NCHW (what KernelHead takes; LDS transpose).
+ * ph_gn_sum_planes: sum over `nlev` <= 4 levels of ReLU(GroupNorm(y_l)) -> bf16 NHWC planes (the sum over levels, :221,
+ *                  without an fp32 sum buffer); ys / stats / gammas / betas are HOST arrays of `nlev` device pointers. */
 int ph_nhwc_ingest(const float* src, const float* add /* nullable */, uint16_t* dst, int B, int64_t HW, int prec, void* stream);
 size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo);
 int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize, int stride,
                  int B, int H, int W, int prec, void* stream);
 int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B, void* stream);
+int ph_gn_sum_planes(const float* const* ys, const float* const* stats, const float* const* gammas, const float* const* betas,
+                     int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec, void* stream);
 int ph_gn_apply(const float* y, const float* stats /* nullable */, const float* gamma, const float* beta, int groups, int mode,
                 int accumulate, uint16_t* planes /* nullable */, float* outf /* nullable */, int B, int H, int W, int prec,
                 void* stream);

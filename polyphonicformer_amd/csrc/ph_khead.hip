@@ -147,37 +147,51 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     }
 }
 
-// partial [B][nwg][256][2] -> stats [B][groups][2] = (mean, rstd); one block per frame, fp64 combine
-__global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ partial, float* __restrict__ stats, int nwg,
-                                                     int groups, int64_t HW, float eps) {
-    __shared__ double sh[256][2];
-    const int b = blockIdx.x, c = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int w = 0; w < nwg; ++w) {
-        const float* p = partial + (((int64_t)b * nwg + w) * 256 + c) * 2;
-        s += (double)p[0];
-        q += (double)p[1];
+// partial [B][nwg][256][2] -> stats [B][groups][2] = (mean, rstd); one block of 1024 threads per frame: 4 threads
+// per channel take interleaved workgroups with 4 independent accumulator pairs each (the loads of a chain of nwg
+// dependent additions were 80 us at nwg = 256), fp64 combine in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void k_gn_finalize(const float* __restrict__ partial, float* __restrict__ stats, int nwg,
+                                                      int groups, int64_t HW, float eps) {
+    __shared__ double sh[4][256][2];
+    const int b = blockIdx.x, c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
+    const float2* p = (const float2*)partial + ((int64_t)b * nwg) * 256 + c;
+    int w = q;
+    for (; w + 12 < nwg; w += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 v = p[(int64_t)(w + 4 * j) * 256];
+            s[j] += (double)v.x;
+            t[j] += (double)v.y;
+        }
     }
-    sh[c][0] = s;
-    sh[c][1] = q;
+    for (; w < nwg; w += 4) {
+        const float2 v = p[(int64_t)w * 256];
+        s[0] += (double)v.x;
+        t[0] += (double)v.y;
+    }
+    sh[q][c][0] = (s[0] + s[1]) + (s[2] + s[3]);
+    sh[q][c][1] = (t[0] + t[1]) + (t[2] + t[3]);
     __syncthreads();
     const int cpg = 256 / groups;
-    if (c < groups) {
+    if (threadIdx.x < groups) {
+        const int gidx = threadIdx.x;
         double ss = 0.0, qq = 0.0;
-        for (int j = 0; j < cpg; ++j) { ss += sh[c * cpg + j][0]; qq += sh[c * cpg + j][1]; }
+        for (int j = 0; j < cpg; ++j)
+            for (int k = 0; k < 4; ++k) { ss += sh[k][gidx * cpg + j][0]; qq += sh[k][gidx * cpg + j][1]; }
         const double n = (double)cpg * (double)HW;
         const double mean = ss / n;
         double var = qq / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        stats[((int64_t)b * groups + c) * 2] = (float)mean;
-        stats[((int64_t)b * groups + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[((int64_t)b * groups + gidx) * 2] = (float)mean;
+        stats[((int64_t)b * groups + gidx) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
 extern "C" int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B,
                               void* stream) {
     PH_CHECK_ARG(partial && stats && nwg > 0 && groups > 0 && 256 % groups == 0 && HW > 0 && B > 0, "bad pointer or size");
-    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, stats, nwg, groups, HW, eps);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(1024), 0, (hipStream_t)stream, partial, stats, nwg, groups, HW, eps);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -385,7 +399,7 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
         a.partial[0] = partial + (size_t)m * B * nwg * 256 * 2;
         if (PA == 1) hipLaunchKernelGGL(k_khead_stats<1>, grid, block, lds, s, a);
         else hipLaunchKernelGGL(k_khead_stats<2>, grid, block, lds, s, a);
-        hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(256), 0, s, a.partial[0], stats + (size_t)m * B * groups * 2, nwg,
+        hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(1024), 0, s, a.partial[0], stats + (size_t)m * B * groups * 2, nwg,
                            groups, HW, eps);
     }
     // pass 2: (loc, sem) -> loc, sem, x ; then depth

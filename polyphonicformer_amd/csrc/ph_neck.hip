@@ -316,12 +316,102 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, c
             } else {
                 *d = o;
             }
-        } else {   // PH_GN_TO_NCHW: strided 4-byte stores (the 64 threads of a pixel hit 64 channel rows; a block's
-                   // 4 consecutive pixels share each 16-byte piece) -- small maps, written once
-            float* d = outf + ((int64_t)b * 256 + c4) * HW + p;
-            d[0] = o.x; d[HW] = o.y; d[2 * HW] = o.z; d[3 * HW] = o.w;
         }
     }
+}
+
+// fp32 NHWC -> GroupNorm affine + ReLU -> fp32 NCHW through an LDS transpose: a block takes 32 pixels x 256
+// channels, reads whole 1 KiB pixel vectors and writes 128-byte runs of 32 pixels per channel row
+__global__ __launch_bounds__(256) void k_gn_to_nchw(const float* __restrict__ y, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int groups,
+                                                    float* __restrict__ out, int64_t HW) {
+    __shared__ float t[256][33];
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c4 = (threadIdx.x & 63) * 4, pq = threadIdx.x >> 6;
+    const int cpg = 256 / groups;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sc[e] = 1.f; sh[e] = 0.f;
+        if (stats) {
+            const float* st = stats + ((int64_t)b * groups + (c4 + e) / cpg) * 2;
+            sc[e] = st[1] * gamma[c4 + e];
+            sh[e] = beta[c4 + e] - st[0] * sc[e];
+        }
+    }
+    const bool act = stats != nullptr;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int pl = k * 4 + pq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + pl < HW) v = *(const float4*)(y + ((int64_t)b * HW + p0 + pl) * 256 + c4);
+        float o[4] = {v.x * sc[0] + sh[0], v.y * sc[1] + sh[1], v.z * sc[2] + sh[2], v.w * sc[3] + sh[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[c4 + e][pl] = act ? fmaxf(o[e], 0.f) : o[e];
+    }
+    __syncthreads();
+    const int pl = threadIdx.x & 31, cr = threadIdx.x >> 5;       // 8 channel rows per pass
+    if (p0 + pl < HW) {
+#pragma unroll 4
+        for (int c = cr; c < 256; c += 8) out[((int64_t)b * 256 + c) * HW + p0 + pl] = t[c][pl];
+    }
+}
+
+// sum over `nlev` levels of ReLU(GroupNorm(y_l)) -> bf16 NHWC plane(s) of the sum (semantic_fpn.py:221): the fp32
+// sum never exists in memory (one pass over the level outputs instead of a read-modify-write per level)
+struct GnSumArgs {
+    const float* y[4];
+    const float* stats[4];
+    const float* gamma[4];
+    const float* beta[4];
+};
+
+template <int PA>
+__global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nlev, int groups, uint16_t* __restrict__ planes,
+                                                       int B, int64_t HW) {
+    const int b = blockIdx.z;
+    const int c4 = (threadIdx.x & 63) * 4;
+    const int cpg = 256 / groups;
+    float4 sc[4], sh[4];
+    for (int l = 0; l < nlev; ++l) {
+        float s_[4], h_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* st = a.stats[l] + ((int64_t)b * groups + (c4 + e) / cpg) * 2;
+            s_[e] = st[1] * a.gamma[l][c4 + e];
+            h_[e] = a.beta[l][c4 + e] - st[0] * s_[e];
+        }
+        sc[l] = make_float4(s_[0], s_[1], s_[2], s_[3]);
+        sh[l] = make_float4(h_[0], h_[1], h_[2], h_[3]);
+    }
+    const int64_t plane = (int64_t)B * HW * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < HW; p += (int64_t)gridDim.x * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < nlev; ++l) {   // level order 0, 1, 2, 3 like Python's sum()
+            const float4 o = gn_relu4(*(const float4*)(a.y[l] + ((int64_t)b * HW + p) * 256 + c4), sc[l], sh[l], true);
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, acc);
+    }
+}
+
+extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stats, const float* const* gammas,
+                                const float* const* betas, int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec,
+                                void* stream) {
+    PH_CHECK_ARG(ys && stats && gammas && betas && planes && nlev >= 1 && nlev <= 4 && B > 0 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(groups > 0 && 256 % groups == 0, "bad group count");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    GnSumArgs a;
+    for (int l = 0; l < 4; ++l) {
+        const int k = l < nlev ? l : 0;
+        a.y[l] = ys[k]; a.stats[l] = stats[k]; a.gamma[l] = gammas[k]; a.beta[l] = betas[k];
+    }
+    const int gx = (int)((HW + 3) / 4 < 2048 ? (HW + 3) / 4 : 2048);
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_planes<1>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
+    else hipLaunchKernelGGL(k_gn_sum_planes<2>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
 }
 
 extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamma, const float* beta, int groups, int mode,
@@ -332,6 +422,13 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
     PH_CHECK_ARG(((mode == PH_GN_TO_PLANES || mode == PH_GN_UP2_PLANES) && planes) || ((mode == PH_GN_ACCUM || mode == PH_GN_TO_NCHW) && outf),
                  "output pointer missing for this mode");
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    if (mode == PH_GN_TO_NCHW) {
+        const int64_t HW = (int64_t)H * W;
+        hipLaunchKernelGGL(k_gn_to_nchw, dim3((unsigned)((HW + 31) / 32), B), dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta,
+                           groups ? groups : 1, outf, HW);
+        PH_CHECK_LAUNCH();
+        return PH_OK;
+    }
     const int64_t npix = (int64_t)H * W * (mode == PH_GN_UP2_PLANES ? 4 : 1);
     int gx = (int)((npix + 3) / 4 < 2048 ? (npix + 3) / 4 : 2048);
     const dim3 grid(gx, 1, B);

@@ -411,9 +411,17 @@ def gn_apply(y, stats, pk, groups, mode, B, H, W, prec, planes=None, outf=None, 
                                _lib.ptr(outf), B, H, W, prec, _lib.stream_ptr()), "ph_gn_apply")
 
 
+def gn_sum_planes(ys, stats, pks, groups, planes, B, HW, prec):
+    lib = _lib.load()
+    n = len(ys)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.ph_gn_sum_planes(arr(ys), arr(stats), arr([p["gamma"] for p in pks]), arr([p["beta"] for p in pks]), n, groups,
+                                    _lib.ptr(planes), B, HW, prec, _lib.stream_ptr()), "ph_gn_sum_planes")
+
+
 class NeckPlan:
     """buffers + launch sequence of SemanticFPNWrapper.forward for one (B, level shapes): channels-last bf16 planes
-    between the convs, fp32 channels-last conv outputs, the fp32 level sum, three fp32 NCHW outputs"""
+    between the convs, fp32 channels-last conv outputs (one per level for the fused level sum), three fp32 NCHW outputs"""
 
     def __init__(self, B, shapes, prec, device):
         self.B, self.shapes, self.prec = B, shapes, prec
@@ -428,46 +436,45 @@ class NeckPlan:
         big = max(h * w for h, w in shapes)
         self.xa = e((P, B, big, 256), torch.int16)                 # conv input planes (ping)
         self.xb = e((P, B, self.Ho * self.Wo, 256), torch.int16)   # conv input planes (pong, <= output size)
-        self.y = e((B, self.Ho * self.Wo, 256), torch.float32)     # conv output (pre-norm)
-        self.sum = e((B, self.Ho * self.Wo, 256), torch.float32)   # sum over levels
+        self.ys = [e((B, self.Ho * self.Wo, 256), torch.float32) for _ in range(4)]   # last conv output of each level
+        self.y = e((B, self.Ho * self.Wo, 256), torch.float32)     # other conv outputs (pre-norm)
         lib = _lib.load()
         self.partial = e((lib.ph_conv_nhwc_partial_floats(B, self.Ho, self.Wo),), torch.float32)
+        self.lstats = [e((B, 256, 2), torch.float32) for _ in range(4)]
         self.stats = e((B, 256, 2), torch.float32)
         self.outs = [e((B, 256, self.Ho, self.Wo), torch.float32) for _ in range(3)]
 
-    def _conv_gn(self, xp, pk, H, W, groups):
-        """conv + stats; returns the conv output size"""
+    def _conv_gn(self, xp, pk, H, W, groups, y, stats):
+        """conv + statistics; returns the conv output size"""
         B, prec = self.B, self.prec
         k, s = pk["k"], pk["s"]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
-        conv_nhwc(xp, pk, self.y, self.partial, B, H, W, prec)
+        conv_nhwc(xp, pk, y, self.partial, B, H, W, prec)
         nwg = ((Wo + 63) // 64) * ((Ho + 1) // 2)
-        gn_finalize(self.partial, self.stats, nwg, groups, Ho * Wo, B)
+        gn_finalize(self.partial, stats, nwg, groups, Ho * Wo, B)
         return Ho, Wo
 
     def run(self, feats, pk, groups, posenc, pos_level):
         B, prec = self.B, self.prec
-        first = True
         for lvl in range(4):
             H, W = self.shapes[lvl]
             nhwc_ingest(feats[lvl], posenc if lvl == pos_level else None, prec, self.xa)
             src = self.xa
             convs = pk["levels"][lvl]
             for j, c in enumerate(convs):
-                H, W = self._conv_gn(src, c, H, W, groups)
                 if j + 1 < len(convs):      # every non-final conv of levels 2 and 3 is followed by an x2 upsample
+                    H, W = self._conv_gn(src, c, H, W, groups, self.y, self.stats)
                     dst = self.xb if src is self.xa else self.xa
                     gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=dst)
                     H, W, src = 2 * H, 2 * W, dst
                 else:
+                    H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl])
                     if (H, W) != (self.Ho, self.Wo):
                         raise _lib.PolyheadError("level does not end at the stride-8 size")
-                    gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_ACCUM, B, H, W, prec, outf=self.sum, accumulate=not first)
-                    first = False
-        # the level sum as conv input planes, then conv_pred / aux convs (1x1 + GN + ReLU) -> fp32 NCHW
-        gn_apply(self.sum, None, None, groups, _lib.PH_GN_TO_PLANES, B, self.Ho, self.Wo, prec, planes=self.xb)
+        # sum over levels of ReLU(GN(.)) straight to conv input planes, then conv_pred / aux convs -> fp32 NCHW
+        gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
         for o, c in zip(self.outs, pk["outs"]):
-            self._conv_gn(self.xb, c, self.Ho, self.Wo, groups)
+            self._conv_gn(self.xb, c, self.Ho, self.Wo, groups, self.y, self.stats)
             gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_TO_NCHW, B, self.Ho, self.Wo, prec, outf=o)
         return self.outs[:len(pk["outs"])]
 
