@@ -15,7 +15,9 @@
 #include "ph_common.h"
 
 // ------------------------------------------------------------------------------------------------------------
-// fp32 NCHW [B][256][HW] (+ add[256][HW], nullable) -> bf16 NHWC planes [PA][B][HW][256]
+// fp32 NCHW [B][256][HW] (+ add[256][HW], nullable) -> bf16 NHWC planes [PA][B][HW][256]; 64 channels x 64 pixels per
+// block (256-byte runs in, whole 128-byte lines out).  A 256-channel x 32-pixel variant that writes whole 512-byte
+// pixel vectors was 50 % slower at the stride-4 level (256 rows 512 KB apart per block).
 template <int PA>
 __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ src, const float* __restrict__ add,
                                                      uint16_t* __restrict__ dst, int B, int64_t HW) {
@@ -56,16 +58,17 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, M = output pixels, N = 256 output channels, K = KS*KS*256 ordered (tap, channel).
-// Workgroup (8 waves) = 2 output rows x 64 output pixels x all 256 channels; wave (wm, wn) owns output row wm and
-// channels 64 wn .. 64 wn + 63: two 32-pixel M tiles x two 32-channel N tiles of 32x32x16 MFMA = 64 accumulator
-// VGPRs.  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
+// Workgroup (8 waves) = 2 output rows x 64 output pixels x all 256 channels; wave w owns channels 32 w .. 32 w + 31
+// of all 128 pixels: four 32-pixel M tiles of 32x32x16 MFMA = 64 accumulator VGPRs.  Per k-step a wave reads four A
+// fragments from LDS and ONE B fragment from L2 (a 64-pixel x 64-channel wave tile needs two: the CU's 64 B/clk L1
+// request path then runs as long as the matrix pipe).  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
 // time ([pixel][CH + 8] bf16: the 16-byte pad makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots);
 // an A fragment is one ds_read_b128 at a pixel offset given by the tap.  Weights are pre-packed B fragments
 // ([col tile][k-step] blocks of 1 KiB, pack.pack_b32) streamed from L2, one k-step ahead.
 // Roofline: MFMA (2*9*256*256 flop per output pixel); L2 weight stream = 1.18 MB per 128 output pixels.
 constexpr int CV_TW = 64, CV_TH = 2;
 
-template <int KS, int S> struct ConvGeo {
+template <int KS, int S, int PA> struct ConvGeo {
     static constexpr int IR = (CV_TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;   // input patch rows / cols
     static constexpr int CH = (S == 1) ? 64 : 32;                                  // channels per LDS stage
     static constexpr int LDP = CH + 8;                                             // pixel stride (elements)
@@ -76,30 +79,26 @@ template <int PA, int KS, int S>
 __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ X, int64_t x_plane,
                                                    const uint16_t* __restrict__ Wp, int64_t w_plane, float* __restrict__ Y,
                                                    float* __restrict__ partial, int B, int H, int W, int Ho, int Wo) {
-    using G = ConvGeo<KS, S>;
+    using G = ConvGeo<KS, S, PA>;
     constexpr int CH = G::CH, LDP = G::LDP, IR = G::IR, IC = G::IC, PAD = KS / 2;
     constexpr int KSTEPS_TOTAL = KS * KS * 256 / 16;
+    constexpr int DEPTH = 4;                                                // B fragments requested this many k-steps ahead
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
-    __shared__ float red[2][256][2];                                        // per output row: channel (sum, sumsq)
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);               // this wave's 32 output channels
     const int b = blockIdx.z, oy0 = blockIdx.y * CV_TH, ox0 = blockIdx.x * CV_TW;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const int m = lane & 31, kg = lane >> 5;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[4];          // [output row * 2 + 32-pixel half]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][ct][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     const uint16_t* xb = X + (int64_t)b * H * W * 256;
-    // this lane's B-fragment stream: column tiles 2 wn, 2 wn + 1
-    const uint16_t* wbase = Wp + ((int64_t)(wn * 2) * KSTEPS_TOTAL) * 512 + lane * 8;
+    const uint16_t* wbase = Wp + ((int64_t)wn * KSTEPS_TOTAL) * 512 + lane * 8;   // this lane's B-fragment stream
 
     for (int c0 = 0; c0 < 256; c0 += CH) {
         __syncthreads();                                  // previous chunk's readers are done
@@ -118,84 +117,72 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             }
         }
         __syncthreads();
-        // ---- MFMAs of this chunk: taps x (CH / 16) k-steps, weights one k-step ahead
+        // ---- MFMAs of this chunk: taps x (CH / 16) k-steps; the wave's B fragment of k-step j + DEPTH is requested
+        //      while k-step j runs (L2 latency is several k-steps long)
         constexpr int NK = KS * KS * (CH / 16);
         auto kstep_of = [&](int j) {                      // j-th k-step of the chunk -> global k-step index
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             return tap * 16 + (c0 >> 4) + kk;             // (tap * 256 + c0 + kk * 16) / 16
         };
-        uint4 bq[2][PA][2];
+        uint4 bq[DEPTH][PA];
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < NK) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                bq[0][p][ct] = *(const uint4*)(wbase + p * w_plane + ((int64_t)ct * KSTEPS_TOTAL + kstep_of(0)) * 512);
+                for (int p = 0; p < PA; ++p) bq[d][p] = *(const uint4*)(wbase + p * w_plane + (int64_t)kstep_of(d) * 512);
+            }
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
-            if (j + 1 < NK) {
+            uint4 bcur[PA];
 #pragma unroll
-                for (int p = 0; p < PA; ++p)
+            for (int p = 0; p < PA; ++p) bcur[p] = bq[j % DEPTH][p];
+            if (j + DEPTH < NK) {
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        bq[(j + 1) & 1][p][ct] = *(const uint4*)(wbase + p * w_plane + ((int64_t)ct * KSTEPS_TOTAL + kstep_of(j + 1)) * 512);
+                for (int p = 0; p < PA; ++p) bq[j % DEPTH][p] = *(const uint4*)(wbase + p * w_plane + (int64_t)kstep_of(j + DEPTH) * 512);
             }
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             const int dy = tap / KS, dx = tap - dy * KS;
-            uint4 a[PA][2];
+            uint4 a[PA][4];
 #pragma unroll
             for (int p = 0; p < PA; ++p)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int px = (mt * 32 + m) * S + dx, row = wm * S + dy;
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int px = ((mt & 1) * 32 + m) * S + dx, row = (mt >> 1) * S + dy;
                     a[p][mt] = *(const uint4*)(lds + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
                 }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    acc[mt][ct] = mfma32(a[0][mt], bq[j & 1][0][ct], acc[mt][ct]);
-                    if (PA == 2) {
-                        acc[mt][ct] = mfma32(a[0][mt], bq[j & 1][PA - 1][ct], acc[mt][ct]);
-                        acc[mt][ct] = mfma32(a[PA - 1][mt], bq[j & 1][0][ct], acc[mt][ct]);
-                    }
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[mt] = mfma32(a[0][mt], bcur[0], acc[mt]);
+                if (PA == 2) {
+                    acc[mt] = mfma32(a[0][mt], bcur[PA - 1], acc[mt]);
+                    acc[mt] = mfma32(a[PA - 1][mt], bcur[0], acc[mt]);
                 }
+            }
         }
     }
 
     // ---- epilogue: fp32 NHWC store (32 lanes = 128 contiguous bytes of a pixel) + GroupNorm partial sums
-    const int oy = oy0 + wm;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int px = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;        // C layout: row = pixel, col = channel
-            const int ox = ox0 + px;
-            const bool ok = oy < Ho && ox < Wo;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float v = acc[mt][ct][r];
-                if (ok) {
-                    Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + wn * 64 + ct * 32 + m] = v;
-                    s1[ct] += v;
-                    s2[ct] += v * v;
-                }
+            const int px = (mt & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
+            const int ox = ox0 + px, oy = oy0 + (mt >> 1);
+            if (oy < Ho && ox < Wo) {
+                const float v = acc[mt][r];
+                Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + wn * 32 + m] = v;
+                s1 += v;
+                s2 += v * v;
             }
         }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const float a1 = s1[ct] + __shfl_xor(s1[ct], 32), a2 = s2[ct] + __shfl_xor(s2[ct], 32);
-        if (kg == 0) {
-            red[wm][wn * 64 + ct * 32 + m][0] = a1;
-            red[wm][wn * 64 + ct * 32 + m][1] = a2;
-        }
-    }
-    __syncthreads();
-    if (tid < 256) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (kg == 0) {
         const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
-        float* o = partial + (((int64_t)b * nwg + wg) * 256 + tid) * 2;
-        o[0] = red[0][tid][0] + red[1][tid][0];
-        o[1] = red[0][tid][1] + red[1][tid][1];
+        float* o = partial + (((int64_t)b * nwg + wg) * 256 + wn * 32 + m) * 2;
+        o[0] = s1;
+        o[1] = s2;
     }
 }
 
@@ -215,7 +202,7 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     hipStream_t s = (hipStream_t)stream;
 #define PH_CV(PA, KS, S)                                                                                                 \
     do {                                                                                                                 \
-        const size_t lds = (size_t)PA * ConvGeo<KS, S>::PLANE * sizeof(uint16_t);                                        \
+        const size_t lds = (size_t)PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
         static bool once = false;                                                                                        \
         if (!once) {                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
