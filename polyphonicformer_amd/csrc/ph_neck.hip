@@ -100,23 +100,55 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     const uint16_t* xb = X + (int64_t)b * H * W * 256;
     const uint16_t* wbase = Wp + ((int64_t)wn * KSTEPS_TOTAL) * 512 + lane * 8;   // this lane's B-fragment stream
 
-    for (int c0 = 0; c0 < 256; c0 += CH) {
-        __syncthreads();                                  // previous chunk's readers are done
-        // ---- stage the patch of channels [c0, c0 + CH): 16-byte pieces, zero outside the image
-        constexpr int PIECES = CH / 8;
-        for (int idx = tid; idx < IR * IC * PIECES; idx += 512) {
-            const int piece = idx % PIECES, pix = idx / PIECES;
-            const int r = pix / IC, x = pix - r * IC;
-            const int iy = iy0 + r, ix = ix0 + x;
-            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    // Stride-1 single-plane instantiations double-buffer the patch: chunk c + 1 travels HBM -> registers while the
+    // MFMAs of chunk c run and is written to the other LDS buffer after them (one barrier per chunk).  Vector-memory
+    // operations of a wave retire in order, so the prefetch is issued AFTER the first DEPTH weight fragments: the
+    // k-steps that use those do not wait for it.
+    constexpr bool DB = (PA == 1 && S == 1);
+    constexpr int PIECES = CH / 8;
+    constexpr int NPRE = (IR * IC * PIECES + 511) / 512;
+    auto patch_load = [&](int c0, int k, uint4 (&v)[PA]) {      // k-th piece of this thread, zero outside the image
+        const int idx = tid + k * 512;
+        const int piece = idx % PIECES, pix = idx / PIECES;
+        const int r = pix / IC, x = pix - r * IC;
+        const int iy = iy0 + r, ix = ix0 + x;
+        const bool in = idx < IR * IC * PIECES && iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (in) v = *(const uint4*)(xb + p * x_plane + ((int64_t)iy * W + ix) * 256 + c0 + piece * 8);
-                *(uint4*)(lds + p * G::PLANE + pix * LDP + piece * 8) = v;
-            }
+        for (int p = 0; p < PA; ++p) {
+            v[p] = make_uint4(0, 0, 0, 0);
+            if (in) v[p] = *(const uint4*)(xb + p * x_plane + ((int64_t)iy * W + ix) * 256 + c0 + piece * 8);
+        }
+    };
+    auto patch_store = [&](uint16_t* buf, int k, const uint4 (&v)[PA]) {
+        const int idx = tid + k * 512;
+        if (idx < IR * IC * PIECES) {
+            const int piece = idx % PIECES, pix = idx / PIECES;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) *(uint4*)(buf + p * G::PLANE + pix * LDP + piece * 8) = v[p];
+        }
+    };
+    if (DB) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            uint4 v[PA];
+            patch_load(0, k, v);
+            patch_store(lds, k, v);
         }
         __syncthreads();
+    }
+
+    for (int c0 = 0; c0 < 256; c0 += CH) {
+        const uint16_t* cur = lds + (DB ? ((c0 / CH) & 1) * (PA * G::PLANE) : 0);
+        if (!DB) {
+            __syncthreads();                              // previous chunk's readers are done
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                uint4 v[PA];
+                patch_load(c0, k, v);
+                patch_store(lds, k, v);
+            }
+            __syncthreads();
+        }
         // ---- MFMAs of this chunk: taps x (CH / 16) k-steps; the wave's B fragment of k-step j + DEPTH is requested
         //      while k-step j runs (L2 latency is several k-steps long)
         constexpr int NK = KS * KS * (CH / 16);
@@ -131,6 +163,12 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #pragma unroll
                 for (int p = 0; p < PA; ++p) bq[d][p] = *(const uint4*)(wbase + p * w_plane + (int64_t)kstep_of(d) * 512);
             }
+        uint4 pre[DB ? NPRE : 1][PA];
+        const bool more = DB && c0 + CH < 256;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) patch_load(c0 + CH, k, pre[k]);
+        }
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             uint4 bcur[PA];
@@ -148,7 +186,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int px = ((mt & 1) * 32 + m) * S + dx, row = (mt >> 1) * S + dy;
-                    a[p][mt] = *(const uint4*)(lds + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
+                    a[p][mt] = *(const uint4*)(cur + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
                 }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -158,6 +196,14 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
                     acc[mt] = mfma32(a[PA - 1][mt], bcur[0], acc[mt]);
                 }
             }
+        }
+        if (DB) {
+            if (more) {
+                uint16_t* nxt = lds + (((c0 / CH) + 1) & 1) * (PA * G::PLANE);
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k) patch_store(nxt, k, pre[k]);
+            }
+            __syncthreads();
         }
     }
 
@@ -202,7 +248,7 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     hipStream_t s = (hipStream_t)stream;
 #define PH_CV(PA, KS, S)                                                                                                 \
     do {                                                                                                                 \
-        const size_t lds = (size_t)PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
+        const size_t lds = (size_t)((PA == 1 && S == 1) ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
         static bool once = false;                                                                                        \
         if (!once) {                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
