@@ -58,18 +58,22 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, M = output pixels, N = 256 output channels, K = KS*KS*256 ordered (tap, channel).
-// Workgroup (8 waves) = 2 output rows x 64 output pixels x all 256 channels; wave w owns channels 32 w .. 32 w + 31
-// of all 128 pixels: four 32-pixel M tiles of 32x32x16 MFMA = 64 accumulator VGPRs.  Per k-step a wave reads four A
+// Workgroup (8 waves) = TH output rows x 64 output pixels x all 256 channels (TH = 4 or 2, ConvGeo); wave w owns
+// channels 32 w .. 32 w + 31 of all TH * 64 pixels: 2 TH 32-pixel M tiles of 32x32x16 MFMA.  Per k-step a wave reads four A
 // fragments from LDS and ONE B fragment from L2 (a 64-pixel x 64-channel wave tile needs two: the CU's 64 B/clk L1
 // request path then runs as long as the matrix pipe).  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
 // time ([pixel][CH + 8] bf16: the 16-byte pad makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots);
 // an A fragment is one ds_read_b128 at a pixel offset given by the tap.  Weights are pre-packed B fragments
 // ([col tile][k-step] blocks of 1 KiB, pack.pack_b32) streamed from L2, one k-step ahead.
 // Roofline: MFMA (2*9*256*256 flop per output pixel); L2 weight stream = 1.18 MB per 128 output pixels.
-constexpr int CV_TW = 64, CV_TH = 2;
+constexpr int CV_TW = 64;
 
 template <int KS, int S, int PA> struct ConvGeo {
-    static constexpr int IR = (CV_TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;   // input patch rows / cols
+    // output rows per workgroup: 4 for the double-buffered stride-1 single-plane kernels (one workgroup per CU, 128
+    // accumulator VGPRs per wave, every weight fragment feeds 8 MFMAs), 2 otherwise
+    static constexpr int TH = (PA == 1 && S == 1) ? 4 : 2;
+    static constexpr int MT = TH * 2;                                              // 32-pixel M tiles per wave
+    static constexpr int IR = (TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;       // input patch rows / cols
     static constexpr int CH = (S == 1) ? 64 : 32;                                  // channels per LDS stage
     static constexpr int LDP = CH + 8;                                             // pixel stride (elements)
     static constexpr int PLANE = IR * IC * LDP;                                    // elements per precision plane
@@ -87,13 +91,14 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);               // this wave's 32 output channels
-    const int b = blockIdx.z, oy0 = blockIdx.y * CV_TH, ox0 = blockIdx.x * CV_TW;
+    constexpr int MT = G::MT;
+    const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * CV_TW;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const int m = lane & 31, kg = lane >> 5;
 
-    f32x16_t acc[4];          // [output row * 2 + 32-pixel half]
+    f32x16_t acc[MT];         // [output row * 2 + 32-pixel half]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
@@ -180,22 +185,23 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             }
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             const int dy = tap / KS, dx = tap - dy * KS;
-            uint4 a[PA][4];
+            uint4 a[PA][MT];
 #pragma unroll
             for (int p = 0; p < PA; ++p)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const int px = ((mt & 1) * 32 + m) * S + dx, row = (mt >> 1) * S + dy;
                     a[p][mt] = *(const uint4*)(cur + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
                 }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 acc[mt] = mfma32(a[0][mt], bcur[0], acc[mt]);
                 if (PA == 2) {
                     acc[mt] = mfma32(a[0][mt], bcur[PA - 1], acc[mt]);
                     acc[mt] = mfma32(a[PA - 1][mt], bcur[0], acc[mt]);
                 }
             }
+            if (MT > 4) __builtin_amdgcn_sched_barrier(0);   // 128 accumulator VGPRs: keep the A fragments of later k-steps out
         }
         if (DB) {
             if (more) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     // ---- epilogue: fp32 NHWC store (32 lanes = 128 contiguous bytes of a pixel) + GroupNorm partial sums
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int px = (mt & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
@@ -232,8 +238,17 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     }
 }
 
+static int conv_th(int ksize, int stride, int prec) { return (prec == PH_PREC_BF16 && stride == 1) ? 4 : 2; }
+
+// workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
+extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {
+    const int th = conv_th(ksize, stride, prec);
+    return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + th - 1) / th);
+}
+
+// upper bound over all instantiations (2-row tiles)
 extern "C" size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo) {
-    return (size_t)B * ((Wo + CV_TW - 1) / CV_TW) * ((Ho + CV_TH - 1) / CV_TH) * 256 * 2;
+    return (size_t)B * ((Wo + CV_TW - 1) / CV_TW) * ((Ho + 1) / 2) * 256 * 2;
 }
 
 extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize,
@@ -243,7 +258,8 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    const dim3 grid((Wo + CV_TW - 1) / CV_TW, (Ho + CV_TH - 1) / CV_TH, B);
+    const int th = conv_th(ksize, stride, prec);
+    const dim3 grid((Wo + CV_TW - 1) / CV_TW, (Ho + th - 1) / th, B);
     const int64_t x_plane = (int64_t)B * H * W * 256;
     hipStream_t s = (hipStream_t)stream;
 #define PH_CV(PA, KS, S)                                                                                                 \

@@ -450,7 +450,7 @@ class NeckPlan:
         k, s = pk["k"], pk["s"]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
         conv_nhwc(xp, pk, y, self.partial, B, H, W, prec)
-        nwg = _lib.load().ph_conv_nhwc_partial_floats(B, Ho, Wo) // (B * 512)      # workgroups per frame
+        nwg = _lib.load().ph_conv_nhwc_workgroups(k, s, Ho, Wo, prec)
         gn_finalize(self.partial, stats, nwg, groups, Ho * Wo, B)
         return Ho, Wo
 

@@ -45,8 +45,8 @@ def test_conv_nhwc(gpu, prec, k, s, H, W):
     got = y.cpu().reshape(B, Ho, Wo, 256).permute(0, 3, 1, 2).double()
     tol = 1e-5 if prec == _lib.PH_PREC_BF16 else 5e-5       # exact products of the bf16 operands / dropped lo*lo terms
     assert Hh.rel_err(got, ref) < tol
-    nwg = _lib.load().ph_conv_nhwc_partial_floats(B, Ho, Wo) // (B * 512)      # workgroups per frame
-    pr = partial.cpu().reshape(B, nwg, 256, 2).double().sum(1)
+    nwg = lib.ph_conv_nhwc_workgroups(k, s, Ho, Wo, prec)
+    pr = partial.cpu()[:B * nwg * 512].reshape(B, nwg, 256, 2).double().sum(1)   # the buffer is sized for the upper bound
     assert Hh.rel_err(pr[..., 0], got.sum((2, 3))) < 1e-4 and Hh.rel_err(pr[..., 1], (got * got).sum((2, 3))) < 1e-4
     stats = torch.empty((B, 32, 2), dtype=torch.float32, device=gpu)
     E.gn_finalize(partial, stats, nwg, 32, Ho * Wo, B)
