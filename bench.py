@@ -193,6 +193,41 @@ def neck_leg(wl, precision, dev, B=8, steps=5):
             "note": "7 conv3x3 + GN + ReLU towers, x2 upsamples, level sum, conv_pred + 2 aux convs; channels-last implicit GEMM"}
 
 
+def full_head_leg(wl, head, precision, dev, B=8, steps=5):
+    """secondary number: the whole head as `Polyphonic.simple_test` wires it (polyphonic_former.py:145-161), through the
+    module API: FPN levels -> rpn_head.simple_test_rpn (SemanticFPNWrapper + KernelHead post-neck) ->
+    roi_head.simple_test_mask_preds (3 stages + upsample); fp32 NCHW tensors at every API boundary"""
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    L = wl["n_thing"] + wl["n_stuff"]
+    torch.manual_seed(5)
+    neck = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=wl["Nq"], num_classes=L, num_thing_classes=wl["n_thing"],
+                          num_stuff_classes=wl["n_stuff"], cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=neck))
+    kh.init_weights()
+    kh.eval().to(dev)
+    kh.set_precision(precision)
+    H0, W0 = wl["H"] * 2, wl["W"] * 2
+    g = torch.Generator().manual_seed(6)
+    feats = tuple(torch.randn(B, 256, H0 >> i, W0 >> i, generator=g).to(dev) for i in range(4))
+    metas = [dict(img_shape=(wl["H"] * 8, wl["W"] * 8, 3), ori_shape=(wl["H"] * 8, wl["W"] * 8, 3),
+                  batch_input_shape=(wl["H"] * 8, wl["W"] * 8))] * B
+
+    def run():
+        (pf, xf, mp, cs, seg, df, dp, dpr, aspp) = kh.simple_test_rpn(feats, metas)
+        return head.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
+
+    t = time_op(run, steps)
+    return {"frames_per_step": B, "frames_per_s": round(B / (t * 1e-3), 1), "ms_per_step": round(t, 4),
+            "note": "FPN levels (fp32 NCHW) -> SemanticFPNWrapper -> KernelHead -> KernelUpdateIterHead.simple_test_mask_preds, "
+                    "module API, no HIP graph"}
+
+
 def panoptic_leg(wl, head, plan, dev):
     """get_panoptic (a7, SURVEY 8d: reported separately) on ONE frame of the step's outputs; host wall time,
     including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
@@ -382,6 +417,10 @@ def main():
                 res["semantic_fpn_neck"] = neck_leg(wl, args.precision, dev)
             except Exception as e:
                 res["semantic_fpn_neck"] = {"error": repr(e)}
+            try:
+                res["full_head_from_fpn"] = full_head_leg(wl, head, args.precision, dev)
+            except Exception as e:
+                res["full_head_from_fpn"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         print(json.dumps(res))
