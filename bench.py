@@ -58,14 +58,15 @@ def build_head(wl, precision, out_dtype, device, seed=0):
     return head
 
 
-def synth_inputs(wl, B, seed):
-    """BASELINE.md section 2, isolated-IterHead inputs (dense ~50 % foreground masks)."""
+def synth_inputs(wl, B, seed, mask_bias=0.0):
+    """BASELINE.md section 2, isolated-IterHead inputs (dense ~50 % foreground masks; SURVEY 8d's sparse variant is
+    `--mask-bias -2`).  The kernels' work does not depend on the mask density (1-bit masks, dense MFMA)."""
     g = torch.Generator().manual_seed(seed)
     N = wl["Nq"] + wl["n_stuff"]
     H, W = wl["H"], wl["W"]
     return dict(x=torch.randn(B, 256, H, W, generator=g), dfe=torch.randn(B, 256, H, W, generator=g),
                 k0=torch.randn(B, N, 256, generator=g), q0=torch.randn(1, 1, 256, generator=g).expand(B, N, 256),
-                m0=torch.randn(B, N, H, W, generator=g))
+                m0=torch.randn(B, N, H, W, generator=g) + mask_bias)
 
 
 def time_op(fn, iters, warm=2):
@@ -125,6 +126,20 @@ def algorithmic_bytes(plan, kernel):
     if kernel == "binarize":
         return p.B * p.N * p.HW * 4 + bits
     return None
+
+
+def algorithmic_rates(wl, N, frames_per_launch, fps_per_gpu, precision):
+    """B_alg = (S+1)*2*C*HW*e + N*HW*e (initial mask logits) + 2*N*HW*e + 2*N*4*HW*e + S*P*e_w / frames,
+    F_alg = S*8*N*C*HW + S*N*(7.73e6 + 2048 N + 512 L); e = 2 (bf16 planes and outputs), weights bf16"""
+    HW, S, C = wl["H"] * wl["W"], wl["S"], 256
+    L = wl["n_thing"] + wl["n_stuff"]
+    e = 2
+    pw = 4.02e6 * 2 * (2 if precision != "bf16" else 1)
+    b_alg = (S + 1) * 2 * C * HW * e + N * HW * e + 2 * N * HW * e + 2 * N * 4 * HW * e + S * pw / frames_per_launch
+    f_alg = S * 8 * N * C * HW + S * N * (7.73e6 + 2048 * N + 512 * L)
+    gbps, tf = b_alg * fps_per_gpu / 1e9, f_alg * fps_per_gpu / 1e12
+    return {"bytes_per_frame": int(b_alg), "flop_per_frame": int(f_alg), "achieved_GBps": round(gbps, 1),
+            "fraction_hbm": round(gbps / 8000.0, 4), "achieved_TFLOPs": round(tf, 1), "fraction_mfma_bf16": round(tf / 2500.0, 4)}
 
 
 def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
@@ -289,6 +304,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-head", action="store_true")
     ap.add_argument("--no-neck", action="store_true")
+    ap.add_argument("--mask-bias", type=float, default=0.0, help="added to the initial mask logits (-2: sparse masks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -318,7 +334,7 @@ def main():
     head = build_head(wl, args.precision, out_dtype, dev)
     N = wl["Nq"] + wl["n_stuff"]
     plan = head._plan(B, N, wl["H"], wl["W"], dev)      # single-stream plan (also used for the per-kernel timings)
-    inp = synth_inputs(wl, B, seed=1234 + rank)         # each rank: its own frames
+    inp = synth_inputs(wl, B, seed=1234 + rank, mask_bias=args.mask_bias)         # each rank: its own frames
     in_dt = args.input_dtype if args.input_dtype != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
     if in_dt == "bf16":
@@ -387,6 +403,11 @@ def main():
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(times[dom], 4),
                          "frames_per_launch": kplan.B,
                          "achievable_read_GBps_measured": 5400.0},
+            # SURVEY 8d "Reporting": whole-path algorithmic rates of the timed step (B_alg / F_alg per frame incl. the
+            # per-stage weight stream amortised over the frames of a launch)
+            "algorithmic": algorithmic_rates(wl, N, kplan.B, fps / world, args.precision),
+            "per_stage_ms": {"frames": kplan.B, "non_final": round(times["pool"] + times["query_pre"] + times["query_post"] + times["dynconv_bits"], 4),
+                             "final_incl_upsample": round(times["pool"] + times["query_pre"] + times["query_post"] + 2 * times["dynconv_logits"] + 2 * times["upsample2x"], 4)},
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
