@@ -202,7 +202,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
 #pragma unroll
             for (int k = 0; k < C::DPW; ++k)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(iptr + piece_off[k] + dma_lane_off),
-                                                 (PH_LDS void*)((PH_LDS char*)lds + buf * C::TILEB + piece_lds[k]), 16, 0, 0);
+                                                 (PH_LDS void*)((PH_LDS char*)lds + buf * C::TILEB + piece_lds[k]), 16, 0, PH_CPOL_STREAM);
         }
         ++ti;
         iptr += 2 * CONV_T;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
 #pragma unroll
                 for (int k = 0; k < 32 / RPI; ++k) {
                     const int row = rt * 32 + k * RPI + lane / LPR;
-                    if (row < N) *(u32x4_t*)(ub + k * rpi_bytes + patch_lane_off) = v[k];
+                    if (row < N) __builtin_nontemporal_store(v[k], (u32x4_t*)(ub + k * rpi_bytes + patch_lane_off));
                 }
             }
         }

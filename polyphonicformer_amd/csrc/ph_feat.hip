@@ -15,8 +15,9 @@ __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, u
         float v[8];
         const float* s = src + row * HW + px;
         if (px + 8 <= HW && ((HW & 3) == 0)) {
-            const float4 a = *(const float4*)(s), b = *(const float4*)(s + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            const uint4 a = ld_nt16(s), b = ld_nt16(s + 4);
+            v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+            v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (px + e < HW) ? s[e] : 0.f;
@@ -28,10 +29,9 @@ __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, u
             else f2bf_split(v[e], hi[e], lo[e]);
         }
         uint16_t* d = planes + row * HWp + px;
-        *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+        st_nt16(d, make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7])));
         if (P == 2)
-            *(uint4*)(d + plane_stride) =
-                make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+            st_nt16(d + plane_stride, make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7])));
     }
 }
 
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
         float v[4] = {-1.f, -1.f, -1.f, -1.f};
         if (live && px < HW) {
             if (vec_ok && px + 4 <= HW) {
-                const float4 q = *(const float4*)(src + px);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                const uint4 q = ld_nt16(src + px);
+                v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = src[px + e];
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
                     const uint2 q = *(const uint2*)(row + x0);
                     v[1] = bf2f(q.x & 0xFFFF); v[2] = bf2f(q.x >> 16); v[3] = bf2f(q.y & 0xFFFF); v[4] = bf2f(q.y >> 16);
                 } else {
-                    const float4 q = *(const float4*)(row + x0);
-                    v[1] = q.x; v[2] = q.y; v[3] = q.z; v[4] = q.w;
+                    const uint4 q = ld_nt16(row + x0);
+                    v[1] = __uint_as_float(q.x); v[2] = __uint_as_float(q.y); v[3] = __uint_as_float(q.z); v[4] = __uint_as_float(q.w);
                 }
             } else {
 #pragma unroll
@@ -186,10 +186,10 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
             T* d = dst + (p * 2 * H + yo) * W2 + 2 * x0;
             if (VEC) {
                 if (sizeof(T) == 2) {
-                    *(uint4*)d = make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7]));
+                    st_nt16(d, make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7])));
                 } else {
-                    *(float4*)d = make_float4(o[0], o[1], o[2], o[3]);
-                    *(float4*)((float*)d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    st_nt16(d, make_float4(o[0], o[1], o[2], o[3]));
+                    st_nt16((float*)d + 4, make_float4(o[4], o[5], o[6], o[7]));
                 }
             } else {
 #pragma unroll

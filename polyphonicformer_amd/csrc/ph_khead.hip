@@ -206,7 +206,7 @@ __device__ __forceinline__ void kh_flush_patch(const uint16_t* patch, uint16_t* 
     for (int it = 0; it < 4; ++it) {
         const int rl = it * 8 + (lane >> 3), piece = lane & 7;
         const uint4 v = *(const uint4*)(patch + rl * KH_PLD + piece * 8);
-        *(uint4*)(dst_plane + row0_off + (int64_t)rl * HWp + piece * 8) = v;
+        st_nt16(dst_plane + row0_off + (int64_t)rl * HWp + piece * 8, v);
     }
 }
 
