@@ -60,6 +60,11 @@ __device__ __forceinline__ void st_nt16(void* p, uint4 v) { __builtin_nontempora
 __device__ __forceinline__ void st_nt16(void* p, float4 v) {
     __builtin_nontemporal_store(ph_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, (ph_u32x4*)p);
 }
+typedef unsigned ph_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ld_nt8(const void* p) {
+    const ph_u32x2 v = __builtin_nontemporal_load((const ph_u32x2*)p);
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ uint4 ld_nt16(const void* p) {
     const ph_u32x4 v = __builtin_nontemporal_load((const ph_u32x4*)p);
     return make_uint4(v.x, v.y, v.z, v.w);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
             float v[6];
             if (VEC) {
                 if (sizeof(T) == 2) {
-                    const uint2 q = *(const uint2*)(row + x0);
+                    const uint2 q = *(const uint2*)(row + x0);   // cached: every source row is read by two row pairs (nt: 175 -> 223 us)
                     v[1] = bf2f(q.x & 0xFFFF); v[2] = bf2f(q.x >> 16); v[3] = bf2f(q.y & 0xFFFF); v[4] = bf2f(q.y >> 16);
                 } else {
                     const uint4 q = ld_nt16(row + x0);
