@@ -43,8 +43,8 @@ __device__ __forceinline__ void kh_load_tile(float (&v)[8][4], const float* __re
         const int64_t px = px0 + p4;
         const float* s = src + (int64_t)row * HW + px;
         if (px + 4 <= HW && ((HW & 3) == 0)) {
-            const float4 t = *(const float4*)s;
-            v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+            const uint4 t = ld_nt16(s);      // the fp32 map is read once per pass
+            v[q][0] = __uint_as_float(t.x); v[q][1] = __uint_as_float(t.y); v[q][2] = __uint_as_float(t.z); v[q][3] = __uint_as_float(t.w);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[q][e] = (px + e < HW) ? s[e] : 0.f;

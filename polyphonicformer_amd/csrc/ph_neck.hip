@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ s
         const int64_t p = p0 + tx;
         float v = 0.f;
         if (p < HW) {
-            v = src[((int64_t)b * 256 + c0 + c) * HW + p];
+            v = __builtin_nontemporal_load(src + ((int64_t)b * 256 + c0 + c) * HW + p);
             if (add) v += add[(int64_t)(c0 + c) * HW + p];
         }
         t[c][tx] = v;
@@ -394,7 +394,10 @@ __global__ __launch_bounds__(256) void k_gn_to_nchw(const float* __restrict__ y,
     for (int k = 0; k < 8; ++k) {
         const int pl = k * 4 + pq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p0 + pl < HW) v = *(const float4*)(y + ((int64_t)b * HW + p0 + pl) * 256 + c4);
+        if (p0 + pl < HW) {
+            const uint4 q = ld_nt16(y + ((int64_t)b * HW + p0 + pl) * 256 + c4);
+            v = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+        }
         float o[4] = {v.x * sc[0] + sh[0], v.y * sc[1] + sh[1], v.z * sc[2] + sh[2], v.w * sc[3] + sh[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[c4 + e][pl] = act ? fmaxf(o[e], 0.f) : o[e];
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nl
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < HW; p += (int64_t)gridDim.x * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int l = 0; l < nlev; ++l) {   // level order 0, 1, 2, 3 like Python's sum()
-            const float4 o = gn_relu4(*(const float4*)(a.y[l] + ((int64_t)b * HW + p) * 256 + c4), sc[l], sh[l], true);
+            const uint4 q = ld_nt16(a.y[l] + ((int64_t)b * HW + p) * 256 + c4);
+            const float4 o = gn_relu4(make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)), sc[l], sh[l], true);
             acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }
         st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, acc);
