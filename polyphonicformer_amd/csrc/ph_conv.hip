@@ -260,7 +260,8 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
 #pragma unroll
                 for (int k = 0; k < 32 / RPI; ++k) {
                     const int row = rt * 32 + k * RPI + lane / LPR;
-                    if (row < N) __builtin_nontemporal_store(v[k], (u32x4_t*)(ub + k * rpi_bytes + patch_lane_off));
+                    // default (cached) stores: the x2 upsample reads these logits next (non-temporal: 117 -> 150 us)
+                    if (row < N) *(u32x4_t*)(ub + k * rpi_bytes + patch_lane_off) = v[k];
                 }
             }
         }
