@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #define PH_LDS __attribute__((address_space(3)))
-template <int NBUF, int NW>
+template <int NBUF, int NW, int AUX>
 __global__ __launch_bounds__(NW * 64) void k_dmabw(const char* __restrict__ base, int64_t row_stride, int64_t tile_stride,
                                                    int tiles_per_wg, int64_t wg_stride, uint32_t* out, int nmfma, int nlds) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(NW * 64) void k_dmabw(const char* __restrict__ base
             const int jj = wave + NW * k;
             const char* ub = wbase + (int64_t)t * tile_stride + (int64_t)(jj * 8) * row_stride;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + lane_off),
-                                             (PH_LDS void*)(lds + buf * 32768 + jj * 1024), 16, 0, 0);
+                                             (PH_LDS void*)(lds + buf * 32768 + jj * 1024), 16, 0, AUX);
         }
     };
     int ti = 0;
@@ -50,11 +50,14 @@ extern "C" int dmabw(const void* base, int64_t row_stride, int64_t tile_stride, 
                      int nbuf, void* out, void* stream, int nmfma, int nlds) {
     hipStream_t s = (hipStream_t)stream;
     if (nbuf == 4) {
-        hipFuncSetAttribute((const void*)k_dmabw<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-        hipLaunchKernelGGL((k_dmabw<4, 8>), dim3(wgs), dim3(512), 4 * 32768, s, (const char*)base, row_stride, tile_stride, tiles_per_wg, wg_stride, (uint32_t*)out, nmfma, nlds);
-    } else {
-        hipFuncSetAttribute((const void*)k_dmabw<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
-        hipLaunchKernelGGL((k_dmabw<2, 8>), dim3(wgs), dim3(512), 2 * 32768, s, (const char*)base, row_stride, tile_stride, tiles_per_wg, wg_stride, (uint32_t*)out, nmfma, nlds);
+        hipFuncSetAttribute((const void*)k_dmabw<4, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        hipLaunchKernelGGL((k_dmabw<4, 8, 0>), dim3(wgs), dim3(512), 4 * 32768, s, (const char*)base, row_stride, tile_stride, tiles_per_wg, wg_stride, (uint32_t*)out, nmfma, nlds);
+    } else if (nbuf == 2) {
+        hipFuncSetAttribute((const void*)k_dmabw<2, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768);
+        hipLaunchKernelGGL((k_dmabw<2, 8, 0>), dim3(wgs), dim3(512), 2 * 32768, s, (const char*)base, row_stride, tile_stride, tiles_per_wg, wg_stride, (uint32_t*)out, nmfma, nlds);
+    } else {   // nbuf == 418: ring of 4 with the nt | sc1 cache policy the product kernels use
+        hipFuncSetAttribute((const void*)k_dmabw<4, 8, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        hipLaunchKernelGGL((k_dmabw<4, 8, 18>), dim3(wgs), dim3(512), 4 * 32768, s, (const char*)base, row_stride, tile_stride, tiles_per_wg, wg_stride, (uint32_t*)out, nmfma, nlds);
     }
     return (int)hipGetLastError();
 }

@@ -24,5 +24,7 @@ for nbuf, per_cu in ((4, 1), (2, 2)):
     run(f"ring {nbuf} x 32 KiB, {per_cu} WG/CU | rows 1.5 MB apart, tiles interleaved over WGs  ", B * 65536, 128 * wgs, tpw, 128, wgs, nbuf)
     run(f"ring {nbuf} x 32 KiB, {per_cu} WG/CU | tile-major layout (32 KiB contiguous per tile)  ", 128, 32768, tpw, tpw * 32768, wgs, nbuf)
 tpw = B * 512 // 256
+run("ring 4 x 32 KiB, 1 WG/CU | rows 1.5 MB apart, contiguous range, cache policy nt|sc1           ", B * 65536, 128, tpw, tpw * 128, 256, 418)
+run("ring 4 x 32 KiB, 1 WG/CU | tile-major layout, cache policy nt|sc1                            ", 128, 32768, tpw, tpw * 32768, 256, 418)
 for nmfma, nlds in ((8, 0), (16, 0), (20, 0), (32, 0), (0, 16), (0, 32), (20, 32)):
     run(f"ring 4, 8 waves, + {nmfma} MFMA 32x32x16 and {nlds} dependent tr-reads per wave per tile", B * 65536, 128, tpw, tpw * 128, 256, 4, nmfma, nlds)
