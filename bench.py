@@ -402,7 +402,7 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(times[dom], 4),
                          "frames_per_launch": kplan.B,
-                         "achievable_read_GBps_measured": 5400.0},
+                         "achievable_read_GBps_measured": 5800.0},   # tools/dmabw.py: compute-free LDS-DMA ring, same pattern and cache policy
             # SURVEY 8d "Reporting": whole-path algorithmic rates of the timed step (B_alg / F_alg per frame incl. the
             # per-stage weight stream amortised over the frames of a launch)
             "algorithmic": algorithmic_rates(wl, N, kplan.B, fps / world, args.precision),
