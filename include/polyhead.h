@@ -54,7 +54,8 @@ int ph_ingest_features(const float* src, uint16_t* planes, int B, int64_t HW, in
 
 /* fp32 mask logits [B][N][HW] -> mask bits.  kernel_update_head.py:236-238
  * (sigmoid -> > hard_mask_thr(0.5) -> float), stated as logit > 0. */
-int ph_binarize(const float* logits, uint32_t* bits, int B, int N, int64_t HW, void* stream);
+int ph_binarize(const float* logits, int64_t logits_batch_stride /* elements; 0 = N*HW (contiguous) */, uint32_t* bits,
+                int B, int N, int64_t HW, void* stream);
 
 /* ---- A7: masked pooling -------------------------------------------------------------------
  * kernel_update_head.py:241-242  einsum('bnhw,bchw->bnc') for x and depth_feats in one pass

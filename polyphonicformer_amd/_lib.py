@@ -32,7 +32,7 @@ SIGNATURES = {
     "ph_version": (C.c_int, []),
     "ph_last_error_string": (C.c_char_p, []),
     "ph_ingest_features": (C.c_int, [_P, _P, _I, _L, _I, _P]),
-    "ph_binarize": (C.c_int, [_P, _P, _I, _I, _L, _P]),
+    "ph_binarize": (C.c_int, [_P, _L, _P, _I, _I, _L, _P]),
     "ph_pool": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "ph_query_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,

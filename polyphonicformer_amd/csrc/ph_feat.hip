@@ -54,7 +54,7 @@ extern "C" int ph_ingest_features(const float* src, uint16_t* planes, int B, int
 // ---------------------------------------------------------------------------------------------
 // binarize: logits [B][N][HW] -> bits [B][Npad][HWp/32].  One wave produces two words per step
 // with __ballot (lane = pixel).  Rows >= N and pixels >= HW come out 0.
-__global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logits, uint32_t* __restrict__ bits,
+__global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logits, int64_t lbs, uint32_t* __restrict__ bits,
                                                   int B, int N, int Npad, int64_t HW, int64_t HWp) {
     // one row (b, n) per blockIdx.y; each lane tests 4 consecutive pixels (16-byte load); a wave covers
     // 256 px = 8 words; the 8 lanes of a word OR their nibbles together with three xor-shuffles
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
     const int row = blockIdx.y;
     const int b = row / Npad, n = row - b * Npad;
     const bool live = n < N;
-    const float* src = logits + ((int64_t)b * N + n) * HW;
+    const float* src = logits + (int64_t)b * lbs + (int64_t)n * HW;
     uint32_t* dst = bits + (int64_t)row * (HWp / 32);
     const bool vec_ok = (HW & 3) == 0;
     for (int c = blockIdx.x * 4 + wave; (int64_t)c * 256 < HWp; c += gridDim.x * 4) {
@@ -86,14 +86,18 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
     }
 }
 
-extern "C" int ph_binarize(const float* logits, uint32_t* bits, int B, int N, int64_t HW, void* stream) {
+extern "C" int ph_binarize(const float* logits, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
+                           void* stream) {
     PH_CHECK_ARG(logits && bits && B > 0 && N > 0 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(logits_batch_stride == 0 || logits_batch_stride >= (int64_t)N * HW, "batch stride smaller than a frame");
+    if (!logits_batch_stride) logits_batch_stride = (int64_t)N * HW;
     const int Npad = ph_n_padded(N);
     const int64_t HWp = ph_hw_padded(HW);
     PH_CHECK_ARG((int64_t)B * Npad <= 65535, "B * Npad must be <= 65535");
     int gx = (int)((HWp + 1023) / 1024);          // 4 waves x 256 px per block step
     if (gx > 8) gx = 8;
-    hipLaunchKernelGGL(k_binarize, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, logits, bits, B, N, Npad, HW, HWp);
+    hipLaunchKernelGGL(k_binarize, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, logits, logits_batch_stride, bits, B, N, Npad,
+                       HW, HWp);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

@@ -79,7 +79,7 @@ def binarize(m, out=None):
     if out is None:
         out = torch.empty((B, n_padded(N), hw_padded(H * W) // 32), dtype=torch.int32, device=m.device)
     lib = _lib.load()
-    _lib.check(lib.ph_binarize(_lib.ptr(m), _lib.ptr(out), B, N, H * W, _lib.stream_ptr()), "ph_binarize")
+    _lib.check(lib.ph_binarize(_lib.ptr(m), 0, _lib.ptr(out), B, N, H * W, _lib.stream_ptr()), "ph_binarize")
     return out
 
 
@@ -368,15 +368,16 @@ class KernelHeadPlan:
         if self.n_stuff:                                                               # :329-331 (device copy)
             self.mask_preds[:, self.Nq:].copy_(self.seg_preds[:, self.n_thing_cls:self.n_cls])
         # object features: binarise the THING logits, pool x (:314-320), add to the kernels (:324-326)
-        _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
+        _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
         th = self.mask_preds[:, :self.Nq]
         # thing rows are the first Nq rows of every frame: bits_th = bits rows [0, Npad_th) when the paddings agree,
         # otherwise binarise the slice separately
         if n_padded(self.Nq) == n_padded(self.N) and self.n_stuff == 0:
             bits_th = self.bits
         else:
-            th_c = th.contiguous()
-            _lib.check(lib.ph_binarize(_lib.ptr(th_c), _lib.ptr(self.bits_th), B, self.Nq, HW, s()), "ph_binarize")
+            # the thing rows are the first Nq rows of every frame of mask_preds: read in place (batch stride N * HW)
+            _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), self.N * HW, _lib.ptr(self.bits_th), B, self.Nq, HW, s()),
+                       "ph_binarize")
             bits_th = self.bits_th
         pool(self.xp, None, bits_th, self.Nq, HW, prec, self.nsplit, out=self.partial)
         stuff = pk.w_seg_f32[self.n_thing_cls:self.n_cls] if self.n_stuff else None
