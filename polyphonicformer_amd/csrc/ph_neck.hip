@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nl
     const int c4 = (threadIdx.x & 63) * 4;
     const int cpg = 256 / groups;
     float4 sc[4], sh[4];
-    for (int l = 0; l < nlev; ++l) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        sc[l] = make_float4(0.f, 0.f, 0.f, 0.f); sh[l] = sc[l];
+        if (l >= nlev) continue;
         float s_[4], h_[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -440,10 +443,16 @@ __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nl
     const int64_t plane = (int64_t)B * HW * 256;
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < HW; p += (int64_t)gridDim.x * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int l = 0; l < nlev; ++l) {   // level order 0, 1, 2, 3 like Python's sum()
-            const uint4 q = ld_nt16(a.y[l] + ((int64_t)b * HW + p) * 256 + c4);
-            const float4 o = gn_relu4(make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)), sc[l], sh[l], true);
-            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        uint4 q[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)        // all level loads in flight together
+            if (l < nlev) q[l] = ld_nt16(a.y[l] + ((int64_t)b * HW + p) * 256 + c4);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {      // level order 0, 1, 2, 3 like Python's sum()
+            if (l < nlev) {
+                const float4 o = gn_relu4(make_float4(__uint_as_float(q[l].x), __uint_as_float(q[l].y), __uint_as_float(q[l].z), __uint_as_float(q[l].w)), sc[l], sh[l], true);
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
         }
         st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, acc);
     }
@@ -460,7 +469,7 @@ extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stat
         const int k = l < nlev ? l : 0;
         a.y[l] = ys[k]; a.stats[l] = stats[k]; a.gamma[l] = gammas[k]; a.beta[l] = betas[k];
     }
-    const int gx = (int)((HW + 3) / 4 < 2048 ? (HW + 3) / 4 : 2048);
+    const int gx = (int)((HW + 3) / 4 < 8192 ? (HW + 3) / 4 : 8192);
     if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_planes<1>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
     else hipLaunchKernelGGL(k_gn_sum_planes<2>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
     PH_CHECK_LAUNCH();
