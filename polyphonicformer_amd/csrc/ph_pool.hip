@@ -97,27 +97,32 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
     // LDS-DMA of chunk c: features = 16 wave-instructions of 1 KiB (8 channel rows x 128 B) per plane, mask
     // words = NBI instructions of 64 x 4 B (row = l>>1, word = l&1).  Nothing in the loop is a VGPR load, so the
     // only vector-memory wait is the vmcnt(0) in front of the barrier.
-    auto issue_chunk = [&](int c, int buf) {
-        for (int j = wave; j < 16 * PA; j += 4) {
+    // piece k of this wave's PER_CHUNK DMA instructions for chunk c: k < 4 PA features, then mask words
+    auto issue_piece = [&](int c, int buf, int k) {
+        if (k < 4 * PA) {
+            const int j = wave + 4 * k;
             const int p = j >> 4, jj = j & 15;
             const int row = jj * 8 + (lane >> 3);
             const int q = (lane & 7) ^ pool_swz(row);
             const uint16_t* src = fbase + p * plane_stride + (int64_t)row * HWp + (int64_t)c * POOL_CHUNK + q * 8;
             uint16_t* dst = lds + (buf * PA + p) * POOL_FT + jj * 512;          // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, PH_CPOL_STREAM);
-        }
-        // every wave issues the same number of mask-word instructions (a wave past the end repeats the last one:
-        // the duplicate rewrites identical bytes), so ONE compile-time vmcnt covers a whole chunk for every wave
-#pragma unroll
-        for (int k = 0; k < NBW; ++k) {
-            int j = wave + 4 * k;
+        } else {
+            // every wave issues the same number of mask-word instructions (a wave past the end repeats the last one:
+            // the duplicate rewrites identical bytes), so ONE compile-time vmcnt covers a whole chunk for every wave
+            int j = wave + 4 * (k - 4 * PA);
             if (j > NBI - 1) j = NBI - 1;
             int row = j * 32 + (lane >> 1);
             if (row > Npad - 1) row = Npad - 1;                                    // tail lanes re-read the last row
             const uint32_t* src = brow + (int64_t)row * words_per_row + c * 2 + (lane & 1);
             uint32_t* dst = lbits + buf * (NBI * 64) + j * 64;                    // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 4, 0, 0);   // default policy: a 128-byte line of mask words serves 16 chunks (nt here: 181 -> 270 us)
+            // default policy: a 128-byte line of mask words serves 16 chunks (nt here: 181 -> 270 us)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 4, 0, 0);
         }
+    };
+    auto issue_chunk = [&](int c, int buf) {
+#pragma unroll
+        for (int k = 0; k < PER_CHUNK; ++k) issue_piece(c, buf, k);
     };
 
 #pragma unroll
@@ -138,9 +143,11 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // every wave is past compute(c-1): its buffer, (cur + NBUF-1) % NBUF, is free for chunk c + NBUF-1
+        // ... its DMA instructions are issued BETWEEN the row tiles of this chunk's MFMAs: a DMA issue can block on the
+        // memory pipe for hundreds of cycles, during which the matrix pipe now has this wave's MFMAs to run
         int nb = cur + POOL_NBUF - 1;
         if (nb >= POOL_NBUF) nb -= POOL_NBUF;
-        if (c + POOL_NBUF - 1 < c1) issue_chunk(c + POOL_NBUF - 1, nb);
+        const bool more = c + POOL_NBUF - 1 < c1;
         const uint32_t ft = lds_addr(lds + cur * PA * POOL_FT);
         const uint32_t wb = lds_addr(lbits + cur * (NBI * 64));
         // B fragments (this lane's channel row, 4 k-steps of 8 pixels in its 32-pixel half) and the mask words
@@ -174,6 +181,11 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
 #pragma unroll
                 for (int p = 0; p < PA; ++p)
                     acc[rt] = mfma32(__builtin_bit_cast(uint4, a[rt & 1][t]), __builtin_bit_cast(uint4, xf[p][t]), acc[rt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int k = rt; k < PER_CHUNK; k += NRT) issue_piece(c + POOL_NBUF - 1, nb, k);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         cur = cur + 1 == POOL_NBUF ? 0 : cur + 1;
