@@ -161,6 +161,26 @@ int ph_khead_conv_gn(const float* f0, const float* f1, const float* f2, const ui
                      uint16_t* loc_planes, uint16_t* sem_planes, uint16_t* x_planes, uint16_t* dfe_planes,
                      float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
                      void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream);
+/* ph_khead_fused: the same two passes with the three static 1x1 convs applied to the normalised tile while it is
+ * still in LDS (second GEMM of the apply pass): loc and sem never reach HBM, and the mask / seg / depth logits leave
+ * the kernel directly.  Replaces ph_khead_conv_gn + 3 x ph_dynconv + the stuff-row copy (kernel_head.py:250-331).
+ *   w2_init / w2_seg / w2_dd: bf16 planes [P][rows32/32][16][64][8] = MFMA 32x32x16 A fragments of
+ *     init_kernels.weight [n_init][256], conv_seg.weight [n_seg][256], conv_direct_depth.weight [1][256], rows zero
+ *     padded to a multiple of 32 (block (row tile, k-step): lane l holds row (l & 31), k = 16*step + 8*(l >> 5) .. +8);
+ *   bias_seg [rows32(n_seg)], bias_dd [32] fp32 (init_kernels has no bias);
+ *   mask_preds fp32 [B][n_init + n_stuff][HW]: rows [0, n_init) = init_kernels(loc), rows [n_init, ..) = seg rows
+ *     [stuff_lo, stuff_lo + n_stuff) (cat_stuff_mask, :329-331; n_stuff = 0: none);
+ *   seg_preds fp32 [B][n_seg][HW]; depth_pred fp32 [B][1][HW]; x_planes / dfe_planes / x_f32 / dfe_f32 as above
+ *   (dfe_planes doubles as the scratch that carries loc from the first to the second apply launch).
+ *   The mask bits of these logits (use_binary, :310-314) are ph_binarize's: emitting them from this epilogue (ballot per
+ *   accumulator register) measured slower than that separate pass. */
+int ph_khead_fused(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+                   const float* gn_affine, int groups, float eps,
+                   const uint16_t* w2_init, int n_init, const uint16_t* w2_seg, const float* bias_seg, int n_seg,
+                   const uint16_t* w2_dd, const float* bias_dd, int stuff_lo, int n_stuff,
+                   uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
+                   float* mask_preds, float* seg_preds, float* depth_pred,
+                   void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream);
 int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[Nq][256]*/,
                        const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
                        int B, int n_thing_queries, int n_stuff, void* stream);

@@ -41,6 +41,8 @@ SIGNATURES = {
     "ph_dynconv": (C.c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _I, _L, _I, _I, _L, _I, _P]),
     "ph_khead_workspace_bytes": (C.c_size_t, [_I, _L, _I]),
     "ph_khead_conv_gn": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
+    "ph_khead_fused": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
     "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -1,11 +1,14 @@
 // A1-A5 -- KernelHead after `localization_fpn` (polyphonic/kernel_head.py:245-347):
 //   loc / sem / dfe = ReLU(GroupNorm(conv1x1(f0 / f1 / f2)))   (ConvModule: conv(no bias) -> GN -> ReLU)
-//   x = sem + loc
+//   x = sem + loc ; mask logits = init_kernels(loc) ; seg_preds = conv_seg(sem) ; depth_pred = conv_direct_depth(dfe)
 // GroupNorm needs per-(frame, group) statistics of the conv OUTPUT over all pixels, so the conv is
 // evaluated twice: a statistics pass that keeps only per-channel sum / sum of
-// squares, and an apply pass that normalises and writes bf16 planes (and, on request, the fp32 NCHW
-// tensors the reference API hands out).  Recomputing the 256x256xHW GEMM is cheaper than a round
-// trip of its output through HBM: both passes are bound by reading the fp32 input map.
+// squares, and an apply pass that normalises, writes bf16 planes (and, on request, the fp32 NCHW
+// tensors the reference API hands out) and -- fused entry point -- multiplies the normalised tile, still in
+// LDS, with the static 1x1 kernels that consume it, so loc / sem never exist in HBM.
+// Both passes run at the speed of their HBM streams: with the GEMM compiled out they take the same time
+// (stats 5.0 TB/s of fp32 reads; apply ~4 TB/s of mixed fp32 reads / 128-byte bf16 row writes), and two tiles
+// in flight or a double-buffered LDS tile change nothing (measured) -- bytes are what is left to remove.
 //
 // GEMM core (shared by both passes): M = 256 output channels, N = 64-pixel tile, K = 256.
 // One workgroup = 8 waves; wave w owns output channels 32w..32w+31 and holds its A operand (conv
@@ -14,54 +17,86 @@
 #include "ph_common.h"
 
 constexpr int KH_T = 64;
-constexpr int KH_LDT = KH_T + 32;
+constexpr int KH_LDT = KH_T + 32;       // row stride 48 dwords: the transposing reads are bank-conflict free
 constexpr int KH_THREADS = 512;
 
 struct KHArgs {
-    const float* f[2];            // input maps fp32 [B][256][HW]
-    const uint16_t* w[2];         // conv weights, bf16 planes [PA][256][256] (out, in)
+    const float* f[3];            // input maps fp32 [B][256][HW]       (stats: all three, map = blockIdx.z; apply: f[0])
+    const uint16_t* w[3];         // conv weights, bf16 planes [PA][256][256] (out, in)
     int64_t w_plane;
-    const float* gamma[2];
-    const float* beta[2];
-    const float* stats[2];        // [B][groups][2] (mean, rstd)              (apply)
-    float* partial[2];            // [B][nwg][256][2] (sum, sumsq)            (stats)
-    uint16_t* planes[2];          // outputs bf16 planes [PA][B][256][HWp]   (apply)
-    uint16_t* sum_planes;         // planes of map0 + map1 (x_feats) or null
-    float* f32[2];                // optional fp32 NCHW outputs
+    float* partial[3];            // [B][nwg][256][2] (sum, sumsq)            (stats)
+    const float* gamma;           // apply: one map per launch
+    const float* beta;
+    const float* stats;           // [B][groups][2] (mean, rstd)
+    uint16_t* planes;             // output bf16 planes [PA][B][256][HWp] of this map, or null
+    const uint16_t* add_planes;   // ADD: planes of the map added to this one (loc_feats, written by the previous launch)
+    uint16_t* sum_planes;         // ADD: planes of the sum (x_feats); may alias add_planes
+    float* f32;                   // optional fp32 NCHW output of this map
     float* f32_sum;               // optional fp32 x_feats
+    // fused static 1x1 conv on the normalised tile (null w2: none)
+    const uint16_t* w2;           // MFMA 32x32x16 A fragments [PA][m2_tiles][16][64 lanes][8]
+    int64_t w2_plane;
+    const float* bias2;           // [m2_tiles * 32] or null
+    float* out2;                  // fp32 [B][out2_rows][HW], rows [0, n2) written
+    float* out2b;                 // optional second destination of rows [dual_lo, dual_lo + dual_n): row0b + (row - dual_lo)
+    int m2_tiles, n2, out2_rows, dual_lo, dual_n, out2b_rows, out2b_row0;
+    uint16_t* blocks_out;         // optional: this map as per-(frame, wave, tile) register-layout blocks (see kh_block)
+    const uint16_t* blocks_in;    // ADD == 2: the map to add, in that form
+    int w2_lds;                   // 1: the fragments are copied to LDS once per workgroup (bf16 precision, <= 6 row tiles)
     int B, groups, tiles_per_wg;
     int64_t HW, HWp;
 };
 
-// tile [256 c][64 px] fp32: 16 threads per channel row, 4 px each, 8 rows-of-threads per pass.
-// Split in two so that the HBM loads of the NEXT tile are in flight during the MFMA phase of the current one.
-__device__ __forceinline__ void kh_load_tile(float (&v)[8][4], const float* __restrict__ src, int64_t HW, int64_t px0, int tid) {
+// tile [256 c][64 px] fp32: 16 threads per channel row, 4 px each, 32 channel rows per pass (8 passes).
+// Every load is unconditional (column clamped into the map, zeroed when it is staged into LDS) and addressed as
+// a uniform base (map + 32 q rows) plus ONE 32-bit lane offset: no branches, no per-load address registers.
+// `more` = false (nothing left to prefetch): the same loads, all on the first bytes of the map (one cached line).
+// AL4: HW % 4 == 0 (16-byte loads); otherwise four 4-byte loads per thread and pass.
+template <bool AL4>
+__device__ __forceinline__ void kh_load_tile(float (&v)[8][4], const float* __restrict__ src, int64_t HW, int64_t px0, int tid,
+                                             bool more) {
+    const int row_in = tid >> 4, p4 = (tid & 15) * 4;
+    const int64_t qstride = more ? 32 * HW : 0;
+    if (AL4) {
+        int64_t col = px0 + p4;
+        if (col > HW - 4) col = HW - 4;
+        const uint32_t voff = more ? (uint32_t)(((int64_t)row_in * HW + col) * 4) : 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int idx = tid + q * KH_THREADS;
-        const int row = idx >> 4, p4 = (idx & 15) * 4;
-        const int64_t px = px0 + p4;
-        const float* s = src + (int64_t)row * HW + px;
-        if (px + 4 <= HW && ((HW & 3) == 0)) {
-            const uint4 t = ld_nt16(s);      // the fp32 map is read once per pass
+        for (int q = 0; q < 8; ++q) {
+            const char* ub = (const char*)(src + (int64_t)q * qstride);
+            const uint4 t = ld_nt16(ub + voff);      // the fp32 map is read once per pass
             v[q][0] = __uint_as_float(t.x); v[q][1] = __uint_as_float(t.y); v[q][2] = __uint_as_float(t.z); v[q][3] = __uint_as_float(t.w);
-        } else {
+        }
+    } else {
+        uint32_t voff[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q][e] = (px + e < HW) ? s[e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            int64_t col = px0 + p4 + e;
+            if (col > HW - 1) col = HW - 1;
+            voff[e] = more ? (uint32_t)(((int64_t)row_in * HW + col) * 4) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const char* ub = (const char*)(src + (int64_t)q * qstride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = __builtin_nontemporal_load((const float*)(ub + voff[e]));
         }
     }
 }
 
 template <int PA>
-__device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* lds, int tid) {
-    // fp32 -> bf16 plane(s) in LDS
+__device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* lds, int tid, int64_t HW, int64_t px0) {
+    // fp32 -> bf16 plane(s) in LDS; columns past the map are zero
+    const int row_in = tid >> 4, p4 = (tid & 15) * 4;
+    bool ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ok[e] = px0 + p4 + e < HW;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int idx = tid + q * KH_THREADS;
-        const int row = idx >> 4, p4 = (idx & 15) * 4;
+        const int row = q * 32 + row_in;
         uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f2bf_split(v[q][e], hi[e], lo[e]);
+        for (int e = 0; e < 4; ++e) f2bf_split(ok[e] ? v[q][e] : 0.f, hi[e], lo[e]);
         *(uint2*)(lds + row * KH_LDT + p4) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
         if (PA == 2) *(uint2*)(lds + 256 * KH_LDT + row * KH_LDT + p4) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
     }
@@ -78,6 +113,7 @@ __device__ __forceinline__ void kh_load_a(uint4 (&af)[PA][16], const uint16_t* _
     }
 }
 
+// acc[32 rows of A][32 px of column tile ct] over K = 256 channels of the LDS tile
 template <int PA>
 __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uint16_t* lds, int ct, int lane) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
@@ -99,19 +135,20 @@ __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uin
             acc = mfma32(af[0][ks], bf[PA - 1], acc);
             acc = mfma32(af[PA - 1][ks], bf[0], acc);
         }
+        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bounds how many B fragments are read ahead (registers)
     }
     return acc;
 }
 
-// ---- pass 1: per-channel sum / sum of squares of the conv output -------------------------------
-template <int PA>
+// ---- pass 1: per-channel sum / sum of squares of the conv output; the three maps in one launch (blockIdx.z) ------
+template <int PA, bool AL4>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-    const int b = blockIdx.y;
-    const float* src = a.f[0] + (int64_t)b * 256 * a.HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
+    const int b = blockIdx.y, m = blockIdx.z;
+    const float* src = a.f[m] + (int64_t)b * 256 * a.HW;
     uint4 af[PA][16];
-    kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+    kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
     const int ntiles = (int)(a.HWp / KH_T);
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
@@ -119,12 +156,12 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     float stg[8][4];
-    if (t0 < t1) kh_load_tile(stg, src, a.HW, (int64_t)t0 * KH_T, tid);
+    kh_load_tile<AL4>(stg, src, a.HW, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();
-        kh_store_tile<PA>(stg, lds, tid);
+        kh_store_tile<PA>(stg, lds, tid, a.HW, (int64_t)t * KH_T);
         __syncthreads();
-        if (t + 1 < t1) kh_load_tile(stg, src, a.HW, (int64_t)(t + 1) * KH_T, tid);   // in flight during the MFMAs
+        kh_load_tile<AL4>(stg, src, a.HW, (int64_t)(t + 1) * KH_T, tid, t + 1 < t1);   // in flight during the MFMAs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
@@ -133,12 +170,12 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
         }
     }
     // reduce over the 32 pixel lanes of each half-wave, lanes 0 / 32 hold the channel totals
-    float* out = a.partial[0] + ((int64_t)b * gridDim.x + blockIdx.x) * 256 * 2;
+    float* out = a.partial[m] + ((int64_t)b * gridDim.x + blockIdx.x) * 256 * 2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float x = s1[r], y = s2[r];
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { x += __shfl_xor(x, m); y += __shfl_xor(y, m); }
+        for (int q = 1; q < 32; q <<= 1) { x += __shfl_xor(x, q); y += __shfl_xor(y, q); }
         if ((lane & 31) == 0) {
             const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
             out[ch * 2] = x;
@@ -196,127 +233,226 @@ extern "C" int ph_gn_finalize(const float* partial, float* stats, int nwg, int g
     return PH_OK;
 }
 
-// ---- pass 2: normalise + ReLU, write planes (and fp32), optional sum of two maps ----------------
-constexpr int KH_PLD = KH_T + 8;    // row stride (elements) of a per-wave [32 ch][64 px] store patch
-
-// bf16 patch [32 ch][64 px] of this wave -> planes: 8 lanes x 16 B per channel row = whole 128-byte lines
-__device__ __forceinline__ void kh_flush_patch(const uint16_t* patch, uint16_t* dst_plane, int64_t row0_off, int64_t HWp,
-                                               int lane) {
+// ---- pass 2: normalise + ReLU; planes (+ fp32) out; ADD: x_feats = this map + the previous launch's map;
+//      w2: static 1x1 conv of the normalised tile (second GEMM, tile still in LDS) -----------------------------
+__device__ __forceinline__ void kh_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// this wave's 32 channel rows of the LDS tile <-> planes: 8 lanes x 16 B per channel row = whole 128-byte lines
+__device__ __forceinline__ void kh_flush_rows(const uint16_t* rows, uint16_t* dst_plane, int64_t row0_off, int64_t HWp, int lane) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int rl = it * 8 + (lane >> 3), piece = lane & 7;
-        const uint4 v = *(const uint4*)(patch + rl * KH_PLD + piece * 8);
+        const uint4 v = *(const uint4*)(rows + rl * KH_LDT + piece * 8);
         st_nt16(dst_plane + row0_off + (int64_t)rl * HWp + piece * 8, v);
     }
 }
+// vals (fp32, D layout of the two 32x32 tiles) -> bf16 plane(s) in this wave's rows of the LDS tile
+template <int PA>
+__device__ __forceinline__ void kh_vals_to_rows(const float (&vals)[2][16], uint16_t* rows, int lane) {
+    const int g = lane >> 5;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+            uint32_t hi, lo;
+            f2bf_split(vals[ct][r], hi, lo);
+            rows[rl * KH_LDT + ct * 32 + (lane & 31)] = (uint16_t)hi;
+            if (PA == 2) rows[256 * KH_LDT + rl * KH_LDT + ct * 32 + (lane & 31)] = (uint16_t)lo;
+        }
+}
 
-template <int PA, int NMAP>
+template <int PA, int ADD, bool AL4>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* patches = lds + PA * 256 * KH_LDT;                     // [8 waves][32][KH_PLD] (one plane at a time)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-    uint16_t* patch = patches + wave * (32 * KH_PLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
+    uint16_t* rows = lds + wave * 32 * KH_LDT;                       // this wave's channel rows (plane p: + p * 256 * KH_LDT)
     const int b = blockIdx.y;
     const int cpg = 256 / a.groups;
     const int64_t oplane = (int64_t)a.B * 256 * a.HWp;
-    // per-channel affine of the normalisation (rstd*gamma, beta - mean*rstd*gamma) in LDS: 64 registers saved
-    float2* ss = (float2*)(patches + 8 * 32 * KH_PLD);               // [NMAP][256]
-    for (int i = tid; i < NMAP * 256; i += KH_THREADS) {
-        const int m = i >> 8, ch = i & 255;
-        const float* st = a.stats[m] + ((int64_t)b * a.groups + ch / cpg) * 2;
+    // per-channel affine of the normalisation (rstd*gamma, beta - mean*rstd*gamma) in LDS
+    float2* ss = (float2*)(lds + PA * 256 * KH_LDT);                 // [256]
+    for (int ch = tid; ch < 256; ch += KH_THREADS) {
+        const float* st = a.stats + ((int64_t)b * a.groups + ch / cpg) * 2;
         const float mean = st[0], rstd = st[1];
-        ss[i] = make_float2(rstd * a.gamma[m][ch], a.beta[m][ch] - mean * rstd * a.gamma[m][ch]);
+        ss[ch] = make_float2(rstd * a.gamma[ch], a.beta[ch] - mean * rstd * a.gamma[ch]);
     }
-    __syncthreads();
-    constexpr bool HOIST = (PA == 1 && NMAP == 1);   // a single map: its weights stay in registers across tiles
-    uint4 af[HOIST ? NMAP : 1][PA][16];
-    if (HOIST) {
-#pragma unroll
-        for (int m = 0; m < NMAP; ++m) kh_load_a<PA>(af[m], a.w[m], a.w_plane, wave, lane);
+    // bf16 precision: the A fragments of the second GEMM live in LDS behind the tile (<= 96 KiB); split precision
+    // (two planes of everything) and more than 192 rows read them from L2
+    float* b2l = (float*)(ss + 256);                                 // [<= 256] bias of the second GEMM
+    if (a.w2)
+        for (int i = tid; i < a.m2_tiles * 32; i += KH_THREADS) b2l[i] = a.bias2 ? a.bias2[i] : 0.f;
+    uint16_t* w2l = lds + PA * 256 * KH_LDT + 256 * 4 + 256 * 2;     // after ss ([256] float2) and b2l ([256] float)
+    if (PA == 1 && a.w2 && a.w2_lds) {
+        const int n16 = a.m2_tiles * 16 * 64;                        // 16-byte pieces
+        for (int i = tid; i < n16; i += KH_THREADS) *(uint4*)(w2l + i * 8) = *(const uint4*)(a.w2 + (int64_t)i * 8);
     }
+    constexpr bool HOIST = (PA == 1);   // bf16 precision: the 64 weight registers stay resident across the tiles
+    uint4 af[PA][16];
+    if (HOIST) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+    const float* src = a.f[0] + (int64_t)b * 256 * a.HW;
     const int ntiles = (int)(a.HWp / KH_T);
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     float stg[8][4];
-    if (t0 < t1) kh_load_tile(stg, a.f[0] + (int64_t)b * 256 * a.HW, a.HW, (int64_t)t0 * KH_T, tid);
+    kh_load_tile<AL4>(stg, src, a.HW, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         const int64_t px0 = (int64_t)t * KH_T;
         const int64_t row0 = ((int64_t)b * 256 + wave * 32) * a.HWp + px0;       // this wave's first channel row, tile start
-        float keep[2][16];
+        __syncthreads();                      // every wave is done with the previous tile in LDS (second GEMM / flush)
+        kh_store_tile<PA>(stg, lds, tid, a.HW, px0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        kh_load_tile<AL4>(stg, src, a.HW, px0 + KH_T, tid, t + 1 < t1);            // next tile in flight during this one
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 addv[PA][4];
+        uint32_t addb[PA][2][8];
+        if (ADD == 1) {                                                            // the other map's bf16 rows of this wave
 #pragma unroll
-        for (int m = 0; m < NMAP; ++m) {
-            __syncthreads();
-            kh_store_tile<PA>(stg, lds, tid);
-            __syncthreads();
-            // next (tile, map) in flight during this one's MFMAs and stores
-            if (m + 1 < NMAP) kh_load_tile(stg, a.f[m + 1] + (int64_t)b * 256 * a.HW, a.HW, px0, tid);
-            else if (t + 1 < t1) kh_load_tile(stg, a.f[0] + (int64_t)b * 256 * a.HW, a.HW, px0 + KH_T, tid);
-            if (!HOIST) kh_load_a<PA>(af[0], a.w[m], a.w_plane, wave, lane);
-            float vals[2][16];
+            for (int p = 0; p < PA; ++p)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const f32x16_t acc = kh_gemm<PA>(af[HOIST ? m : 0], lds, ct, lane);
-                const int64_t px = px0 + ct * 32 + (lane & 31);
-                const bool inside = px < a.HW;
+                for (int it = 0; it < 4; ++it)
+                    addv[p][it] = *(const uint4*)(a.add_planes + p * oplane + row0 + (int64_t)(it * 8 + (lane >> 3)) * a.HWp + (lane & 7) * 8);
+        }
+        const int64_t blk = (((int64_t)b * 8 + wave) * ntiles + t) * 2048;         // this wave's block of this tile (kh_block)
+        if (ADD == 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float2 af2 = ss[m * 256 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
-                    float v = fmaxf(acc[r] * af2.x + af2.y, 0.f);
-                    if (!inside) v = 0.f;                                    // planes are zero padded
-                    vals[ct][r] = v;
-                    if (a.f32[m] && inside) {
-                        const int ch = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        a.f32[m][((int64_t)b * 256 + ch) * a.HW + px] = v;
-                    }
+            for (int p = 0; p < PA; ++p)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp)
+                        addb[p][ct][rp] = *(const uint32_t*)(a.blocks_in + p * oplane + blk + ((ct * 8 + rp) * 64 + lane) * 2);
+        }
+        if (!HOIST) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+        float vals[2][16];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
+            const int64_t px = px0 + ct * 32 + (lane & 31);
+            const bool inside = px < a.HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 af2 = ss[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+                float v = fmaxf(acc[r] * af2.x + af2.y, 0.f);
+                if (!inside) v = 0.f;                                    // planes are zero padded
+                vals[ct][r] = v;
+                if (a.f32 && inside) {
+                    float* ub = a.f32 + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;   // uniform
+                    ub[(uint32_t)(4 * g * a.HW + (lane & 31))] = v;
                 }
             }
-            // map m through the store patch, one bf16 plane at a time
+        }
+        if (a.blocks_out) {
+            // kh_block: [ct 2][r pair 8][64 lanes] x 32 bit = accumulator registers (2 rp, 2 rp + 1) as a bf16 pair --
+            // what the next launch adds to its own accumulators with 16 coalesced loads and no LDS round trip
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    uint32_t h0, l0, h1, l1;
+                    f2bf_split(vals[ct][2 * rp], h0, l0);
+                    f2bf_split(vals[ct][2 * rp + 1], h1, l1);
+                    *(uint32_t*)(a.blocks_out + blk + ((ct * 8 + rp) * 64 + lane) * 2) = pack2(h0, h1);
+                    if (PA == 2) *(uint32_t*)(a.blocks_out + oplane + blk + ((ct * 8 + rp) * 64 + lane) * 2) = pack2(l0, l1);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                      // every wave is done reading the input tile: its rows now take the outputs
+        if (ADD) {
+            // x_feats = semantic_feats + loc_feats (kernel_head.py:303): loc comes back as the bf16 plane(s) the previous
+            // launch wrote (exact to 2^-17 in fp32 precision; one extra bf16 rounding of loc in bf16 precision)
+            float sumv[2][16];
+            if (ADD == 1) {         // from planes: through this wave's LDS rows into the accumulator layout
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        *(uint4*)(rows + p * 256 * KH_LDT + (it * 8 + (lane >> 3)) * KH_LDT + (lane & 7) * 8) = addv[p][it];
+                kh_wave_sync();
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                        uint32_t hi, lo;
-                        f2bf_split(vals[ct][r], hi, lo);
-                        patch[rl * KH_PLD + ct * 32 + (lane & 31)] = (uint16_t)(p == 0 ? hi : lo);
+                        const int o = ((r & 3) + 8 * (r >> 2) + 4 * g) * KH_LDT + ct * 32 + (lane & 31);
+                        float s = vals[ct][r] + bf2f(rows[o]);
+                        if (PA == 2) s += bf2f(rows[256 * KH_LDT + o]);
+                        sumv[ct][r] = s;
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                kh_flush_patch(patch, a.planes[m] + p * oplane, row0, a.HWp, lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (NMAP == 2) {
-                if (m == 0) {
+                kh_wave_sync();
+            } else {                // from register-layout blocks: no transposition at all
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) keep[ct][r] = vals[ct][r];
-                } else {
-                    // x_feats = semantic_feats + loc_feats   (kernel_head.py:303)
+                    for (int rp = 0; rp < 8; ++rp) {
+                        float s0 = vals[ct][2 * rp], s1 = vals[ct][2 * rp + 1];
 #pragma unroll
-                    for (int p = 0; p < PA; ++p) {
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int64_t px = px0 + ct * 32 + (lane & 31);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
-                                const float sum = keep[ct][r] + vals[ct][r];
-                                uint32_t hi, lo;
-                                f2bf_split(sum, hi, lo);
-                                patch[rl * KH_PLD + ct * 32 + (lane & 31)] = (uint16_t)(p == 0 ? hi : lo);
-                                if (p == 0 && a.f32_sum && px < a.HW)
-                                    a.f32_sum[((int64_t)b * 256 + wave * 32 + rl) * a.HW + px] = sum;
-                            }
+                        for (int p = 0; p < PA; ++p) {
+                            s0 += bf2f(addb[p][ct][rp] & 0xFFFFu);
+                            s1 += __uint_as_float(addb[p][ct][rp] & 0xFFFF0000u);
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_wave_barrier();
-                        kh_flush_patch(patch, a.sum_planes + p * oplane, row0, a.HWp, lane);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_wave_barrier();
+                        sumv[ct][2 * rp] = s0;
+                        sumv[ct][2 * rp + 1] = s1;
+                    }
+            }
+            if (a.f32_sum) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int64_t px = px0 + ct * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (px < a.HW) {
+                            float* ub = a.f32_sum + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;
+                            ub[(uint32_t)(4 * g * a.HW + (lane & 31))] = sumv[ct][r];
+                        }
+                }
+            }
+            kh_vals_to_rows<PA>(sumv, rows, lane);
+            kh_wave_sync();
+#pragma unroll
+            for (int p = 0; p < PA; ++p) kh_flush_rows(rows + p * 256 * KH_LDT, a.sum_planes + p * oplane, row0, a.HWp, lane);
+            kh_wave_sync();
+        }
+        kh_vals_to_rows<PA>(vals, rows, lane);
+        if (a.planes) {
+            kh_wave_sync();
+#pragma unroll
+            for (int p = 0; p < PA; ++p) kh_flush_rows(rows + p * 256 * KH_LDT, a.planes + p * oplane, row0, a.HWp, lane);
+        }
+        if (a.w2) {
+            // second GEMM: rows of the static 1x1 conv (init_kernels / conv_seg / conv_direct_depth, kernel_head.py:256,295,285)
+            // x the normalised tile; 32-row x 32-px output tiles dealt round-robin to the waves, weights as ready-made A
+            // fragments (LDS in bf16 precision, L2 otherwise)
+            __syncthreads();
+            const int ntile2 = a.m2_tiles * 2;
+            for (int i = wave; i < ntile2; i += 8) {
+                const int rt = i >> 1, ct = i & 1;
+                uint4 a2[PA][16];
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks)
+                        a2[p][ks] = (PA == 1 && a.w2_lds) ? *(const uint4*)(w2l + ((rt * 16 + ks) * 64 + lane) * 8)
+                                            : *(const uint4*)(a.w2 + p * a.w2_plane + ((int64_t)(rt * 16 + ks) * 64 + lane) * 8);
+                const f32x16_t acc = kh_gemm<PA>(a2, lds, ct, lane);
+                const int64_t px = px0 + ct * 32 + (lane & 31);
+                const bool inside = px < a.HW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowu = rt * 32 + (r & 3) + 8 * (r >> 2);        // uniform part of the row
+                    const int row = rowu + 4 * g;
+                    const float v = acc[r] + b2l[row];
+                    const bool wr = inside && row < a.n2;
+                    const bool dual = a.out2b && row >= a.dual_lo && row < a.dual_lo + a.dual_n;
+                    if (wr) {
+                        float* ub = a.out2 + ((int64_t)b * a.out2_rows + rowu) * a.HW + px0 + ct * 32;
+                        __builtin_nontemporal_store(v, ub + (uint32_t)(4 * g * a.HW + (lane & 31)));
+                        if (dual) {
+                            float* ub2 = a.out2b + ((int64_t)b * a.out2b_rows + a.out2b_row0 + rowu - a.dual_lo) * a.HW + px0 + ct * 32;
+                            __builtin_nontemporal_store(v, ub2 + (uint32_t)(4 * g * a.HW + (lane & 31)));
+                        }
                     }
                 }
             }
@@ -356,17 +492,25 @@ extern "C" size_t ph_khead_workspace_bytes(int B, int64_t HW, int groups) {
     return (size_t)3 * B * nwg * 256 * 2 * sizeof(float) + (size_t)3 * B * groups * 2 * sizeof(float);
 }
 
-extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
-                                const float* gn_affine, int groups, float eps, uint16_t* loc_planes,
-                                uint16_t* sem_planes, uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32,
-                                float* dfe_f32, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec,
-                                void* stream) {
-    PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && loc_planes && sem_planes && x_planes && dfe_planes && workspace,
-                 "null pointer");
-    PH_CHECK_ARG(B > 0 && HW > 0 && groups > 0 && 256 % groups == 0, "bad size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+struct KhFused {                  // the static 1x1 convs of the fused entry point (all null for ph_khead_conv_gn)
+    const uint16_t* w2[3];
+    const float* bias2[3];
+    int n2[3];
+    float* out2[3];
+    int out2_rows[3];
+    int stuff_lo, n_stuff, n_init;
+    uint16_t* loc_blocks;         // scratch for loc between the first two launches (a planes-sized buffer)
+};
+
+static int kh_run(const float* const fm[3], const uint16_t* wplanes, const float* gn_affine, int groups, float eps,
+                  uint16_t* const outp[3], const uint16_t* add1, uint16_t* sum1, float* x_f32, float* dfe_f32,
+                  const KhFused* fu, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream,
+                  const char* fn) {
+    if (!(B > 0 && HW > 0 && groups > 0 && 256 % groups == 0)) { ph_set_error("%s: bad size", fn); return PH_EINVAL; }
+    if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT)) { ph_set_error("%s: prec must be PH_PREC_BF16 or PH_PREC_SPLIT", fn); return PH_EINVAL; }
+    if (B > 65535) { ph_set_error("%s: B must be <= 65535", fn); return PH_EINVAL; }
     if (workspace_bytes < ph_khead_workspace_bytes(B, HW, groups)) {
-        ph_set_error("ph_khead_conv_gn: workspace too small");
+        ph_set_error("%s: workspace too small", fn);
         return PH_EWORKSPACE;
     }
     const int PA = prec == PH_PREC_SPLIT ? 2 : 1;
@@ -376,52 +520,126 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
     float* stats = partial + (size_t)3 * B * nwg * 256 * 2;
-    const float* fm[3] = {f0, f1, f2};
     const size_t lds = (size_t)PA * 256 * KH_LDT * sizeof(uint16_t);
-    const size_t lds_apply = lds + (size_t)8 * 32 * KH_PLD * sizeof(uint16_t) + 2 * 256 * sizeof(float2);
+    const size_t lds_apply = lds + 256 * sizeof(float2) + 256 * sizeof(float);
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void*)k_khead_stats<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_khead_stats<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_khead_apply<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_khead_apply<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_khead_apply<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_khead_apply<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* ks[] = {(const void*)k_khead_stats<1, true>, (const void*)k_khead_stats<1, false>,
+                            (const void*)k_khead_stats<2, true>, (const void*)k_khead_stats<2, false>,
+                            (const void*)k_khead_apply<1, 0, true>, (const void*)k_khead_apply<1, 0, false>,
+                            (const void*)k_khead_apply<1, 1, true>, (const void*)k_khead_apply<1, 1, false>,
+                            (const void*)k_khead_apply<1, 2, true>, (const void*)k_khead_apply<1, 2, false>,
+                            (const void*)k_khead_apply<2, 0, true>, (const void*)k_khead_apply<2, 0, false>,
+                            (const void*)k_khead_apply<2, 1, true>, (const void*)k_khead_apply<2, 1, false>,
+                            (const void*)k_khead_apply<2, 2, true>, (const void*)k_khead_apply<2, 2, false>};
+        for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
-    KHArgs a;
+    KHArgs a = {};
     a.B = B; a.groups = groups; a.tiles_per_wg = tpw; a.HW = HW; a.HWp = HWp;
     a.w_plane = (int64_t)3 * 256 * 256;
     const dim3 grid(nwg, B), block(KH_THREADS);
-    for (int m = 0; m < 3; ++m) {   // pass 1 (+ finalize) per map
-        a.f[0] = fm[m];
-        a.w[0] = wplanes + (size_t)m * 256 * 256;
-        a.partial[0] = partial + (size_t)m * B * nwg * 256 * 2;
-        if (PA == 1) hipLaunchKernelGGL(k_khead_stats<1>, grid, block, lds, s, a);
-        else hipLaunchKernelGGL(k_khead_stats<2>, grid, block, lds, s, a);
-        hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(1024), 0, s, a.partial[0], stats + (size_t)m * B * groups * 2, nwg,
-                           groups, HW, eps);
-    }
-    // pass 2: (loc, sem) -> loc, sem, x ; then depth
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 3; ++m) {
         a.f[m] = fm[m];
         a.w[m] = wplanes + (size_t)m * 256 * 256;
-        a.gamma[m] = gn_affine + (size_t)m * 512;
-        a.beta[m] = gn_affine + (size_t)m * 512 + 256;
-        a.stats[m] = stats + (size_t)m * B * groups * 2;
-        a.f32[m] = nullptr;
+        a.partial[m] = partial + (size_t)m * B * nwg * 256 * 2;
     }
-    a.planes[0] = loc_planes; a.planes[1] = sem_planes; a.sum_planes = x_planes; a.f32_sum = x_f32;
-    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 2>), grid, block, lds_apply, s, a);
-    else hipLaunchKernelGGL((k_khead_apply<2, 2>), grid, block, lds_apply, s, a);
-    a.f[0] = f2; a.w[0] = wplanes + (size_t)2 * 256 * 256;
-    a.gamma[0] = gn_affine + 2 * 512; a.beta[0] = gn_affine + 2 * 512 + 256;
-    a.stats[0] = stats + (size_t)2 * B * groups * 2;
-    a.planes[0] = dfe_planes; a.f32[0] = dfe_f32; a.sum_planes = nullptr; a.f32_sum = nullptr;
-    if (PA == 1) hipLaunchKernelGGL((k_khead_apply<1, 1>), grid, block, lds_apply, s, a);
-    else hipLaunchKernelGGL((k_khead_apply<2, 1>), grid, block, lds_apply, s, a);
+    const bool al4 = (HW % 4) == 0;
+#define KH_LAUNCH(K, G, L, ...)                                                                   \
+    do {                                                                                          \
+        if (PA == 1 && al4) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, true>), G, block, L, s, a);   \
+        else if (PA == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, false>), G, block, L, s, a);    \
+        else if (al4) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, true>), G, block, L, s, a);         \
+        else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, false>), G, block, L, s, a);                 \
+    } while (0)
+    // pass 1: the three maps in one launch, then one finalize over the 3 * B (map, frame) pairs
+    KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps);
+    // pass 2: loc ; sem (+ x = sem + loc, loc read back from the planes the first launch wrote) ; depth
+    for (int m = 0; m < 3; ++m) {
+        a.f[0] = fm[m];
+        a.w[0] = wplanes + (size_t)m * 256 * 256;
+        a.gamma = gn_affine + (size_t)m * 512;
+        a.beta = gn_affine + (size_t)m * 512 + 256;
+        a.stats = stats + (size_t)m * B * groups * 2;
+        a.planes = outp[m];
+        a.add_planes = m == 1 ? add1 : nullptr;
+        a.sum_planes = m == 1 ? sum1 : nullptr;
+        a.f32 = m == 2 ? dfe_f32 : nullptr;
+        a.f32_sum = m == 1 ? x_f32 : nullptr;
+        a.w2 = nullptr; a.out2b = nullptr; a.blocks_out = nullptr; a.blocks_in = nullptr;
+        int add = m == 1 ? 1 : 0;
+        if (fu) {
+            a.w2 = fu->w2[m];
+            a.m2_tiles = (fu->n2[m] + 31) / 32;
+            a.w2_plane = (int64_t)a.m2_tiles * 16 * 512;
+            a.bias2 = fu->bias2[m];
+            a.n2 = fu->n2[m];
+            a.out2 = fu->out2[m];
+            a.out2_rows = fu->out2_rows[m];
+            if (m == 0) {                                    // loc leaves as register-layout blocks, not as planes
+                a.blocks_out = fu->loc_blocks;
+            }
+            if (m == 1) {
+                a.blocks_in = fu->loc_blocks;
+                add = 2;
+                if (fu->n_stuff > 0) {                       // stuff logits also go to the mask tensor (kernel_head.py:329-331)
+                    a.out2b = fu->out2[0];
+                    a.out2b_rows = fu->out2_rows[0];
+                    a.out2b_row0 = fu->n_init;
+                    a.dual_lo = fu->stuff_lo;
+                    a.dual_n = fu->n_stuff;
+                }
+            }
+        }
+        a.w2_lds = (PA == 1 && a.w2 && lds_apply + (size_t)a.m2_tiles * 16 * 1024 <= 160 * 1024) ? 1 : 0;
+        const size_t lds_m = lds_apply + (a.w2_lds ? (size_t)a.m2_tiles * 16 * 1024 : 0);
+        if (add == 2) KH_LAUNCH(k_khead_apply, grid, lds_m, 2);
+        else if (add == 1) KH_LAUNCH(k_khead_apply, grid, lds_m, 1);
+        else KH_LAUNCH(k_khead_apply, grid, lds_m, 0);
+    }
+#undef KH_LAUNCH
     PH_CHECK_LAUNCH();
     return PH_OK;
+}
+
+extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+                                const float* gn_affine, int groups, float eps, uint16_t* loc_planes,
+                                uint16_t* sem_planes, uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32,
+                                float* dfe_f32, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec,
+                                void* stream) {
+    PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && loc_planes && sem_planes && x_planes && dfe_planes && workspace,
+                 "null pointer");
+    const float* fm[3] = {f0, f1, f2};
+    uint16_t* outp[3] = {loc_planes, sem_planes, dfe_planes};
+    return kh_run(fm, wplanes, gn_affine, groups, eps, outp, loc_planes, x_planes, x_f32, dfe_f32, nullptr, workspace,
+                  workspace_bytes, B, HW, prec, stream, __func__);
+}
+
+extern "C" int ph_khead_fused(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+                              const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
+                              const uint16_t* w2_seg, const float* bias_seg, int n_seg, const uint16_t* w2_dd,
+                              const float* bias_dd, int stuff_lo, int n_stuff, uint16_t* x_planes, uint16_t* dfe_planes,
+                              float* x_f32, float* dfe_f32, float* mask_preds, float* seg_preds, float* depth_pred,
+                              void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream) {
+    PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && x_planes && dfe_planes && workspace, "null pointer");
+    PH_CHECK_ARG(w2_init && w2_seg && w2_dd && mask_preds && seg_preds && depth_pred, "null pointer");
+    PH_CHECK_ARG(n_init > 0 && n_init <= 256 && n_seg > 0 && n_seg <= 256 && n_stuff >= 0 && stuff_lo >= 0 &&
+                     stuff_lo + n_stuff <= n_seg, "bad row counts (at most 256 rows per static conv)");
+    const float* fm[3] = {f0, f1, f2};
+    // loc travels from the first to the second launch as register-layout blocks parked in the depth planes (which the
+    // third launch then overwrites); sem is never stored
+    uint16_t* outp[3] = {nullptr, nullptr, dfe_planes};
+    KhFused fu;
+    fu.w2[0] = w2_init; fu.w2[1] = w2_seg; fu.w2[2] = w2_dd;
+    fu.bias2[0] = nullptr; fu.bias2[1] = bias_seg; fu.bias2[2] = bias_dd;
+    fu.n2[0] = n_init; fu.n2[1] = n_seg; fu.n2[2] = 1;
+    fu.out2[0] = mask_preds; fu.out2[1] = seg_preds; fu.out2[2] = depth_pred;
+    fu.out2_rows[0] = n_init + n_stuff; fu.out2_rows[1] = n_seg; fu.out2_rows[2] = 1;
+    fu.stuff_lo = stuff_lo; fu.n_stuff = n_stuff; fu.n_init = n_init;
+    fu.loc_blocks = dfe_planes;
+    return kh_run(fm, wplanes, gn_affine, groups, eps, outp, nullptr, x_planes, x_f32, dfe_f32, &fu, workspace,
+                  workspace_bytes, B, HW, prec, stream, __func__);
 }
 
 extern "C" int ph_khead_proposals(const float* partial, int nsplit, const float* w_init, const float* w_stuff,

@@ -313,6 +313,10 @@ class KernelHeadPack:
         self.seg_bias = sb.to(device)
         db = z(32); db[0] = float(g("conv_direct_depth.bias")[0])
         self.dd_bias = db.to(device)
+        # the same three weights as MFMA A fragments for the fused second GEMM of ph_khead_fused
+        from .pack import pack_b32
+        frag = lambda pl: torch.stack([pack_b32(pl[p].cpu()) for p in range(P)], 0).contiguous().to(device)
+        self.init_frag, self.seg_frag, self.dd_frag = frag(self.init_planes), frag(self.seg_planes), frag(self.dd_planes)
         self.w_init_f32 = w_init.float().contiguous().to(device)
         self.w_seg_f32 = w_seg.float().contiguous().to(device)
         self.w_dd_f32 = sd["conv_direct_depth.weight"].detach().float().contiguous().to(device)   # [1,256,1,1]
@@ -334,7 +338,6 @@ class KernelHeadPlan:
         dev = torch.device(device)
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         self.f = [e((B, 256, H, W), torch.float32) for _ in range(3)]
-        self.loc_p, self.sem_p = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
         self.xp, self.dp = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
         self.x_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
         self.dfe_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
@@ -342,11 +345,12 @@ class KernelHeadPlan:
         self.seg_preds = e((B, pack.n_seg, H, W), torch.float32)
         self.depth_pred = e((B, 1, H, W), torch.float32)
         self.bits = e((B, n_padded(self.N), HWp // 32), torch.int32)
-        self.bits_th = e((B, n_padded(self.Nq), HWp // 32), torch.int32)
+        self.bits_th = torch.zeros((B, n_padded(self.Nq), HWp // 32), dtype=torch.int32, device=dev)   # padding rows stay 0
         self.nsplit = nsplit or default_nsplit(B, self.HW)
         self.partial = e((B, self.nsplit, n_padded(self.Nq), 512), torch.float32)
         self.proposal = e((B, self.N, 256), torch.float32)
         self.ws = e((_lib.load().ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
+        self.w_stuff = pack.w_seg_f32[num_thing_classes:num_classes].contiguous() if self.n_stuff else None
 
     def set_inputs(self, feats):
         for dst, src in zip(self.f, feats):
@@ -355,34 +359,28 @@ class KernelHeadPlan:
     def run(self):
         lib, pk, s = _lib.load(), self.pack, _lib.stream_ptr
         B, HW, prec = self.B, self.HW, pk.prec
-        _lib.check(lib.ph_khead_conv_gn(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
-                                        _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(self.loc_p), _lib.ptr(self.sem_p),
-                                        _lib.ptr(self.xp), _lib.ptr(self.dp), _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32),
-                                        _lib.ptr(self.ws), self.ws.numel(), B, HW, prec, s()), "ph_khead_conv_gn")
-        # init_kernels(loc) -> thing mask logits (rows [0, Nq) of mask_preds)           kernel_head.py:256
-        static_conv(self.loc_p, pk.init_planes, pk.init_bias, self.Nq, HW, prec, self.mask_preds, self.N)
-        # conv_seg(sem) -> seg_preds                                                     :295
-        static_conv(self.sem_p, pk.seg_planes, pk.seg_bias, pk.n_seg, HW, prec, self.seg_preds, pk.n_seg)
-        # conv_direct_depth(dfe) -> depth_pred                                           :285
-        static_conv(self.dp, pk.dd_planes, pk.dd_bias, 1, HW, prec, self.depth_pred, 1)
-        if self.n_stuff:                                                               # :329-331 (device copy)
-            self.mask_preds[:, self.Nq:].copy_(self.seg_preds[:, self.n_thing_cls:self.n_cls])
-        # object features: binarise the THING logits, pool x (:314-320), add to the kernels (:324-326)
+        # conv1x1+GN+ReLU x3, x = sem + loc, and the static 1x1 convs on the normalised tiles (kernel_head.py:250-331):
+        # init_kernels(loc) -> thing rows of mask_preds (:256), conv_seg(sem) -> seg_preds (:295) and its stuff rows ->
+        # the remaining rows of mask_preds (:329-331), conv_direct_depth(dfe) -> depth_pred (:285)
+        _lib.check(lib.ph_khead_fused(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
+                                      _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
+                                      _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
+                                      _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
+                                      _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
+                                      _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), _lib.ptr(self.ws), self.ws.numel(),
+                                      B, HW, prec, s()), "ph_khead_fused")
+        # object features: binarise the logits once (all rows: the decode stages start from these bits), pool x over the
+        # THING rows (:314-320), add to the kernels (:324-326)
         _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
-        th = self.mask_preds[:, :self.Nq]
-        # thing rows are the first Nq rows of every frame: bits_th = bits rows [0, Npad_th) when the paddings agree,
-        # otherwise binarise the slice separately
-        if n_padded(self.Nq) == n_padded(self.N) and self.n_stuff == 0:
-            bits_th = self.bits
+        if n_padded(self.Nq) == n_padded(self.N):
+            bits_th = self.bits                      # rows >= Nq are pooled too; ph_khead_proposals ignores them
         else:
-            # the thing rows are the first Nq rows of every frame of mask_preds: read in place (batch stride N * HW)
-            _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), self.N * HW, _lib.ptr(self.bits_th), B, self.Nq, HW, s()),
-                       "ph_binarize")
+            # the thing rows are the first Nq rows of every frame: copy their words (row padding differs)
+            self.bits_th[:, :self.Nq].copy_(self.bits[:, :self.Nq])
             bits_th = self.bits_th
         pool(self.xp, None, bits_th, self.Nq, HW, prec, self.nsplit, out=self.partial)
-        stuff = pk.w_seg_f32[self.n_thing_cls:self.n_cls] if self.n_stuff else None
         _lib.check(lib.ph_khead_proposals(_lib.ptr(self.partial), self.nsplit, _lib.ptr(pk.w_init_f32),
-                                          _lib.ptr(stuff.contiguous()) if stuff is not None else None,
+                                          _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
 
 
