@@ -181,8 +181,8 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
     t_a1 = time_op(run_a1, steps)
     return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
             "a1_only_ms_per_step": round(t_a1, 4),
-            "note": "KernelHead post-neck (3 x conv1x1+GN+ReLU two-pass, static 1x1 convs, object pooling) + 3-stage decode, "
-                    "bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
+            "note": "KernelHead post-neck (3 x conv1x1+GN+ReLU two-pass with the static 1x1 convs fused into the apply pass, "
+                    "object pooling) + 3-stage decode, bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
 
 
 def neck_leg(wl, precision, dev, B=8, steps=5):

@@ -223,6 +223,33 @@ def test_kernel_head_vs_oracle_ragged(gpu, weights, H, W, B):
         assert Hh.rel_err(out[0].cpu().reshape(B, N, 256), ref["proposal_feats"].reshape(B, N, 256)) < 1e-3
 
 
+@pytest.mark.parametrize("precision,Nq", [("bf16", 200), ("fp32", 200), ("bf16", 37)])
+def test_kernel_head_row_counts(gpu, precision, Nq):
+    """init_kernels with 7 row tiles (cfg5's 200 proposals: the fused second GEMM reads its fragments from L2 instead of
+    LDS) and with a ragged 37 rows, random-init weights, against the oracle."""
+    torch.manual_seed(5)
+    n_thing, n_stuff = 8, 11
+    h = HEADS.build(dict(type="KernelHead", num_proposals=Nq, num_classes=n_thing + n_stuff, num_thing_classes=n_thing,
+                         num_stuff_classes=n_stuff, in_channels=256, out_channels=256, cat_stuff_mask=True,
+                         feat_downsample_stride=2, feat_refine_stride=1, feat_refine=False, use_binary=True,
+                         conv_normal_init=True, proposal_feats_with_obj=True, xavier_init_kernel=False, kernel_init_std=1,
+                         loss_seg=dict(type="FocalLoss", use_sigmoid=True), loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True),
+                         localization_fpn=None))
+    h.init_weights()
+    sd = {k: v.detach().clone() for k, v in h.state_dict().items()}
+    h.eval().to(gpu)
+    h.set_precision(precision)
+    B, H, W = 2, 12, 20
+    feats = Hh.neck_inputs(77, B, 256, H, W)
+    ref = O.kernel_head_post_neck(sd, *feats, n_thing, n_thing + n_stuff, 32)
+    out = h.simple_test_rpn([f.to(gpu) for f in feats], [Hh.img_meta(H * 8, W * 8)] * B)
+    tol = TOL[precision]
+    for name, t in (("x_feats", out[1]), ("mask_preds", out[2]), ("seg_preds", out[4]), ("depth_feats", out[5]),
+                    ("depth_pred", out[7])):
+        assert t.shape == ref[name].shape, name
+        assert Hh.rel_err(t.cpu(), ref[name]) < tol, (name, Hh.rel_err(t.cpu(), ref[name]))
+
+
 def test_whole_path_a1_a6(gpu, weights):
     """KernelHead -> KernelUpdateIterHead exactly as Polyphonic.simple_test wires them
     (polyphonic_former.py:145-161), with the plane/bit hand-off, vs the oracle's run_head."""
