@@ -208,6 +208,54 @@ def neck_leg(wl, precision, dev, B=8, steps=5):
             "note": "7 conv3x3 + GN + ReLU towers, x2 upsamples, level sum, conv_pred + 2 aux convs; channels-last implicit GEMM"}
 
 
+def assign_leg(dev, B=16, N=100, G=40, H=128, W=256, steps=20):
+    """secondary number (first part): the pixel sums of the mask Hungarian assigner's costs for a batch of
+    training crops (512 x 1024 at assign stride 4), one `ph_match_sums` launch; the reference does three einsums + four
+    row sums per image (polyphonic/funcs/assigner.py:113-129,178-194).  Also the host part per image (cost algebra +
+    scipy Hungarian) and the same pixel sums by the CPU oracle."""
+    from polyphonicformer_amd import assigner as A
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(B, N, H, W, generator=g) * 2).to(dev)
+    t = (torch.rand(B, G, H, W, generator=g) > 0.7).float().to(dev)
+    v = (torch.rand(B, H, W, generator=g) > 0.1).float().to(dev)
+    lib = A._lib.load()
+    part = torch.empty((B, lib.ph_match_nsplit(H * W, B), lib.ph_match_record_floats(N, G)), dtype=torch.float32, device=dev)
+
+    def kernel():
+        A._lib.check(lib.ph_match_sums(A._lib.ptr(z), A._lib.ptr(t), A._lib.ptr(v), A._lib.ptr(part), B, N, G, H * W,
+                                       A._lib.stream_ptr()), "ph_match_sums")
+
+    ms = time_op(kernel, steps)
+    nbytes = B * (N + G + 1) * H * W * 4
+    a = A.build_assigner(dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                              dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                              mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True)))
+    cls, lab = torch.randn(N, 8, generator=g).to(dev), torch.randint(0, 8, (G,), generator=g).to(dev)
+    a.assign(z[0], cls, t[0], lab, None, gt_valid=v[0])          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(B):
+        a.assign(z[i], cls, t[i], lab, None, gt_valid=v[i])
+    torch.cuda.synchronize()
+    per_img = (time.perf_counter() - t0) / B * 1e3
+    out = {"images_per_launch": B, "N": N, "G": G, "HxW": [H, W], "pixel_sums_ms_per_launch": round(ms, 4),
+           "pixel_sums_GBps": round(nbytes / ms / 1e6, 1), "bytes_per_launch": nbytes,
+           "assign_ms_per_image_incl_host_hungarian": round(per_img, 3),
+           "note": "one pass over mask logits + gt masks + valid (fp32 in, sigmoid fused, bf16 hi/lo MFMA over the pixel axis)"}
+    try:
+        from oracle import assign_oracle as AO
+        torch.set_num_threads(16)
+        zc, tc, vc = z[0].cpu(), t[0].cpu(), v[0].cpu()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            AO.dice_cost(zc, tc, vc)
+            AO.mask_cost(zc, tc, vc)
+        out["cpu_oracle_costs_ms_per_image"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    except Exception as e:      # the oracle is optional here
+        out["cpu_oracle_costs_ms_per_image"] = repr(e)
+    return out
+
+
 def full_head_leg(wl, head, precision, dev, B=8, steps=5):
     """secondary number: the whole head as `Polyphonic.simple_test` wires it (polyphonic_former.py:145-161), through the
     module API: FPN levels -> rpn_head.simple_test_rpn (SemanticFPNWrapper + KernelHead post-neck) ->
@@ -442,6 +490,11 @@ def main():
                 res["full_head_from_fpn"] = full_head_leg(wl, head, args.precision, dev)
             except Exception as e:
                 res["full_head_from_fpn"] = {"error": repr(e)}
+        if world == 1 and not args.no_neck:
+            try:
+                res["hungarian_assign"] = assign_leg(dev)
+            except Exception as e:
+                res["hungarian_assign"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         print(json.dumps(res))

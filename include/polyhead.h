@@ -185,6 +185,19 @@ int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[
                        const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
                        int B, int n_thing_queries, int n_stuff, void* stream);
 
+/* ---- N4 (first part): matching costs of the mask Hungarian assigner (polyphonic/funcs/assigner.py:113-129 DiceCost,
+ * :164-194 MaskCost with pred_act = sigmoid, gt_valid as MaskHungarianAssignerWithDepth.assign :478-498 passes it) --
+ * every pixel sum of B images in one pass: logits fp32 [B][N][HW] (mask logits, sigmoid applied inside), gt fp32
+ * [B][G][HW] (soft masks; pad unused rows with zeros), valid fp32 [B][HW] of 0/1 or NULL.  N <= 256, G <= 127.
+ * partial: fp32 [B][ph_match_nsplit(HW, B)][ph_match_record_floats(N, G)]; the caller adds the records of one image in
+ * order.  Record (Npad = ph_n_padded(N), Gpad = ph_n_padded(G + 1)):
+ *   A[Npad][Gpad] (A[n][g] = sum p t v; column G = S[n] = sum p v) | Q[Npad] = sum p^2 v | C[Gpad] = sum t^2 v |
+ *   T[Gpad] = sum t v | V = sum v. */
+int64_t ph_match_record_floats(int N, int G);
+int ph_match_nsplit(int64_t HW, int B);
+int ph_match_sums(const float* logits, const float* gt, const float* valid, float* partial, int B, int N, int G,
+                  int64_t HW, void* stream);
+
 /* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
  * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.
  * activate: act_mask[k] = sigmoid(mask_up[q_idx[k]]), act_depth[k] = depth_act(depth_up[q_idx[k]]),

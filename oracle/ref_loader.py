@@ -487,3 +487,46 @@ def neck_cfg(C=256, groups=32, num_feats=128):
                 positional_encoding=dict(type="SinePositionalEncoding", num_feats=num_feats, normalize=True),
                 cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
                 norm_cfg=dict(type="GN", num_groups=groups, requires_grad=True))
+
+
+def load_reference_assigner():
+    """polyphonic/funcs/assigner.py (MaskHungarianAssigner[WithDepth], DiceCost, MaskCost, DepthCost) together with the
+    vendored mmdet FocalLossCost (mmdet/core/bbox/match_costs/match_cost.py:54-99), loaded by file path.  Stand-ins:
+    `AssignResult` (a record of num_gts / gt_inds / max_overlaps / labels, mmdet/core/bbox/assigners/assign_result.py:41-48),
+    `BaseAssigner` (an empty base), the MATCH_COST registry and `build_match_cost` (registry build)."""
+    load_reference()
+    core = sys.modules["mmdet.core"]
+
+    class AssignResult:
+        def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+            self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+            self._extra = {}
+
+        def set_extra_property(self, k, v):
+            self._extra[k] = v
+
+    core.AssignResult = AssignResult
+    core.BaseAssigner = type("BaseAssigner", (), {})
+    MATCH_COST = Registry("match_cost")
+    mc = _mod("mmdet.core.bbox.match_costs")
+    b = _mod("mmdet.core.bbox.match_costs.builder")
+    b.MATCH_COST = MATCH_COST
+    b.build_match_cost = lambda cfg, default_args=None: MATCH_COST.build(cfg)
+    iou = _mod("mmdet.core.bbox.iou_calculators")
+    iou.bbox_overlaps = None        # box costs are not on this path
+    tr = _mod("mmdet.core.bbox.transforms")
+    tr.bbox_cxcywh_to_xyxy = tr.bbox_xyxy_to_cxcywh = None
+
+    def load(modname, relpath):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_ROOT, relpath))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        parent, _, child = modname.rpartition(".")
+        setattr(sys.modules[parent], child, m)
+        spec.loader.exec_module(m)
+        return m
+
+    load("mmdet.core.bbox.match_costs.match_cost", "mmdet/core/bbox/match_costs/match_cost.py")
+    a = load("polyphonic.funcs.assigner", "polyphonic/funcs/assigner.py")
+    return types.SimpleNamespace(module=a, MATCH_COST=MATCH_COST, Assigner=a.MaskHungarianAssignerWithDepth,
+                                 AssignerNoDepth=a.MaskHungarianAssigner, AssignResult=AssignResult)

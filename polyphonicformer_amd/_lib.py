@@ -44,6 +44,9 @@ SIGNATURES = {
     "ph_khead_fused": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
                                  _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "ph_match_record_floats": (C.c_int64, [_I, _I]),
+    "ph_match_nsplit": (C.c_int, [_L, _I]),
+    "ph_match_sums": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
     "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ph_panoptic_argmax": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32), _I, _P, _P, _P]),

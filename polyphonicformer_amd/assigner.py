@@ -1,0 +1,233 @@
+"""SURVEY.md 8f N4 (first part): the mask Hungarian assigner of the training path, with its pixel sums on the device.
+
+Mirrors polyphonic/funcs/assigner.py -- `MaskHungarianAssignerWithDepth` (:363-542, the one the shipped config builds,
+configs/_base_/models/polyphonic_former.py:170-192), `MaskHungarianAssigner` (:199-360), `DiceCost` (:80-146),
+`MaskCost` (:149-196) -- and mmdet's `FocalLossCost` (mmdet/core/bbox/match_costs/match_cost.py:54-99): same registry
+names, constructor kwargs, `assign(...)` signature and `AssignResult` fields.  What changes is where the arithmetic runs:
+the three `einsum`s over all pixels and the four row sums of one image (DiceCost.dice_loss :113-129, MaskCost.__call__
+:178-194) are ONE pass of `ph_match_sums` (csrc/ph_match.hip: bf16 hi/lo MFMA contraction over the pixel axis with the
+sigmoid fused in); the [N, G] cost algebra and `scipy.optimize.linear_sum_assignment` stay on the host, as in the
+reference (:511-519).  `DepthCost` is accepted with weight 0 (the shipped configs; :165-173 of the config) and refused
+otherwise -- it is not part of this widening step.  No CPU fallback: tensors must live on the GPU."""
+import numpy as np
+import torch
+
+from . import _lib
+from .registry import Registry
+
+try:
+    from scipy.optimize import linear_sum_assignment
+except ImportError:                                    # the reference raises at assign time (:513-515)
+    linear_sum_assignment = None
+
+BBOX_ASSIGNERS = Registry("bbox_assigner")
+MATCH_COST = Registry("match_cost")
+
+
+def build_match_cost(cfg):
+    return MATCH_COST.build(cfg)
+
+
+def build_assigner(cfg):
+    return BBOX_ASSIGNERS.build(cfg)
+
+
+class AssignResult:
+    """the fields of mmdet's AssignResult the heads read (mmdet/core/bbox/assigners/assign_result.py:41-48)"""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+        self._extra_properties = {}
+
+    def set_extra_property(self, key, value):
+        self._extra_properties[key] = value
+
+    def get_extra_property(self, key):
+        return self._extra_properties.get(key)
+
+
+class MatchSums:
+    """every pixel sum the mask costs need, for a batch of images, from one `ph_match_sums` launch"""
+
+    def __init__(self, mask_logits, gt_masks, gt_valid=None):
+        """mask_logits [B, N, H, W] fp32 cuda; gt_masks [B, G, H, W] (soft masks, zero rows as padding);
+        gt_valid [B, H, W] of 0/1 or None"""
+        if not mask_logits.is_cuda:
+            raise _lib.PolyheadError("MatchSums: tensors must be on the GPU (no CPU fallback in the product path)")
+        B, N, H, W = mask_logits.shape
+        G = gt_masks.shape[1]
+        lib = _lib.load()
+        lg = mask_logits.detach().float().contiguous()
+        gt = gt_masks.detach().float().contiguous()
+        va = gt_valid.detach().float().contiguous() if gt_valid is not None else None
+        ns, rec = lib.ph_match_nsplit(H * W, B), lib.ph_match_record_floats(N, G)
+        part = torch.empty((B, ns, rec), dtype=torch.float32, device=lg.device)
+        _lib.check(lib.ph_match_sums(_lib.ptr(lg), _lib.ptr(gt) if G else None, _lib.ptr(va), _lib.ptr(part), B, N, G, H * W,
+                                     _lib.stream_ptr()), "ph_match_sums")
+        r = part.sum(1)                                                  # fixed order over the splits
+        Np, Gp = (N + 31) // 32 * 32, (G + 1 + 31) // 32 * 32      # ph_n_padded
+        A = r[:, :Np * Gp].reshape(B, Np, Gp)
+        o = Np * Gp
+        self.A = A[:, :N, :G]                                            # sum p t v
+        self.S = A[:, :N, G]                                             # sum p v
+        self.Q = r[:, o:o + N]                                           # sum p^2 v
+        self.C = r[:, o + Np:o + Np + G]                                 # sum t^2 v
+        self.T = r[:, o + Np + Gp:o + Np + Gp + G]                       # sum t v
+        self.V = r[:, o + Np + 2 * Gp]                                   # sum v (H*W without gt_valid)
+
+
+@MATCH_COST.register_module()
+class FocalLossCost:
+    """mmdet/core/bbox/match_costs/match_cost.py:54-99 ([N, L] logits: host-sized arithmetic, plain torch)"""
+
+    def __init__(self, weight=1., alpha=0.25, gamma=2, eps=1e-12):
+        self.weight, self.alpha, self.gamma, self.eps = weight, alpha, gamma, eps
+
+    def __call__(self, cls_pred, gt_labels):
+        p = cls_pred.sigmoid()
+        neg = -(1 - p + self.eps).log() * (1 - self.alpha) * p.pow(self.gamma)
+        pos = -(p + self.eps).log() * self.alpha * (1 - p).pow(self.gamma)
+        return (pos[:, gt_labels] - neg[:, gt_labels]) * self.weight
+
+
+@MATCH_COST.register_module()
+class DiceCost:
+    """assigner.py:80-146.  `from_sums` is the device path; only pred_act with sigmoid is built (shipped configs)."""
+
+    def __init__(self, weight=1., pred_act=False, act_mode='sigmoid', eps=1e-3):
+        self.weight, self.pred_act, self.act_mode, self.eps = weight, pred_act, act_mode, eps
+
+    def from_sums(self, s, i):
+        d = (2 * s.A[i]) / ((s.Q[i] + self.eps)[:, None] + (s.C[i] + self.eps)[None])          # :125-129
+        return -d * self.weight
+
+    def __call__(self, mask_preds, gt_masks, gt_valid=None):
+        _need_sigmoid(self)
+        return self.from_sums(MatchSums(mask_preds[None], gt_masks[None], None if gt_valid is None else gt_valid[None]), 0)
+
+
+@MATCH_COST.register_module()
+class MaskCost:
+    """assigner.py:149-196"""
+
+    def __init__(self, weight=1., pred_act=False, act_mode='sigmoid'):
+        self.weight, self.pred_act, self.act_mode = weight, pred_act, act_mode
+
+    def from_sums(self, s, i):
+        pos = s.A[i]                                                                            # :185 / :192
+        neg = s.V[i] - s.S[i][:, None] - s.T[i][None] + s.A[i]        # sum (1 - p)(1 - t) v           :186 / :193
+        return -(pos + neg) / s.V[i] * self.weight                                              # :190 / :194
+
+    def __call__(self, cls_pred, target, gt_valid=None):
+        _need_sigmoid(self)
+        return self.from_sums(MatchSums(cls_pred[None], target[None], None if gt_valid is None else gt_valid[None]), 0)
+
+
+@MATCH_COST.register_module()
+class DepthCost:
+    """assigner.py:49-77: accepted for config compatibility with weight 0 (what the shipped configs set)"""
+
+    def __init__(self, weight=1., loss_fn=None, depth_act_mode='monodepth'):
+        self.weight = weight
+        if weight != 0:
+            raise NotImplementedError("DepthCost with a non-zero weight is outside this build's scope (SURVEY.md 8f N4)")
+
+
+@MATCH_COST.register_module()
+class DepthMatchLoss:
+    def __init__(self, **kw):
+        pass
+
+
+def _need_sigmoid(c):
+    if not (c.pred_act and c.act_mode == 'sigmoid'):
+        raise NotImplementedError("only pred_act=True with act_mode='sigmoid' (the shipped configs) runs on the device")
+
+
+def _hungarian(cost, topk):
+    """assigner.py:509-531"""
+    cost = cost.detach().cpu()
+    if linear_sum_assignment is None:
+        raise ImportError('Please run "pip install scipy" to install scipy first.')
+    if topk == 1:
+        return linear_sum_assignment(cost)
+    rows, cols = [], []
+    for _ in range(topk):
+        r, c = linear_sum_assignment(cost)
+        rows.append(r)
+        cols.append(c)
+        cost[r] = 1e10
+    return np.concatenate(rows), np.concatenate(cols)
+
+
+class _MaskAssignerBase:
+    def __init__(self, cls_cost=dict(type='ClassificationCost', weight=1.), mask_cost=dict(type='SigmoidCost', weight=1.0),
+                 dice_cost=dict(), depth_cost=None, boundary_cost=None, topk=1):
+        self.cls_cost = build_match_cost(cls_cost)
+        self.mask_cost = build_match_cost(mask_cost)
+        self.dice_cost = build_match_cost(dice_cost)
+        if boundary_cost is not None:
+            raise NotImplementedError("boundary_cost is not used by the shipped configs")
+        self.boundary_cost = None
+        self.depth_cost = build_match_cost(depth_cost) if depth_cost is not None else None
+        self.topk = topk
+        for c in (self.mask_cost, self.dice_cost):
+            if c.weight != 0:
+                _need_sigmoid(c)
+
+    def costs(self, sums, i, cls_pred, gt_labels):
+        """weighted cost matrix [N, G] of image i of a `MatchSums` batch (assigner.py:478-506)"""
+        cost = 0
+        if self.cls_cost.weight != 0 and cls_pred is not None:
+            cost = cost + self.cls_cost(cls_pred, gt_labels)
+        if self.mask_cost.weight != 0:
+            cost = cost + self.mask_cost.from_sums(sums, i)
+        if self.dice_cost.weight != 0:
+            cost = cost + self.dice_cost.from_sums(sums, i)
+        return cost
+
+    def _assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid, gt_pids=None):
+        num_gts, num_bboxes = gt_bboxes.size(0), bbox_pred.size(0)
+        gt_inds = bbox_pred.new_full((num_bboxes,), -1, dtype=torch.long)                      # :463-468
+        labels = bbox_pred.new_full((num_bboxes,), -1, dtype=torch.long)
+        if num_gts == 0 or num_bboxes == 0:                                                    # :469-475
+            if num_gts == 0:
+                gt_inds[:] = 0
+            return AssignResult(num_gts, gt_inds, None, labels=labels)
+        sums = MatchSums(bbox_pred[None], gt_bboxes[None], None if gt_valid is None else gt_valid[None])
+        cost = self.costs(sums, 0, cls_pred, gt_labels)
+        rows, cols = _hungarian(cost, self.topk)
+        rows = torch.from_numpy(rows).to(bbox_pred.device)
+        cols = torch.from_numpy(cols).to(bbox_pred.device)
+        gt_inds[:] = 0                                                                         # :535-540
+        gt_inds[rows] = cols + 1
+        labels[rows] = gt_labels[cols]
+        res = AssignResult(num_gts, gt_inds, None, labels=labels)
+        if gt_pids is not None:                                                                # :343-349
+            pids = bbox_pred.new_full((num_bboxes,), -1, dtype=torch.long)
+            pids[rows] = gt_pids[cols]
+            res.set_extra_property("pids", pids)
+        return res
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaskHungarianAssignerWithDepth(_MaskAssignerBase):
+    """assigner.py:363-542"""
+
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta=None, gt_bboxes_ignore=None, depth_pred=None,
+               gt_depth=None, gt_valid=None, eps=1e-7):
+        assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
+        return self._assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid)
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaskHungarianAssigner(_MaskAssignerBase):
+    """assigner.py:199-360 (no gt_valid, optional gt_pids)"""
+
+    def __init__(self, cls_cost=dict(type='ClassificationCost', weight=1.), mask_cost=dict(type='SigmoidCost', weight=1.0),
+                 dice_cost=dict(), boundary_cost=None, topk=1):
+        super().__init__(cls_cost, mask_cost, dice_cost, None, boundary_cost, topk)
+
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_pids=None, img_meta=None, gt_bboxes_ignore=None, eps=1e-7):
+        assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
+        return self._assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, None, gt_pids)

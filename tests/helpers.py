@@ -166,3 +166,35 @@ def fpn_inputs(seed, B, C, H0, W0):
     """4 FPN levels (strides 4, 8, 16, 32 of an 4*H0 x 4*W0 image) ~ N(0, 1)"""
     g = torch.Generator().manual_seed(seed)
     return [torch.randn(B, C, H0 >> i, W0 >> i, generator=g) for i in range(4)]
+
+
+def assign_case(seed, N, G, L, H, W, with_valid=True, with_cls=True):
+    """one image of the training-time assignment: mask logits [N,H,W], class logits [N,L], soft ground-
+    truth masks [G,H,W] (binary blobs averaged over 2x2, i.e. what the x4 bilinear downsample of polyphonic_former.py:77-80
+    produces: values k/4), labels [G], valid [H,W] of 0/1.  Half of the predictions are noisy copies of a gt mask, so the
+    assignment is decided by the mask costs, the rest is noise."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(2 * H).float(), torch.arange(2 * W).float(), indexing="ij")
+    gts = []
+    for _ in range(G):
+        cy, cx = torch.rand(1, generator=g) * 2 * H, torch.rand(1, generator=g) * 2 * W
+        ry, rx = 2 + torch.rand(1, generator=g) * H * 0.6, 2 + torch.rand(1, generator=g) * W * 0.6
+        gts.append((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).float())
+    gt_hi = torch.stack(gts) if G else torch.zeros(0, 2 * H, 2 * W)
+    gt = torch.nn.functional.avg_pool2d(gt_hi[None], 2)[0] if G else torch.zeros(0, H, W)
+    logits = torch.randn(N, H, W, generator=g) * 2
+    for n in range(0, N, 2):
+        if G:
+            k = int(torch.randint(0, G, (1,), generator=g))
+            logits[n] = (gt[k] - 0.5) * 6 + torch.randn(H, W, generator=g)
+    cls = torch.randn(N, L, generator=g) if with_cls else None
+    labels = torch.randint(0, L, (G,), generator=g)
+    valid = (torch.rand(H, W, generator=g) > 0.15).float() if with_valid else None
+    return dict(mask_logits=logits, cls_logits=cls, gt_masks=gt, gt_labels=labels, gt_valid=valid)
+
+
+ASSIGN_CASES = [dict(seed=11, N=100, G=7, L=8, H=24, W=40, with_valid=True),
+                dict(seed=12, N=100, G=33, L=8, H=16, W=24, with_valid=True),
+                dict(seed=13, N=37, G=3, L=8, H=7, W=13, with_valid=False),
+                dict(seed=14, N=200, G=64, L=8, H=12, W=20, with_valid=True),
+                dict(seed=15, N=20, G=1, L=8, H=8, W=8, with_valid=True, with_cls=False)]

@@ -1,0 +1,51 @@
+"""CPU: the assignment oracle (oracle/assign_oracle.py) against goldens written by the reference's own assigner
+(oracle/gen_golden_assign.py -> tests/golden/assign.npz), and the host-side logic of the product assigner that needs no GPU."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from oracle import assign_oracle as AO
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return Hh.load_golden("assign.npz")
+
+
+@pytest.mark.parametrize("i", range(len(Hh.ASSIGN_CASES)))
+def test_oracle_costs_and_assignment_match_reference(gold, i):
+    c = Hh.assign_case(**Hh.ASSIGN_CASES[i])
+    cost = AO.cost_matrix(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
+    assert Hh.rel_err(cost, gold[f"c{i}_cost"]) < 1e-6
+    inds, labels = AO.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
+    assert np.array_equal(inds.numpy(), gold[f"c{i}_gt_inds"])
+    assert np.array_equal(labels.numpy(), gold[f"c{i}_labels"])
+
+
+def test_oracle_empty_ground_truth(gold):
+    c = Hh.assign_case(seed=16, N=10, G=0, L=8, H=8, W=8)
+    inds, labels = AO.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
+    assert np.array_equal(inds.numpy(), gold["empty_gt_inds"]) and np.array_equal(labels.numpy(), gold["empty_labels"])
+
+
+def test_product_assigner_registry_and_guards():
+    """registry names / kwargs of the shipped config (configs/_base_/models/polyphonic_former.py:170-192); no CPU fallback"""
+    from polyphonicformer_amd import assigner as A, _lib
+    a = A.build_assigner(dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                              dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                              mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True),
+                              depth_cost=dict(type='DepthCost', weight=0., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.),
+                                              depth_act_mode='sigmoid')))
+    assert a.topk == 1 and a.depth_cost.weight == 0
+    c = Hh.assign_case(seed=16, N=10, G=0, L=8, H=8, W=8)
+    r = a.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, gt_valid=c["gt_valid"])
+    assert r.num_gts == 0 and bool((r.gt_inds == 0).all()) and bool((r.labels == -1).all())      # assigner.py:469-475
+    c = Hh.assign_case(**Hh.ASSIGN_CASES[2])
+    with pytest.raises(_lib.PolyheadError):                                                      # CPU tensors: refuse
+        a.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, gt_valid=c["gt_valid"])
+    with pytest.raises(NotImplementedError):
+        A.build_match_cost(dict(type='DepthCost', weight=1.0))
+    # FocalLossCost is host arithmetic: identical to the oracle's restatement
+    cls, lab = torch.randn(9, 5), torch.tensor([0, 4, 2])
+    assert torch.allclose(A.FocalLossCost(weight=2.0)(cls, lab), AO.focal_cost(cls, lab, 2.0))
