@@ -471,6 +471,27 @@ def main():
                                               "note": "same step + 2 ingest launches (fp32 NCHW -> bf16 planes) inside the timed region"}
             except Exception as e:
                 res["fp32_feature_inputs"] = {"error": repr(e)}
+        if world == 1 and args.precision == "bf16" and not args.no_kernel_head:
+            # the same function in the precision the parity contract (1e-3 relative fp32) is tested in: every bf16 operand
+            # split hi + lo (3 MFMAs per product), fp32 NCHW inputs, fp32 outputs
+            try:
+                from polyphonicformer_amd.engine import DualDecodePlan
+                Bf = 32
+                head32 = build_head(wl, "fp32", torch.float32, dev)
+                p32 = head32._plan(Bf // 2, N, wl["H"], wl["W"], dev)
+                r32 = DualDecodePlan(p32.packs, Bf, N, wl["H"], wl["W"], p32.prec, torch.float32, dev)
+                i32 = synth_inputs(wl, Bf, seed=99)
+                r32.set_inputs(*[i32[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")])
+                r32.capture()
+                t = time_op(r32.replay, 10)
+                res["fp32_grade_precision"] = {"value": round(Bf / (t * 1e-3), 2), "unit": "frames/s", "ms_per_step": round(t, 4),
+                                               "frames_per_step": Bf, "dtype": "bf16x3 (hi/lo split operands, fp32 accumulate)",
+                                               "note": "precision 'fp32': per-stage error <= 1.6e-5 relative vs the reference's goldens "
+                                                       "(tests/test_gpu_parity.py); fp32 NCHW features in, fp32 logits out"}
+                del r32, p32, head32, i32
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["fp32_grade_precision"] = {"error": repr(e)}
         if world == 1 and not args.no_kernel_head:
             try:
                 res["with_kernel_head"] = kernel_head_leg(wl, head, args.precision, out_dtype, dev)
