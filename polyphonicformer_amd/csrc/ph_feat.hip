@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
     const unsigned total = (unsigned)planes * hp * segs;             // checked < 2^31 by the launcher
     const unsigned nthreads = gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
+    const bool uniform_row = (segs % 64) == 0;                       // fp32 store exchange below
     for (unsigned base = blockIdx.x * blockDim.x; base < total; base += nthreads) {
         const unsigned idx = base + threadIdx.x;
         const bool live = idx < total;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
                     const uint2 q = *(const uint2*)(row + x0);   // cached: every source row is read by two row pairs (nt: 175 -> 223 us)
                     v[1] = bf2f(q.x & 0xFFFF); v[2] = bf2f(q.x >> 16); v[3] = bf2f(q.y & 0xFFFF); v[4] = bf2f(q.y >> 16);
                 } else {
-                    const uint4 q = ld_nt16(row + x0);
+                    const uint4 q = *(const uint4*)(row + x0);   // cached, as above
                     v[1] = __uint_as_float(q.x); v[2] = __uint_as_float(q.y); v[3] = __uint_as_float(q.z); v[4] = __uint_as_float(q.w);
                 }
             } else {
@@ -192,8 +193,25 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
                 if (sizeof(T) == 2) {
                     st_nt16(d, make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7])));
                 } else {
-                    st_nt16(d, make_float4(o[0], o[1], o[2], o[3]));
-                    st_nt16((float*)d + 4, make_float4(o[4], o[5], o[6], o[7]));
+                    // each lane owns 32 contiguous bytes: as two 16-byte stores per lane every instruction would write
+                    // half of each 32-byte piece (partial lines with non-temporal stores: 3.3 TB/s).  Exchange so that
+                    // one instruction covers 1 KiB contiguously: lane l stores what lane (l >> 1) [+ 32] computed.
+                    if (uniform_row) {       // the wave = 64 consecutive segments of one output row, all live
+                        float a4[4], b4[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float lo_v = __shfl(o[c], lane >> 1), hi_v = __shfl(o[4 + c], lane >> 1);
+                            const float lo_w = __shfl(o[c], 32 + (lane >> 1)), hi_w = __shfl(o[4 + c], 32 + (lane >> 1));
+                            a4[c] = (lane & 1) ? hi_v : lo_v;
+                            b4[c] = (lane & 1) ? hi_w : lo_w;
+                        }
+                        float* wrow = (float*)d - 8 * lane;                   // first output of lane 0 of this wave
+                        st_nt16(wrow + 4 * lane, make_float4(a4[0], a4[1], a4[2], a4[3]));
+                        st_nt16(wrow + 256 + 4 * lane, make_float4(b4[0], b4[1], b4[2], b4[3]));
+                    } else {
+                        st_nt16(d, make_float4(o[0], o[1], o[2], o[3]));
+                        st_nt16((float*)d + 4, make_float4(o[4], o[5], o[6], o[7]));
+                    }
                 }
             } else {
 #pragma unroll

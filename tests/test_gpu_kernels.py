@@ -152,7 +152,7 @@ def test_dynconv(gpu, prec, N, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("H,W", [(8, 16), (5, 7), (1, 3)])
+@pytest.mark.parametrize("H,W", [(8, 16), (5, 7), (1, 3), (4, 256), (3, 512)])   # 256 / 512: whole waves per row (fp32 store exchange)
 def test_upsample2x(gpu, dtype, H, W):
     x = torch.randn(3, 5, H, W, generator=torch.Generator().manual_seed(5)).to(dtype)
     out = E.upsample2x(x.to(gpu)).cpu().float()
