@@ -337,7 +337,8 @@ class KernelHeadPlan:
         HWp = hw_padded(self.HW)
         dev = torch.device(device)
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
-        self.f = [e((B, 256, H, W), torch.float32) for _ in range(3)]
+        self.f = [None, None, None]        # set_inputs: borrowed from the caller or allocated on first copy
+        self._borrowed = set()
         self.xp, self.dp = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
         self.x_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
         self.dfe_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
@@ -353,8 +354,18 @@ class KernelHeadPlan:
         self.w_stuff = pack.w_seg_f32[num_thing_classes:num_classes].contiguous() if self.n_stuff else None
 
     def set_inputs(self, feats):
-        for dst, src in zip(self.f, feats):
-            dst.copy_(src)
+        """the three post-neck maps: contiguous fp32 device tensors of the plan's shape are used where they are (the
+        kernels only read them; a captured graph keeps pointing at them, so they stay referenced here), anything
+        else is copied into the plan's own buffers"""
+        for i, src in enumerate(feats):
+            if (src.dtype == torch.float32 and src.is_contiguous() and src.device == self.xp.device
+                    and tuple(src.shape) == (self.B, 256, self.H, self.W)):
+                self.f[i] = src.detach()
+            else:
+                if self.f[i] is None or self.f[i].data_ptr() in self._borrowed:
+                    self.f[i] = torch.empty((self.B, 256, self.H, self.W), dtype=torch.float32, device=self.xp.device)
+                self.f[i].copy_(src)
+        self._borrowed = {t.data_ptr() for t, src in zip(self.f, feats) if t.data_ptr() == src.data_ptr()}
 
     def run(self):
         lib, pk, s = _lib.load(), self.pack, _lib.stream_ptr

@@ -14,7 +14,7 @@ kh = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=L, num_t
                       num_stuff_classes=53, cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
                       use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
                       loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=None))
-kh.init_weights(); kh.eval().to(dev); kh.set_precision('bf16'); kh.emit_fp32_features = False
+kh.init_weights(); kh.eval().to(dev); kh.set_precision(sys.argv[2] if len(sys.argv) > 2 else 'bf16'); kh.emit_fp32_features = False
 kplan = E.KernelHeadPlan(kh._get_pack(dev), B, 128, 256, 80, L, True, dev, want_f32=False)
 g = torch.Generator().manual_seed(3)
 kplan.set_inputs([torch.randn(B, 256, 128, 256, generator=g).relu().to(dev) for _ in range(3)])
