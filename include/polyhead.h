@@ -34,7 +34,8 @@ extern "C" {
 enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWORKSPACE = -4 };
 enum { PH_PREC_BF16 = 1, PH_PREC_SPLIT = 3 };   /* number of bf16 MFMA products per logical product */
 enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1 };
-enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3 };   /* ph_gn_apply modes */
+enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3, PH_GN_TO_CPLANES = 4 };   /* ph_gn_apply modes */
+enum { PH_IN_F32_NCHW = 0, PH_IN_PLANES = 1 };   /* ph_khead_fused input_format */
 
 #define PH_C 256          /* channels: in_channels == out_channels == feat_channels == 256 */
 #define PH_HEADS 8        /* num_heads (head dim 32) */
@@ -172,15 +173,19 @@ int ph_khead_conv_gn(const float* f0, const float* f1, const float* f2, const ui
  *     [stuff_lo, stuff_lo + n_stuff) (cat_stuff_mask, :329-331; n_stuff = 0: none);
  *   seg_preds fp32 [B][n_seg][HW]; depth_pred fp32 [B][1][HW]; x_planes / dfe_planes / x_f32 / dfe_f32 as above
  *   (dfe_planes doubles as the scratch that carries loc from the first to the second apply launch).
+ *   input_format: PH_IN_F32_NCHW -- f0/f1/f2 are the fp32 maps [B][256][HW] of the reference boundary;
+ *     PH_IN_PLANES -- they are bf16 planes [P][B][256][HWp], zero in [HW, HWp) (what ph_gn_apply PH_GN_TO_CPLANES
+ *     writes: the neck hands its outputs over at 2 bytes per element; in bf16 precision the results are bit-identical
+ *     to feeding the fp32 maps, whose first use is the same rounding).
  *   The mask bits of these logits (use_binary, :310-314) are ph_binarize's: emitting them from this epilogue (ballot per
  *   accumulator register) measured slower than that separate pass. */
-int ph_khead_fused(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
                    const float* gn_affine, int groups, float eps,
                    const uint16_t* w2_init, int n_init, const uint16_t* w2_seg, const float* bias_seg, int n_seg,
                    const uint16_t* w2_dd, const float* bias_dd, int stuff_lo, int n_stuff,
                    uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
                    float* mask_preds, float* seg_preds, float* depth_pred,
-                   void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream);
+                   void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
 int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[Nq][256]*/,
                        const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
                        int B, int n_thing_queries, int n_stuff, void* stream);

@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
 PH_PREC_BF16, PH_PREC_SPLIT = 1, 3
 PH_OUT_F32, PH_OUT_BF16 = 0, 1
-PH_GN_TO_PLANES, PH_GN_UP2_PLANES, PH_GN_ACCUM, PH_GN_TO_NCHW = 0, 1, 2, 3
+PH_GN_TO_PLANES, PH_GN_UP2_PLANES, PH_GN_ACCUM, PH_GN_TO_NCHW, PH_GN_TO_CPLANES = 0, 1, 2, 3, 4
+PH_IN_F32_NCHW, PH_IN_PLANES = 0, 1
 
 W_NAMES = ["DYN", "INP", "IG", "UG", "FC", "QKV", "OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN"]
 V_NAMES = ["DYN_CNT", "DYN_B", "INP_B", "IG_B", "UG_B", "LN_IG_G", "LN_IG_B", "LN_UG_G", "LN_UG_B",
@@ -42,7 +43,7 @@ SIGNATURES = {
     "ph_khead_workspace_bytes": (C.c_size_t, [_I, _L, _I]),
     "ph_khead_conv_gn": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_khead_fused": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
-                                 _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
+                                 _P, _P, _P, _P, _Z, _I, _L, _I, _I, _P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_match_record_floats": (C.c_int64, [_I, _I]),
     "ph_match_nsplit": (C.c_int, [_L, _I]),

@@ -22,6 +22,7 @@ constexpr int KH_THREADS = 512;
 
 struct KHArgs {
     const float* f[3];            // input maps fp32 [B][256][HW]       (stats: all three, map = blockIdx.z; apply: f[0])
+    const uint16_t* fp[3];        // INFMT 2: the same maps as bf16 planes [PA][B][256][HWp], zero in [HW, HWp)
     const uint16_t* w[3];         // conv weights, bf16 planes [PA][256][256] (out, in)
     int64_t w_plane;
     float* partial[3];            // [B][nwg][256][2] (sum, sumsq)            (stats)
@@ -102,6 +103,43 @@ __device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* 
     }
 }
 
+// INFMT 2 -- the maps arrive as bf16 channel planes (the neck's hand-off, ph_gn_apply PH_GN_TO_CPLANES): a tile is 256 rows
+// x 128 bytes per plane, 4 x 16 bytes per thread, copied to LDS as it is (no conversion, half the bytes)
+template <int PA>
+__device__ __forceinline__ void kh_load_tile_planes(uint4 (&q)[PA][4], const uint16_t* __restrict__ planes, int64_t oplane,
+                                                    int64_t HWp, int64_t px0, int tid, bool more) {
+    const uint32_t voff = more ? (uint32_t)((((int64_t)(tid >> 3)) * HWp + px0 + (tid & 7) * 8) * 2) : 0u;
+    const int64_t qstride = more ? 64 * HWp : 0;
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            q[p][it] = ld_nt16((const char*)(planes + p * oplane + it * qstride) + voff);
+}
+template <int PA>
+__device__ __forceinline__ void kh_store_tile_planes(const uint4 (&q)[PA][4], uint16_t* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            *(uint4*)(lds + p * 256 * KH_LDT + (it * 64 + (tid >> 3)) * KH_LDT + (tid & 7) * 8) = q[p][it];
+}
+// staging registers of one tile in either input format
+template <int PA, int INFMT> struct KhStage {
+    float v[8][4];
+    __device__ __forceinline__ void load(const KHArgs& a, int m, int b, int64_t px0, int tid, bool more) {
+        kh_load_tile<INFMT == 1>(v, a.f[m] + (int64_t)b * 256 * a.HW, a.HW, px0, tid, more);
+    }
+    __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t HW, int64_t px0) const { kh_store_tile<PA>(v, lds, tid, HW, px0); }
+};
+template <int PA> struct KhStage<PA, 2> {
+    uint4 q[PA][4];
+    __device__ __forceinline__ void load(const KHArgs& a, int m, int b, int64_t px0, int tid, bool more) {
+        kh_load_tile_planes<PA>(q, a.fp[m] + (int64_t)b * 256 * a.HWp, (int64_t)a.B * 256 * a.HWp, a.HWp, px0, tid, more);
+    }
+    __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t, int64_t) const { kh_store_tile_planes<PA>(q, lds, tid); }
+};
+
 template <int PA>
 __device__ __forceinline__ void kh_load_a(uint4 (&af)[PA][16], const uint16_t* __restrict__ w, int64_t w_plane, int wave,
                                           int lane) {
@@ -141,12 +179,11 @@ __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uin
 }
 
 // ---- pass 1: per-channel sum / sum of squares of the conv output; the three maps in one launch (blockIdx.z) ------
-template <int PA, bool AL4>
+template <int PA, int INFMT>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
     const int b = blockIdx.y, m = blockIdx.z;
-    const float* src = a.f[m] + (int64_t)b * 256 * a.HW;
     uint4 af[PA][16];
     kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
     const int ntiles = (int)(a.HWp / KH_T);
@@ -155,13 +192,13 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-    float stg[8][4];
-    kh_load_tile<AL4>(stg, src, a.HW, (int64_t)t0 * KH_T, tid, t0 < t1);
+    KhStage<PA, INFMT> stg;
+    stg.load(a, m, b, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();
-        kh_store_tile<PA>(stg, lds, tid, a.HW, (int64_t)t * KH_T);
+        stg.store(lds, tid, a.HW, (int64_t)t * KH_T);
         __syncthreads();
-        kh_load_tile<AL4>(stg, src, a.HW, (int64_t)(t + 1) * KH_T, tid, t + 1 < t1);   // in flight during the MFMAs
+        stg.load(a, m, b, (int64_t)(t + 1) * KH_T, tid, t + 1 < t1);   // in flight during the MFMAs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
@@ -264,7 +301,7 @@ __device__ __forceinline__ void kh_vals_to_rows(const float (&vals)[2][16], uint
         }
 }
 
-template <int PA, int ADD, bool AL4>
+template <int PA, int ADD, int INFMT>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
@@ -292,20 +329,19 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     constexpr bool HOIST = (PA == 1);   // bf16 precision: the 64 weight registers stay resident across the tiles
     uint4 af[PA][16];
     if (HOIST) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
-    const float* src = a.f[0] + (int64_t)b * 256 * a.HW;
     const int ntiles = (int)(a.HWp / KH_T);
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
-    float stg[8][4];
-    kh_load_tile<AL4>(stg, src, a.HW, (int64_t)t0 * KH_T, tid, t0 < t1);
+    KhStage<PA, INFMT> stg;
+    stg.load(a, 0, b, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         const int64_t px0 = (int64_t)t * KH_T;
         const int64_t row0 = ((int64_t)b * 256 + wave * 32) * a.HWp + px0;       // this wave's first channel row, tile start
         __syncthreads();                      // every wave is done with the previous tile in LDS (second GEMM / flush)
-        kh_store_tile<PA>(stg, lds, tid, a.HW, px0);
+        stg.store(lds, tid, a.HW, px0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        kh_load_tile<AL4>(stg, src, a.HW, px0 + KH_T, tid, t + 1 < t1);            // next tile in flight during this one
+        stg.load(a, 0, b, px0 + KH_T, tid, t + 1 < t1);                            // next tile in flight during this one
         __builtin_amdgcn_sched_barrier(0);
         uint4 addv[PA][4];
         uint32_t addb[PA][2][8];
@@ -502,7 +538,7 @@ struct KhFused {                  // the static 1x1 convs of the fused entry poi
     uint16_t* loc_blocks;         // scratch for loc between the first two launches (a planes-sized buffer)
 };
 
-static int kh_run(const float* const fm[3], const uint16_t* wplanes, const float* gn_affine, int groups, float eps,
+static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplanes, const float* gn_affine, int groups, float eps,
                   uint16_t* const outp[3], const uint16_t* add1, uint16_t* sum1, float* x_f32, float* dfe_f32,
                   const KhFused* fu, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream,
                   const char* fn) {
@@ -524,14 +560,13 @@ static int kh_run(const float* const fm[3], const uint16_t* wplanes, const float
     const size_t lds_apply = lds + 256 * sizeof(float2) + 256 * sizeof(float);
     static bool once = false;
     if (!once) {
-        const void* ks[] = {(const void*)k_khead_stats<1, true>, (const void*)k_khead_stats<1, false>,
-                            (const void*)k_khead_stats<2, true>, (const void*)k_khead_stats<2, false>,
-                            (const void*)k_khead_apply<1, 0, true>, (const void*)k_khead_apply<1, 0, false>,
-                            (const void*)k_khead_apply<1, 1, true>, (const void*)k_khead_apply<1, 1, false>,
-                            (const void*)k_khead_apply<1, 2, true>, (const void*)k_khead_apply<1, 2, false>,
-                            (const void*)k_khead_apply<2, 0, true>, (const void*)k_khead_apply<2, 0, false>,
-                            (const void*)k_khead_apply<2, 1, true>, (const void*)k_khead_apply<2, 1, false>,
-                            (const void*)k_khead_apply<2, 2, true>, (const void*)k_khead_apply<2, 2, false>};
+        const void* ks[] = {
+#define KH_ALL(F) (const void*)k_khead_stats<1, F>, (const void*)k_khead_stats<2, F>, (const void*)k_khead_apply<1, 0, F>, \
+    (const void*)k_khead_apply<1, 1, F>, (const void*)k_khead_apply<1, 2, F>, (const void*)k_khead_apply<2, 0, F>,         \
+    (const void*)k_khead_apply<2, 1, F>, (const void*)k_khead_apply<2, 2, F>
+            KH_ALL(0), KH_ALL(1), KH_ALL(2)
+#undef KH_ALL
+        };
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once = true;
     }
@@ -540,24 +575,28 @@ static int kh_run(const float* const fm[3], const uint16_t* wplanes, const float
     a.w_plane = (int64_t)3 * 256 * 256;
     const dim3 grid(nwg, B), block(KH_THREADS);
     for (int m = 0; m < 3; ++m) {
-        a.f[m] = fm[m];
+        a.f[m] = (const float*)fm[m];
+        a.fp[m] = (const uint16_t*)fm[m];
         a.w[m] = wplanes + (size_t)m * 256 * 256;
         a.partial[m] = partial + (size_t)m * B * nwg * 256 * 2;
     }
-    const bool al4 = (HW % 4) == 0;
-#define KH_LAUNCH(K, G, L, ...)                                                                   \
-    do {                                                                                          \
-        if (PA == 1 && al4) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, true>), G, block, L, s, a);   \
-        else if (PA == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, false>), G, block, L, s, a);    \
-        else if (al4) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, true>), G, block, L, s, a);         \
-        else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, false>), G, block, L, s, a);                 \
+    const int fmt = in_planes ? 2 : ((HW % 4) == 0 ? 1 : 0);      // kernel input format: fp32 scalar / fp32 x4 / bf16 planes
+#define KH_LAUNCH(K, G, L, ...)                                                                      \
+    do {                                                                                             \
+        if (PA == 1 && fmt == 0) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 0>), G, block, L, s, a);    \
+        else if (PA == 1 && fmt == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 1>), G, block, L, s, a); \
+        else if (PA == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 2>), G, block, L, s, a);           \
+        else if (fmt == 0) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 0>), G, block, L, s, a);          \
+        else if (fmt == 1) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 1>), G, block, L, s, a);          \
+        else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 2>), G, block, L, s, a);                        \
     } while (0)
     // pass 1: the three maps in one launch, then one finalize over the 3 * B (map, frame) pairs
     KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
     hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps);
     // pass 2: loc ; sem (+ x = sem + loc, loc read back from the planes the first launch wrote) ; depth
     for (int m = 0; m < 3; ++m) {
-        a.f[0] = fm[m];
+        a.f[0] = (const float*)fm[m];
+        a.fp[0] = (const uint16_t*)fm[m];
         a.w[0] = wplanes + (size_t)m * 256 * 256;
         a.gamma = gn_affine + (size_t)m * 512;
         a.beta = gn_affine + (size_t)m * 512 + 256;
@@ -610,23 +649,25 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
                                 void* stream) {
     PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && loc_planes && sem_planes && x_planes && dfe_planes && workspace,
                  "null pointer");
-    const float* fm[3] = {f0, f1, f2};
+    const void* fm[3] = {f0, f1, f2};
     uint16_t* outp[3] = {loc_planes, sem_planes, dfe_planes};
-    return kh_run(fm, wplanes, gn_affine, groups, eps, outp, loc_planes, x_planes, x_f32, dfe_f32, nullptr, workspace,
+    return kh_run(fm, 0, wplanes, gn_affine, groups, eps, outp, loc_planes, x_planes, x_f32, dfe_f32, nullptr, workspace,
                   workspace_bytes, B, HW, prec, stream, __func__);
 }
 
-extern "C" int ph_khead_fused(const float* f0, const float* f1, const float* f2, const uint16_t* wplanes,
+extern "C" int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
                               const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
                               const uint16_t* w2_seg, const float* bias_seg, int n_seg, const uint16_t* w2_dd,
                               const float* bias_dd, int stuff_lo, int n_stuff, uint16_t* x_planes, uint16_t* dfe_planes,
                               float* x_f32, float* dfe_f32, float* mask_preds, float* seg_preds, float* depth_pred,
-                              void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream) {
+                              void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format,
+                              void* stream) {
     PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && x_planes && dfe_planes && workspace, "null pointer");
+    PH_CHECK_ARG(input_format == PH_IN_F32_NCHW || input_format == PH_IN_PLANES, "bad input_format");
     PH_CHECK_ARG(w2_init && w2_seg && w2_dd && mask_preds && seg_preds && depth_pred, "null pointer");
     PH_CHECK_ARG(n_init > 0 && n_init <= 256 && n_seg > 0 && n_seg <= 256 && n_stuff >= 0 && stuff_lo >= 0 &&
                      stuff_lo + n_stuff <= n_seg, "bad row counts (at most 256 rows per static conv)");
-    const float* fm[3] = {f0, f1, f2};
+    const void* fm[3] = {f0, f1, f2};
     // loc travels from the first to the second launch as register-layout blocks parked in the depth planes (which the
     // third launch then overwrites); sem is never stored
     uint16_t* outp[3] = {nullptr, nullptr, dfe_planes};
@@ -638,7 +679,7 @@ extern "C" int ph_khead_fused(const float* f0, const float* f1, const float* f2,
     fu.out2_rows[0] = n_init + n_stuff; fu.out2_rows[1] = n_seg; fu.out2_rows[2] = 1;
     fu.stuff_lo = stuff_lo; fu.n_stuff = n_stuff; fu.n_init = n_init;
     fu.loc_blocks = dfe_planes;
-    return kh_run(fm, wplanes, gn_affine, groups, eps, outp, nullptr, x_planes, x_f32, dfe_f32, &fu, workspace,
+    return kh_run(fm, input_format == PH_IN_PLANES ? 1 : 0, wplanes, gn_affine, groups, eps, outp, nullptr, x_planes, x_f32, dfe_f32, &fu, workspace,
                   workspace_bytes, B, HW, prec, stream, __func__);
 }
 

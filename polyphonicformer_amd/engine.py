@@ -339,6 +339,7 @@ class KernelHeadPlan:
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
         self.f = [None, None, None]        # set_inputs: borrowed from the caller or allocated on first copy
         self._borrowed = set()
+        self.in_planes = False
         self.xp, self.dp = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
         self.x_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
         self.dfe_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
@@ -357,6 +358,15 @@ class KernelHeadPlan:
         """the three post-neck maps: contiguous fp32 device tensors of the plan's shape are used where they are (the
         kernels only read them; a captured graph keeps pointing at them, so they stay referenced here), anything
         else is copied into the plan's own buffers"""
+        self.in_planes = feats[0].dtype == torch.int16
+        if self.in_planes:          # bf16 planes [P][B][256][HWp] from the neck (SemanticFPNWrapper.forward_planes)
+            P = 2 if self.pack.prec == _lib.PH_PREC_SPLIT else 1
+            for i, src in enumerate(feats):
+                if tuple(src.shape) != (P, self.B, 256, hw_padded(self.HW)) or not src.is_contiguous():
+                    raise _lib.PolyheadError("plane inputs must be contiguous int16 [P][B][256][HWp]")
+                self.f[i] = src
+            self._borrowed = {t.data_ptr() for t in self.f}
+            return
         for i, src in enumerate(feats):
             if (src.dtype == torch.float32 and src.is_contiguous() and src.device == self.xp.device
                     and tuple(src.shape) == (self.B, 256, self.H, self.W)):
@@ -379,7 +389,8 @@ class KernelHeadPlan:
                                       _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
                                       _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
                                       _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), _lib.ptr(self.ws), self.ws.numel(),
-                                      B, HW, prec, s()), "ph_khead_fused")
+                                      B, HW, prec, _lib.PH_IN_PLANES if self.in_planes else _lib.PH_IN_F32_NCHW, s()),
+                   "ph_khead_fused")
         # object features: binarise the logits once (all rows: the decode stages start from these bits), pool x over the
         # THING rows (:314-320), add to the kernels (:324-326)
         _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
@@ -453,6 +464,7 @@ class NeckPlan:
         self.lstats = [e((B, 256, 2), torch.float32) for _ in range(4)]
         self.stats = e((B, 256, 2), torch.float32)
         self.outs = [e((B, 256, self.Ho, self.Wo), torch.float32) for _ in range(3)]
+        self.pouts = None                                          # plane outputs, allocated on first use
 
     def _conv_gn(self, xp, pk, H, W, groups, y, stats):
         """conv + statistics; returns the conv output size"""
@@ -464,7 +476,7 @@ class NeckPlan:
         gn_finalize(self.partial, stats, nwg, groups, Ho * Wo, B)
         return Ho, Wo
 
-    def run(self, feats, pk, groups, posenc, pos_level):
+    def run(self, feats, pk, groups, posenc, pos_level, to_planes=False):
         B, prec = self.B, self.prec
         for lvl in range(4):
             H, W = self.shapes[lvl]
@@ -483,10 +495,17 @@ class NeckPlan:
                         raise _lib.PolyheadError("level does not end at the stride-8 size")
         # sum over levels of ReLU(GN(.)) straight to conv input planes, then conv_pred / aux convs -> fp32 NCHW
         gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
-        for o, c in zip(self.outs, pk["outs"]):
+        if to_planes and self.pouts is None:
+            P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+            self.pouts = [torch.empty((P, B, 256, hw_padded(self.Ho * self.Wo)), dtype=torch.int16, device=self.xa.device)
+                          for _ in range(3)]
+        for i, c in enumerate(pk["outs"]):
             self._conv_gn(self.xb, c, self.Ho, self.Wo, groups, self.y, self.stats)
-            gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_TO_NCHW, B, self.Ho, self.Wo, prec, outf=o)
-        return self.outs[:len(pk["outs"])]
+            if to_planes:       # bf16 channel planes, the decode path's feature format (KernelHead hand-off)
+                gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_TO_CPLANES, B, self.Ho, self.Wo, prec, planes=self.pouts[i])
+            else:
+                gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_TO_NCHW, B, self.Ho, self.Wo, prec, outf=self.outs[i])
+        return (self.pouts if to_planes else self.outs)[:len(pk["outs"])]
 
 
 class DualDecodePlan:

@@ -112,12 +112,23 @@ class KernelHead(nn.Module):
         otherwise the three post-neck maps [B,256,H,W]."""
         if self.training:
             raise NotImplementedError("training is outside the implemented hot path")
-        feats = self.localization_fpn(img) if self.localization_fpn is not None else list(img)
-        if not isinstance(feats, (list, tuple)) or len(feats) != 3:
-            raise NotImplementedError("with_depth needs the neck's three maps (kernel_head.py:272-276)")
-        E._require_gpu(feats[0], "localization feats")
-        B, C, H, W = feats[0].shape
-        dev = feats[0].device
+        neck = self.localization_fpn
+        handoff = neck is not None and hasattr(neck, "forward_planes") and getattr(neck, "num_aux_convs", 0) == 2 \
+            and getattr(neck, "precision", None) == self.precision
+        if handoff:
+            # this build's neck: its three maps come over as bf16 planes (half the bytes, no conversion pass in front of
+            # the GEMMs; bit-identical in bf16 precision because the first use of the fp32 maps is that same rounding)
+            E._require_gpu(img[0], "FPN levels")
+            feats = neck.forward_planes(img)
+            B, (H, W) = img[0].shape[0], tuple(img[1].shape[-2:])
+            dev = feats[0].device
+        else:
+            feats = neck(img) if neck is not None else list(img)
+            if not isinstance(feats, (list, tuple)) or len(feats) != 3:
+                raise NotImplementedError("with_depth needs the neck's three maps (kernel_head.py:272-276)")
+            E._require_gpu(feats[0], "localization feats")
+            B, C, H, W = feats[0].shape
+            dev = feats[0].device
         pack = self._get_pack(dev)
         cat_stuff = self.cat_stuff_mask and not self.training
         key = (B, H, W, cat_stuff, self.emit_fp32_features)
@@ -126,7 +137,7 @@ class KernelHead(nn.Module):
             self._plans = {key: E.KernelHeadPlan(pack, B, H, W, self.num_thing_classes, self.num_classes, cat_stuff, dev,
                                                  want_f32=self.emit_fp32_features)}
             plan = self._plans[key]
-        plan.set_inputs([f.float() for f in feats])
+        plan.set_inputs(list(feats) if handoff else [f.float() for f in feats])
         plan.run()
         N = plan.N
         proposal_feats = plan.proposal.reshape(B, N, 256, 1, 1)

@@ -118,7 +118,15 @@ class SemanticFPNWrapper(nn.Module):
         return self._pos[key]
 
     # ---- forward (semantic_fpn.py:198-235) ---------------------------------------------------------------------
-    def forward(self, inputs):
+    def forward_planes(self, inputs):
+        """the same maps as `forward`, as the decode path's feature format: bf16 planes [P][B][256][HWp] (int16 tensors,
+        hi or hi/lo) -- the internal hand-off to KernelHead (ph_khead_fused, PH_IN_PLANES).  Only with the aux convs
+        (three outputs), which is the configuration KernelHead needs."""
+        if self.num_aux_convs != 2:
+            raise NotImplementedError("forward_planes needs the three outputs (num_aux_convs = 2)")
+        return self.forward(inputs, _planes=True)
+
+    def forward(self, inputs, _planes=False):
         x0 = inputs[0]
         E._require_gpu(x0, "inputs[0]")
         dev, B = x0.device, x0.shape[0]
@@ -129,7 +137,9 @@ class SemanticFPNWrapper(nn.Module):
             plan = E.NeckPlan(B, shapes, prec, dev)
             self._plans[(B, shapes, str(dev), self.precision)] = plan
         add = self._posenc(*shapes[self.cat_coors_level], dev) if self.pos_cfg is not None else None
-        outs = plan.run([t.float().contiguous() for t in inputs[:4]], pk, G, add, self.cat_coors_level)
+        outs = plan.run([t.float().contiguous() for t in inputs[:4]], pk, G, add, self.cat_coors_level, to_planes=_planes)
+        if _planes:
+            return outs
         if self.num_aux_convs > 0:
             return outs
         return [outs[0]] if self.return_list else outs[0]

@@ -157,3 +157,40 @@ def test_kernel_head_with_its_neck(gpu):
     for name, t in (("x_feats", out[1]), ("seg_preds", out[4]), ("depth_feats", out[5]), ("depth_pred", out[7])):
         assert Hh.rel_err(t.cpu(), ref[name]) < 1e-3, name
     assert Hh.rel_err(out[2].cpu(), ref["mask_preds"]) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_plane_handoff_equals_fp32_boundary(gpu, precision):
+    """KernelHead with its neck takes the neck's maps as bf16 planes (SemanticFPNWrapper.forward_planes ->
+    ph_khead_fused PH_IN_PLANES); the same head fed the neck's fp32 NCHW maps through the reference boundary must give
+    the same result: bit-identical in bf16 precision (the first use of an fp32 map is the same rounding), to hi/lo
+    accuracy in fp32 precision."""
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    neck_cfg = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                    upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                    cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                    norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    cfg = dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11,
+               in_channels=256, out_channels=256, cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+               use_binary=True, conv_normal_init=True, proposal_feats_with_obj=True, kernel_init_std=1,
+               loss_seg=dict(type="FocalLoss", use_sigmoid=True))
+    kh = HEADS.build(dict(cfg, localization_fpn=neck_cfg))
+    sd = Hh.seeded_fill({k: tuple(v.shape) for k, v in kh.state_dict().items()}, 43)
+    kh.load_state_dict(sd)
+    kh.eval().to(gpu)
+    kh.set_precision(precision)
+    bare = HEADS.build(dict(cfg, localization_fpn=None))
+    bare.load_state_dict({k: v for k, v in sd.items() if not k.startswith("localization_fpn.")})
+    bare.eval().to(gpu)
+    bare.set_precision(precision)
+    feats = tuple(f.to(gpu) for f in Hh.fpn_inputs(seed=44, B=2, C=256, H0=24, W0=40))     # stride-8 map 12 x 20 (HW % 128 != 0)
+    metas = [Hh.img_meta(96, 160)] * 2
+    a = kh.simple_test_rpn(feats, metas)
+    maps = [m.clone() for m in kh.localization_fpn(feats)]
+    b = bare.simple_test_rpn(maps, metas)
+    for i, name in ((0, "proposal_feats"), (1, "x_feats"), (2, "mask_preds"), (4, "seg_preds"), (5, "depth_feats"), (7, "depth_pred")):
+        if precision == "bf16":
+            assert torch.equal(a[i], b[i]), name
+        else:
+            assert Hh.rel_err(a[i].cpu(), b[i].cpu()) < 2e-5, name
