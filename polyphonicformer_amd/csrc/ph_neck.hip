@@ -466,45 +466,51 @@ template <int PA>
 __global__ __launch_bounds__(256) void k_gn_to_cplanes(const float* __restrict__ y, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int groups, uint16_t* __restrict__ planes, int64_t HW, int64_t HWp,
-                                                       int B) {
+                                                       int B, int tiles_per_wg) {
     extern __shared__ float tt[];                                 // [256][65]
     const int b = blockIdx.y;
-    const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int c4 = (threadIdx.x & 63) * 4, pq = threadIdx.x >> 6;
     const int cpg = 256 / groups;
-    float sc[4], sh[4];
+    float sc[4], sh[4];                                           // set up once, used for `tiles_per_wg` tiles
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float* st = stats + ((int64_t)b * groups + (c4 + e) / cpg) * 2;
         sc[e] = st[1] * gamma[c4 + e];
         sh[e] = beta[c4 + e] - st[0] * sc[e];
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int pl = k * 4 + pq;
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + pl < HW) {
-            const uint4 q = ld_nt16(y + ((int64_t)b * HW + p0 + pl) * 256 + c4);
-            o[0] = fmaxf(__uint_as_float(q.x) * sc[0] + sh[0], 0.f);
-            o[1] = fmaxf(__uint_as_float(q.y) * sc[1] + sh[1], 0.f);
-            o[2] = fmaxf(__uint_as_float(q.z) * sc[2] + sh[2], 0.f);
-            o[3] = fmaxf(__uint_as_float(q.w) * sc[3] + sh[3], 0.f);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tt[(c4 + e) * 65 + pl] = o[e];
-    }
-    __syncthreads();
     const int piece = threadIdx.x & 7, r0 = threadIdx.x >> 3;       // 32 channel rows per pass, 8 x 16 B per row
     const int64_t oplane = (int64_t)B * 256 * HWp;
+    const int64_t ntiles = HWp / 64;
+    for (int ti = 0; ti < tiles_per_wg; ++ti) {
+        const int64_t tile = (int64_t)blockIdx.x * tiles_per_wg + ti;
+        if (tile >= ntiles) break;
+        const int64_t p0 = tile * 64;
+        if (ti) __syncthreads();                                  // the previous tile has been read out of LDS
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-        const int row = ps * 32 + r0;
-        uint32_t hi[8], lo[8];
+        for (int k = 0; k < 16; ++k) {
+            const int pl = k * 4 + pq;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p0 + pl < HW) {
+                const uint4 q = ld_nt16(y + ((int64_t)b * HW + p0 + pl) * 256 + c4);
+                o[0] = fmaxf(__uint_as_float(q.x) * sc[0] + sh[0], 0.f);
+                o[1] = fmaxf(__uint_as_float(q.y) * sc[1] + sh[1], 0.f);
+                o[2] = fmaxf(__uint_as_float(q.z) * sc[2] + sh[2], 0.f);
+                o[3] = fmaxf(__uint_as_float(q.w) * sc[3] + sh[3], 0.f);
+            }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f2bf_split(tt[row * 65 + piece * 8 + e], hi[e], lo[e]);
-        uint16_t* d = planes + ((int64_t)b * 256 + row) * HWp + p0 + piece * 8;
-        *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
-        if (PA == 2) *(uint4*)(d + oplane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+            for (int e = 0; e < 4; ++e) tt[(c4 + e) * 65 + pl] = o[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 32 + r0;
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f2bf_split(tt[row * 65 + piece * 8 + e], hi[e], lo[e]);
+            uint16_t* d = planes + ((int64_t)b * 256 + row) * HWp + p0 + piece * 8;
+            *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+            if (PA == 2) *(uint4*)(d + oplane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+        }
     }
 }
 
@@ -588,7 +594,11 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
     if (mode == PH_GN_TO_CPLANES) {
         PH_CHECK_ARG(stats && B <= 65535, "PH_GN_TO_CPLANES needs statistics (and B <= 65535)");
         const int64_t HW = (int64_t)H * W, HWp = ph_hw_padded(HW);
-        const dim3 grid((unsigned)(HWp / 64), B);
+        const int64_t ntiles = HWp / 64;
+        int tpw = (int)((ntiles * B + 1023) / 1024);          // ~1024 workgroups: the affine set-up is amortised over the tiles
+        if (tpw < 1) tpw = 1;
+        if (const char* e = getenv("PH_CPLANES_TPW")) tpw = atoi(e);
+        const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), B);
         const size_t lds = 256 * 65 * sizeof(float);
         static bool once = false;
         if (!once) {
@@ -596,8 +606,8 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
             (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             once = true;
         }
-        if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_to_cplanes<1>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B);
-        else hipLaunchKernelGGL(k_gn_to_cplanes<2>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B);
+        if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_to_cplanes<1>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
+        else hipLaunchKernelGGL(k_gn_to_cplanes<2>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
         PH_CHECK_LAUNCH();
         return PH_OK;
     }
