@@ -308,7 +308,6 @@ class KernelHeadPack:
         self.seg_planes = _planes_of(_pad_rows32(w_seg), P).to(device)
         self.dd_planes = _planes_of(_pad_rows32(w_dd), P).to(device)
         z = lambda n: torch.zeros(n, dtype=torch.float32)
-        self.init_bias = z(self.init_planes.shape[1]).to(device)
         sb = z(self.seg_planes.shape[1]); sb[:self.n_seg] = g("conv_seg.bias").float()
         self.seg_bias = sb.to(device)
         db = z(32); db[0] = float(g("conv_direct_depth.bias")[0])

@@ -161,6 +161,43 @@ def test_upsample2x(gpu, dtype, H, W):
     assert (out - ref).abs().max() <= tol * ref.abs().max()
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("H,W,B", [(8, 16, 2), (6, 13, 1)])
+def test_khead_conv_gn_planes_entry_point(gpu, prec, H, W, B):
+    """ph_khead_conv_gn, the pre-fusion entry point (loc / sem / x / depth planes out, loc read back through LDS for the
+    sum): against torch conv1x1 -> GroupNorm(32) -> ReLU (kernel_head.py:250-251,264-265,277-278,303)"""
+    g = torch.Generator().manual_seed(17)
+    HW, P = H * W, (2 if prec == _lib.PH_PREC_SPLIT else 1)
+    f = [torch.randn(B, 256, H, W, generator=g).relu() for _ in range(3)]
+    w = torch.randn(3, 256, 256, generator=g) * 0.05
+    gam, bet = 1 + 0.1 * torch.randn(3, 256, generator=g), 0.1 * torch.randn(3, 256, generator=g)
+    ref = [F.relu(F.group_norm(F.conv2d(f[m].double(), w[m].double()[:, :, None, None]), 32, gam[m].double(), bet[m].double(), 1e-5))
+           for m in range(3)]
+    wh = w.to(torch.bfloat16)
+    planes = [wh.view(torch.int16)]
+    if P == 2:
+        planes.append((w - wh.float()).to(torch.bfloat16).view(torch.int16))
+    wpl = torch.stack(planes, 0).contiguous().to(gpu)                      # [P][3][256][256]
+    gn = torch.stack([gam, bet], 1).contiguous().to(gpu)                   # [3][2][256]
+    HWp = E.hw_padded(HW)
+    mk = lambda: torch.full((P, B, 256, HWp), 0x7fc0, dtype=torch.int16, device=gpu)
+    loc, sem, xs, dfe = mk(), mk(), mk(), mk()
+    xf, df = torch.empty(B, 256, H, W, device=gpu), torch.empty(B, 256, H, W, device=gpu)
+    lib = _lib.load()
+    ws = torch.empty(lib.ph_khead_workspace_bytes(B, HW, 32), dtype=torch.uint8, device=gpu)
+    fd = [t.to(gpu) for t in f]
+    _lib.check(lib.ph_khead_conv_gn(_lib.ptr(fd[0]), _lib.ptr(fd[1]), _lib.ptr(fd[2]), _lib.ptr(wpl), _lib.ptr(gn), 32, 1e-5,
+                                    _lib.ptr(loc), _lib.ptr(sem), _lib.ptr(xs), _lib.ptr(dfe), _lib.ptr(xf), _lib.ptr(df),
+                                    _lib.ptr(ws), ws.numel(), B, HW, prec, _lib.stream_ptr()), "ph_khead_conv_gn")
+    tol = 2e-2 if prec == _lib.PH_PREC_BF16 else 1e-4
+    rec = lambda pl: planes_to_float(pl.cpu())[..., :HW].reshape(B, 256, H, W)
+    for got, want in ((rec(loc), ref[0]), (rec(sem), ref[1]), (rec(dfe), ref[2]), (rec(xs), ref[0] + ref[1]),
+                      (xf.cpu().double(), ref[0] + ref[1]), (df.cpu().double(), ref[2])):
+        assert (got - want).abs().max() <= tol * want.abs().max()
+    for pl in (loc, sem, xs, dfe):
+        assert (planes_to_float(pl.cpu())[..., HW:] == 0).all()            # zero padding
+
+
 def test_errors_are_reported(gpu):
     lib = _lib.load()
     assert lib.ph_version() == 100
