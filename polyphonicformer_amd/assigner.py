@@ -47,19 +47,31 @@ class AssignResult:
 
 
 class MatchSums:
-    """every pixel sum the mask costs need, for a batch of images, from one `ph_match_sums` launch"""
+    """every pixel sum the mask costs need, for a batch of images, from one `ph_match_sums` launch (one per block of 127
+    ground-truth masks when an image has more)"""
+
+    GMAX = 127          # ph_match_sums: G + 1 columns <= 128
 
     def __init__(self, mask_logits, gt_masks, gt_valid=None):
         """mask_logits [B, N, H, W] fp32 cuda; gt_masks [B, G, H, W] (soft masks, zero rows as padding);
         gt_valid [B, H, W] of 0/1 or None"""
         if not mask_logits.is_cuda:
             raise _lib.PolyheadError("MatchSums: tensors must be on the GPU (no CPU fallback in the product path)")
-        B, N, H, W = mask_logits.shape
         G = gt_masks.shape[1]
-        lib = _lib.load()
         lg = mask_logits.detach().float().contiguous()
-        gt = gt_masks.detach().float().contiguous()
+        gt = gt_masks.detach().float()
         va = gt_valid.detach().float().contiguous() if gt_valid is not None else None
+        parts = [self._block(lg, gt[:, g0:g0 + self.GMAX].contiguous(), va) for g0 in range(0, max(G, 1), self.GMAX)]
+        self.A = torch.cat([p[0] for p in parts], 2)                     # sum p t v            [B, N, G]
+        self.S, self.Q, self.V = parts[0][1], parts[0][2], parts[0][5]   # sum p v, sum p^2 v [B, N]; sum v [B]
+        self.C = torch.cat([p[3] for p in parts], 1)                     # sum t^2 v            [B, G]
+        self.T = torch.cat([p[4] for p in parts], 1)                     # sum t v              [B, G]
+
+    @staticmethod
+    def _block(lg, gt, va):
+        B, N, H, W = lg.shape
+        G = gt.shape[1]
+        lib = _lib.load()
         ns, rec = lib.ph_match_nsplit(H * W, B), lib.ph_match_record_floats(N, G)
         part = torch.empty((B, ns, rec), dtype=torch.float32, device=lg.device)
         _lib.check(lib.ph_match_sums(_lib.ptr(lg), _lib.ptr(gt) if G else None, _lib.ptr(va), _lib.ptr(part), B, N, G, H * W,
@@ -68,12 +80,8 @@ class MatchSums:
         Np, Gp = (N + 31) // 32 * 32, (G + 1 + 31) // 32 * 32      # ph_n_padded
         A = r[:, :Np * Gp].reshape(B, Np, Gp)
         o = Np * Gp
-        self.A = A[:, :N, :G]                                            # sum p t v
-        self.S = A[:, :N, G]                                             # sum p v
-        self.Q = r[:, o:o + N]                                           # sum p^2 v
-        self.C = r[:, o + Np:o + Np + G]                                 # sum t^2 v
-        self.T = r[:, o + Np + Gp:o + Np + Gp + G]                       # sum t v
-        self.V = r[:, o + Np + 2 * Gp]                                   # sum v (H*W without gt_valid)
+        return (A[:, :N, :G], A[:, :N, G], r[:, o:o + N], r[:, o + Np:o + Np + G], r[:, o + Np + Gp:o + Np + Gp + G],
+                r[:, o + Np + 2 * Gp])
 
 
 @MATCH_COST.register_module()

@@ -87,3 +87,17 @@ def test_assigner_without_depth_and_pids(gpu):
     assert torch.equal(r.gt_inds.cpu(), ref_inds)
     got = r.get_extra_property("pids").cpu()
     assert torch.equal(got[ref_inds > 0], (99 + ref_inds[ref_inds > 0]))
+
+
+def test_more_than_127_ground_truth_masks(gpu):
+    """an image with more instances than one launch takes columns for: the sums are gathered block-wise"""
+    from polyphonicformer_amd import assigner as A
+    c = Hh.assign_case(seed=23, N=200, G=150, L=8, H=10, W=16)
+    ref_inds, ref_labels = AO.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
+    ref_cost = AO.cost_matrix(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
+    d = _dev(c, gpu)
+    a = A.build_assigner(dict(CFG))
+    sums = A.MatchSums(d["mask_logits"][None], d["gt_masks"][None], d["gt_valid"][None])
+    assert Hh.rel_err(a.costs(sums, 0, d["cls_logits"], d["gt_labels"]).cpu(), ref_cost) < 1e-4
+    r = a.assign(d["mask_logits"], d["cls_logits"], d["gt_masks"], d["gt_labels"], None, gt_valid=d["gt_valid"])
+    assert torch.equal(r.gt_inds.cpu(), ref_inds) and torch.equal(r.labels.cpu(), ref_labels)
