@@ -250,6 +250,29 @@ def test_kernel_head_row_counts(gpu, precision, Nq):
         assert Hh.rel_err(t.cpu(), ref[name]) < tol, (name, Hh.rel_err(t.cpu(), ref[name]))
 
 
+def test_kernel_head_without_stuff_rows(gpu, weights):
+    """cat_stuff_mask=False (kernel_head.py:329 skipped): N = num_proposals, no dual store of the stuff logits"""
+    sd = {k[len("rpn_head."):]: v for k, v in weights.items() if k.startswith("rpn_head.")}
+    h = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11,
+                         in_channels=256, out_channels=256, cat_stuff_mask=False, feat_downsample_stride=2, feat_refine=False,
+                         use_binary=True, conv_normal_init=True, proposal_feats_with_obj=True, kernel_init_std=1,
+                         loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=None))
+    h.load_state_dict(sd)
+    h.eval().to(gpu)
+    h.set_precision("fp32")
+    B, H, W = 2, 8, 24
+    feats = Hh.neck_inputs(91, B, 256, H, W)
+    ref = O.kernel_head_post_neck(sd, *feats, 8, 19, 32, cat_stuff_mask=False)
+    out = h.simple_test_rpn([f.to(gpu) for f in feats], [Hh.img_meta(H * 8, W * 8)] * B)
+    assert out[2].shape == (B, 100, H, W) and out[0].shape == (B, 100, 256, 1, 1) and out[6].shape[1] == 1
+    for name, t in (("x_feats", out[1]), ("mask_preds", out[2]), ("seg_preds", out[4]), ("depth_feats", out[5]),
+                    ("depth_pred", out[7])):
+        assert Hh.rel_err(t.cpu(), ref[name]) < 1e-3, name
+    flips = int(((out[2].cpu() > 0) != (ref["mask_preds"] > 0)).sum())
+    if flips == 0:
+        assert Hh.rel_err(out[0].cpu().reshape(B, 100, 256), ref["proposal_feats"].reshape(B, 100, 256)) < 1e-3
+
+
 def test_whole_path_a1_a6(gpu, weights):
     """KernelHead -> KernelUpdateIterHead exactly as Polyphonic.simple_test wires them
     (polyphonic_former.py:145-161), with the plane/bit hand-off, vs the oracle's run_head."""
