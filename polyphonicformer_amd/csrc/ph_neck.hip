@@ -117,14 +117,20 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 constexpr int CV_TW = 64;
 
 template <int KS, int S, int PA> struct ConvGeo {
-    // output rows per workgroup: 4 for the double-buffered stride-1 single-plane kernels (one workgroup per CU, 128
-    // accumulator VGPRs per wave, every weight fragment feeds 8 MFMAs), 2 otherwise
-    static constexpr int TH = (PA == 1 && S == 1) ? 4 : 2;
+    // output rows per workgroup: 4 for the double-buffered single-plane kernels (one workgroup per CU, 128 accumulator
+    // VGPRs per wave, every weight fragment feeds 8 MFMAs; stride 2 takes 16-channel chunks so that two 9-row patches
+    // fit in LDS), 2 otherwise
+    static constexpr int TH = (PA == 1) ? 4 : 2;
     static constexpr int MT = TH * 2;                                              // 32-pixel M tiles per wave
     static constexpr int IR = (TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;       // input patch rows / cols
-    static constexpr int CH = (S == 1) ? 64 : 32;                                  // channels per LDS stage
+    static constexpr int CH = (S == 1) ? 64 : (PA == 1 ? 16 : 32);                 // channels per LDS stage
     static constexpr int LDP = CH + 8;                                             // pixel stride (elements)
-    static constexpr int PLANE = IR * IC * LDP;                                    // elements per precision plane
+    // stride 2: the patch columns are stored de-interleaved (even columns, then odd columns), so that the 32 lanes of an
+    // A-fragment read (consecutive OUTPUT pixels = every second input column) walk consecutive LDS pixels like the
+    // stride-1 kernels do
+    static constexpr int HALF = (IC + 1) / 2;
+    static constexpr int ICS = (S == 2) ? 2 * HALF : IC;                           // stored columns per patch row
+    static constexpr int PLANE = IR * ICS * LDP;                                   // elements per precision plane
 };
 
 template <int PA, int KS, int S>
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     // MFMAs of chunk c run and is written to the other LDS buffer after them (one barrier per chunk).  Vector-memory
     // operations of a wave retire in order, so the prefetch is issued AFTER the first DEPTH weight fragments: the
     // k-steps that use those do not wait for it.
-    constexpr bool DB = (PA == 1 && S == 1);
+    constexpr bool DB = (PA == 1);
     constexpr int PIECES = CH / 8;
     constexpr int NPRE = (IR * IC * PIECES + 511) / 512;
     auto patch_load = [&](int c0, int k, uint4 (&v)[PA]) {      // k-th piece of this thread, zero outside the image
@@ -176,8 +182,10 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
         const int idx = tid + k * 512;
         if (idx < IR * IC * PIECES) {
             const int piece = idx % PIECES, pix = idx / PIECES;
+            const int r = pix / IC, x = pix - r * IC;
+            const int slot = r * G::ICS + (S == 2 ? (x & 1) * G::HALF + (x >> 1) : x);
 #pragma unroll
-            for (int p = 0; p < PA; ++p) *(uint4*)(buf + p * G::PLANE + pix * LDP + piece * 8) = v[p];
+            for (int p = 0; p < PA; ++p) *(uint4*)(buf + p * G::PLANE + slot * LDP + piece * 8) = v[p];
         }
     };
     if (DB) {
@@ -238,8 +246,9 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             for (int p = 0; p < PA; ++p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int px = ((mt & 1) * 32 + m) * S + dx, row = (mt >> 1) * S + dy;
-                    a[p][mt] = *(const uint4*)(cur + p * G::PLANE + (row * IC + px) * LDP + kk * 16 + kg * 8);
+                    const int row = (mt >> 1) * S + dy;
+                    const int px = (S == 2) ? (dx & 1) * G::HALF + (mt & 1) * 32 + m + (dx >> 1) : (mt & 1) * 32 + m + dx;
+                    a[p][mt] = *(const uint4*)(cur + p * G::PLANE + (row * G::ICS + px) * LDP + kk * 16 + kg * 8);
                 }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     }
 }
 
-static int conv_th(int ksize, int stride, int prec) { return (prec == PH_PREC_BF16 && stride == 1) ? 4 : 2; }
+static int conv_th(int ksize, int stride, int prec) { return prec == PH_PREC_BF16 ? 4 : 2; }
 
 // workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
 extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {
@@ -312,7 +321,7 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     hipStream_t s = (hipStream_t)stream;
 #define PH_CV(PA, KS, S)                                                                                                 \
     do {                                                                                                                 \
-        const size_t lds = (size_t)((PA == 1 && S == 1) ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
+        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
         static bool once = false;                                                                                        \
         if (!once) {                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
