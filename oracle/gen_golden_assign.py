@@ -21,6 +21,7 @@ CFG = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type=
 def main():
     ns = R.load_reference_assigner()
     a = ns.Assigner(**CFG)
+    sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler()
     out = {}
     for i, case in enumerate(Hh.ASSIGN_CASES):
         c = Hh.assign_case(**case)
@@ -31,6 +32,12 @@ def main():
         out[f"c{i}_cost"] = cost.numpy().astype(np.float32)
         out[f"c{i}_gt_inds"] = r.gt_inds.numpy()
         out[f"c{i}_labels"] = r.labels.numpy()
+        # the sampler that follows the assigner in forward_train (kernel_update.py:247-251, funcs/sampler.py:93-113)
+        sr = sampler.sample(r, c["mask_logits"], c["gt_masks"], depth=c["mask_logits"] * 0.5)
+        out[f"c{i}_pos_inds"], out[f"c{i}_neg_inds"] = sr.pos_inds.numpy(), sr.neg_inds.numpy()
+        out[f"c{i}_pos_assigned_gt_inds"], out[f"c{i}_pos_gt_labels"] = sr.pos_assigned_gt_inds.numpy(), sr.pos_gt_labels.numpy()
+        out[f"c{i}_pos_gt_masks_sum"] = sr.pos_gt_masks.sum((1, 2)).numpy().astype(np.float32)
+        out[f"c{i}_pos_depth_sum"] = sr.pos_depth.sum((1, 2)).numpy().astype(np.float32)
         print(i, case, "matched", int((r.gt_inds > 0).sum()))
     # empty ground truth (assigner.py:469-475)
     c = Hh.assign_case(seed=16, N=10, G=0, L=8, H=8, W=8)

@@ -21,6 +21,7 @@ except ImportError:                                    # the reference raises at
     linear_sum_assignment = None
 
 BBOX_ASSIGNERS = Registry("bbox_assigner")
+BBOX_SAMPLERS = Registry("bbox_sampler")
 MATCH_COST = Registry("match_cost")
 
 
@@ -30,6 +31,10 @@ def build_match_cost(cfg):
 
 def build_assigner(cfg):
     return BBOX_ASSIGNERS.build(cfg)
+
+
+def build_sampler(cfg):
+    return BBOX_SAMPLERS.build(cfg)
 
 
 class AssignResult:
@@ -239,3 +244,46 @@ class MaskHungarianAssigner(_MaskAssignerBase):
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_pids=None, img_meta=None, gt_bboxes_ignore=None, eps=1e-7):
         assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
         return self._assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, None, gt_pids)
+
+
+class MaskSamplingResult:
+    """funcs/sampler.py:7-78 -- the record `get_targets` reads (kernel_update_head.py:443-590): index bookkeeping on the
+    assignment, no arithmetic"""
+
+    def __init__(self, pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags, depth=None):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_masks, self.neg_masks = masks[pos_inds], masks[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.pos_depth = depth[pos_inds] if depth is not None else None            # :34-35
+        self.neg_depth = depth[neg_inds] if depth is not None else None
+        self.num_gts = gt_masks.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1            # :38
+        if gt_masks.numel() == 0:                                                  # :40-43
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_masks = torch.empty_like(gt_masks)
+        else:
+            self.pos_gt_masks = gt_masks[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+
+    @property
+    def masks(self):
+        return torch.cat([self.pos_masks, self.neg_masks])
+
+    @property
+    def info(self):
+        return {'pos_inds': self.pos_inds, 'neg_inds': self.neg_inds, 'pos_masks': self.pos_masks, 'neg_masks': self.neg_masks,
+                'pos_is_gt': self.pos_is_gt, 'num_gts': self.num_gts, 'pos_assigned_gt_inds': self.pos_assigned_gt_inds}
+
+
+@BBOX_SAMPLERS.register_module()
+class MaskPseudoSampler:
+    """funcs/sampler.py:81-113: every assigned prediction is a positive, every background one a negative"""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def sample(self, assign_result, masks, gt_masks, depth=None, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        gt_flags = masks.new_zeros(masks.shape[0], dtype=torch.uint8)
+        return MaskSamplingResult(pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags, depth)

@@ -49,3 +49,21 @@ def test_product_assigner_registry_and_guards():
     # FocalLossCost is host arithmetic: identical to the oracle's restatement
     cls, lab = torch.randn(9, 5), torch.tensor([0, 4, 2])
     assert torch.allclose(A.FocalLossCost(weight=2.0)(cls, lab), AO.focal_cost(cls, lab, 2.0))
+
+
+@pytest.mark.parametrize("i", range(len(Hh.ASSIGN_CASES)))
+def test_mask_pseudo_sampler_matches_reference(gold, i):
+    """the sampler that follows the assigner in forward_train (funcs/sampler.py:93-113): index bookkeeping, runs on any
+    device; fed the reference's own assignment it must reproduce the reference sampler's record"""
+    from polyphonicformer_amd import assigner as A
+    c = Hh.assign_case(**Hh.ASSIGN_CASES[i])
+    r = A.AssignResult(c["gt_masks"].shape[0], torch.from_numpy(gold[f"c{i}_gt_inds"]), None,
+                       labels=torch.from_numpy(gold[f"c{i}_labels"]))
+    sr = A.build_sampler(dict(type="MaskPseudoSampler")).sample(r, c["mask_logits"], c["gt_masks"], depth=c["mask_logits"] * 0.5)
+    assert np.array_equal(sr.pos_inds.numpy(), gold[f"c{i}_pos_inds"]) and np.array_equal(sr.neg_inds.numpy(), gold[f"c{i}_neg_inds"])
+    assert np.array_equal(sr.pos_assigned_gt_inds.numpy(), gold[f"c{i}_pos_assigned_gt_inds"])
+    assert np.array_equal(sr.pos_gt_labels.numpy(), gold[f"c{i}_pos_gt_labels"])
+    assert np.allclose(sr.pos_gt_masks.sum((1, 2)).numpy(), gold[f"c{i}_pos_gt_masks_sum"], rtol=1e-6)
+    assert np.allclose(sr.pos_depth.sum((1, 2)).numpy(), gold[f"c{i}_pos_depth_sum"], rtol=1e-5, atol=1e-4)
+    assert sr.num_gts == c["gt_masks"].shape[0] and sr.masks.shape[0] == c["mask_logits"].shape[0]
+    assert int(sr.pos_is_gt.sum()) == 0
