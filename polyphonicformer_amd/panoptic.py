@@ -30,26 +30,29 @@ def select_segments(cls_scores, num_proposals, num_thing_classes, max_per_img):
 
 
 def accept_loop(scores, labels, area, orig, num_thing_classes, instance_score_thr, overlap_thr):
-    """kernel_update.py:497-533 on the two per-segment pixel histograms.  Returns (newid[K], segments_info)."""
+    """kernel_update.py:497-533 on the two per-segment pixel histograms.  Returns (newid[K], segments_info).
+    Whether a segment is kept depends on its own counts only (:503-512); the loop of the reference merely numbers the
+    kept ones in descending-score order (:497), so the tests are evaluated for all K at once and only the kept
+    segments are visited."""
     K = len(scores)
     newid = np.zeros(K, dtype=np.int32)
-    info, seg = [], 0
-    for k in torch.argsort(-scores).tolist():                                # :497 (same call, same tie order)
-        cls = int(labels[k])
-        isthing = cls < num_thing_classes
-        if isthing and float(scores[k]) < instance_score_thr:                # :503
-            continue
-        mask_area, original_area = int(area[k]), int(orig[k])
-        if mask_area > 0 and original_area > 0:                              # :510
-            if mask_area / original_area < overlap_thr:                      # :511
-                continue
-            seg += 1
-            newid[k] = seg
-            if isthing:
-                info.append({'id': seg, 'isthing': isthing, 'score': float(scores[k]), 'category_id': cls,
-                             'instance_id': k})
-            else:
-                info.append({'id': seg, 'isthing': isthing, 'category_id': cls, 'area': mask_area})
+    order = torch.argsort(-scores).numpy()                                   # :497 (same call, same tie order)
+    sc, lab = scores.numpy(), labels.numpy()
+    area, orig = np.asarray(area, dtype=np.int64), np.asarray(orig, dtype=np.int64)
+    isthing = lab < num_thing_classes
+    keep = ~(isthing & (sc < instance_score_thr))                            # :503
+    keep &= (area > 0) & (orig > 0)                                          # :510
+    with np.errstate(divide="ignore", invalid="ignore"):
+        keep &= ~((area / np.where(orig > 0, orig, 1)) < overlap_thr)        # :511 (python float division, as there)
+    info = []
+    for seg, k in enumerate((k for k in order if keep[k]), start=1):
+        k = int(k)
+        cls = int(lab[k])
+        newid[k] = seg
+        if cls < num_thing_classes:
+            info.append({'id': seg, 'isthing': True, 'score': float(scores[k]), 'category_id': cls, 'instance_id': k})
+        else:
+            info.append({'id': seg, 'isthing': False, 'category_id': cls, 'area': int(area[k])})
     return newid, info
 
 
