@@ -247,43 +247,47 @@ class MaskHungarianAssigner(_MaskAssignerBase):
 
 
 class MaskSamplingResult:
-    """funcs/sampler.py:7-78 -- the record `get_targets` reads (kernel_update_head.py:443-590): index bookkeeping on the
-    assignment, no arithmetic"""
+    """the record `get_targets` reads (kernel_update_head.py:443-590), field for field what funcs/sampler.py:26-51 builds:
+    positives / negatives of one image, their predictions, and for the positives the matched ground truth.  Index
+    bookkeeping only."""
 
     def __init__(self, pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags, depth=None):
+        pick = lambda t, idx: None if t is None else t[idx]
         self.pos_inds, self.neg_inds = pos_inds, neg_inds
-        self.pos_masks, self.neg_masks = masks[pos_inds], masks[neg_inds]
-        self.pos_is_gt = gt_flags[pos_inds]
-        self.pos_depth = depth[pos_inds] if depth is not None else None            # :34-35
-        self.neg_depth = depth[neg_inds] if depth is not None else None
-        self.num_gts = gt_masks.shape[0]
-        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1            # :38
-        if gt_masks.numel() == 0:                                                  # :40-43
-            assert self.pos_assigned_gt_inds.numel() == 0
+        self.pos_masks, self.neg_masks = pick(masks, pos_inds), pick(masks, neg_inds)
+        self.pos_depth, self.neg_depth = pick(depth, pos_inds), pick(depth, neg_inds)
+        self.pos_is_gt = pick(gt_flags, pos_inds)
+        self.num_gts = int(gt_masks.shape[0])
+        self.pos_assigned_gt_inds = pick(assign_result.gt_inds, pos_inds) - 1      # gt_inds are 1-based, 0 = background
+        if gt_masks.numel():
+            self.pos_gt_masks = gt_masks[self.pos_assigned_gt_inds]
+        else:                                                                       # no ground truth: nothing can be positive
+            if self.pos_assigned_gt_inds.numel():
+                raise AssertionError("positives without ground truth")
             self.pos_gt_masks = torch.empty_like(gt_masks)
-        else:
-            self.pos_gt_masks = gt_masks[self.pos_assigned_gt_inds, :]
-        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+        self.pos_gt_labels = pick(assign_result.labels, pos_inds)
 
     @property
     def masks(self):
-        return torch.cat([self.pos_masks, self.neg_masks])
+        """positives first, then negatives"""
+        return torch.cat((self.pos_masks, self.neg_masks), 0)
 
     @property
     def info(self):
-        return {'pos_inds': self.pos_inds, 'neg_inds': self.neg_inds, 'pos_masks': self.pos_masks, 'neg_masks': self.neg_masks,
-                'pos_is_gt': self.pos_is_gt, 'num_gts': self.num_gts, 'pos_assigned_gt_inds': self.pos_assigned_gt_inds}
+        keys = ("pos_inds", "neg_inds", "pos_masks", "neg_masks", "pos_is_gt", "num_gts", "pos_assigned_gt_inds")
+        return {k: getattr(self, k) for k in keys}
 
 
 @BBOX_SAMPLERS.register_module()
 class MaskPseudoSampler:
-    """funcs/sampler.py:81-113: every assigned prediction is a positive, every background one a negative"""
+    """funcs/sampler.py:81-113 -- no sampling: every matched prediction is a positive, every background one a negative"""
 
     def __init__(self, **kwargs):
         pass
 
     def sample(self, assign_result, masks, gt_masks, depth=None, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
-        gt_flags = masks.new_zeros(masks.shape[0], dtype=torch.uint8)
-        return MaskSamplingResult(pos_inds, neg_inds, masks, gt_masks, assign_result, gt_flags, depth)
+        gi = assign_result.gt_inds
+        pos = (gi > 0).nonzero().flatten()             # ascending and unique by construction
+        neg = (gi == 0).nonzero().flatten()
+        flags = torch.zeros(masks.shape[0], dtype=torch.uint8, device=masks.device)
+        return MaskSamplingResult(pos, neg, masks, gt_masks, assign_result, flags, depth)
