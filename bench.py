@@ -185,7 +185,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
                     "object pooling) + 3-stage decode, bf16 plane hand-off, fp32 post-neck inputs resident in HBM"}
 
 
-def neck_leg(wl, precision, dev, B=8, steps=5):
+def neck_leg(wl, precision, dev, B=16, steps=5):
     """secondary number: SemanticFPNWrapper.forward, the step that produces the hot path's three input
     maps, at the cfg2 FPN sizes (strides 4..32 of 1024x2048), fp32 NCHW levels resident in HBM"""
     from polyphonicformer_amd.registry import NECKS
@@ -256,7 +256,7 @@ def assign_leg(dev, B=16, N=100, G=40, H=128, W=256, steps=20):
     return out
 
 
-def full_head_leg(wl, head, precision, dev, B=8, steps=5):
+def full_head_leg(wl, head, precision, dev, B=16, steps=5):
     """secondary number: the whole head as `Polyphonic.simple_test` wires it (polyphonic_former.py:145-161), through the
     module API: FPN levels -> rpn_head.simple_test_rpn (SemanticFPNWrapper + KernelHead post-neck) ->
     roi_head.simple_test_mask_preds (3 stages + upsample); fp32 NCHW tensors at every API boundary"""
