@@ -388,24 +388,46 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, c
     if (mode == PH_GN_UP2_PLANES) {
         const int Ho = 2 * H, Wo = 2 * W;
         const int64_t plane = (int64_t)B * Ho * Wo * 256;
-        for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < (int64_t)Ho * Wo; p += (int64_t)gridDim.x * 4) {
-            const int oy = (int)(p / Wo), ox = (int)(p - (int64_t)oy * Wo);
-            // source coordinate (o + 0.5) / 2 - 0.5, clamped at 0 (PyTorch area_pixel_compute_source_index)
-            float fy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-            const float ly = fy - y0, lx = fx - x0;
-            const float4 v00 = gn_relu4(*(const float4*)(yb + ((int64_t)y0 * W + x0) * 256 + c4), sc, sh, act);
-            const float4 v01 = gn_relu4(*(const float4*)(yb + ((int64_t)y0 * W + x1) * 256 + c4), sc, sh, act);
-            const float4 v10 = gn_relu4(*(const float4*)(yb + ((int64_t)y1 * W + x0) * 256 + c4), sc, sh, act);
-            const float4 v11 = gn_relu4(*(const float4*)(yb + ((int64_t)y1 * W + x1) * 256 + c4), sc, sh, act);
-            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-            float4 o;
-            o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
-            o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
-            o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
-            o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
-            st_planes4<PA>(planes + ((int64_t)b * Ho * Wo + p) * 256 + c4, plane, o);
+        // A wave takes the 2x2 output block anchored at the ODD output coordinates (2y+1, 2x+1): its four pixels blend the
+        // same four source pixels (y, x) .. (y+1, x+1) with weights {.75, .25} x {.75, .25}, so a source vector is loaded and
+        // normalised once per block instead of once per output pixel (4 loads per 4 outputs, was 16).  Blocks y = -1 /
+        // x = -1 / y = H-1 / x = W-1 hold the first / last output row / column: their taps are the clamped ones of the
+        // per-pixel formula below, which every output goes through, so the values are those of the per-pixel kernel.
+        const int nbx = W + 1;
+        const int64_t nblk = (int64_t)(H + 1) * nbx;
+        for (int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); q < nblk; q += (int64_t)gridDim.x * 4) {
+            const int by = (int)(q / nbx) - 1, bx = (int)(q - (int64_t)(by + 1) * nbx) - 1;
+            const int r0 = by < 0 ? 0 : by, r1 = by + 1 > H - 1 ? H - 1 : by + 1;
+            const int k0 = bx < 0 ? 0 : bx, k1 = bx + 1 > W - 1 ? W - 1 : bx + 1;
+            const float4 s00 = gn_relu4(*(const float4*)(yb + ((int64_t)r0 * W + k0) * 256 + c4), sc, sh, act);
+            const float4 s01 = gn_relu4(*(const float4*)(yb + ((int64_t)r0 * W + k1) * 256 + c4), sc, sh, act);
+            const float4 s10 = gn_relu4(*(const float4*)(yb + ((int64_t)r1 * W + k0) * 256 + c4), sc, sh, act);
+            const float4 s11 = gn_relu4(*(const float4*)(yb + ((int64_t)r1 * W + k1) * 256 + c4), sc, sh, act);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oy = 2 * by + 1 + dy, ox = 2 * bx + 1 + dx;
+                    if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+                    // source coordinate (o + 0.5) / 2 - 0.5, clamped at 0 (PyTorch area_pixel_compute_source_index)
+                    const float fy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+                    const int y0 = (int)fy, x0 = (int)fx;
+                    const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+                    const float ly = fy - y0, lx = fx - x0;
+                    // (y0, y1) is (r0, r1) except in the clamped border blocks, where a tap with weight 0 may lie outside
+                    // the block: pick by index, the weight-0 operand only has to be finite
+                    const float4 v00 = y0 == r0 ? (x0 == k0 ? s00 : s01) : (x0 == k0 ? s10 : s11);
+                    const float4 v01 = y0 == r0 ? (x1 == k1 ? s01 : s00) : (x1 == k1 ? s11 : s10);
+                    const float4 v10 = y1 == r1 ? (x0 == k0 ? s10 : s11) : (x0 == k0 ? s00 : s01);
+                    const float4 v11 = y1 == r1 ? (x1 == k1 ? s11 : s10) : (x1 == k1 ? s01 : s00);
+                    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+                    float4 o;
+                    o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+                    o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+                    o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+                    o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+                    st_planes4<PA>(planes + ((int64_t)b * Ho * Wo + (int64_t)oy * Wo + ox) * 256 + c4, plane, o);
+                }
         }
         return;
     }
@@ -627,7 +649,7 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
         PH_CHECK_LAUNCH();
         return PH_OK;
     }
-    const int64_t npix = (int64_t)H * W * (mode == PH_GN_UP2_PLANES ? 4 : 1);
+    const int64_t npix = mode == PH_GN_UP2_PLANES ? (int64_t)(H + 1) * (W + 1) : (int64_t)H * W;   // UP2: 2x2 output blocks
     int gx = (int)((npix + 3) / 4 < 2048 ? (npix + 3) / 4 : 2048);
     const dim3 grid(gx, 1, B);
     if (!groups) groups = 1;
