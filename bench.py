@@ -376,15 +376,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=48, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=96, help="frames per step per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16"],
                     help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
                          "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
-                    help="2 = two half-batches on two skewed HIP streams (engine.DualDecodePlan)")
+    ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="n > 1: n part-batches on n skewed HIP streams, one HIP graph (engine.DualDecodePlan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-head", action="store_true")
     ap.add_argument("--no-neck", action="store_true")
@@ -425,9 +425,9 @@ def main():
         gin[0], gin[1] = gin[0].to(torch.bfloat16), gin[1].to(torch.bfloat16)
     plan.set_inputs(*gin)
     runner = plan
-    if args.streams == 2:
+    if args.streams > 1:
         from polyphonicformer_amd.engine import DualDecodePlan
-        runner = DualDecodePlan(plan.packs, B, N, wl["H"], wl["W"], plan.prec, out_dtype, dev)
+        runner = DualDecodePlan(plan.packs, B, N, wl["H"], wl["W"], plan.prec, out_dtype, dev, parts=args.streams)
         runner.set_inputs(*gin)
     if args.no_graph:
         step = runner.run
@@ -460,8 +460,8 @@ def main():
 
     if rank == 0:
         # per-launch timings in the geometry the timed region launches: one half-batch plan when two streams are used
-        kplan = runner.halves[0] if args.streams == 2 else plan
-        nplans = 2 if args.streams == 2 else 1
+        kplan = runner.halves[0] if args.streams > 1 else plan
+        nplans = args.streams if args.streams > 1 else 1
         times, counts = kernel_breakdown(kplan)
         per_step = {k: times[k] * counts[k] * nplans for k in times}
         dom = max((k for k in per_step if algorithmic_bytes(kplan, k)), key=lambda k: per_step[k])

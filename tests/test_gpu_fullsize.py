@@ -121,3 +121,31 @@ def test_cfg5_shape_stage_vs_oracle(gpu, precision):
                        ("depth", nd, ref["depth"]), ("dobj", dobj.reshape(1, N, 256), ref["dobj"])):
         e = Hh.rel_err(t.cpu(), r)
         assert e < tol, (name, e)
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_cfg2_multi_stream_plan_equals_single_plan(head_cfg2, parts, monkeypatch):
+    """engine.DualDecodePlan (the bench's runner: part-batches on skewed streams inside one HIP graph) against one
+    DecodePlan over the same frames: bit-identical outputs (frames are independent; uneven split with parts = 3).  The
+    split-K factor of the pooling depends on the batch size by default (it fixes the order of the fp32 partial sums),
+    so it is pinned for the comparison."""
+    monkeypatch.setenv("PH_POOL_NSPLIT", "4")
+    wl, head = head_cfg2
+    dev = torch.device("cuda:0")
+    B, N = 7, wl["Nq"] + wl["n_stuff"]
+    inp = bench.synth_inputs(wl, B, seed=77)
+    gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
+    gin[0], gin[1] = gin[0].to(torch.bfloat16), gin[1].to(torch.bfloat16)
+    one = head._plan(B, N, wl["H"], wl["W"], dev)
+    one.set_inputs(*gin)
+    one.run()
+    ref = {k: v.clone() for k, v in one.outputs().items()}
+    multi = E.DualDecodePlan(one.packs, B, N, wl["H"], wl["W"], one.prec, torch.bfloat16, dev, parts=parts)
+    multi.set_inputs(*gin)
+    multi.capture()
+    multi.replay()
+    torch.cuda.synchronize()
+    out = multi.outputs()
+    assert multi.sizes == ([4, 3] if parts == 2 else [3, 2, 2])
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
