@@ -152,20 +152,20 @@ def blob_logits(g, K, h, w, sharp=6.0, rmin=0.04, rvar=0.10):
     return sharp * (1.0 - d) + 0.3 * torch.randn(K, h, w, generator=g)
 
 
-def merge_fixture(ns, tag="merge"):
+def merge_fixture(ns, tag="merge", cases=None, seed0=400):
     """Crafted inputs straight into the reference's get_panoptic (kernel_update.py:421-535)."""
     cfg = Hh.FULL
     ih = R.build_iter_head(ns, S=1, N_thing_q=cfg["Nq"], C=32, F=64, heads=4,
                            n_thing=cfg["n_thing"], n_stuff=cfg["n_stuff"])
     N, L = cfg["Nq"] + cfg["n_stuff"], cfg["n_thing"] + cfg["n_stuff"]
     out = {}
-    cases = [  # (h2, w2, img_meta)  h2,w2 = stride-4 (x2-upsampled) logits size
+    cases = cases or [  # (h2, w2, img_meta)  h2,w2 = stride-4 (x2-upsampled) logits size
         ("a", 24, 48, Hh.img_meta(96, 192)),
         ("b", 24, 48, Hh.img_meta(90, 180, pad_to=(96, 192), ori=(135, 270))),
         ("c", 16, 40, Hh.img_meta(64, 160, ori=(48, 120))),
     ]
     for ci, (nm, h2, w2, meta) in enumerate(cases):
-        g = torch.Generator().manual_seed(400 + ci)
+        g = torch.Generator().manual_seed(seed0 + ci)
         m_up = blob_logits(g, N, h2, w2)
         m_up[cfg["Nq"]:] = blob_logits(g, cfg["n_stuff"], h2, w2, sharp=3.0, rmin=0.15, rvar=0.3)   # stuff: broad
         cls = torch.rand(N, L, generator=g)
@@ -238,6 +238,11 @@ def main():
     video_fixture()
     tracker_fixture()
     merge_fixture(ns)
+    # round 2: non-integer scale factors in BOTH resampling steps, ori_shape != img_shape (merge2.npz)
+    merge_fixture(ns, tag="merge2", seed0=500, cases=[
+        ("d", 24, 48, Hh.img_meta(93, 187, pad_to=(100, 200), ori=(140, 281))),
+        ("e", 19, 37, Hh.img_meta(70, 141, pad_to=(75, 150), ori=(53, 107))),
+    ])
     run_family(ns, Hh.MINI, "mini", B=2, H=6, W=10, store_all=True)
     shapes = run_family(ns, Hh.FULL, "full", B=2, H=8, W=16, store_all=False)
     with open(os.path.join(OUT, "full_state_keys.json"), "w") as f:

@@ -414,12 +414,12 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
 #define PH_CONV_LAUNCH(BITS, T)                                                                                      \
     do {                                                                                                             \
         constexpr int lds = ConvCfg<PA, NRT, BITS, T>::LDSB;                                                         \
-        static bool once = false;                                                                                    \
-        if (!once) {                                                                                                 \
+        static const bool once = [&] {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)k_dynconv<PA, NRT, BITS, T>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
-            once = true;                                                                                             \
-        }                                                                                                            \
+            return true;                                                                                             \
+        }();                                                                                             \
+        (void)once;                                                                                                            \
         hipLaunchKernelGGL((k_dynconv<PA, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
                            bits_out, (T*)logits_out, obs, B, N, HW, HWp);                                            \
     } while (0)

@@ -558,8 +558,7 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     float* stats = partial + (size_t)3 * B * nwg * 256 * 2;
     const size_t lds = (size_t)PA * 256 * KH_LDT * sizeof(uint16_t);
     const size_t lds_apply = lds + 256 * sizeof(float2) + 256 * sizeof(float);
-    static bool once = false;
-    if (!once) {
+    static const bool once = [&] {
         const void* ks[] = {
 #define KH_ALL(F) (const void*)k_khead_stats<1, F>, (const void*)k_khead_stats<2, F>, (const void*)k_khead_apply<1, 0, F>, \
     (const void*)k_khead_apply<1, 1, F>, (const void*)k_khead_apply<1, 2, F>, (const void*)k_khead_apply<2, 0, F>,         \
@@ -568,8 +567,9 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
 #undef KH_ALL
         };
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+        return true;
+    }();
+    (void)once;
     KHArgs a = {};
     a.B = B; a.groups = groups; a.tiles_per_wg = tpw; a.HW = HW; a.HWp = HWp;
     a.w_plane = (int64_t)3 * 256 * 256;

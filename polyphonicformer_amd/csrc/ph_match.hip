@@ -235,11 +235,11 @@ extern "C" int ph_match_sums(const float* logits, const float* gt, const float* 
     hipStream_t s = (hipStream_t)stream;
 #define MT_CASE(R, C)                                                                                             \
     if (rtw == R && nct <= C) {                                                                                   \
-        static bool once = false;                                                                                 \
-        if (!once) {                                                                                              \
+        static const bool once = [&] {                                                                                              \
             (void)hipFuncSetAttribute((const void*)k_match_sums<R, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            once = true;                                                                                          \
-        }                                                                                                         \
+            return true;                                                                                          \
+        }();                                                                                          \
+        (void)once;                                                                                                         \
         hipLaunchKernelGGL((k_match_sums<R, C>), grid, block, lds, s, a);                                          \
         PH_CHECK_LAUNCH();                                                                                        \
         return PH_OK;                                                                                             \

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ ac
             const float p = FROM_PROBS ? act_mask[(int64_t)k * src_hw + px] : sample_out(act_mask + (int64_t)k * src_hw, G, o);
             if (p >= 0.5f) atomicAdd(&hist[K + k], 1);          // original_area  (kernel_update.py:508)
             const float v = scores[k] * p;                       // cur_prob_masks (:492)
-            if (v > best) { best = v; bi = k; }                  // argmax(0): first maximal index (:494)
+            // argmax(0): first maximal index (:494); like torch.argmax a NaN counts as the maximum (the first NaN wins)
+            if (v > best || (v != v && best == best)) { best = v; bi = k; }
         }
         ids[px] = bi;
         atomicAdd(&hist[bi], 1);                                 // mask_area      (:506-507)

@@ -322,12 +322,12 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
 #define PH_CV(PA, KS, S)                                                                                                 \
     do {                                                                                                                 \
         const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
-        static bool once = false;                                                                                        \
-        if (!once) {                                                                                                     \
+        static const bool once = [&] {                                                                                                     \
             (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                       (int)lds);                                                                         \
-            once = true;                                                                                                 \
-        }                                                                                                                \
+            return true;                                                                                                 \
+        }();                                                                                                 \
+        (void)once;                                                                                                                \
         hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
                            B, H, W, Ho, Wo);                                                                             \
     } while (0)
@@ -631,12 +631,12 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
         if (const char* e = getenv("PH_CPLANES_TPW")) tpw = atoi(e);
         const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), B);
         const size_t lds = 256 * 65 * sizeof(float);
-        static bool once = false;
-        if (!once) {
+        static const bool once = [&] {
             (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            once = true;
-        }
+            return true;
+        }();
+        (void)once;
         if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_to_cplanes<1>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
         else hipLaunchKernelGGL(k_gn_to_cplanes<2>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
         PH_CHECK_LAUNCH();

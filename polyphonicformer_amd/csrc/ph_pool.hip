@@ -4,20 +4,22 @@
 // `nsplit` pixel ranges.  One workgroup = (pixel range, 128-channel group, frame); its 4 waves own
 // 32 channels each (one 32x32x16 MFMA column tile) and ALL query rows:
 //   B operand (features): the [128 ch][64 px] tile goes HBM -> LDS by LDS-DMA in whole 128-byte lines
-//     (global_load_lds_dwordx4, double buffered, XOR-swizzled on the source side) and is read back as
-//     fragments with ds_read_b128: lane (channel j, half g), step t <-> pixel 64*chunk + 32*g + 8*t + e
-//     (the k-slot <-> pixel map is a free permutation as long as A agrees).  Every feature byte is read
-//     from HBM exactly once; fragment-shaped loads straight from HBM (16 B per lane at a 64 KB stride)
-//     measured 3.4 TB/s, whole-line DMA removes the 8x request amplification at the L1/TA.
+//     (global_load_lds_dwordx4 with the nt|sc1 stream policy, a POOL_NBUF = 4 deep ring: three chunks in flight
+//     while one is consumed, counted vmcnt + raw s_barrier, XOR-swizzled on the source side) and is read back
+//     as fragments with ds_read_b128: lane (channel j, half g), step t <-> pixel 64*chunk + 32*g + 8*t + e (the
+//     k-slot <-> pixel map is a free permutation as long as A agrees).  Every feature byte is read from HBM
+//     exactly once.
 //   A operand (mask bits -> {0,1} bf16): the chunk's mask words also arrive by LDS-DMA (2 words per query
-//     row); an A fragment is ONE ds_read_b128 from a 256-entry byte -> 8 x bf16 lookup table in LDS, so no
-//     expanded mask tile exists at all (36 KiB of LDS per workgroup -> 4 workgroups per CU, 64 KiB of HBM
-//     loads in flight per CU).  {0,1} is exact in bf16, so split precision only doubles the feature operand.
-// Measured alternatives at cfg2, B = 24 (805 MB per launch): fragment-shaped 16-byte loads straight from HBM
-// into VGPRs (128-byte lane stride, shared expanded mask tile) 3.4 TB/s; 32 B per lane at a 64 KB lane stride with a
-// 3-deep register ring and no barriers 2.1 TB/s (request amplification at the L1/TA dominates); this whole-line
-// DMA version 3.7 TB/s against a 5.2-5.7 TB/s pure-read yardstick (ph_selftest_readbw).  It is latency bound:
-// 70 % of wave cycles wait on vmcnt/barrier with 64 KiB of loads in flight per CU (profiles/r01).
+//     row, default cache policy: a 128-byte line serves 16 chunks); an A fragment is ONE ds_read_b128 from a
+//     256-entry byte -> 8 x bf16 lookup table in LDS, so no expanded mask tile exists at all.  LDS per
+//     workgroup at cfg2 (bf16): 4 x 16 KiB feature ring + 4 KiB table + 4 x 1.25 KiB mask words = 73 KiB
+//     -> 2 workgroups per CU, 96 KiB of feature loads in flight per CU.  {0,1} is exact in bf16, so split
+//     precision only doubles the feature operand.
+// Measured history at cfg2, B = 24 (805 MB per launch): fragment-shaped 16-byte loads straight from HBM into
+// VGPRs 3.4 TB/s; 32 B per lane at a 64 KB lane stride with a 3-deep register ring and no barriers 2.1 TB/s
+// (request amplification at the L1/TA); whole-line DMA, double buffered 3.7 TB/s (70 % of wave cycles waiting on
+// vmcnt/barrier with 64 KiB in flight per CU); this 4-deep ring 4.3 TB/s, with the nt|sc1 policy 4.5-4.7 TB/s
+// against a 5.2-5.8 TB/s pure-read yardstick (profiles/r01).
 // Roofline: HBM: 2*256*HWp*2 B of features per frame vs 2*Npad*512*HWp flop.
 #include "ph_common.h"
 
@@ -206,11 +208,11 @@ template <int PA, int NRT>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
                         int nsplit, hipStream_t s) {
     const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
-    static bool once = false;
-    if (!once) {
+    static const bool once = [&] {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+        return true;
+    }();
+    (void)once;
     hipLaunchKernelGGL((k_pool<PA, NRT>), dim3(nsplit, d ? 4 : 2, B), dim3(256), lds, s, x, d, bits, partial, B, HWp,
                        nsplit);
 }

@@ -865,12 +865,12 @@ static void launch_query(const QArgs& a, int phases, hipStream_t s) {
     size_t region = (size_t)NW * PA * ROWS * (a.Npad + 8) * 2;       // attention P buffers
     if (region < (size_t)2 * PA * PLANE * 2) region = (size_t)2 * PA * PLANE * 2;
     const size_t lds_post = (size_t)PA * PLANE * 2 + red + region;
-    static bool once = false;
-    if (!once) {   // allow the full 160 KiB of a CU; the per-launch size below is what is actually used
+    static const bool once = [&] {   // allow the full 160 KiB of a CU; the per-launch size below is what is actually used
         (void)hipFuncSetAttribute((const void*)k_query_pre<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_query_post<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
-    }
+        return true;
+    }();
+    (void)once;
     const dim3 grid(a.Npad / ROWS, 2, a.B);
     if (phases & 1) hipLaunchKernelGGL((k_query_pre<PA, NRT>), grid, dim3(NTHREADS), lds_pre, s, a);
     if (phases & 2) hipLaunchKernelGGL((k_query_post<PA, NRT>), grid, dim3(NTHREADS), lds_post, s, a);

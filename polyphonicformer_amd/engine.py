@@ -193,10 +193,24 @@ class DecodePlan:
         self.mask_up = e((B, N, 2 * H, 2 * W), out_dtype)
         self.depth_up = e((B, N, 2 * H, 2 * W), out_dtype)
         self.graph = None
+        self.handoff_runs = 0          # runs that started from another kernel's planes (tests observe the path taken)
 
     @property
     def out_code(self):
         return _lib.PH_OUT_F32 if self.out_dtype == torch.float32 else _lib.PH_OUT_BF16
+
+    def renew_outputs(self):
+        """Give the next `run` fresh output tensors (allocation only, no copy).  The reference's methods return tensors the
+        caller owns (SURVEY 8b "Threading / ownership"): the module API calls this before every run, so that results kept
+        from an earlier call -- e.g. the key frame's while the reference frame is decoded,
+        polyphonic_former_video.py:208-242 -- are never overwritten.  Captured plans (bench) keep their fixed buffers."""
+        if self.graph is not None:
+            raise _lib.PolyheadError("renew_outputs on a captured plan")
+        e = lambda t: torch.empty_like(t)
+        self.mask, self.depth, self.mask_up, self.depth_up = e(self.mask), e(self.depth), e(self.mask_up), e(self.depth_up)
+        last = self.stage_out[-1]
+        for k in ("obj", "dobj", "cls"):
+            last[k] = e(last[k])
 
     def set_inputs(self, x, dfe, k0, q0, m0):
         """x / dfe: fp32 NCHW (converted to bf16 planes by the ingest kernel inside `run`), or -- bf16 precision
@@ -221,19 +235,23 @@ class DecodePlan:
             ingest(self.dfe, self.prec, out=self.dp)
         binarize(self.m0, out=self.bits)
 
-    def stages(self):
+    def stages(self, xp=None, dp=None):
+        """the S stages on the plan's own planes, or on read-only planes another kernel produced; the mask bits are
+        always the plan's own (they are rewritten by every non-final stage)"""
+        xp = self.xp if xp is None else xp
+        dp = self.dp if dp is None else dp
         k, q = self.k0, self.q0
         for s in range(self.S):
             last = s == self.S - 1
-            pool(self.xp, self.dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial)
+            pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
                             outs=self.stage_out[s], workspace=self.ws)
             if not last:
-                dynconv(self.xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, bits_out=self.bits)
+                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, bits_out=self.bits)
             else:
-                dynconv(self.xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, logits_out=self.mask,
+                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, logits_out=self.mask,
                         out_dtype=self.out_code)
-                dynconv(self.dp, o["kern"], o["kbias"], 1, self.N, self.HW, self.prec, logits_out=self.depth,
+                dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, self.prec, logits_out=self.depth,
                         out_dtype=self.out_code)
             k, q = o["obj"], o["dobj"]
         upsample2x(self.mask, out=self.mask_up)
@@ -245,12 +263,14 @@ class DecodePlan:
         self.stages()
 
     def run_from_planes(self, xp, dp, bits, k0, q0):
-        """same, starting from feature planes / mask bits another kernel already produced
-        (KernelHead hand-off): no ingest pass.  `bits` is consumed (overwritten by the stages)."""
-        self.xp, self.dp, self.bits = xp, dp, bits
+        """same, starting from feature planes / mask bits another kernel already produced (KernelHead hand-off): no
+        ingest pass.  The planes are only read; the bits are copied (0.6 MB per frame at cfg2) because the stages
+        rewrite them, so the producer's tensors stay valid for its caller."""
+        self.handoff_runs += 1
+        self.bits.copy_(bits)
         self.k0.copy_(k0.reshape(self.B, self.N, 256))
         self.q0.copy_(q0.reshape(self.B, self.N, 256))
-        self.stages()
+        self.stages(xp, dp)
 
     def capture(self):
         """record `run` into a HIP graph (replay with `replay`)"""
@@ -352,6 +372,15 @@ class KernelHeadPlan:
         self.proposal = e((B, self.N, 256), torch.float32)
         self.ws = e((_lib.load().ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
         self.w_stuff = pack.w_seg_f32[num_thing_classes:num_classes].contiguous() if self.n_stuff else None
+
+    def renew_outputs(self):
+        """fresh tensors for everything `KernelHead.simple_test_rpn` hands to its caller (the 9-tuple and the plane / bit
+        hand-off to KernelUpdateIterHead), see DecodePlan.renew_outputs"""
+        e = lambda t: None if t is None else torch.empty_like(t)
+        self.xp, self.dp, self.bits = e(self.xp), e(self.dp), e(self.bits)
+        self.x_f32, self.dfe_f32 = e(self.x_f32), e(self.dfe_f32)
+        self.mask_preds, self.seg_preds, self.depth_pred = e(self.mask_preds), e(self.seg_preds), e(self.depth_pred)
+        self.proposal = e(self.proposal)
 
     def set_inputs(self, feats):
         """the three post-neck maps: contiguous fp32 device tensors of the plan's shape are used where they are (the

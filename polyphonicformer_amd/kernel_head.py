@@ -114,7 +114,7 @@ class KernelHead(nn.Module):
             raise NotImplementedError("training is outside the implemented hot path")
         neck = self.localization_fpn
         handoff = neck is not None and hasattr(neck, "forward_planes") and getattr(neck, "num_aux_convs", 0) == 2 \
-            and getattr(neck, "precision", None) == self.precision
+            and E.PREC.get(getattr(neck, "precision", None)) == E.PREC[self.precision]      # codes: 'split' == 'fp32'
         if handoff:
             # this build's neck: its three maps come over as bf16 planes (half the bytes, no conversion pass in front of
             # the GEMMs; bit-identical in bf16 precision because the first use of the fp32 maps is that same rounding)
@@ -137,6 +137,7 @@ class KernelHead(nn.Module):
             self._plans = {key: E.KernelHeadPlan(pack, B, H, W, self.num_thing_classes, self.num_classes, cat_stuff, dev,
                                                  want_f32=self.emit_fp32_features)}
             plan = self._plans[key]
+        plan.renew_outputs()         # the 9-tuple (and the hand-off planes) belong to the caller from here on
         plan.set_inputs(list(feats) if handoff else [f.float() for f in feats])
         plan.run()
         N = plan.N

@@ -93,6 +93,7 @@ class KernelUpdateIterHead(nn.Module):
         if not self.mask_head[-1].loss_cls.use_sigmoid:
             raise NotImplementedError("libpolyhead: sigmoid classification only (the shipped config)")
         plan = self._plan(B, N, H, W, x.device)
+        plan.renew_outputs()         # results are the caller's: an earlier call's tensors are never overwritten
         ho = getattr(x, "_ph_handoff", None)
         if (ho is not None and ho["prec"] == plan.prec and ho["mask_preds"] is mask_preds
                 and ho["depth_feats"] is depth_feats and tuple(ho["xp"].shape) == tuple(plan.xp.shape)

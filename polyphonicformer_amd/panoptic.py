@@ -36,7 +36,9 @@ def accept_loop(scores, labels, area, orig, num_thing_classes, instance_score_th
     segments are visited."""
     K = len(scores)
     newid = np.zeros(K, dtype=np.int32)
-    order = torch.argsort(-scores).numpy()                                   # :497 (same call, same tie order)
+    # :497; the reference's argsort is not stable, so its order among EQUAL scores is unspecified: stable = ascending
+    # index among ties, deterministic (and what torch's CPU sort gives for the reference's call too)
+    order = torch.argsort(-scores, stable=True).numpy()
     sc, lab = scores.numpy(), labels.numpy()
     area, orig = np.asarray(area, dtype=np.int64), np.asarray(orig, dtype=np.int64)
     isthing = lab < num_thing_classes

@@ -94,8 +94,10 @@ class SemanticFPNWrapper(nn.Module):
 
     # ---- packed parameters ---------------------------------------------------------------------------------
     def _pack(self, dev):
-        key = (str(dev), self.precision)
+        # keyed on the parameter versions too: load_state_dict / init_weights / fine-tuning after a first forward re-pack
+        key = (str(dev), self.precision, tuple(p._version for p in self.parameters()))
         if key not in self._packs:
+            self._packs.clear()
             prec = E.PREC[self.precision]
             P = 2 if prec == _lib.PH_PREC_SPLIT else 1
 

@@ -2,9 +2,10 @@
 drop-in for `QuasiDenseEmbedTracker` (polyphonic/video/qdtrack/trackers/quasi_dense_embed_tracker.py:8-207).
 
 The tracker is *host logic*: stateful, strictly sequential in frame order, data-dependent control flow over
-<= max_per_img detections and a memo of a few hundred rows (the reference runs it as ~10 tiny torch ops plus
-Python loops with `.item()`-style syncs).  It is mirrored here as Python over CPU tensors, same constructor
-kwargs, same `match(bboxes, labels, track_feats, frame_id)` signature and return value, same registry name.
+<= max_per_img detections and a memory of a few hundred rows.  This build keeps that memory as a struct of arrays
+(`_TrackTable`) and formulates de-duplication, affinity and greedy assignment as array operations; constructor
+kwargs, the `match(bboxes, labels, track_feats, frame_id)` signature / return value and the registry name are the
+reference's, and the integer ids are pinned to the reference class's own output (tests/golden/tracker.npz).
 With frames sharded over GPUs (`dist.shard_frames`) every rank all-gathers the per-frame records
 (`dist.allgather_track_records`) and replays `match` in frame order; integer track ids are then identical to the
 single-process run (`replay_tracking`, tests/test_tracker.py and tests/test_dist_gloo.py)."""
@@ -16,140 +17,178 @@ TRACKERS = Registry("trackers")
 
 
 def bbox_overlaps(b1, b2, eps=1e-6):
-    """IoU matrix, mmdet.core.bbox_overlaps(mode='iou', is_aligned=False) for xyxy boxes [n,4] x [m,4]"""
-    if b1.shape[0] == 0 or b2.shape[0] == 0:
-        return b1.new_zeros((b1.shape[0], b2.shape[0]))
-    area1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
-    area2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
-    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
-    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
-    wh = (rb - lt).clamp(min=0)
-    overlap = wh[..., 0] * wh[..., 1]
-    union = area1[:, None] + area2[None, :] - overlap
-    union = torch.max(union, union.new_tensor([eps]))
-    return overlap / union
+    """IoU matrix of xyxy boxes [n,4] x [m,4] (what mmdet.core.bbox_overlaps(mode='iou') returns)"""
+    n, m = b1.shape[0], b2.shape[0]
+    if n == 0 or m == 0:
+        return b1.new_zeros((n, m))
+    x1 = torch.maximum(b1[:, None, 0], b2[None, :, 0])
+    y1 = torch.maximum(b1[:, None, 1], b2[None, :, 1])
+    x2 = torch.minimum(b1[:, None, 2], b2[None, :, 2])
+    y2 = torch.minimum(b1[:, None, 3], b2[None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    return inter / (a1[:, None] + a2[None, :] - inter).clamp(min=eps)
+
+
+class _TrackTable:
+    """The tracker's memory as a struct of arrays: one row per live tracklet, in creation order (the order the
+    affinity columns are laid out in, which decides ties), plus the most recent frames' unmatched detections
+    ("backdrops", newest frame first).  Rows are updated / appended / expired with index operations; nothing here is
+    per-object Python state."""
+
+    def __init__(self, backdrop_frames):
+        self.ids = torch.zeros((0,), dtype=torch.long)
+        self.box = torch.zeros((0, 5))
+        self.emb = torch.zeros((0, 0))
+        self.lab = torch.zeros((0,), dtype=torch.long)
+        self.seen = torch.zeros((0,), dtype=torch.long)          # frame a row was last matched in
+        self.backdrop_frames = backdrop_frames
+        self.backdrops = []                                       # [(box, emb, lab)], newest first
+
+    def __len__(self):
+        return int(self.ids.numel())
+
+    def columns(self):
+        """(ids, labels, embeds) of everything a detection can be matched to: tracklets, then backdrops (id -1)"""
+        ids, lab, emb = [self.ids], [self.lab], [self.emb]
+        for (bb, be, bl) in self.backdrops:
+            ids.append(torch.full((be.shape[0],), -1, dtype=torch.long))
+            lab.append(bl)
+            emb.append(be)
+        return torch.cat(ids), torch.cat(lab), torch.cat(emb, 0)
+
+    def absorb(self, ids, box, emb, lab, frame, momentum):
+        """matched detections refresh their rows (embedding = exponential moving average), unknown ids append rows"""
+        if ids.numel() == 0:
+            return
+        pos = {int(t): r for r, t in enumerate(self.ids.tolist())}
+        row = torch.tensor([pos.get(int(t), -1) for t in ids.tolist()], dtype=torch.long)
+        old, new = row >= 0, row < 0
+        if old.any():
+            r = row[old]
+            self.emb[r] = (1 - momentum) * self.emb[r] + momentum * emb[old]
+            self.box[r], self.lab[r], self.seen[r] = box[old], lab[old], frame
+        if new.any():
+            k = int(new.sum())
+            self.ids = torch.cat([self.ids, ids[new]])
+            self.box = torch.cat([self.box, box[new]], 0)
+            self.emb = torch.cat([self.emb.reshape(-1, emb.shape[1]), emb[new]], 0)
+            self.lab = torch.cat([self.lab, lab[new]])
+            self.seen = torch.cat([self.seen, torch.full((k,), frame, dtype=torch.long)])
+
+    def expire(self, frame, max_age):
+        live = (frame - self.seen) < max_age
+        if not bool(live.all()):
+            self.ids, self.box, self.emb, self.lab, self.seen = (self.ids[live], self.box[live], self.emb[live],
+                                                                  self.lab[live], self.seen[live])
+
+    def push_backdrop(self, box, emb, lab):
+        self.backdrops.insert(0, (box, emb, lab))
+        del self.backdrops[self.backdrop_frames:]
+        if self.backdrop_frames == 0:
+            self.backdrops = []
 
 
 @TRACKERS.register_module()
 class QuasiDenseEmbedTracker(object):
+    """Quasi-dense embedding tracker with the constructor kwargs, `match` signature and integer-id semantics of
+    polyphonic/video/qdtrack/trackers/quasi_dense_embed_tracker.py:8-207 (pinned by tests/golden/tracker.npz, which the
+    reference class produced).  This build's formulation: detections are de-duplicated with one triangular IoU test,
+    the memory is a `_TrackTable`, the affinity matrix is computed once and the greedy one-to-one assignment walks the
+    detections in score order with a `taken` mask over tracklet columns.  The reference also carries a per-tracklet
+    velocity that nothing reads (its `match` ignores `memo_vs`); it is not kept."""
 
     def __init__(self, init_score_thr=0.8, obj_score_thr=0.5, match_score_thr=0.5, memo_tracklet_frames=10,
                  memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3,
                  nms_class_iou_thr=0.7, with_cats=True, match_metric='bisoftmax'):
-        assert 0 <= memo_momentum <= 1.0
-        assert memo_tracklet_frames >= 0
-        assert memo_backdrop_frames >= 0
+        if not (0 <= memo_momentum <= 1.0) or memo_tracklet_frames < 0 or memo_backdrop_frames < 0:
+            raise AssertionError("bad memo configuration")
+        if match_metric not in ('bisoftmax', 'softmax', 'cosine'):
+            raise AssertionError(f"unknown match_metric {match_metric}")
         self.init_score_thr, self.obj_score_thr, self.match_score_thr = init_score_thr, obj_score_thr, match_score_thr
         self.memo_tracklet_frames, self.memo_backdrop_frames = memo_tracklet_frames, memo_backdrop_frames
         self.memo_momentum, self.nms_conf_thr = memo_momentum, nms_conf_thr
         self.nms_backdrop_iou_thr, self.nms_class_iou_thr, self.with_cats = nms_backdrop_iou_thr, nms_class_iou_thr, with_cats
-        assert match_metric in ['bisoftmax', 'softmax', 'cosine']
         self.match_metric = match_metric
         self.num_tracklets = 0
-        self.tracklets = dict()
-        self.backdrops = []
+        self.table = _TrackTable(memo_backdrop_frames)
 
     @property
     def empty(self):
-        return False if self.tracklets else True
+        return len(self.table) == 0
 
-    def update_memo(self, ids, bboxes, embeds, labels, frame_id):
-        """quasi_dense_embed_tracker.py:47-102"""
-        tracklet_inds = ids > -1
-        for id, bbox, embed, label in zip(ids[tracklet_inds], bboxes[tracklet_inds], embeds[tracklet_inds],
-                                          labels[tracklet_inds]):
-            id = int(id)
-            if id in self.tracklets:
-                t = self.tracklets[id]
-                velocity = (bbox - t['bbox']) / (frame_id - t['last_frame'])
-                t['bbox'] = bbox
-                t['embed'] = (1 - self.memo_momentum) * t['embed'] + self.memo_momentum * embed
-                t['last_frame'] = frame_id
-                t['label'] = label
-                t['velocity'] = (t['velocity'] * t['acc_frame'] + velocity) / (t['acc_frame'] + 1)
-                t['acc_frame'] += 1
-            else:
-                self.tracklets[id] = dict(bbox=bbox, embed=embed, label=label, last_frame=frame_id,
-                                          velocity=torch.zeros_like(bbox), acc_frame=0)
-        backdrop_inds = torch.nonzero(ids == -1, as_tuple=False).squeeze(1)
-        ious = bbox_overlaps(bboxes[backdrop_inds, :-1], bboxes[:, :-1])
-        for i, ind in enumerate(backdrop_inds):
-            if (ious[i, :ind] > self.nms_backdrop_iou_thr).any():
-                backdrop_inds[i] = -1
-        backdrop_inds = backdrop_inds[backdrop_inds > -1]
-        self.backdrops.insert(0, dict(bboxes=bboxes[backdrop_inds], embeds=embeds[backdrop_inds],
-                                      labels=labels[backdrop_inds]))
-        invalid_ids = [k for k, v in self.tracklets.items() if frame_id - v['last_frame'] >= self.memo_tracklet_frames]
-        for k in invalid_ids:
-            self.tracklets.pop(k)
-        if len(self.backdrops) > self.memo_backdrop_frames:
-            self.backdrops.pop()
+    # -- pieces of `match` ---------------------------------------------------------------------------------
+    def _dedup(self, box):
+        """a detection is dropped when ANY higher-scored detection (kept or not) overlaps it by more than the IoU
+        threshold of its own score class (:147-155)"""
+        iou = bbox_overlaps(box[:, :4], box[:, :4])
+        thr = torch.where(box[:, 4] < self.obj_score_thr, torch.tensor(self.nms_backdrop_iou_thr),
+                          torch.tensor(self.nms_class_iou_thr))
+        return ~(torch.tril(iou, -1) > thr[:, None]).any(1), iou
 
-    @property
-    def memo(self):
-        """quasi_dense_embed_tracker.py:104-135"""
-        memo_embeds, memo_ids, memo_bboxes, memo_labels, memo_vs = [], [], [], [], []
-        for k, v in self.tracklets.items():
-            memo_bboxes.append(v['bbox'][None, :])
-            memo_embeds.append(v['embed'][None, :])
-            memo_ids.append(k)
-            memo_labels.append(v['label'].view(1, 1))
-            memo_vs.append(v['velocity'][None, :])
-        memo_ids = torch.tensor(memo_ids, dtype=torch.long).view(1, -1)
-        for backdrop in self.backdrops:
-            backdrop_ids = torch.full((1, backdrop['embeds'].size(0)), -1, dtype=torch.long)
-            memo_bboxes.append(backdrop['bboxes'])
-            memo_embeds.append(backdrop['embeds'])
-            memo_ids = torch.cat([memo_ids, backdrop_ids], dim=1)
-            memo_labels.append(backdrop['labels'][:, None])
-            memo_vs.append(torch.zeros_like(backdrop['bboxes']))
-        return (torch.cat(memo_bboxes, dim=0), torch.cat(memo_labels, dim=0).squeeze(1), torch.cat(memo_embeds, dim=0),
-                memo_ids.squeeze(0), torch.cat(memo_vs, dim=0))
+    def _affinity(self, emb, lab, memo_emb, memo_lab):
+        """[detections x memory columns] match scores (:165-182)"""
+        if self.match_metric == 'cosine':
+            unit = torch.nn.functional.normalize
+            s = unit(emb, p=2, dim=1) @ unit(memo_emb, p=2, dim=1).t()
+        else:
+            dot = emb @ memo_emb.t()
+            s = dot.softmax(dim=1)
+            if self.match_metric == 'bisoftmax':
+                s = (s + dot.softmax(dim=0)) / 2
+        if self.with_cats:
+            s = s * (lab[:, None] == memo_lab[None, :]).float()
+        return s
+
+    def _assign(self, score, det_conf, memo_ids):
+        """greedy, in detection (score) order: best still-free column; a tracklet column is consumed by a confident
+        detection, a weak detection that resembles a tracklet is marked -2 (neither a new track nor a backdrop),
+        matches to backdrop columns assign nothing (:183-197)"""
+        n = score.shape[0]
+        out = torch.full((n,), -1, dtype=torch.long)
+        taken = torch.zeros(score.shape[1], dtype=torch.bool)
+        for i in range(n):
+            conf, j = score[i].masked_fill(taken, 0).max(0)
+            if not conf > self.match_score_thr or memo_ids[j] < 0:
+                continue
+            if det_conf[i] > self.obj_score_thr:
+                out[i] = memo_ids[j]
+                taken[j] = True
+            elif conf > self.nms_conf_thr:
+                out[i] = -2
+        return out
 
     def match(self, bboxes, labels, track_feats, frame_id, asso_tau=-1):
-        """quasi_dense_embed_tracker.py:137-207.  bboxes [n,5] (x1,y1,x2,y2,score), labels [n], track_feats [n,256]."""
-        bboxes, labels, track_feats = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().cpu().float()
-        _, inds = bboxes[:, -1].sort(descending=True)
-        bboxes, labels, embeds = bboxes[inds, :], labels[inds], track_feats[inds, :]
-        valids = bboxes.new_ones((bboxes.size(0)))
-        ious = bbox_overlaps(bboxes[:, :-1], bboxes[:, :-1])
-        for i in range(1, bboxes.size(0)):
-            thr = self.nms_backdrop_iou_thr if bboxes[i, -1] < self.obj_score_thr else self.nms_class_iou_thr
-            if (ious[i, :i] > thr).any():
-                valids[i] = 0
-        valids = valids == 1
-        bboxes, labels, embeds = bboxes[valids, :], labels[valids], embeds[valids, :]
-        ids = torch.full((bboxes.size(0),), -1, dtype=torch.long)
-        if bboxes.size(0) > 0 and not self.empty:
-            memo_bboxes, memo_labels, memo_embeds, memo_ids, memo_vs = self.memo
-            if self.match_metric == 'bisoftmax':
-                feats = torch.mm(embeds, memo_embeds.t())
-                scores = (feats.softmax(dim=1) + feats.softmax(dim=0)) / 2
-            elif self.match_metric == 'softmax':
-                scores = torch.mm(embeds, memo_embeds.t()).softmax(dim=1)
-            else:
-                scores = torch.mm(torch.nn.functional.normalize(embeds, p=2, dim=1),
-                                  torch.nn.functional.normalize(memo_embeds, p=2, dim=1).t())
-            if self.with_cats:
-                scores *= (labels.view(-1, 1) == memo_labels.view(1, -1)).float()
-            for i in range(bboxes.size(0)):
-                conf, memo_ind = torch.max(scores[i, :], dim=0)
-                id = memo_ids[memo_ind]
-                if conf > self.match_score_thr:
-                    if id > -1:
-                        if bboxes[i, -1] > self.obj_score_thr:
-                            ids[i] = id
-                            scores[:i, memo_ind] = 0
-                            scores[i + 1:, memo_ind] = 0
-                        else:
-                            if conf > self.nms_conf_thr:
-                                ids[i] = -2
-        new_inds = (ids == -1) & (bboxes[:, 4] > self.init_score_thr)
-        num_news = int(new_inds.sum())
-        ids[new_inds] = torch.arange(self.num_tracklets, self.num_tracklets + num_news, dtype=torch.long)
-        self.num_tracklets += num_news
-        self.update_memo(ids, bboxes, embeds, labels, frame_id)
-        return bboxes, labels, ids
+        """bboxes [n,5] (x1,y1,x2,y2,score), labels [n], track_feats [n,256] -> (bboxes, labels, ids) of the kept
+        detections in descending-score order; ids >= 0 track, -1 unmatched, -2 suppressed."""
+        box, lab, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().cpu().float()
+        order = box[:, 4].sort(descending=True)[1]
+        box, lab, emb = box[order], lab[order], emb[order]
+        keep, _ = self._dedup(box)
+        box, lab, emb = box[keep], lab[keep], emb[keep]
+        ids = torch.full((box.shape[0],), -1, dtype=torch.long)
+        if box.shape[0] and not self.empty:
+            memo_ids, memo_lab, memo_emb = self.table.columns()
+            ids = self._assign(self._affinity(emb, lab, memo_emb, memo_lab), box[:, 4], memo_ids)
+        born = (ids == -1) & (box[:, 4] > self.init_score_thr)
+        k = int(born.sum())
+        ids[born] = torch.arange(self.num_tracklets, self.num_tracklets + k, dtype=torch.long)
+        self.num_tracklets += k
+        self._remember(ids, box, emb, lab, frame_id)
+        return box, lab, ids
+
+    def _remember(self, ids, box, emb, lab, frame_id):
+        """:47-102: tracked detections go to the table; the still-unmatched ones that no higher-scored detection covers
+        become this frame's backdrops; tracklets unseen for `memo_tracklet_frames` frames are forgotten"""
+        tracked = ids > -1
+        self.table.absorb(ids[tracked], box[tracked], emb[tracked], lab[tracked], frame_id, self.memo_momentum)
+        loose = ids == -1
+        iou = bbox_overlaps(box[:, :4], box[:, :4])
+        covered = (torch.tril(iou, -1) > self.nms_backdrop_iou_thr).any(1)
+        bd = loose & ~covered
+        self.table.push_backdrop(box[bd], emb[bd], lab[bd])
+        self.table.expire(frame_id, self.memo_tracklet_frames)
 
 
 def replay_tracking(records, tracker_cfg=None, tracker=None):

@@ -198,3 +198,23 @@ ASSIGN_CASES = [dict(seed=11, N=100, G=7, L=8, H=24, W=40, with_valid=True),
                 dict(seed=13, N=37, G=3, L=8, H=7, W=13, with_valid=False),
                 dict(seed=14, N=200, G=64, L=8, H=12, W=20, with_valid=True),
                 dict(seed=15, N=20, G=1, L=8, H=8, W=8, with_valid=True, with_cls=False)]
+
+
+def stage_cfg(C=256, F=2048, heads=8, L=19, n_thing=8, n_stuff=11):
+    """`mask_head` config dict with the shipped structure (configs/_base_/models/polyphonic_former.py:111-165) at
+    parametric width; the same dict `oracle/ref_loader.py` builds the reference heads from when it generates goldens"""
+    return dict(
+        type="KernelUpdateHead", num_thing_classes=n_thing, num_stuff_classes=n_stuff,
+        num_classes=L, num_ffn_fcs=2, num_heads=heads, num_cls_fcs=1, num_mask_fcs=1,
+        feedforward_channels=F, in_channels=C, out_channels=C, dropout=0.0, mask_thr=0.5,
+        conv_kernel_size=1, mask_upsample_stride=2, ffn_act_cfg=dict(type="ReLU", inplace=True),
+        with_ffn=True, feat_transform_cfg=dict(conv_cfg=dict(type="Conv2d"), act_cfg=None),
+        kernel_updator_cfg=dict(type="KernelUpdator", in_channels=C, feat_channels=C,
+                                out_channels=C, input_feat_shape=3,
+                                act_cfg=dict(type="ReLU", inplace=True), norm_cfg=dict(type="LN")),
+        loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+        loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+        loss_dice=dict(type="DiceLoss", loss_weight=4.0),
+        loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+        loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid"),
+        depth_act_mode="sigmoid")

@@ -1,0 +1,147 @@
+"""GPU: the BASELINE.json configurations at their FULL sizes against the CPU oracle.
+
+  * cfg2  1024x2048 -> 128x256, N = 153 (100 + 53), L = 133, S = 3: every stage teacher-forced from the oracle's own
+    stage inputs (one frame, ~1 s of CPU), both precisions, plus the IDENTICAL-INPUTS form of the test: the oracle is
+    fed the bf16-rounded feature maps the device consumes (that is what cfg2's "bf16" inputs are), so the measured
+    error is the path's arithmetic and not the input rounding.
+  * cfg3  same map size, N = 111 (the shipped video head), two frames.
+  * cfg5  1242x375 padded to 1248x384 -> 48x156, N = 253 (200 + 53), S = 3: teacher-forced per stage AND
+    `simple_test_mask_preds` free running (flip rate of the hard threshold inside the recurrence reported and bounded).
+
+Tolerances: see TOL_IDENT / TOL below and tests/test_gpu_parity.py's header."""
+import pytest
+import torch
+
+import bench
+import helpers as Hh
+from oracle import poly_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TOL = {"fp32": 1e-3, "bf16": 3e-2, "mixed": 1e-3}
+# identical (bf16-rounded) feature inputs on both sides: north_star's 1e-3 for the modes that claim it
+TOL_IDENT = {"fp32": 1e-3, "mixed": 1e-3, "bf16": 3e-2}
+
+CFG2 = dict(H=128, W=256, Nq=100, n_thing=80, n_stuff=53, S=3, F=2048)
+CFG3 = dict(H=128, W=256, Nq=100, n_thing=8, n_stuff=11, S=3, F=2048)
+CFG5 = dict(H=48, W=156, Nq=200, n_thing=80, n_stuff=53, S=3, F=2048)
+
+
+def _head_and_sd(wl, precision, gpu, out_dtype=torch.float32, seed=0):
+    head = bench.build_head(wl, precision, out_dtype, gpu, seed=seed)
+    sd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
+    return head, sd
+
+
+def _teacher_forced(head, sd, wl, inp, gpu, tol, feats_dtype=None):
+    """every stage on the oracle's own stage inputs; returns {(stage, output): rel err}"""
+    B = inp["x"].shape[0]
+    N = wl["Nq"] + wl["n_stuff"]
+    ref = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"], return_stages=True)
+    x, dfe = inp["x"].to(gpu), inp["dfe"].to(gpu)
+    if feats_dtype is not None:
+        x, dfe = x.to(feats_dtype), dfe.to(feats_dtype)
+    k, q, m = inp["k0"].reshape(B, N, 256), inp["q0"].reshape(B, N, 256), inp["m0"]
+    errs = {}
+    for s in range(wl["S"]):
+        r = ref["stages"][s]
+        cls, nm, obj, nd, dobj = head.mask_head[s](x, k.to(gpu).reshape(B, N, 256, 1, 1), m.to(gpu),
+                                                    depth_proposal=q.to(gpu).reshape(B, N, 256, 1, 1), depth_feats=dfe)
+        got = dict(cls=cls, mask=nm, obj=obj.reshape(B, N, 256), depth=nd, dobj=dobj.reshape(B, N, 256))
+        for name, t in got.items():
+            errs[(s, name)] = Hh.rel_err(t.float().cpu(), r[name])
+        k, q, m = r["obj"], r["dobj"], r["mask"]                 # teacher forcing: the oracle's outputs feed the next stage
+    worst = max(errs.values())
+    print("teacher-forced rel err:", {f"s{s}.{n}": f"{v:.1e}" for (s, n), v in errs.items()})
+    assert worst < tol, (worst, errs)
+    return errs
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg2_full_size_stage_vs_oracle(gpu, precision):
+    """cfg2 at its full size against the oracle (fp32 NCHW inputs, as the reference API hands them)"""
+    head, sd = _head_and_sd(CFG2, precision, gpu)
+    inp = bench.synth_inputs(CFG2, 1, seed=11)
+    _teacher_forced(head, sd, CFG2, inp, gpu, TOL[precision])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg2_identical_bf16_inputs(gpu, precision):
+    """both sides consume the SAME bf16-rounded feature maps (cfg2's input dtype): what is left is the arithmetic error of
+    the path itself.  The modes that claim north_star's 1e-3 are gated at 1e-3 here."""
+    head, sd = _head_and_sd(CFG2, precision, gpu)
+    inp = bench.synth_inputs(CFG2, 1, seed=12)
+    inp["x"], inp["dfe"] = inp["x"].bfloat16().float(), inp["dfe"].bfloat16().float()
+    fd = torch.bfloat16 if precision == "bf16" else None          # bf16 NCHW tensors are adopted as planes (no ingest)
+    _teacher_forced(head, sd, CFG2, inp, gpu, TOL_IDENT[precision], feats_dtype=fd)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg3_video_head_size_two_frames(gpu, precision):
+    head, sd = _head_and_sd(CFG3, precision, gpu, seed=2)
+    inp = bench.synth_inputs(CFG3, 2, seed=13)
+    _teacher_forced(head, sd, CFG3, inp, gpu, TOL[precision])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg5_teacher_forced_and_free_running(gpu, precision):
+    """cfg5's shape (48x156: HW = 7488 is not a multiple of 128, N = 253 -> 8 row tiles), all three stages"""
+    wl = CFG5
+    head, sd = _head_and_sd(wl, precision, gpu, seed=5)
+    inp = bench.synth_inputs(wl, 1, seed=14)
+    _teacher_forced(head, sd, wl, inp, gpu, TOL[precision])
+    # free running through simple_test_mask_preds
+    N = wl["Nq"] + wl["n_stuff"]
+    ref = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])
+    g = {k: v.to(gpu) for k, v in inp.items()}
+    metas = [Hh.img_meta(375, 1242, pad_to=(384, 1248))]
+    obj, cls, mask, mask_up = head.simple_test_mask_preds(g["x"], g["k0"].reshape(1, N, 256, 1, 1), g["m0"], None, metas,
+                                                          depth_feats=g["dfe"], depth_proposal=g["q0"].reshape(1, N, 256, 1, 1))
+    assert mask_up.shape == (1, N, 96, 312) and obj.shape == (1, N, 256, 1, 1)
+    flips = ((mask.float().cpu() > 0) != (ref["mask"] > 0)).float().mean().item()
+    e = {n: Hh.rel_err(t.float().cpu(), r) for n, t, r in (("obj", obj.reshape(1, N, 256), ref["obj"]), ("cls", cls, ref["cls"]),
+                                                            ("mask", mask, ref["mask"]), ("mask_up", mask_up, ref["mask_up"]))}
+    print(f"cfg5 free-running {precision}: flip rate {flips:.2e}, rel err {e}")
+    if precision == "fp32":
+        assert flips < 1e-3
+        assert max(e.values()) < (1e-3 if flips == 0 else 5e-2)
+    else:
+        assert flips < 0.05 and e["obj"] < 0.1
+
+
+def test_api_outputs_survive_the_next_call(gpu):
+    """the reference returns fresh tensors; results kept from frame t must not change when frame
+    t + 1 is decoded with the same shapes (e.g. the key / reference frames of polyphonic_former_video.py:208-242)"""
+    wl = dict(H=16, W=32, Nq=100, n_thing=8, n_stuff=11, S=2, F=2048)
+    head, _ = _head_and_sd(wl, "bf16", gpu)
+    N = wl["Nq"] + wl["n_stuff"]
+    metas = [Hh.img_meta(128, 256)]
+    outs = []
+    for seed in (21, 22):
+        g = {k: v.to(gpu) for k, v in bench.synth_inputs(wl, 1, seed=seed).items()}
+        outs.append(head.simple_test_mask_preds(g["x"], g["k0"].reshape(1, N, 256, 1, 1), g["m0"], None, metas,
+                                                depth_feats=g["dfe"], depth_proposal=g["q0"].reshape(1, N, 256, 1, 1)))
+        if seed == 21:
+            keep = [t.clone() for t in outs[0]]
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], keep):
+        assert torch.equal(a, b)                                  # frame t's tensors are untouched
+    assert not torch.equal(outs[0][2], outs[1][2])                # and frame t+1 really produced something else
+    # KernelHead: the 9-tuple of call 1 survives call 2, and its hand-off still decodes to the same result afterwards
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    from test_gpu_parity import _full_weights, _iter_head, _kernel_head
+    w = _full_weights()
+    kh, ih = _kernel_head(w, "fp32"), _iter_head(w, 2, precision="fp32")
+    m8 = [Hh.img_meta(64, 128)]
+    r1 = kh.simple_test_rpn([f.to(gpu) for f in Hh.neck_inputs(31, 1, 256, 8, 16)], m8)
+    snap = [t.clone() for t in (r1[0], r1[1], r1[2], r1[4], r1[5], r1[7])]
+    d1 = ih.simple_test_mask_preds(r1[1], r1[0], r1[2], r1[3], m8, depth_preds=r1[7], depth_feats=r1[5], depth_proposal=r1[6])
+    d1 = [t.clone() for t in d1]
+    r2 = kh.simple_test_rpn([f.to(gpu) for f in Hh.neck_inputs(32, 1, 256, 8, 16)], m8)
+    ih.simple_test_mask_preds(r2[1], r2[0], r2[2], r2[3], m8, depth_preds=r2[7], depth_feats=r2[5], depth_proposal=r2[6])
+    for a, b in zip((r1[0], r1[1], r1[2], r1[4], r1[5], r1[7]), snap):
+        assert torch.equal(a, b)
+    d1b = ih.simple_test_mask_preds(r1[1], r1[0], r1[2], r1[3], m8, depth_preds=r1[7], depth_feats=r1[5], depth_proposal=r1[6])
+    for a, b in zip(d1, d1b):
+        assert torch.equal(a, b)

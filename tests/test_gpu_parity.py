@@ -18,7 +18,7 @@ import torch
 
 import helpers as Hh
 from oracle import poly_oracle as O
-from oracle.ref_loader import stage_cfg          # config dict builder only (no reference import)
+from helpers import stage_cfg
 from polyphonicformer_amd import _lib, engine as E
 from polyphonicformer_amd.registry import HEADS, TRANSFORMER_LAYER
 import polyphonicformer_amd.kernel_update  # noqa: F401  (registers the heads)
@@ -285,7 +285,7 @@ def test_whole_path_a1_a6(gpu, weights):
     assert hasattr(xf, "_ph_handoff")
     obj, cls, mask, mask_up = ih.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
     plan = next(iter(ih._plans.values()))
-    assert plan.xp is xf._ph_handoff["xp"]          # the hand-off path ran (no ingest)
+    assert plan.handoff_runs == 1                   # the hand-off path ran (no ingest)
     flips = ((mask.cpu() > 0) != (ref["mask"] > 0)).float().mean().item()
     print("a1->a6 free-running flip rate:", flips)
     # free running through 1 + 3 hard thresholds: a logit within rounding of 0 binarises differently and moves a whole

@@ -102,11 +102,12 @@ def _info_equal(a, b):
             assert x["area"] == y["area"]
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
 def test_merge_crafted(case):
     """integer id map: bit-exact against the reference's get_panoptic on crafted inputs
-    (duplicated query, equal scores, rescale + crop geometries)."""
-    z = Hh.load_golden("merge.npz")
+    (duplicated query, equal scores, rescale + crop geometries; d, e: non-integer scale factors in both
+    resampling steps with ori_shape != img_shape)."""
+    z = Hh.load_golden("merge.npz" if case in "abc" else "merge2.npz")
     cfg = Hh.FULL
     h, w, bh, bw, oh, ow = [int(v) for v in z[f"{case}_meta"]]
     meta = Hh.img_meta(h, w, pad_to=(bh, bw), ori=(oh, ow))
