@@ -32,6 +32,13 @@ void ph_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// ---- the hard mask threshold (kernel_update_head.py:236-238, kernel_head.py:314-317): `sigmoid(z) > 0.5` in fp32.
+// Evaluated as the reference does -- 1 / (1 + exp(-z)), every operation rounded to fp32 -- the comparison is true exactly
+// for z > 1.5 * 2^-24: below that 1 - z rounds to 1 - 2^-24 or 1, 2 - 2^-24 rounds to 2, and 1 / 2 = 0.5.  (Probe on
+// torch's CPU sigmoid: smallest z with sigmoid(z) > 0.5 is 97 * 2^-30.)  `z > 0` would differ on 0 < z <= 1.5 * 2^-24:
+// 3.6e-8 of N(0, 1) logits, i.e. about one pixel in four full-size frames -- enough to move a pooled feature by 1e-3.
+#define PH_BIN_THR 0x1.8p-24f
+
 // ---- bf16 bit helpers (round to nearest even; inputs are finite in this code base) ----------
 // gfx950 has a hardware round-to-nearest-even conversion (v_cvt_pk_bf16_f32); the compiler selects
 // it for fp32 -> __bf16 conversions.

@@ -338,7 +338,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
                 // stale data (observed; the documented hazard names only the lane-select operand)
                 unsigned long long m[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] > 0.f);
+                for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] > PH_BIN_THR);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
-                    const unsigned long long m = __ballot(acc[r] > 0.f);
+                    const unsigned long long m = __ballot(acc[r] > PH_BIN_THR);
                     const uint32_t lo = (uint32_t)m & pxmask, hi = (uint32_t)(m >> 32) & pxmask;
                     asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(lo), "n"(rr));
                     asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"(hi), "n"(rr + 4));

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
                 for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = src[px + e];
             }
         }
-        const uint32_t nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+        const uint32_t nib = (v[0] > PH_BIN_THR ? 1u : 0u) | (v[1] > PH_BIN_THR ? 2u : 0u) | (v[2] > PH_BIN_THR ? 4u : 0u) | (v[3] > PH_BIN_THR ? 8u : 0u);
         uint32_t word = nib << (4 * (lane & 7));
         word |= __shfl_xor(word, 1);
         word |= __shfl_xor(word, 2);

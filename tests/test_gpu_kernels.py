@@ -78,10 +78,13 @@ def test_ingest(gpu, prec, H, W):
 @pytest.mark.parametrize("N,H,W", [(111, 8, 16), (7, 6, 13), (153, 16, 24)])
 def test_binarize(gpu, N, H, W):
     m = torch.randn(2, N, H, W, generator=torch.Generator().manual_seed(2))
-    m[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30])
+    # boundary of the reference's definition `sigmoid(m) > 0.5` in fp32: true from 97 * 2^-30 on (1.5 * 2^-24 is the
+    # last value whose sigmoid still rounds to 0.5)
+    m[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 96 * 2.0 ** -30, 97 * 2.0 ** -30, 2.0 ** -24, 2.0 ** -23])
     bits = E.binarize(m.to(gpu))
     got = unpack_bits(bits, N, H * W)
-    assert torch.equal(got, (m > 0).float().reshape(2, N, -1))
+    assert torch.equal(got, (m.sigmoid() > 0.5).float().reshape(2, N, -1))       # kernel_update_head.py:236-238
+    assert got[0, 0, :8].tolist() == [0, 0, 0, 0, 0, 1, 0, 1]
     full = unpack_bits(bits, bits.shape[1], bits.shape[2] * 32)
     assert full[:, N:].sum() == 0 and full[:, :, H * W:].sum() == 0
 
@@ -97,7 +100,7 @@ def test_pool(gpu, prec, N, H, W, nsplit):
     bits = E.binarize(m.to(gpu))
     part = E.pool(xp, dp, bits, N, HW, prec, nsplit=nsplit).cpu().double()
     got = part.sum(1)[:, :N]
-    M = (m > 0).double().reshape(B, N, HW)
+    M = (m.sigmoid() > 0.5).double().reshape(B, N, HW)
     xq, dq = planes_to_float(xp.cpu())[..., :HW], planes_to_float(dp.cpu())[..., :HW]
     ref = torch.cat([torch.einsum("bnk,bck->bnc", M, xq), torch.einsum("bnk,bck->bnc", M, dq)], -1)
     # exact products, fp32 accumulation over <= HW terms
@@ -145,7 +148,7 @@ def test_dynconv(gpu, prec, N, H, W):
         bits = torch.full((B, Npad, E.hw_padded(HW) // 32), -1, dtype=torch.int32, device=gpu)
         E.dynconv(xp, kern, kbias_d, br, N, HW, prec, bits_out=bits)
         got = unpack_bits(bits, N, HW)
-        want = (out.cpu().reshape(B, N, HW) > 0).float()
+        want = (out.cpu().reshape(B, N, HW).sigmoid() > 0.5).float()
         assert torch.equal(got, want)
         full = unpack_bits(bits, Npad, bits.shape[2] * 32)
         assert full[:, N:].sum() == 0 and full[:, :, HW:].sum() == 0
