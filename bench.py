@@ -98,9 +98,10 @@ def kernel_breakdown(plan, iters=10):
     t["pool"] = time_op(lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial), iters)
     for name, ph in (("query_pre", 1), ("query_post", 2)):
         t[name] = time_op(lambda ph=ph: E.query_stage(p.partial, p.bits, p.k0, p.q0, p.packs[0], p.N, p.HW,
-                                                      outs=p.stage_out[0], workspace=p.ws, phases=ph), iters)
-    t["dynconv_bits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.prec, bits_out=p.bits), iters)
-    t["dynconv_logits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.prec,
+                                                      outs=p.stage_out[0], workspace=p.ws, phases=ph,
+                                                      kern_fmt=p.mode.kern_fmt), iters)
+    t["dynconv_bits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits), iters)
+    t["dynconv_logits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv,
                                                     logits_out=p.mask, out_dtype=p.out_code), iters)
     t["upsample2x"] = time_op(lambda: E.upsample2x(p.mask, out=p.mask_up), iters)
     counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
@@ -111,7 +112,7 @@ def kernel_breakdown(plan, iters=10):
 def algorithmic_bytes(plan, kernel):
     """ALGORITHMIC bytes one launch of `kernel` must move."""
     p = plan
-    P = 2 if p.prec == 3 else 1
+    P = p.mode.FP
     from polyphonicformer_amd.engine import hw_padded, n_padded
     HWp, Npad = hw_padded(p.HW), n_padded(p.N)
     eo = 4 if p.out_dtype == torch.float32 else 2
@@ -166,7 +167,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
     kplan = E.KernelHeadPlan(kh._get_pack(dev), B, H, W, wl["n_thing"], L, True, dev, want_f32=False)
     g = torch.Generator().manual_seed(3)
     kplan.set_inputs([torch.randn(B, 256, H, W, generator=g).relu().to(dev) for _ in range(3)])
-    dplan = E.DecodePlan([h.stage_pack(dev, precision) for h in head.mask_head], B, N, H, W, E.PREC[precision], out_dtype, dev)
+    dplan = E.DecodePlan([h.stage_pack(dev, precision) for h in head.mask_head], B, N, H, W, E.MODES[precision], out_dtype, dev)
     q0 = kh._get_pack(dev).w_dd_f32.reshape(1, 1, 256).expand(B, N, 256)
 
     def run():
@@ -188,7 +189,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
     try:
         kplan2 = E.KernelHeadPlan(kh._get_pack(dev), B, H, W, wl["n_thing"], L, True, dev, want_f32=False)
         kplan2.set_inputs([torch.randn(B, 256, H, W, generator=g).relu().to(dev) for _ in range(3)])
-        dplan2 = E.DecodePlan([h.stage_pack(dev, precision) for h in head.mask_head], B, N, H, W, E.PREC[precision], out_dtype, dev)
+        dplan2 = E.DecodePlan([h.stage_pack(dev, precision) for h in head.mask_head], B, N, H, W, E.MODES[precision], out_dtype, dev)
         sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 
         def issue():
@@ -486,9 +487,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=96, help="frames per step per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp16", "fp32"],
+                    help="engine.MODES: bf16 = one bf16 plane everywhere (fast, ~6e-3 per stage); mixed = bf16 feature planes as "
+                         "given, fp32-grade arithmetic on them (<= 1e-3 on identical inputs), fp16 logits out; fp16 = fp16 planes / "
+                         "kernels / logits (cfg5), fp32-grade query side; fp32 = every operand hi + lo (parity grade)")
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
-    ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+    ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16", "fp16"],
                     help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
                          "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
     ap.add_argument("--no-graph", action="store_true")
@@ -533,20 +537,21 @@ def main():
 
     wl = WORKLOADS[args.workload]
     B = args.frames
-    out_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    out_dtype = {"bf16": torch.bfloat16, "mixed": torch.float16, "fp16": torch.float16, "fp32": torch.float32}[args.precision]
     head = build_head(wl, args.precision, out_dtype, dev)
     N = wl["Nq"] + wl["n_stuff"]
     plan = head._plan(B, N, wl["H"], wl["W"], dev)      # single-stream plan (also used for the per-kernel timings)
     inp = synth_inputs(wl, B, seed=1234 + rank, mask_bias=args.mask_bias)         # each rank: its own frames
-    in_dt = args.input_dtype if args.input_dtype != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
+    in_dt = args.input_dtype if args.input_dtype != "auto" else {"bf16": "bf16", "mixed": "bf16", "fp16": "fp16", "fp32": "fp32"}[args.precision]
     gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
-    if in_dt == "bf16":
-        gin[0], gin[1] = gin[0].to(torch.bfloat16), gin[1].to(torch.bfloat16)
+    if in_dt in ("bf16", "fp16"):
+        tdt = torch.bfloat16 if in_dt == "bf16" else torch.float16
+        gin[0], gin[1] = gin[0].to(tdt), gin[1].to(tdt)
     plan.set_inputs(*gin)
     runner = plan
     if args.streams > 1:
         from polyphonicformer_amd.engine import DualDecodePlan
-        runner = DualDecodePlan(plan.packs, B, N, wl["H"], wl["W"], plan.prec, out_dtype, dev, parts=args.streams)
+        runner = DualDecodePlan(plan.packs, B, N, wl["H"], wl["W"], plan.mode, out_dtype, dev, parts=args.streams)
         runner.set_inputs(*gin)
     if args.no_graph:
         step = runner.run
@@ -611,7 +616,10 @@ def main():
             "metric": "frames/sec kernel-update+mask fwd, 1024x2048 N=153 S=3", "value": round(fps, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (fp32-grade split)",
+            "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "mixed": "bf16 (feature planes as given; hi/lo bf16 query GEMMs and dynamic kernels, fp16 logits)",
+                      "fp16": "fp16 (planes, dynamic kernels, logits; hi/lo bf16 query GEMMs)",
+                      "fp32": "bf16x3 (fp32-grade split)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: KernelUpdateIterHead.simple_test_mask_preds, "
                                    f"{wl['H'] * 8}x{wl['W'] * 8}, stride-8 {wl['H']}x{wl['W']}, N={N}, S={wl['S']}, "
@@ -635,7 +643,7 @@ def main():
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "track_allgather": tag,
         }
-        if world == 1 and in_dt == "bf16" and not args.no_kernel_head:
+        if world == 1 and in_dt in ("bf16", "fp16") and not args.no_kernel_head:
             # the same step when the features arrive as fp32 NCHW (the reference's dtype) and go through the ingest kernel
             try:
                 gin32 = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
@@ -655,7 +663,7 @@ def main():
                 Bf = 32
                 head32 = build_head(wl, "fp32", torch.float32, dev)
                 p32 = head32._plan(Bf // 2, N, wl["H"], wl["W"], dev)
-                r32 = DualDecodePlan(p32.packs, Bf, N, wl["H"], wl["W"], p32.prec, torch.float32, dev)
+                r32 = DualDecodePlan(p32.packs, Bf, N, wl["H"], wl["W"], p32.mode, torch.float32, dev)
                 i32 = synth_inputs(wl, Bf, seed=99)
                 r32.set_inputs(*[i32[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")])
                 r32.capture()

@@ -32,8 +32,15 @@ extern "C" {
 #define PH_VERSION 100
 
 enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWORKSPACE = -4 };
-enum { PH_PREC_BF16 = 1, PH_PREC_SPLIT = 3 };   /* number of bf16 MFMA products per logical product */
-enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1 };
+/* Arithmetic of an operator = element format of its 16-bit operands x planes per operand:
+ *   PH_PREC_BF16         bf16, one plane each                          (1 MFMA per product, ~2^-9 per operand)
+ *   PH_PREC_BF16_KSPLIT  ph_dynconv only: bf16 features in ONE plane, the dynamic kernels as hi + lo planes (2 MFMAs):
+ *                        exact for features that ARE bf16 values, kernels to 2^-17
+ *   PH_PREC_SPLIT        bf16, hi + lo planes of both operands, a.b ~= ah.bh + ah.bl + al.bh (3 MFMAs, ~2^-16)
+ *   PH_PREC_F16          IEEE fp16, one plane each (1 MFMA, ~2^-12 per operand; |values| < 65504) */
+enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5 };
+enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1, PH_OUT_F16 = 2 };
+enum { PH_KERN_BF16_PLANES = 0, PH_KERN_F16 = 1 };   /* ph_query_stage: format of the dynamic conv kernels it emits */
 enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3, PH_GN_TO_CPLANES = 4 };   /* ph_gn_apply modes */
 enum { PH_IN_F32_NCHW = 0, PH_IN_PLANES = 1 };   /* ph_khead_fused input_format */
 
@@ -129,13 +136,17 @@ int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits,
                    float* obj, float* dobj, float* cls, int cls_sigmoid /* kernel_update.py:396-397 */,
                    uint16_t* kern, float* kbias,
                    void* workspace, size_t workspace_bytes,
-                   int B, int N, int64_t HW, int prec, int phases, void* stream);
+                   int B, int N, int64_t HW, int prec /* PH_PREC_BF16 | PH_PREC_SPLIT */,
+                   int kern_format /* PH_KERN_BF16_PLANES: [P][2][B][Npad][256]; PH_KERN_F16: one fp16 plane */,
+                   int phases, void* stream);
 
 /* ---- A13: dynamic 1x1 convolution -----------------------------------------------------------
  * kernel_update_head.py:317-329: logits[b][n][hw] = sum_c kern[b][n][c] * feat[b][c][hw] + kbias[b][n].
  * Either writes the mask bits the next stage pools with (bits_out != NULL; the logits of a
  * non-final stage are consumed only through `> 0`, kernel_update_head.py:236-238) or the logits
- * themselves (logits_out, dtype out_dtype).  `kern` is bf16 planes [P][..][Npad][256] (plane stride
+ * themselves (logits_out, dtype out_dtype = PH_OUT_F32 / BF16 / F16).  `prec` = PH_PREC_BF16 (1 feature plane, 1 kernel
+ * plane), PH_PREC_BF16_KSPLIT (1, 2), PH_PREC_SPLIT (2, 2) or PH_PREC_F16 (fp16 planes, 1, 1).
+ * `kern` is planes [P][..][Npad][256] (plane stride
  * given), `kern_batch_stride` / `kbias_batch_stride` / `out_batch_stride` are the element distances
  * between frames: Npad*256 / Npad / N*HW for per-frame dynamic kernels; 0 / 0 / rows*HW when the
  * same static 1x1 conv weights serve every frame (kernel_head.py:256,285,295 init_kernels,
@@ -144,7 +155,7 @@ int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_
                const float* kbias, int64_t kbias_batch_stride, uint32_t* bits_out, void* logits_out, int out_dtype,
                int64_t out_batch_stride, int B, int N, int64_t HW, int prec, void* stream);
 
-/* ---- A14: x2 bilinear upsample, align_corners=False (kernel_update.py:131-143) ------------- */
+/* ---- A14: x2 bilinear upsample, align_corners=False (kernel_update.py:131-143); dtype PH_OUT_* ------------- */
 int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes /* B*N */, int H, int W, void* stream);
 
 /* ---- A1-A5: KernelHead after localization_fpn (kernel_head.py:245-347) ------------------------

@@ -8,8 +8,9 @@ import torch  # noqa: F401  -- MUST precede dlopen: libpolyhead has to bind to t
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
-PH_PREC_BF16, PH_PREC_SPLIT = 1, 3
-PH_OUT_F32, PH_OUT_BF16 = 0, 1
+PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16 = 1, 2, 3, 5
+PH_OUT_F32, PH_OUT_BF16, PH_OUT_F16 = 0, 1, 2
+PH_KERN_BF16_PLANES, PH_KERN_F16 = 0, 1
 PH_GN_TO_PLANES, PH_GN_UP2_PLANES, PH_GN_ACCUM, PH_GN_TO_NCHW, PH_GN_TO_CPLANES = 0, 1, 2, 3, 4
 PH_IN_F32_NCHW, PH_IN_PLANES = 0, 1
 
@@ -37,7 +38,7 @@ SIGNATURES = {
     "ph_pool": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "ph_query_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
-                                 _P, _Z, _I, _I, _L, _I, _I, _P]),
+                                 _P, _Z, _I, _I, _L, _I, _I, _I, _P]),
     "ph_query_workspace_updator_offset": (C.c_size_t, [_I, _I, _I]),
     "ph_dynconv": (C.c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _I, _L, _I, _I, _L, _I, _P]),
     "ph_khead_workspace_bytes": (C.c_size_t, [_I, _L, _I]),

@@ -57,6 +57,21 @@ __device__ __forceinline__ void f2bf_split(float x, uint32_t& hi, uint32_t& lo) 
 }
 __device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return a | (b << 16); }
 
+// ---- 16-bit element formats of feature planes / dynamic kernels / outputs: bf16 (8-bit mantissa, fp32 range) or IEEE
+// fp16 (11-bit mantissa, |x| < 65504).  A bf16 value is exactly representable in fp16 when it is inside fp16's normal
+// range, so an fp16 plane carries bf16-rounded inputs unchanged and fp32 inputs with 8x finer rounding.
+enum { PH_E_BF16 = 0, PH_E_F16 = 1 };
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2h(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x); }
+__device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+__device__ __forceinline__ uint32_t f2h_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+template <int E> __device__ __forceinline__ uint32_t f2e(float x) { return E == PH_E_F16 ? f2h(x) : f2bf(x); }
+template <int E> __device__ __forceinline__ float e2f(uint32_t h) { return E == PH_E_F16 ? h2f(h) : bf2f(h); }
+template <int E> __device__ __forceinline__ uint32_t f2e_pk(float a, float b) { return E == PH_E_F16 ? f2h_pk(a, b) : f2bf_pk(a, b); }
+
 // ---- streaming (non-temporal) 16-byte accesses for data that is written or read exactly once per kernel: the x2
 // upsample's 965 MB of output per launch went from 5.4 to 6.9 TB/s with them (stores no longer allocate in L2 / MALL)
 // cache policy of the LDS-DMA feature streams (aux operand of global_load_lds on gfx950: 1 = sc0, 2 = nt, 16 = sc1):
@@ -89,6 +104,13 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int E> __device__ __forceinline__ f32x16_t mfma32e(uint4 a, uint4 b, f32x16_t c) {
+    if constexpr (E == PH_E_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return mfma32(a, b, c);
 }
 
 // Transposing LDS read: within each 16-lane group the lanes point at 16 8-byte chunks forming a

@@ -39,10 +39,16 @@ template <int OFF> __device__ __forceinline__ void lds_write_asm(uint32_t byte_a
     const uint32_t h = f2bf(v);
     asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(byte_addr), "v"(h), "n"(OFF) : "memory");
 }
+struct ph_h16 { uint16_t v; };    // fp16 output element (PH_OUT_F16); uint16_t = bf16 output (PH_OUT_BF16)
+template <int OFF> __device__ __forceinline__ void lds_write_asm(uint32_t byte_addr, float v, ph_h16*) {
+    const uint32_t h = f2h(v);
+    asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(byte_addr), "v"(h), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(PH_LDS const void*)p; }
 
 __device__ __forceinline__ void st_out(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_out(uint16_t* p, float v) { *p = (uint16_t)f2bf(v); }
+__device__ __forceinline__ void st_out(ph_h16* p, float v) { p->v = (uint16_t)f2h(v); }
 
 // LDS image of a tile: [256 rows][8 x 16-byte pieces], rows contiguous (128 B) because the tile is
 // written by LDS-DMA (global_load_lds: wave-uniform base + lane*16, no padding possible).  To keep the
@@ -54,25 +60,26 @@ __device__ __forceinline__ int conv_swz(int row) { return ((row >> 1) & 1) << 2;
 
 // ---- MFMA phase of one 32-pixel half: 16 k-steps, B fragments by transposing reads, KB k-steps per batch, the
 // reads of batch i+1 in flight while the MFMAs of batch i run.  Compile-time recursion (immediate offsets).
-template <int PA, int KB, int BI, int K = 0, int P = 0>
-__device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PA][KB][2]) {
+template <int PF, int KB, int BI, int K = 0, int P = 0>
+__device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PF][KB][2]) {
     if constexpr (K < KB) {
         constexpr int OFF = P * (256 * CONV_T * 2) + (BI * KB + K) * 2048;     // plane, k-step (16 rows x 128 B)
         dst[P][K][0] = lds_tr16_asm<OFF>(fa);
         dst[P][K][1] = lds_tr16_asm<OFF + 4 * CONV_T * 2>(fa);                 // 4 rows below
-        if constexpr (P + 1 < PA) conv_read_batch<PA, KB, BI, K, P + 1>(fa, dst);
-        else conv_read_batch<PA, KB, BI, K + 1, 0>(fa, dst);
+        if constexpr (P + 1 < PF) conv_read_batch<PF, KB, BI, K, P + 1>(fa, dst);
+        else conv_read_batch<PF, KB, BI, K + 1, 0>(fa, dst);
     }
 }
 
-template <int PA, int KB, int BI>
-__device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][16], u32x2_t (&bq)[2][PA][KB][2], f32x16_t& acc,
+// PF feature planes x PK kernel planes: (1,1) a.b; (1,2) (a_hi + a_lo).b; (2,2) a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
+template <int PF, int PK, int E, int KB, int BI>
+__device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][16], u32x2_t (&bq)[2][PF][KB][2], f32x16_t& acc,
                                              const float (&bias)[16]) {
     constexpr int NBATCH = 16 / KB;
     if constexpr (BI < NBATCH) {
         if constexpr (BI + 1 < NBATCH) {
-            conv_read_batch<PA, KB, BI + 1>(fa, bq[(BI + 1) & 1]);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PA * KB) : "memory");
+            conv_read_batch<PF, KB, BI + 1>(fa, bq[(BI + 1) & 1]);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PF * KB) : "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -83,18 +90,16 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PA][
         }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-            uint4 bf[PA];
+            uint4 bf[PF];
 #pragma unroll
-            for (int p = 0; p < PA; ++p)
+            for (int p = 0; p < PF; ++p)
                 bf[p] = make_uint4(bq[BI & 1][p][k][0].x, bq[BI & 1][p][k][0].y, bq[BI & 1][p][k][1].x, bq[BI & 1][p][k][1].y);
-            acc = mfma32(af[0][BI * KB + k], bf[0], acc);
-            if (PA == 2) {
-                acc = mfma32(af[0][BI * KB + k], bf[PA - 1], acc);
-                acc = mfma32(af[PA - 1][BI * KB + k], bf[0], acc);
-            }
+            acc = mfma32e<E>(af[0][BI * KB + k], bf[0], acc);
+            if (PF == 2) acc = mfma32e<E>(af[0][BI * KB + k], bf[PF - 1], acc);
+            if (PK == 2) acc = mfma32e<E>(af[PK - 1][BI * KB + k], bf[0], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        conv_batches<PA, KB, BI + 1>(fa, af, bq, acc, bias);
+        conv_batches<PF, PK, E, KB, BI + 1>(fa, af, bq, acc, bias);
     }
 }
 
@@ -134,34 +139,34 @@ constexpr int conv_dma_waves(int nw, int pieces) {
 // 32-pixel half of the tile) and owns the whole LDS of its CU: a ring of NBUF tile buffers, NBUF-1 tiles of DMA
 // in flight while one is consumed (96 KiB at cfg2), plus -- logits output, single-plane precision -- a per-wave
 // transposition patch.
-template <int PA, int NRT, bool BITS, typename OutT> struct ConvCfg {
+template <int PF, int PK, int NRT, bool BITS, typename OutT> struct ConvCfg {
     // 32-pixel halves per wave: one (two waves per row block) while that keeps <= 3 waves per SIMD (168 VGPRs for
-    // the 64-VGPR A operand + fragments); two for wide N and for split precision (A operand = 128 VGPRs)
-    static constexpr int HPW = (PA == 1 && NRT <= 6) ? 1 : 2;
+    // the 64-VGPR A operand + fragments); two for wide N and for two kernel planes (A operand = 128 VGPRs)
+    static constexpr int HPW = (PK == 1 && NRT <= 6) ? 1 : 2;
     static constexpr int NW = 2 * NRT / HPW;
     static constexpr int TILE = 256 * CONV_T;                                  // elements per plane per buffer
-    static constexpr int TILEB = PA * TILE * 2;                                // bytes per ring stage
+    static constexpr int TILEB = PF * TILE * 2;                                // bytes per ring stage
     static constexpr int PATCH_LD = 32 + 16 / (int)sizeof(OutT);               // elements: 32 px + 16 B padding
-    static constexpr bool PATCH = !BITS && PA == 1;
+    static constexpr bool PATCH = !BITS && PF == 1;
     static constexpr int PATCHB = PATCH ? NW * 32 * PATCH_LD * (int)sizeof(OutT) : 0;
     static constexpr int LDS_MAX = 160 * 1024;
-    static constexpr int NDW = conv_dma_waves(NW, 32 * PA);                    // waves that issue DMA
-    static constexpr int DPW = 32 * PA / NDW;                                  // ... instructions each per tile
+    static constexpr int NDW = conv_dma_waves(NW, 32 * PF);                    // waves that issue DMA
+    static constexpr int DPW = 32 * PF / NDW;                                  // ... instructions each per tile
     static constexpr int KBB = NW * 32 * 4;                                    // per-wave copy of its 32 biases
     static constexpr int NBUF = 4 * TILEB + PATCHB + KBB <= LDS_MAX ? 4 : (3 * TILEB + PATCHB + KBB <= LDS_MAX ? 3 : 2);
     static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
 };
 
-template <int PA, int NRT, bool BITS, typename OutT>
-__global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
+template <int PF, int PK, int E, int NRT, bool BITS, typename OutT>
+__global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
                                                           const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
                                                           int64_t kern_batch_stride, const float* __restrict__ kbias,
                                                           int64_t kbias_batch_stride, uint32_t* __restrict__ bits_out,
                                                           OutT* __restrict__ logits_out, int64_t out_batch_stride, int B,
                                                           int N, int64_t HW, int64_t HWp) {
-    using C = ConvCfg<PA, NRT, BITS, OutT>;
+    using C = ConvCfg<PF, PK, NRT, BITS, OutT>;
     constexpr int Npad = NRT * 32, TILE = C::TILE, NBUF = C::NBUF;
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][PA][256][64] | patch[NW][32][PATCH_LD]
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][PF][256][64] | patch[NW][32][PATCH_LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
     float* kb_lds = (float*)((unsigned char*)lds + NBUF * C::TILEB + C::PATCHB) + wave * 32;
     const uint32_t kb_addr = lds_addr(kb_lds) + 16 * g;
 
-    uint4 af[PA][16];      // A operand: this wave's 32 kernel rows, all 16 k-steps
+    uint4 af[PK][16];      // A operand: this wave's 32 kernel rows, all 16 k-steps
 
     // results of the previous tile, written out one iteration late (after the next barrier) so that the
     // vector-memory queue in front of each counted wait is [stores(t-1), DMA(t+1) .. DMA(t+NBUF-1)]
@@ -286,7 +291,7 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
     // loop-carried phi and the compiler would wait vmcnt(0) on them every tile).  The compiler-visible
     // s_waitcnt retires them in its scoreboard; it also drains the ring, once per frame.
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
+    for (int p = 0; p < PK; ++p) {
         const uint16_t* kr = kern + p * kern_plane_stride + (int64_t)b * kern_batch_stride + (rt * 32 + (lane & 31)) * PH_C + g * 8;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) af[p][ks] = *(const uint4*)(kr + ks * 16);
@@ -299,8 +304,9 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
         {
             // tile tg must have landed; up to NBUF-2 younger tiles stay in flight across the barrier
             const int younger = (tg1 - 1 - tg) < (NBUF - 2) ? (tg1 - 1 - tg) : (NBUF - 2);
-            if (NBUF >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::DPW) : "memory");
-            else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPW) : "memory");
+            // (vmcnt holds 6 bits: a smaller count than needed only waits for more than needed)
+            if (NBUF >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::DPW < 63 ? 2 * C::DPW : 63) : "memory");
+            else if (NBUF >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::DPW < 63 ? C::DPW : 63) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -320,10 +326,10 @@ __global__ __launch_bounds__((ConvCfg<PA, NRT, BITS, OutT>::NW * 64)) void k_dyn
         const uint32_t fa = lds0 + cur * C::TILEB + frag_off[h];
         const int half = half0 + h;
         f32x16_t acc;
-        constexpr int KB = 2;                        // 4 * PA reads per batch (KB = 4 measured 7 % slower)
-        u32x2_t bq[2][PA][KB][2];
-        conv_read_batch<PA, KB, 0>(fa, bq[0]);
-        conv_batches<PA, KB, 0>(fa, af, bq, acc, bias);
+        constexpr int KB = 2;                        // 4 * PF reads per batch (KB = 4 measured 7 % slower)
+        u32x2_t bq[2][PF][KB][2];
+        conv_read_batch<PF, KB, 0>(fa, bq[0]);
+        conv_batches<PF, PK, E, KB, 0>(fa, af, bq, acc, bias);
         // ---- epilogue of tile (b, t), 32-pixel half `half`
         const int px_base = t * CONV_T + half * 32;
         const int64_t px = (int64_t)px_base + (lane & 31);
@@ -399,7 +405,7 @@ static int conv_num_cus() {
     return n;
 }
 
-template <int PA, int NRT>
+template <int PF, int PK, int E, int NRT>
 static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps, int64_t kbs, const float* kbias,
                        int64_t bbs, uint32_t* bits_out, void* logits_out, int out_dtype, int64_t obs, int B, int N,
                        int64_t HW, hipStream_t s) {
@@ -410,21 +416,22 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     if (const char* e = getenv("PH_CONV_WGS")) wgs = atoi(e);   // tuning knob
     if (wgs > total) wgs = (int)total;
     if (wgs < 1) wgs = 1;
-    const dim3 grid(wgs), block(ConvCfg<PA, NRT, true, float>::NW * 64);
+    const dim3 grid(wgs), block(ConvCfg<PF, PK, NRT, true, float>::NW * 64);
 #define PH_CONV_LAUNCH(BITS, T)                                                                                      \
     do {                                                                                                             \
-        constexpr int lds = ConvCfg<PA, NRT, BITS, T>::LDSB;                                                         \
+        constexpr int lds = ConvCfg<PF, PK, NRT, BITS, T>::LDSB;                                                     \
         static const bool once = [&] {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_dynconv<PA, NRT, BITS, T>,                                      \
+            (void)hipFuncSetAttribute((const void*)k_dynconv<PF, PK, E, NRT, BITS, T>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
             return true;                                                                                             \
         }();                                                                                             \
         (void)once;                                                                                                            \
-        hipLaunchKernelGGL((k_dynconv<PA, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
+        hipLaunchKernelGGL((k_dynconv<PF, PK, E, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
                            bits_out, (T*)logits_out, obs, B, N, HW, HWp);                                            \
     } while (0)
     if (bits_out) PH_CONV_LAUNCH(true, float);
     else if (out_dtype == PH_OUT_F32) PH_CONV_LAUNCH(false, float);
+    else if (out_dtype == PH_OUT_F16) PH_CONV_LAUNCH(false, ph_h16);
     else PH_CONV_LAUNCH(false, uint16_t);
 #undef PH_CONV_LAUNCH
     return 0;
@@ -436,19 +443,19 @@ extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t 
                           void* stream) {
     PH_CHECK_ARG(planes && kern && kbias && B > 0 && N > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG((bits_out != nullptr) != (logits_out != nullptr), "exactly one of bits_out / logits_out");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
-    PH_CHECK_ARG(out_dtype == PH_OUT_F32 || out_dtype == PH_OUT_BF16, "bad out_dtype");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_BF16_KSPLIT || prec == PH_PREC_F16, "bad prec");
+    PH_CHECK_ARG(out_dtype == PH_OUT_F32 || out_dtype == PH_OUT_BF16 || out_dtype == PH_OUT_F16, "bad out_dtype");
     PH_CHECK_ARG(N <= 256, "at most 256 queries");
     const int nrt = ph_n_padded(N) / 32;
     hipStream_t s = (hipStream_t)stream;
+#define PH_CONV_ARGS planes, kern, kern_plane_stride, kern_batch_stride, kbias, kbias_batch_stride, bits_out, logits_out, \
+                     out_dtype, out_batch_stride, B, N, HW, s
 #define PH_CONV_CASE(R)                                                                                         \
     case R:                                                                                                     \
-        if (prec == PH_PREC_BF16)                                                                               \
-            launch_conv<1, R>(planes, kern, kern_plane_stride, kern_batch_stride, kbias, kbias_batch_stride, bits_out,   \
-                              logits_out, out_dtype, out_batch_stride, B, N, HW, s); \
-        else                                                                                                    \
-            launch_conv<2, R>(planes, kern, kern_plane_stride, kern_batch_stride, kbias, kbias_batch_stride, bits_out,   \
-                              logits_out, out_dtype, out_batch_stride, B, N, HW, s); \
+        if (prec == PH_PREC_BF16) launch_conv<1, 1, PH_E_BF16, R>(PH_CONV_ARGS);                                \
+        else if (prec == PH_PREC_F16) launch_conv<1, 1, PH_E_F16, R>(PH_CONV_ARGS);                             \
+        else if (prec == PH_PREC_BF16_KSPLIT) launch_conv<1, 2, PH_E_BF16, R>(PH_CONV_ARGS);                    \
+        else launch_conv<2, 2, PH_E_BF16, R>(PH_CONV_ARGS);                                                     \
         break;
     switch (nrt) {
         PH_CONV_CASE(1) PH_CONV_CASE(2) PH_CONV_CASE(3) PH_CONV_CASE(4)
@@ -456,6 +463,7 @@ extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t 
         default: ph_set_error("ph_dynconv: unsupported N"); return PH_EUNSUPPORTED;
     }
 #undef PH_CONV_CASE
+#undef PH_CONV_ARGS
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

@@ -4,7 +4,7 @@
 
 // ---------------------------------------------------------------------------------------------
 // ingest: src fp32 [rows = B*256][HW] -> planes [P][rows][HWp]; 8 pixels per thread.
-template <int P>
+template <int P, int E>
 __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, uint16_t* __restrict__ planes,
                                                 int64_t rows, int64_t HW, int64_t HWp) {
     const int64_t plane_stride = rows * HWp;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, u
         uint32_t hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (P == 1) hi[e] = f2bf(v[e]);
+            if (P == 1) hi[e] = f2e<E>(v[e]);
             else f2bf_split(v[e], hi[e], lo[e]);
         }
         uint16_t* d = planes + row * HWp + px;
@@ -37,16 +37,18 @@ __global__ __launch_bounds__(256) void k_ingest(const float* __restrict__ src, u
 
 extern "C" int ph_ingest_features(const float* src, uint16_t* planes, int B, int64_t HW, int prec, void* stream) {
     PH_CHECK_ARG(src && planes && B > 0 && HW > 0, "bad pointer or size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     const int64_t HWp = ph_hw_padded(HW), rows = (int64_t)B * PH_C;
     PH_CHECK_ARG(rows <= 65535, "B * 256 must be <= 65535");
     int gx = (int)((HWp / 8 + 255) / 256);
     if (gx > 8) gx = 8;                          // 8 x 256 threads x 32 B in flight per row
     const dim3 grid(gx, (unsigned)rows);
     if (prec == PH_PREC_BF16)
-        hipLaunchKernelGGL(k_ingest<1>, grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
+        hipLaunchKernelGGL((k_ingest<1, PH_E_BF16>), grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
+    else if (prec == PH_PREC_F16)
+        hipLaunchKernelGGL((k_ingest<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
     else
-        hipLaunchKernelGGL(k_ingest<2>, grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
+        hipLaunchKernelGGL((k_ingest<2, PH_E_BF16>), grid, dim3(256), 0, (hipStream_t)stream, src, planes, rows, HW, HWp);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -106,18 +108,16 @@ extern "C" int ph_binarize(const float* logits, int64_t logits_batch_stride, uin
 // x2 bilinear, align_corners=False.  ATen's formula (aten/native/UpSample.h area_pixel_compute_
 // source_index): src = max((dst + 0.5) * 0.5 - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, n - 1);
 // l1 = src - i0; l0 = 1 - l1; out = h0*(w0*a + w1*b) + h1*(w0*c + w1*d).
-template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p);
-template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld_as_f32<uint16_t>(const uint16_t* p) { return bf2f(*p); }
-template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v);
-template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
-template <> __device__ __forceinline__ void st_from_f32<uint16_t>(uint16_t* p, float v) { *p = (uint16_t)f2bf(v); }
+template <int E> __device__ __forceinline__ float ld_as_f32(const float* p) { return *p; }
+template <int E> __device__ __forceinline__ float ld_as_f32(const uint16_t* p) { return e2f<E>(*p); }
+template <int E> __device__ __forceinline__ void st_from_f32(float* p, float v) { *p = v; }
+template <int E> __device__ __forceinline__ void st_from_f32(uint16_t* p, float v) { *p = (uint16_t)f2e<E>(v); }
 
 // One thread = 4 source columns x 2 source rows -> an 8-column x 4-row output patch (16 B bf16 / 32 B fp32
 // stores per row).  It needs the 4 x 6 source neighbourhood: the 4 rows are loaded once (vector loads), the
 // two edge columns come from the neighbouring lanes by cross-lane shuffles (a real load only at wave / row
 // boundaries), so HBM sees the source once and the destination once (5 * planes*H*W elements).
-template <typename T, bool VEC>
+template <typename T, bool VEC, int E>
 __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T* __restrict__ dst, int64_t planes,
                                                     int H, int W) {
     const int W2 = 2 * W;
@@ -147,24 +147,24 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
             if (VEC) {
                 if (sizeof(T) == 2) {
                     const uint2 q = *(const uint2*)(row + x0);   // cached: every source row is read by two row pairs (nt: 175 -> 223 us)
-                    v[1] = bf2f(q.x & 0xFFFF); v[2] = bf2f(q.x >> 16); v[3] = bf2f(q.y & 0xFFFF); v[4] = bf2f(q.y >> 16);
+                    v[1] = e2f<E>(q.x & 0xFFFF); v[2] = e2f<E>(q.x >> 16); v[3] = e2f<E>(q.y & 0xFFFF); v[4] = e2f<E>(q.y >> 16);
                 } else {
                     const uint4 q = *(const uint4*)(row + x0);   // cached, as above
                     v[1] = __uint_as_float(q.x); v[2] = __uint_as_float(q.y); v[3] = __uint_as_float(q.z); v[4] = __uint_as_float(q.w);
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[1 + c] = ld_as_f32(row + (x0 + c < W ? x0 + c : W - 1));
+                for (int c = 0; c < 4; ++c) v[1 + c] = ld_as_f32<E>(row + (x0 + c < W ? x0 + c : W - 1));
             }
             // edge columns x0-1 and x0+4 from the neighbouring lanes (same source row when j-1 / j+1 exist
             // in this wave), otherwise clamp or load
             const float from_left = __shfl_up(v[4], 1), from_right = __shfl_down(v[1], 1);
             if (j == 0) v[0] = v[1];
             else if (lane > 0) v[0] = from_left;
-            else v[0] = ld_as_f32(row + x0 - 1);
-            if (x0 + 4 >= W) v[5] = VEC ? v[4] : ld_as_f32(row + W - 1);
+            else v[0] = ld_as_f32<E>(row + x0 - 1);
+            if (x0 + 4 >= W) v[5] = VEC ? v[4] : ld_as_f32<E>(row + W - 1);
             else if (lane < 63) v[5] = from_right;
-            else v[5] = ld_as_f32(row + x0 + 4);
+            else v[5] = ld_as_f32<E>(row + x0 + 4);
             // output column 2x   : src = x - 0.25 -> (x-1, x) weights (0.25, 0.75); x = 0: clamped, weights (1, 0)
             // output column 2x+1 : src = x + 0.25 -> (x, x+1 clamped) weights (0.75, 0.25)
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
             T* d = dst + (p * 2 * H + yo) * W2 + 2 * x0;
             if (VEC) {
                 if (sizeof(T) == 2) {
-                    st_nt16(d, make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7])));
+                    st_nt16(d, make_uint4(f2e_pk<E>(o[0], o[1]), f2e_pk<E>(o[2], o[3]), f2e_pk<E>(o[4], o[5]), f2e_pk<E>(o[6], o[7])));
                 } else {
                     // each lane owns 32 contiguous bytes: as two 16-byte stores per lane every instruction would write
                     // half of each 32-byte piece (partial lines with non-temporal stores: 3.3 TB/s).  Exchange so that
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (2 * x0 + e < W2) st_from_f32(d + e, o[e]);
+                    if (2 * x0 + e < W2) st_from_f32<E>(d + e, o[e]);
             }
         }
     }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
 
 extern "C" int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes, int H, int W, void* stream) {
     PH_CHECK_ARG(src && dst && planes > 0 && H > 0 && W > 0, "bad pointer or size");
-    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16, "dtype must be PH_OUT_F32 or PH_OUT_BF16");
+    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16 || dtype == PH_OUT_F16, "dtype must be PH_OUT_F32, PH_OUT_BF16 or PH_OUT_F16");
     const int64_t total = planes * ((H + 1) / 2) * (int64_t)((W + 3) / 4);
     PH_CHECK_ARG(total < (1ll << 31), "planes * H * W / 8 must be < 2^31");
     int64_t blocks = (total + 255) / 256;
@@ -232,11 +232,14 @@ extern "C" int ph_upsample2x(const void* src, void* dst, int dtype, int64_t plan
     const bool vec = (W % 4) == 0;      // rows then start 8-byte (bf16) / 16-byte (fp32) aligned
     hipStream_t s = (hipStream_t)stream;
     if (dtype == PH_OUT_F32) {
-        if (vec) hipLaunchKernelGGL((k_upsample2x<float, true>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
-        else hipLaunchKernelGGL((k_upsample2x<float, false>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
+        if (vec) hipLaunchKernelGGL((k_upsample2x<float, true, 0>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
+        else hipLaunchKernelGGL((k_upsample2x<float, false, 0>), dim3((int)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, planes, H, W);
+    } else if (dtype == PH_OUT_BF16) {
+        if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_BF16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+        else hipLaunchKernelGGL((k_upsample2x<uint16_t, false, PH_E_BF16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
     } else {
-        if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
-        else hipLaunchKernelGGL((k_upsample2x<uint16_t, false>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+        if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_F16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+        else hipLaunchKernelGGL((k_upsample2x<uint16_t, false, PH_E_F16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
     }
     PH_CHECK_LAUNCH();
     return PH_OK;

@@ -63,8 +63,10 @@ __device__ __forceinline__ float sample_out(const float* __restrict__ src, const
     return o.ty.l0 * (o.tx.l0 * a + o.tx.l1 * b) + o.ty.l1 * (o.tx.l0 * c + o.tx.l1 * d);
 }
 
+struct pan_h16 { uint16_t v; };     // fp16 logits (PH_OUT_F16); uint16_t = bf16 logits
 __device__ __forceinline__ float ld_logit(const float* p) { return *p; }
 __device__ __forceinline__ float ld_logit(const uint16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ld_logit(const pan_h16* p) { return h2f(p->v); }
 
 __device__ __forceinline__ float sigmoid_exact(float z) { return (float)(1.0 / (1.0 + exp(-(double)z))); }
 
@@ -156,10 +158,13 @@ extern "C" int ph_panoptic_activate(const void* mask_up, const void* depth_up, i
                                     float* act_depth, float* act_depth0, void* stream) {
     PH_CHECK_ARG(mask_up && depth_up && depth_init_up && q_idx && act_mask && act_depth && act_depth0, "null pointer");
     PH_CHECK_ARG(K > 0 && h2 > 0 && w2 > 0 && (depth_mode == 0 || depth_mode == 1), "bad size / mode");
-    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16, "bad dtype");
+    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_BF16 || dtype == PH_OUT_F16, "bad dtype");
     const int64_t hw = (int64_t)h2 * w2;
     const int grid = grid_for((int64_t)(K + 1) * hw);
-    if (dtype == PH_OUT_F32)
+    if (dtype == PH_OUT_F16)
+        hipLaunchKernelGGL(k_pan_activate<pan_h16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const pan_h16*)mask_up,
+                           (const pan_h16*)depth_up, depth_init_up, q_idx, K, hw, depth_mode, act_mask, act_depth, act_depth0);
+    else if (dtype == PH_OUT_F32)
         hipLaunchKernelGGL(k_pan_activate<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)mask_up,
                            (const float*)depth_up, depth_init_up, q_idx, K, hw, depth_mode, act_mask, act_depth, act_depth0);
     else

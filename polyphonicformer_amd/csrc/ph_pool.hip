@@ -44,13 +44,14 @@ __device__ __forceinline__ uint32_t lds_read32_asm(uint32_t byte_addr) {
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(PH_LDS const void*)p; }
 
-__device__ __forceinline__ uint4 expand8(uint32_t byte) {
-    // 8 mask bits -> 8 bf16 {0, 1.0}
+template <int E> __device__ __forceinline__ uint4 expand8(uint32_t byte) {
+    // 8 mask bits -> 8 x {0, 1.0} in the planes' element format (bf16 0x3F80 / fp16 0x3C00)
+    constexpr uint32_t ONE = E == PH_E_F16 ? 0x3C00u : 0x3F80u;
     uint32_t r[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t lo = (byte >> (2 * p)) & 1u, hi = (byte >> (2 * p + 1)) & 1u;
-        r[p] = lo * 0x3F80u + hi * 0x3F800000u;
+        r[p] = lo * ONE + hi * (ONE << 16);
     }
     return make_uint4(r[0], r[1], r[2], r[3]);
 }
@@ -60,7 +61,7 @@ __device__ __forceinline__ uint4 expand8(uint32_t byte) {
 // ds_read_b128 of 16 consecutive channel rows at one piece index hit 16 distinct 16-byte slots.
 __device__ __forceinline__ int pool_swz(int row) { return (row >> 1) & 7; }
 
-template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/>
+template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/, int E /*element format of the planes*/>
 __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
                                               const uint32_t* __restrict__ bits, float* __restrict__ partial,
                                               int B, int64_t HWp, int nsplit) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
     const int nchunks = (int)(HWp / POOL_CHUNK);
     const int c0 = (int)((int64_t)split * nchunks / nsplit), c1 = (int)((int64_t)(split + 1) * nchunks / nsplit);
 
-    lut[tid] = expand8((uint32_t)tid);                               // byte -> A fragment (8 x {0,1} bf16)
+    lut[tid] = expand8<E>((uint32_t)tid);                               // byte -> A fragment (8 x {0,1} bf16)
 
     f32x16_t acc[NRT];
 #pragma unroll
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int p = 0; p < PA; ++p)
-                    acc[rt] = mfma32(__builtin_bit_cast(uint4, a[rt & 1][t]), __builtin_bit_cast(uint4, xf[p][t]), acc[rt]);
+                    acc[rt] = mfma32e<E>(__builtin_bit_cast(uint4, a[rt & 1][t]), __builtin_bit_cast(uint4, xf[p][t]), acc[rt]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
@@ -204,23 +205,23 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         }
 }
 
-template <int PA, int NRT>
+template <int PA, int NRT, int E>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
                         int nsplit, hipStream_t s) {
     const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
     static const bool once = [&] {
-        (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((k_pool<PA, NRT>), dim3(nsplit, d ? 4 : 2, B), dim3(256), lds, s, x, d, bits, partial, B, HWp,
+    hipLaunchKernelGGL((k_pool<PA, NRT, E>), dim3(nsplit, d ? 4 : 2, B), dim3(256), lds, s, x, d, bits, partial, B, HWp,
                        nsplit);
 }
 
 extern "C" int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int B,
                        int N, int64_t HW, int nsplit, int prec, void* stream) {
     PH_CHECK_ARG(xplanes && bits && partial && B > 0 && N > 0 && HW > 0, "bad pointer or size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     PH_CHECK_ARG(N <= 256, "at most 256 queries");
     const int64_t HWp = ph_hw_padded(HW);
     PH_CHECK_ARG(nsplit >= 1 && nsplit <= HWp / POOL_CHUNK, "nsplit out of range");
@@ -228,8 +229,9 @@ extern "C" int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const u
     hipStream_t s = (hipStream_t)stream;
 #define PH_POOL_CASE(R)                                                                         \
     case R:                                                                                     \
-        if (prec == PH_PREC_BF16) launch_pool<1, R>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s); \
-        else launch_pool<2, R>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s);             \
+        if (prec == PH_PREC_BF16) launch_pool<1, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s); \
+        else if (prec == PH_PREC_F16) launch_pool<1, R, PH_E_F16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s); \
+        else launch_pool<2, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s);             \
         break;
     switch (nrt) {
         PH_POOL_CASE(1) PH_POOL_CASE(2) PH_POOL_CASE(3) PH_POOL_CASE(4)

@@ -35,7 +35,7 @@ struct QArgs {
     float* obj; float* dobj; float* cls; uint16_t* kern; float* kbias;
     uint16_t* Qp; uint16_t* Kp; uint16_t* Vt; float* o1;
     ph_stage_layout lay;
-    int nsplit, B, N, Npad, cls_sigmoid;
+    int nsplit, B, N, Npad, cls_sigmoid, kern_f16;
     int64_t HWp;
 };
 
@@ -820,11 +820,15 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    uint32_t hi, lo;
-                    f2bf_split(Kt.v[rt][ct][r] + bv, hi, lo);
                     const int off = (rt * 16 + g * 4 + r) * 256 + col;
-                    kd[off] = (uint16_t)hi;
-                    if (PA == 2) kd[kplane + off] = (uint16_t)lo;
+                    if (a.kern_f16) {            // PH_KERN_F16: one fp16 plane (the fp16 dynconv's A operand)
+                        kd[off] = (uint16_t)f2h(Kt.v[rt][ct][r] + bv);
+                    } else {
+                        uint32_t hi, lo;
+                        f2bf_split(Kt.v[rt][ct][r] + bv, hi, lo);
+                        kd[off] = (uint16_t)hi;
+                        if (PA == 2) kd[kplane + off] = (uint16_t)lo;
+                    }
                 }
         }
         if (wave == 0) {
@@ -879,13 +883,14 @@ static void launch_query(const QArgs& a, int phases, hipStream_t s) {
 extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits, const float* k_in, const float* q_in,
                               const uint16_t* wb, const float* wf, const ph_stage_layout* layout, float* obj, float* dobj,
                               float* cls, int cls_sigmoid, uint16_t* kern, float* kbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int64_t HW, int prec, int phases,
+                              size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format, int phases,
                               void* stream) {
     PH_CHECK_ARG(phases >= 1 && phases <= 3, "phases must be PH_QUERY_PRE | PH_QUERY_POST");
     PH_CHECK_ARG(partial && bits && k_in && q_in && wb && wf && layout && obj && dobj && cls && kern && kbias && workspace,
                  "null pointer");
     PH_CHECK_ARG(B > 0 && N > 0 && N <= 256 && HW > 0 && nsplit >= 1, "bad size");
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(kern_format == PH_KERN_BF16_PLANES || kern_format == PH_KERN_F16, "bad kern_format");
     PH_CHECK_ARG(layout->ffn_dim > 0 && layout->ffn_dim % 256 == 0, "ffn_dim must be a multiple of 256");
     PH_CHECK_ARG(layout->num_classes > 0 && layout->num_classes <= 1024, "bad num_classes");
     const int PA = prec == PH_PREC_SPLIT ? 2 : 1, Npad = ph_n_padded(N);
@@ -898,7 +903,7 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
     a.obj = obj; a.dobj = dobj; a.cls = cls; a.kern = kern; a.kbias = kbias;
     const size_t pl = (size_t)PA * B * 2 * Npad * 256;
     a.Qp = (uint16_t*)workspace; a.Kp = a.Qp + pl; a.Vt = a.Kp + pl; a.o1 = (float*)(a.Vt + pl);
-    a.lay = *layout; a.cls_sigmoid = cls_sigmoid; a.nsplit = nsplit; a.B = B; a.N = N; a.Npad = Npad; a.HWp = ph_hw_padded(HW);
+    a.lay = *layout; a.cls_sigmoid = cls_sigmoid; a.kern_f16 = kern_format == PH_KERN_F16; a.nsplit = nsplit; a.B = B; a.N = N; a.Npad = Npad; a.HWp = ph_hw_padded(HW);
     hipStream_t s = (hipStream_t)stream;
     if (PA == 1) launch_query<1, 2>(a, phases, s);
     else launch_query<2, 1>(a, phases, s);

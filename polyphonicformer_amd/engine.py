@@ -16,7 +16,37 @@ import torch
 from . import _lib
 from .pack import pack_stage
 
-PREC = {"bf16": _lib.PH_PREC_BF16, "split": _lib.PH_PREC_SPLIT, "fp32": _lib.PH_PREC_SPLIT}
+import collections
+
+# Precision modes of the decode path.  One row = the arithmetic of every operator of a stage:
+#   feat  : element format / planes of the feature maps (ingest, pool)        query : the query-side GEMMs
+#   conv  : the dynamic 1x1 conv (feature planes x kernel planes)             kern_fmt : what the query kernel emits for it
+Mode = collections.namedtuple("Mode", "name feat query conv kern_fmt FP KP feat_dtype")
+MODES = {
+    # fast: bf16 everywhere, one plane (6e-3 per stage against fp32)
+    "bf16": Mode("bf16", _lib.PH_PREC_BF16, _lib.PH_PREC_BF16, _lib.PH_PREC_BF16, _lib.PH_KERN_BF16_PLANES, 1, 1, torch.bfloat16),
+    # bf16 feature planes as they are (cfg2's input dtype), everything computed FROM them at fp32 grade: exact 0/1 x bf16
+    # pooling, hi/lo split query GEMMs, hi/lo dynamic kernels x one feature plane (<= 1e-3 on identical inputs)
+    "mixed": Mode("mixed", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KSPLIT, _lib.PH_KERN_BF16_PLANES, 1, 2, torch.bfloat16),
+    # fp16 feature planes / kernels / outputs (cfg5), fp32-grade query side
+    "fp16": Mode("fp16", _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_F16, _lib.PH_KERN_F16, 1, 1, torch.float16),
+    # parity grade: every operand hi + lo (1.6e-5 per stage)
+    "fp32": Mode("fp32", _lib.PH_PREC_SPLIT, _lib.PH_PREC_SPLIT, _lib.PH_PREC_SPLIT, _lib.PH_KERN_BF16_PLANES, 2, 2, None),
+}
+MODES["split"] = MODES["fp32"]
+# arithmetic of the kernels that know two grades only (KernelHead, the neck, the track head): fast or fp32 grade
+PREC = {"bf16": _lib.PH_PREC_BF16, "split": _lib.PH_PREC_SPLIT, "fp32": _lib.PH_PREC_SPLIT,
+        "mixed": _lib.PH_PREC_SPLIT, "fp16": _lib.PH_PREC_SPLIT}
+OUT_CODE = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}
+
+
+def mode_of(p):
+    """Mode from a Mode, a mode name, or a legacy precision code (PH_PREC_BF16 / PH_PREC_SPLIT)"""
+    if isinstance(p, Mode):
+        return p
+    if isinstance(p, str):
+        return MODES[p]
+    return {_lib.PH_PREC_BF16: MODES["bf16"], _lib.PH_PREC_SPLIT: MODES["fp32"], _lib.PH_PREC_F16: MODES["fp16"]}[p]
 
 
 def hw_padded(hw):
@@ -63,7 +93,7 @@ def ingest(x, prec, out=None):
     if Cc != 256:
         raise _lib.PolyheadError("libpolyhead supports 256 channels (the shipped configs)")
     x = x.contiguous().float()
-    P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+    P = 2 if prec == _lib.PH_PREC_SPLIT else 1          # PH_PREC_BF16 / PH_PREC_F16: one plane
     if out is None:
         out = torch.empty((P, B, 256, hw_padded(H * W)), dtype=torch.int16, device=x.device)
     lib = _lib.load()
@@ -95,11 +125,12 @@ def pool(xp, dp, bits, N, HW, prec, nsplit=None, out=None):
     return out
 
 
-def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=None, workspace=None, phases=3):
+def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=None, workspace=None, phases=3,
+                kern_fmt=_lib.PH_KERN_BF16_PLANES):
     B, nsplit = partial.shape[0], partial.shape[1]
     dev = partial.device
     prec = pack.prec
-    P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+    P = 1 if kern_fmt == _lib.PH_KERN_F16 else (2 if prec == _lib.PH_PREC_SPLIT else 1)     # planes of `kern`
     Npad = n_padded(N)
     lib = _lib.load()
     if outs is None:
@@ -114,7 +145,7 @@ def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=
                                   _lib.ptr(pack.wb), _lib.ptr(pack.wf), C.byref(pack.lay),
                                   _lib.ptr(outs["obj"]), _lib.ptr(outs["dobj"]), _lib.ptr(outs["cls"]),
                                   1 if cls_sigmoid else 0, _lib.ptr(outs["kern"]), _lib.ptr(outs["kbias"]),
-                                  _lib.ptr(workspace), workspace.numel(), B, N, HW, prec, phases, _lib.stream_ptr()),
+                                  _lib.ptr(workspace), workspace.numel(), B, N, HW, prec, kern_fmt, phases, _lib.stream_ptr()),
                "ph_query_stage")
     return outs
 
@@ -150,9 +181,9 @@ def upsample2x(src, out=None):
     planes = src.numel() // (H * W)
     if out is None:
         out = torch.empty(tuple(src.shape[:-2]) + (2 * H, 2 * W), dtype=src.dtype, device=src.device)
-    dt = _lib.PH_OUT_F32 if src.dtype == torch.float32 else _lib.PH_OUT_BF16
-    if src.dtype not in (torch.float32, torch.bfloat16):
-        raise _lib.PolyheadError("upsample2x: fp32 or bf16 only")
+    if src.dtype not in OUT_CODE:
+        raise _lib.PolyheadError("upsample2x: fp32, bf16 or fp16 only")
+    dt = OUT_CODE[src.dtype]
     lib = _lib.load()
     _lib.check(lib.ph_upsample2x(_lib.ptr(src), _lib.ptr(out), dt, planes, H, W, _lib.stream_ptr()), "ph_upsample2x")
     return out
@@ -165,10 +196,13 @@ class DecodePlan:
     def __init__(self, packs, B, N, H, W, prec, out_dtype=torch.float32, device="cuda:0", nsplit=None):
         self.packs, self.S = packs, len(packs)
         self.B, self.N, self.H, self.W, self.HW = B, N, H, W, H * W
-        self.prec, self.out_dtype = prec, out_dtype
+        self.mode = mode_of(prec)
+        self.prec, self.out_dtype = self.mode.feat, out_dtype           # `prec`: the feature planes' code (ingest / pool)
+        if any(p.prec != self.mode.query for p in packs):
+            raise _lib.PolyheadError(f"stage packs are not packed for mode '{self.mode.name}'")
         self.nsplit = nsplit or default_nsplit(B, self.HW)
         dev = torch.device(device)
-        P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+        P, KP = self.mode.FP, self.mode.KP
         Npad, HWp = n_padded(N), hw_padded(self.HW)
         L = packs[0].num_classes
         e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
@@ -183,9 +217,9 @@ class DecodePlan:
         self.dp = e((P, B, 256, HWp), torch.int16)
         self.bits = e((B, Npad, HWp // 32), torch.int32)
         self.partial = e((B, self.nsplit, Npad, 512), torch.float32)
-        self.ws = e((_lib.load().ph_query_workspace_bytes(B, N, prec),), torch.uint8)
+        self.ws = e((_lib.load().ph_query_workspace_bytes(B, N, self.mode.query),), torch.uint8)
         self.stage_out = [dict(obj=e((B, N, 256), torch.float32), dobj=e((B, N, 256), torch.float32),
-                               cls=e((B, N, L), torch.float32), kern=e((P, 2, B, Npad, 256), torch.int16),
+                               cls=e((B, N, L), torch.float32), kern=e((KP, 2, B, Npad, 256), torch.int16),
                                kbias=e((2, B, Npad), torch.float32)) for _ in range(self.S)]
         # outputs
         self.mask = e((B, N, H, W), out_dtype)
@@ -197,7 +231,7 @@ class DecodePlan:
 
     @property
     def out_code(self):
-        return _lib.PH_OUT_F32 if self.out_dtype == torch.float32 else _lib.PH_OUT_BF16
+        return OUT_CODE[self.out_dtype]
 
     def renew_outputs(self):
         """Give the next `run` fresh output tensors (allocation only, no copy).  The reference's methods return tensors the
@@ -213,15 +247,16 @@ class DecodePlan:
             last[k] = e(last[k])
 
     def set_inputs(self, x, dfe, k0, q0, m0):
-        """x / dfe: fp32 NCHW (converted to bf16 planes by the ingest kernel inside `run`), or -- bf16 precision
-        only -- bf16 NCHW tensors, which ARE the plane format when H*W is a multiple of 128: they are adopted
-        as they are and no ingest pass runs."""
-        self.feat_is_bf16 = (x.dtype == torch.bfloat16 and dfe.dtype == torch.bfloat16)
+        """x / dfe: fp32 NCHW (converted to planes by the ingest kernel inside `run`), or 16-bit NCHW tensors of the
+        mode's own plane format (bf16 for 'bf16' / 'mixed', fp16 for 'fp16'), which ARE the plane format when H*W is
+        a multiple of 128: they are adopted as they are and no ingest pass runs."""
+        self.feat_is_bf16 = x.dtype in (torch.bfloat16, torch.float16) and dfe.dtype == x.dtype     # 16-bit plane inputs
         if self.feat_is_bf16:
-            if self.prec != _lib.PH_PREC_BF16 or self.HW % 128:
-                raise _lib.PolyheadError("bf16 feature inputs need precision 'bf16' and H*W % 128 == 0")
-            self.xp.view(torch.bfloat16).reshape(self.B, 256, self.H, self.W).copy_(x)
-            self.dp.view(torch.bfloat16).reshape(self.B, 256, self.H, self.W).copy_(dfe)
+            if self.mode.feat_dtype != x.dtype or self.HW % 128:
+                raise _lib.PolyheadError(f"{x.dtype} feature inputs need a mode with that plane format (bf16: 'bf16' / "
+                                         f"'mixed', fp16: 'fp16'; this plan: '{self.mode.name}') and H*W % 128 == 0")
+            self.xp.view(x.dtype).reshape(self.B, 256, self.H, self.W).copy_(x)
+            self.dp.view(x.dtype).reshape(self.B, 256, self.H, self.W).copy_(dfe)
         else:
             self.x.copy_(x)
             self.dfe.copy_(dfe)
@@ -245,14 +280,13 @@ class DecodePlan:
             last = s == self.S - 1
             pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
-                            outs=self.stage_out[s], workspace=self.ws)
+                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt)
+            cv = self.mode.conv
             if not last:
-                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, bits_out=self.bits)
+                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
             else:
-                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, self.prec, logits_out=self.mask,
-                        out_dtype=self.out_code)
-                dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, self.prec, logits_out=self.depth,
-                        out_dtype=self.out_code)
+                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
+                dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, cv, logits_out=self.depth, out_dtype=self.out_code)
             k, q = o["obj"], o["dobj"]
         upsample2x(self.mask, out=self.mask_up)
         upsample2x(self.depth, out=self.depth_up)

@@ -27,7 +27,7 @@ class KernelUpdateIterHead(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = ConfigDict(test_cfg) if isinstance(test_cfg, dict) else test_cfg
         self.init_mask_head(None, mask_head)
-        self.precision = "fp32"           # "fp32" (split-bf16, parity grade) or "bf16" (fast)
+        self.precision = "fp32"           # a key of engine.MODES: "fp32" (parity grade), "mixed", "fp16", "bf16" (fast)
         self.output_dtype = torch.float32
         self._plans = {}
 
@@ -48,7 +48,7 @@ class KernelUpdateIterHead(nn.Module):
             self.mask_head[i].init_weights()
 
     def set_precision(self, precision, output_dtype=None):
-        assert precision in ("fp32", "split", "bf16")
+        assert precision in E.MODES, f"precision must be one of {sorted(E.MODES)}"
         self.precision = precision
         for h in self.mask_head:
             h.precision = precision
@@ -64,7 +64,7 @@ class KernelUpdateIterHead(nn.Module):
         plan = self._plans.get(key)
         if plan is None:
             self._plans.clear()
-            plan = E.DecodePlan(packs, B, N, H, W, E.PREC[self.precision], self.output_dtype, device)
+            plan = E.DecodePlan(packs, B, N, H, W, E.MODES[self.precision], self.output_dtype, device)
             self._plans[key] = plan
         return plan
 
@@ -95,7 +95,7 @@ class KernelUpdateIterHead(nn.Module):
         plan = self._plan(B, N, H, W, x.device)
         plan.renew_outputs()         # results are the caller's: an earlier call's tensors are never overwritten
         ho = getattr(x, "_ph_handoff", None)
-        if (ho is not None and ho["prec"] == plan.prec and ho["mask_preds"] is mask_preds
+        if (ho is not None and ho["prec"] == plan.prec and plan.mode.name in ("bf16", "fp32") and ho["mask_preds"] is mask_preds
                 and ho["depth_feats"] is depth_feats and tuple(ho["xp"].shape) == tuple(plan.xp.shape)
                 and tuple(ho["bits"].shape) == tuple(plan.bits.shape)):
             # inputs come straight from this package's KernelHead: its bf16 planes and mask bits are reused

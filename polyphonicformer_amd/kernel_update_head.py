@@ -84,7 +84,7 @@ class KernelUpdateHead(nn.Module):
         self.fc_mask = nn.Linear(in_channels, out_channels)
         self.fc_depth = nn.Linear(in_channels, out_channels)
         self.depth_act_mode = depth_act_mode
-        self.precision = "fp32"       # "fp32" = split-bf16 MFMA (parity grade), "bf16" = fast
+        self.precision = "fp32"       # a key of engine.MODES
         self._packs = {}
 
     # -- reference API ----------------------------------------------------------------------------
@@ -99,7 +99,7 @@ class KernelUpdateHead(nn.Module):
             nn.init.normal_(self.fc_mask.weight, mean=0, std=0.01)
 
     def stage_pack(self, device, precision=None):
-        prec = E.PREC[precision or self.precision]
+        prec = E.MODES[precision or self.precision].query
         ver = tuple(p._version for p in self.parameters())
         key = (prec, str(device))
         hit = self._packs.get(key)
@@ -117,19 +117,23 @@ class KernelUpdateHead(nn.Module):
         if tuple(mask_preds.shape[-2:]) != (H, W) or mask_shape is not None:
             raise NotImplementedError("libpolyhead: mask_preds must already be at the feature resolution")
         E._require_gpu(x, "x")
-        prec = E.PREC[self.precision]
+        mode = E.MODES[self.precision]
         pack = self.stage_pack(x.device)
         HW = H * W
-        xp, dp = E.ingest(x, prec), E.ingest(depth_feats, prec)
+        if x.dtype == mode.feat_dtype and depth_feats.dtype == x.dtype and HW % 128 == 0:
+            # 16-bit NCHW tensors of the mode's plane format are the planes themselves
+            xp, dp = (t.contiguous().view(torch.int16).reshape(1, B, 256, HW) for t in (x, depth_feats))
+        else:
+            xp, dp = E.ingest(x, mode.feat), E.ingest(depth_feats, mode.feat)
         bits = E.binarize(mask_preds)
-        partial = E.pool(xp, dp, bits, N, HW, prec)
+        partial = E.pool(xp, dp, bits, N, HW, mode.feat)
         k = proposal_feat.reshape(B, N, 256).float().contiguous()
         q = depth_proposal.reshape(B, N, 256).float().contiguous()      # materialises the expand view
-        o = E.query_stage(partial, bits, k, q, pack, N, HW)
+        o = E.query_stage(partial, bits, k, q, pack, N, HW, kern_fmt=mode.kern_fmt)
         new_mask = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
         new_depth = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
-        E.dynconv(xp, o["kern"], o["kbias"], 0, N, HW, prec, logits_out=new_mask)
-        E.dynconv(dp, o["kern"], o["kbias"], 1, N, HW, prec, logits_out=new_depth)
+        E.dynconv(xp, o["kern"], o["kbias"], 0, N, HW, mode.conv, logits_out=new_mask)
+        E.dynconv(dp, o["kern"], o["kbias"], 1, N, HW, mode.conv, logits_out=new_depth)
         return (o["cls"], new_mask, o["obj"].reshape(B, N, 256, 1, 1), new_depth, o["dobj"].reshape(B, N, 256, 1, 1))
 
     def loss(self, *a, **k):

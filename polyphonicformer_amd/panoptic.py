@@ -112,9 +112,10 @@ def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta
     K = len(q)
     N, h2, w2 = mask_preds.shape
     mask_preds, depth_preds = mask_preds.contiguous(), depth_preds.contiguous()
-    if mask_preds.dtype != depth_preds.dtype or mask_preds.dtype not in (torch.float32, torch.bfloat16):
-        raise _lib.PolyheadError("mask/depth logits must both be fp32 or both bf16")
-    dt = _lib.PH_OUT_F32 if mask_preds.dtype == torch.float32 else _lib.PH_OUT_BF16
+    codes = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}
+    if mask_preds.dtype != depth_preds.dtype or mask_preds.dtype not in codes:
+        raise _lib.PolyheadError("mask/depth logits must both be fp32, both bf16 or both fp16")
+    dt = codes[mask_preds.dtype]
     d0 = depth_init.reshape(h2, w2).float().contiguous()
     qd = q.to(torch.int32).to(dev)
     act_mask = torch.empty((K, h2, w2), dtype=torch.float32, device=dev)

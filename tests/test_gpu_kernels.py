@@ -208,3 +208,79 @@ def test_errors_are_reported(gpu):
     assert rc == -1 and b"ph_pool" in lib.ph_last_error_string()
     with pytest.raises(_lib.PolyheadError):
         E.ingest(torch.zeros(1, 256, 4, 4), _lib.PH_PREC_BF16)       # CPU tensor: no fallback
+
+
+# ---- round 2: fp16 planes, hi/lo kernels over one feature plane, fp16 outputs -------------------------------------------
+def _planes16(t, dtype):
+    return t.to(dtype).view(torch.int16)
+
+
+@pytest.mark.parametrize("N,H,W,nsplit", [(153, 16, 32, 3), (40, 6, 13, 1), (253, 8, 48, 2)])
+def test_pool_fp16_planes(gpu, N, H, W, nsplit):
+    """PH_PREC_F16: {0, 1} x fp16 products are exact, fp32 accumulation"""
+    g = torch.Generator().manual_seed(31)
+    B, HW = 2, H * W
+    x, d = torch.randn(B, 256, H, W, generator=g), torch.randn(B, 256, H, W, generator=g)
+    m = torch.randn(B, N, H, W, generator=g)
+    xp, dp = E.ingest(x.to(gpu), _lib.PH_PREC_F16), E.ingest(d.to(gpu), _lib.PH_PREC_F16)
+    assert torch.equal(xp[0, :, :, :HW].reshape(B, 256, H, W).cpu(), _planes16(x, torch.float16))      # RNE fp16
+    assert (xp[..., HW:] == 0).all()
+    bits = E.binarize(m.to(gpu))
+    got = E.pool(xp, dp, bits, N, HW, _lib.PH_PREC_F16, nsplit=nsplit).cpu().double().sum(1)[:, :N]
+    M = (m.sigmoid() > 0.5).double().reshape(B, N, HW)
+    xq, dq = x.half().double().reshape(B, 256, HW), d.half().double().reshape(B, 256, HW)
+    ref = torch.cat([torch.einsum("bnk,bck->bnc", M, xq), torch.einsum("bnk,bck->bnc", M, dq)], -1)
+    assert (got - ref).abs().max() <= 1e-5 * ref.abs().max()
+    ref32 = torch.cat([torch.einsum("bnk,bck->bnc", M, x.double().reshape(B, 256, HW)),
+                       torch.einsum("bnk,bck->bnc", M, d.double().reshape(B, 256, HW))], -1)
+    assert Hh.rel_err(got, ref32) < 5e-4              # 2^-12 per element, 8x finer than a bf16 plane
+
+
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16_KSPLIT, _lib.PH_PREC_F16])
+@pytest.mark.parametrize("N,H,W", [(111, 8, 16), (153, 16, 32), (40, 6, 13), (253, 8, 48), (20, 4, 32)])
+def test_dynconv_ksplit_and_fp16(gpu, prec, N, H, W):
+    """PH_PREC_BF16_KSPLIT: hi + lo kernel planes x ONE bf16 feature plane (2 MFMAs); PH_PREC_F16: fp16 x fp16.  Products
+    of the stored operands are exact in fp32 accumulation; outputs fp32 / fp16 / bits"""
+    g = torch.Generator().manual_seed(41)
+    B, HW = 2, H * W
+    Npad = E.n_padded(N)
+    x = torch.randn(B, 256, H, W, generator=g)
+    kern_f = torch.randn(2, B, Npad, 256, generator=g) * 0.1
+    kbias = torch.randn(2, B, Npad, generator=g) * 0.1
+    if prec == _lib.PH_PREC_F16:
+        kern = _planes16(kern_f, torch.float16)[None].contiguous().to(gpu)
+        kq = kern_f.half().double()
+        xp = E.ingest(x.to(gpu), _lib.PH_PREC_F16)
+        xq = x.half().double().reshape(B, 256, HW)
+    else:
+        hi = kern_f.to(torch.bfloat16)
+        lo = (kern_f - hi.float()).to(torch.bfloat16)
+        kern = torch.stack([hi.view(torch.int16), lo.view(torch.int16)], 0).contiguous().to(gpu)
+        kq = hi.double() + lo.double()
+        xp = E.ingest(x.to(gpu), _lib.PH_PREC_BF16)
+        xq = x.bfloat16().double().reshape(B, 256, HW)
+    kbias_d = kbias.to(gpu)
+    for br in (0, 1):
+        ref = torch.einsum("bnc,bck->bnk", kq[br, :, :N], xq) + kbias[br, :, :N, None].double()
+        out = torch.empty(B, N, H, W, device=gpu)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, logits_out=out)
+        assert Hh.rel_err(out.cpu().reshape(B, N, HW), ref) < 1e-5
+        # and against the unrounded kernels: 2^-17 (hi/lo) / 2^-12 (fp16) per element
+        ref_k = torch.einsum("bnc,bck->bnk", kern_f[br, :, :N].double(), xq) + kbias[br, :, :N, None].double()
+        assert Hh.rel_err(out.cpu().reshape(B, N, HW), ref_k) < (2e-5 if prec == _lib.PH_PREC_BF16_KSPLIT else 5e-4)
+        out16 = torch.empty(B, N, H, W, device=gpu, dtype=torch.float16)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, logits_out=out16, out_dtype=_lib.PH_OUT_F16)
+        assert Hh.rel_err(out16.float().cpu().reshape(B, N, HW), ref) < 2.0 ** -11           # one fp16 rounding
+        assert torch.equal(out16.cpu(), out.cpu().half())                                    # exactly RNE of the fp32 result
+        bits = torch.full((B, Npad, E.hw_padded(HW) // 32), -1, dtype=torch.int32, device=gpu)
+        E.dynconv(xp, kern, kbias_d, br, N, HW, prec, bits_out=bits)
+        assert torch.equal(unpack_bits(bits, N, HW), (out.cpu().reshape(B, N, HW).sigmoid() > 0.5).float())
+
+
+@pytest.mark.parametrize("H,W", [(8, 16), (5, 7), (4, 256)])
+def test_upsample2x_fp16(gpu, H, W):
+    x = torch.randn(3, 5, H, W, generator=torch.Generator().manual_seed(6)).half()
+    out = E.upsample2x(x.to(gpu))
+    assert out.dtype == torch.float16
+    ref = F.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert (out.cpu().float() - ref).abs().max() <= 2.0 ** -10 * ref.abs().max()
