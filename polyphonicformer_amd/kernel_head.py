@@ -90,7 +90,7 @@ class KernelHead(nn.Module):
             nn.init.normal_(self.init_kernels.weight, 0, self.kernel_init_std)
 
     def set_precision(self, precision):
-        assert precision in ("fp32", "split", "bf16")
+        assert precision in E.PREC, f"precision must be one of {sorted(E.PREC)}"      # 'mixed' / 'fp16' run a1 at fp32 grade
         self.precision = precision
         self._pack, self._plans = None, {}
         if self.localization_fpn is not None and hasattr(self.localization_fpn, "set_precision"):

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (copy what should be judged into profiles/).
-#   bash tools/collect_profiles.sh r01b
+#   bash tools/collect_profiles.sh r02
 set -u
 TAG=${1:-run}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -o d -- python bench.py --no-cpu-baseline --no-kernel-head > $OUT/d_bench.json 2> $OUT/d.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py --streams 1 --frames 24 --no-cpu-baseline --no-kernel-head > $OUT/e_bench.json 2> $OUT/e.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -o d -- python bench.py --no-cpu-baseline --no-kernel-head --no-neck > $OUT/d_bench.json 2> $OUT/d.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py --streams 1 --frames 24 --no-cpu-baseline --no-kernel-head --no-neck > $OUT/e_bench.json 2> $OUT/e.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q -o q -- python tools/query_time.py 64 > $OUT/q_query64.txt 2> $OUT/q.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k -o k -- python tools/a1_profile.py 16 > $OUT/k_a1.txt 2> $OUT/k.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python tools/pool_only.py > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/pool_only.py > /dev/null 2> $OUT/pmc_sq.err
-python tools/dmabw.py > $OUT/dmabw.txt 2>&1
-python tools/readbw.py > $OUT/readbw.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python tools/pool_only.py mixed > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py mixed > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/pool_only.py mixed > /dev/null 2> $OUT/pmc_sq.err
+python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
-ls -R $OUT | head -50
+ls -R $OUT | head -60

@@ -1,20 +1,23 @@
-"""runs only the pooling + conv kernels at the cfg2 shape (for rocprofv3 --pmc passes)"""
+"""runs only the pooling + conv kernels at the cfg2 shape in the launch geometry of the headline step (24 frames per launch),
+for the rocprofv3 --pmc passes.  usage: python tools/pool_only.py [mode = mixed | bf16 | fp16]"""
 import sys, torch
 sys.path.insert(0, ".")
 from polyphonicformer_amd import _lib, engine as E
 dev = torch.device("cuda:0")
+mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed"]
 N, B, H, W = 153, 24, 128, 256
 HW = H * W
-xp = torch.randint(-2**15, 2**15, (1, B, 256, E.hw_padded(HW)), dtype=torch.int16, device=dev) & 0x3FFF
+xp = torch.randint(-2**15, 2**15, (1, B, 256, E.hw_padded(HW)), dtype=torch.int16, device=dev) & 0x3BFF      # finite in bf16 and fp16
 dp = xp.clone()
 bits = torch.randint(-2**31, 2**31 - 1, (B, E.n_padded(N), E.hw_padded(HW) // 32), dtype=torch.int32, device=dev)
-ns = 5
+ns = E.default_nsplit(B, HW)
 part = torch.empty((B, ns, E.n_padded(N), 512), dtype=torch.float32, device=dev)
-kern = torch.zeros((1, 2, B, 160, 256), dtype=torch.int16, device=dev)
+kern = torch.zeros((mode.KP, 2, B, 160, 256), dtype=torch.int16, device=dev)
 kb = torch.zeros((2, B, 160), dtype=torch.float32, device=dev)
-out = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=dev)
+odt = torch.bfloat16 if mode.name == "bf16" else torch.float16
+out = torch.empty((B, N, H, W), dtype=odt, device=dev)
 for _ in range(5):
-    E.pool(xp, dp, bits, N, HW, 1, ns, out=part)
-    E.dynconv(xp, kern, kb, 0, N, HW, 1, bits_out=bits)
-    E.dynconv(xp, kern, kb, 0, N, HW, 1, logits_out=out, out_dtype=1)
+    E.pool(xp, dp, bits, N, HW, mode.feat, ns, out=part)
+    E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, bits_out=bits)
+    E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, logits_out=out, out_dtype=E.OUT_CODE[odt])
 torch.cuda.synchronize()
