@@ -347,6 +347,65 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
                     "module API, no HIP graph"}
 
 
+def video_leg(dev, precision="bf16", frames=6):
+    """BASELINE configs[2] (poly_r50_cityscapes_1x video head, 2-frame clips with tracking query match): wall time per
+    1024x2048 frame of PolyphonicVideo.simple_test after extract_feat (polyphonic_former_video.py:327-405) through the
+    module API -- neck + KernelHead + 3-stage decode + panoptic merge + things -> boxes -> FPN RoIAlign -> track head ->
+    tracker; the shipped video head (100 + 11 queries), classification biases raised so that an un-trained network
+    yields thing segments."""
+    from polyphonicformer_amd.registry import HEADS, ConfigDict
+    from polyphonicformer_amd import video as V
+    import polyphonicformer_amd.kernel_head, polyphonicformer_amd.track_head  # noqa: F401,E401
+    wl = WORKLOADS["cfg3"]
+    L = wl["n_thing"] + wl["n_stuff"]
+    torch.manual_seed(7)
+    neck = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=wl["Nq"], num_classes=L, num_thing_classes=wl["n_thing"],
+                          num_stuff_classes=wl["n_stuff"], cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=neck))
+    kh.init_weights()
+    kh.eval().to(dev)
+    kh.set_precision(precision)
+    ih = build_head(wl, precision, torch.float32, dev, seed=3)
+    ih.test_cfg = ConfigDict(max_per_img=wl["Nq"], mask_thr=0.5, merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))
+    with torch.no_grad():
+        ih.mask_head[-1].fc_cls.bias.fill_(1.0)
+    th = HEADS.build(dict(type="QuasiDenseMaskEmbedHeadGTMask", norm_cfg=dict(type="GN", num_groups=32)))
+    th.init_weights()
+    th.to(dev).eval()
+    th.precision = precision
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+               match_metric="bisoftmax")
+    pipe = V.VideoFramePipeline(kh, ih, th, cfg)
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(31)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(dev) for s in (4, 8, 16, 32)]
+    meta = [dict(img_shape=(H8, W8, 3), ori_shape=(H8, W8, 3), batch_input_shape=(H8, W8))]
+    t_heads, t_assoc, nthing = [], [], []
+    for f in range(frames + 2):
+        x = tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipe.heads(x, meta)[0]
+        t1 = time.perf_counter()
+        pipe.assoc.step(x, res[2][0], res[2][1], res[4])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if f >= 2:
+            t_heads.append(t1 - t0), t_assoc.append(t2 - t1)
+            nthing.append(sum(1 for s_ in res[2][1] if s_["isthing"]))
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"ms_per_frame": round((med(t_heads) + med(t_assoc)) * 1e3, 3), "heads_and_merge_ms": round(med(t_heads) * 1e3, 3),
+            "association_ms": round(med(t_assoc) * 1e3, 3), "thing_segments_per_frame": nthing, "frames_timed": frames,
+            "precision": precision, "note": "one frame at a time (samples_per_gpu = 1 as in the reference), module API, host "
+            "wall time incl. the D2H of the id / depth maps and the host-side tracker"}
+
+
 def panoptic_leg(wl, head, plan, dev):
     """get_panoptic (a7, SURVEY 8d: reported separately) on ONE frame of the step's outputs; host wall time,
     including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
@@ -728,6 +787,11 @@ def main():
                 res["full_head_from_fpn"] = full_head_leg(wl, hk, "bf16", dev)
             except Exception as e:
                 res["full_head_from_fpn"] = {"error": repr(e)}
+        if world == 1 and not args.no_neck:
+            try:
+                res["video_cfg3"] = video_leg(dev)
+            except Exception as e:
+                res["video_cfg3"] = {"error": repr(e)}
         if world == 1 and not args.no_neck:
             try:
                 res["hungarian_assign"] = assign_leg(dev)

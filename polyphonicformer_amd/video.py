@@ -294,3 +294,36 @@ class VideoAssociator:
             ids = ids.tolist()
         return [{"sem": semantic_map(panoptic_seg, segments_info, self.num_thing_classes, self.num_stuff_classes),
                  "track": track_id_map(panoptic_seg, seg_ids, ids), "depth": depth_final}]
+
+
+class VideoFramePipeline:
+    """`PolyphonicVideo.simple_test` after `extract_feat` (polyphonic_former_video.py:327-405), in the reference's order:
+
+        rpn_head.simple_test_rpn(x, img_metas)                      -> proposals, post-neck maps, mask / depth logits
+        roi_head.simple_test(...)                                    -> panoptic_seg, segments_info, depth_final  (a6 + a7)
+        get_things_id_for_tracking -> boxes / RoIAlign on the FPN levels `x` -> track_head -> tracker.match
+        -> [{"sem": uint8 map, "track": float64 map, "depth": fp32 map}]
+
+    One instance per video stream (the tracker is stateful; `init_tracker` starts a new video, :59-61).  Backbone and FPN
+    are the caller's (`x` = the four FPN levels of ONE frame, as `extract_feat` returns them)."""
+
+    def __init__(self, rpn_head, roi_head, track_head, tracker_cfg, strides=(4, 8, 16, 32)):
+        self.rpn_head, self.roi_head = rpn_head, roi_head
+        self.assoc = VideoAssociator(track_head, tracker_cfg, roi_head.num_thing_classes, roi_head.num_stuff_classes, strides)
+
+    def init_tracker(self):
+        self.assoc.init_tracker()
+
+    def heads(self, x, img_metas, rescale=False):
+        """the two heads exactly as :343-357 calls them; returns roi_head.simple_test's result list"""
+        (proposal_feats, x_feats, mask_preds, cls_scores, seg_preds, depth_feats, depth_proposal, depth_pred,
+         semantic_aspp_out) = self.rpn_head.simple_test_rpn(x, img_metas)
+        return self.roi_head.simple_test(x_feats, proposal_feats, mask_preds, cls_scores, img_metas, depth_preds=depth_pred,
+                                         depth_feats=depth_feats, depth_proposal=depth_proposal, imgs_whwh=None,
+                                         aspp_semantic=semantic_aspp_out, rescale=rescale)
+
+    def simple_test(self, x, img_metas, rescale=False, records_only=False):
+        if x[0].shape[0] != 1:
+            raise NotImplementedError("video inference is one frame at a time (samples_per_gpu = 1, as in the reference)")
+        _, _, (panoptic_seg, segments_info), _, depth_final = self.heads(x, img_metas, rescale)[0]
+        return self.assoc.step(x, panoptic_seg, segments_info, depth_final, records_only=records_only)

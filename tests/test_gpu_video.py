@@ -115,3 +115,80 @@ def test_two_frame_clip_association(gpu):
         assert np.array_equal(outs[fi]["track"], want)
         assert outs[fi]["sem"].dtype == np.uint8 and outs[fi]["depth"].dtype == np.float32
     assert V.wire_record(outs[1])["panseg"].dtype == np.uint32
+
+
+def _cfg3_pipeline(gpu, precision="fp32"):
+    """the shipped video head (100 + 11 queries, 8 / 11 classes, S = 3) with this build's neck, crafted so that an
+    un-trained network yields segments: classification biases that let every query pass the score threshold"""
+    import bench
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    from polyphonicformer_amd import video as V
+    wl = bench.WORKLOADS["cfg3"]
+    L = wl["n_thing"] + wl["n_stuff"]
+    torch.manual_seed(7)
+    neck = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=wl["Nq"], num_classes=L, num_thing_classes=wl["n_thing"],
+                          num_stuff_classes=wl["n_stuff"], cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=neck))
+    kh.init_weights()
+    kh.eval().to(gpu)
+    kh.set_precision(precision)
+    ih = bench.build_head(wl, precision, torch.float32, gpu, seed=3)
+    from polyphonicformer_amd.registry import ConfigDict
+    ih.test_cfg = ConfigDict(max_per_img=wl["Nq"], mask_thr=0.5, merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))
+    with torch.no_grad():
+        ih.mask_head[-1].fc_cls.bias.fill_(1.0)                 # sigmoid(1) = 0.73 > instance_score_thr
+    th = HEADS.build(dict(type="QuasiDenseMaskEmbedHeadGTMask", norm_cfg=dict(type="GN", num_groups=32)))
+    sd = Hh.seeded_fill(Hh.TRACK_HEAD_SHAPES, 4321)
+    th.load_state_dict({k[len("track_head."):]: v for k, v in sd.items()})
+    th.to(gpu).eval()
+    th.precision = "fp32"
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+               match_metric="bisoftmax")
+    return V.VideoFramePipeline(kh, ih, th, cfg), sd, cfg, wl
+
+
+def test_cfg3_two_frame_clip_end_to_end(gpu):
+    """BASELINE config 3 at its full size: two 1024 x 2048 frames through heads -> get_panoptic -> things -> boxes -> FPN
+    RoIAlign -> track head -> tracker, in the order of PolyphonicVideo.simple_test (polyphonic_former_video.py:327-405).
+    The association part is checked against the oracle chain fed with the SAME panoptic maps (integer track-id maps
+    bit-exact); the heads + merge are covered against the oracle at this size by tests/test_gpu_configs.py (cfg3) and on
+    the reference's goldens by tests/test_gpu_panoptic.py."""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu)
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(31)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g) for s in (4, 8, 16, 32)]
+    frames = [base, [torch.roll(f, (1, 2), dims=(2, 3)) for f in base]]          # the second frame: the first, shifted
+    meta = [Hh.img_meta(H8, W8)]
+    ref_tr = V.QuasiDenseEmbedTracker(**cfg)
+    cnt, nseg = 1, []
+    for ff in frames:
+        x = tuple(f.to(gpu) for f in ff)
+        res = pipe.heads(x, meta)[0]
+        pan, info = res[2]
+        assert pan.shape == (H8, W8) and pan.dtype == np.int32 and res[4].shape == (H8, W8)
+        out = pipe.assoc.step(x, pan, info, res[4])[0]
+        seg_ids, _, labels, score = V.things_for_tracking(pan, info)
+        nseg.append(len(seg_ids))
+        assert out["sem"].shape == (H8, W8) and out["sem"].dtype == np.uint8 and out["track"].shape == (H8, W8)
+        if not seg_ids:
+            assert not out["track"].any()
+            continue
+        masks = torch.stack([torch.from_numpy(pan == s) for s in seg_ids])
+        rois = torch.cat([torch.zeros(len(seg_ids), 1), VO.mask_stat_boxes(masks)], 1).clamp(min=0)
+        emb = VO.track_embed_head(sd, VO.roi_extract(ff, rois))
+        bb = torch.cat([VO.mask_extent_boxes(masks), torch.tensor(score)[:, None]], 1)
+        ids = ref_tr.match(bb, torch.tensor(labels), emb, cnt)[2] + 1
+        cnt += 1
+        ids[ids == -1] = 0
+        assert np.array_equal(out["track"], V.track_id_map(pan, seg_ids, ids.tolist()))
+        sem_ref = V.semantic_map(pan, info, wl["n_thing"], wl["n_stuff"])
+        assert np.array_equal(out["sem"], sem_ref)
+    print("cfg3 end-to-end: thing segments per frame", nseg)
+    assert max(nseg) > 0            # the crafted biases let things through: the association really ran
