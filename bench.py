@@ -342,9 +342,21 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
         return head.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
 
     t = time_op(run, steps)
-    return {"frames_per_step": B, "frames_per_s": round(B / (t * 1e-3), 1), "ms_per_step": round(t, 4),
-            "note": "FPN levels (fp32 NCHW) -> SemanticFPNWrapper -> KernelHead -> KernelUpdateIterHead.simple_test_mask_preds, "
-                    "module API, no HIP graph"}
+    out = {"frames_per_step": B, "frames_per_s": round(B / (t * 1e-3), 1), "ms_per_step": round(t, 4),
+           "note": "FPN levels (fp32 NCHW) -> SemanticFPNWrapper -> KernelHead -> KernelUpdateIterHead.simple_test_mask_preds, "
+                   "module API (fresh output tensors per call), eager launches"}
+    try:        # the same module-API call sequence captured once into a HIP graph and replayed
+        run()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            keep = run()
+        tg = time_op(graph.replay, steps)
+        out["hip_graph"] = {"frames_per_s": round(B / (tg * 1e-3), 1), "ms_per_step": round(tg, 4)}
+        del keep, graph
+    except Exception as e:
+        out["hip_graph"] = {"error": repr(e)}
+    return out
 
 
 def video_leg(dev, precision="bf16", frames=6):
