@@ -43,3 +43,31 @@ def test_roi_align_analytic_properties():
                 assert abs(float(out[i, 0, ph, pw]) - (0.25 * cx + 0.5 * cy + 1.0)) < 1e-4
     lv = VO.map_roi_levels(torch.tensor([[0, 0, 0, 50., 50.], [0, 0, 0, 120., 120.], [0, 0, 0, 300., 300.], [0, 0, 0, 2000., 900.]]))
     assert lv.tolist() == [0, 1, 2, 3]
+
+
+def test_roi_align_against_atens_bilinear_sampler():
+    """RoIAlign (aligned, 7x7 bins, 2x2 samples per bin) is bilinear sampling at known continuous coordinates followed by
+    a 2x2 mean.  `torch.nn.functional.grid_sample(align_corners=False)` is ATen's own bilinear sampler with the same
+    pixel-centre convention (sample coordinate s in RoIAlign's frame = pixel-centre coordinate s + 0.5): an implementation
+    this build did not write.  For boxes whose samples lie inside [0, H-1] x [0, W-1] (where the two border rules agree)
+    the oracle must reproduce it; random features, so a wrong tap or weight cannot cancel."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8)
+    H, W, C = 48, 80, 5
+    feat = torch.randn(1, C, H, W, generator=g)
+    s = 0.125
+    rois = torch.tensor([[0, 40.0, 24.0, 300.0, 200.0], [0, 100.5, 60.25, 190.0, 140.75], [0, 33.0, 17.0, 47.5, 39.0],
+                         [0, 320.0, 100.0, 600.0, 360.0]])
+    out = VO.roi_align(feat, rois, s)
+    for i, r in enumerate(rois):
+        x1, y1, x2, y2 = [float(v) * s - 0.5 for v in r[1:]]
+        bw, bh = (x2 - x1) / 7, (y2 - y1) / 7
+        ys = torch.tensor([y1 + ph * bh + (iy + 0.5) * bh / 2 for ph in range(7) for iy in range(2)])     # 14 sample rows
+        xs = torch.tensor([x1 + pw * bw + (ix + 0.5) * bw / 2 for pw in range(7) for ix in range(2)])
+        assert ys.min() >= 0 and ys.max() <= H - 1 and xs.min() >= 0 and xs.max() <= W - 1
+        # grid_sample: normalised coordinate of continuous position p (pixel centres at integers) = (2p + 1) / size - 1
+        gy, gx = (2 * ys + 1) / H - 1, (2 * xs + 1) / W - 1
+        grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], -1)[None]                         # [1,14,14,(x,y)]
+        samp = F.grid_sample(feat, grid, mode="bilinear", padding_mode="zeros", align_corners=False)      # [1,C,14,14]
+        want = F.avg_pool2d(samp, 2)[0]
+        assert torch.allclose(out[i], want, atol=2e-5), (i, float((out[i] - want).abs().max()))
