@@ -214,6 +214,39 @@ int ph_match_nsplit(int64_t HW, int B);
 int ph_match_sums(const float* logits, const float* gt, const float* valid, float* partial, int B, int N, int G,
                   int64_t HW, void* stream);
 
+/* ---- N4 (training path): the pixel passes of one stage's losses, kernel_update_head.py:355-441 ------------------------------
+ * Every *_sums entry writes fixed-order partial records (doubles, one per workgroup) that the caller adds up in index
+ * order; every *_grad entry writes d loss / d logits given the coefficients the caller derives from those sums.
+ *  mask : positive prediction rows `pos_rows[P]` of pred / target / weight [rows][HW]; out [P][nsplit][5] = sum BCE-with-logits,
+ *         pixel count, a = sum sig t, b = sum sig^2, c = sum t^2 over the pixels with weight != 0 (loss_mask: mmdet
+ *         cross_entropy_loss.py:74-113, loss_dice: dice_loss.py:9-46).  grad += coef[p][0] (sig - t) + (coef[p][1] t + coef[p][2] sig)
+ *         sig (1 - sig) on those pixels.
+ *  rank : softmax cross entropy over the N mask channels of each pixel against rank_target [B][HW] (int32, ignore_index),
+ *         cross_entropy_loss.py:9-47; out [B * ph_rank_loss_blocks(HW)]; grad (overwritten, all N channels) = scale (softmax - onehot).
+ *  depth: DepthLoss (polyphonic/losses/depth_loss.py:9-65) over 0 < target < 80, weight != 0; out [blocks][5] = n, sum lm^2, sum lm,
+ *         sum r^2, sum |r| with lm = (log p - log t) w, r = (p - t) w / t, p = depth_act(pred); grad (overwritten) =
+ *         ((c0 lm + c1) w / p + (c2 r + c3 sign r) w / t) depth_act'(pred).
+ *  focal: py_sigmoid_focal_loss (focal_loss.py:12-60) on pred [R][L], labels [R] (>= L: background), weight [R][L]. */
+int ph_mask_loss_sums(const float* pred, const float* target, const float* weight, const int32_t* pos_rows, int P, int64_t HW,
+                      int nsplit, double* out, void* stream);
+int ph_mask_loss_grad(const float* pred, const float* target, const float* weight, const int32_t* pos_rows, int P, int64_t HW,
+                      const float* coef, float* grad, void* stream);
+int ph_rank_loss_blocks(int64_t HW);
+int ph_rank_loss_sum(const float* pred, const int32_t* rank_target, int B, int N, int64_t HW, int ignore_index, double* out,
+                     void* stream);
+int ph_rank_loss_grad(const float* pred, const int32_t* rank_target, int B, int N, int64_t HW, int ignore_index, float scale,
+                      float* grad, void* stream);
+int ph_depth_loss_blocks(int64_t total);
+int ph_depth_loss_sums(const float* pred, const float* target, const float* weight, int64_t total, int depth_mode, double* out,
+                       void* stream);
+int ph_depth_loss_grad(const float* pred, const float* target, const float* weight, int64_t total, int depth_mode, float c0,
+                       float c1, float c2, float c3, float* grad, void* stream);
+int ph_focal_loss_blocks(int64_t total);
+int ph_focal_loss_sum(const float* pred, const int64_t* labels, const float* weight, int64_t R, int L, float gamma, float alpha,
+                      double* out, void* stream);
+int ph_focal_loss_grad(const float* pred, const int64_t* labels, const float* weight, int64_t R, int L, float gamma, float alpha,
+                       float scale, float* grad, void* stream);
+
 /* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
  * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.
  * activate: act_mask[k] = sigmoid(mask_up[q_idx[k]]), act_depth[k] = depth_act(depth_up[q_idx[k]]),

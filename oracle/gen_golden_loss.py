@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE (build container only): golden vectors of the TRAINING-side targets and losses of one
+KernelUpdateHead stage, produced by the reference's own classes:
+
+  * `KernelUpdateHead.get_targets` / `_get_target_single`  (polyphonic/kernel_update_head.py:443-591)
+  * `KernelUpdateHead.loss`                                (:355-441)
+  * the vendored mmdet losses it calls -- FocalLoss (py_sigmoid_focal_loss), CrossEntropyLoss (binary_cross_entropy /
+    cross_entropy), DiceLoss (mmdet/models/losses/*.py, loaded from /root/reference, not copied) -- and the project's
+    DepthLoss (polyphonic/losses/depth_loss.py), `accuracy` (mmdet/models/losses/accuracy.py)
+  * `MaskPseudoSampler.sample` (polyphonic/funcs/sampler.py) for the sampling results
+
+plus torch-autograd gradients of the summed losses w.r.t. the predictions (the first step of the backward pass).
+Writes tests/golden/loss.npz.  Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_loss.py"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import helpers as Hh                     # noqa: E402
+from oracle import ref_loader as R       # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def load_real_losses(ns):
+    """the vendored mmdet loss modules + polyphonic's DepthLoss, registered in a registry of their own"""
+    reg = R.Registry("real_losses")
+    mb = sys.modules["mmdet.models.builder"]
+    saved = mb.LOSSES
+    mb.LOSSES = reg
+    mmcv = sys.modules["mmcv"]
+    mmcv.jit = lambda **kw: (lambda f: f)                 # mmcv.jit: a no-op decorator outside parrots
+    sys.modules["mmcv.ops"].sigmoid_focal_loss = None     # CUDA op, not used on CPU (focal_loss.py:225-231)
+
+    def load(modname, relpath):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(R.REF_ROOT, relpath))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        parent, _, child = modname.rpartition(".")
+        setattr(sys.modules[parent], child, m)
+        spec.loader.exec_module(m)
+        return m
+
+    lp = "mmdet/models/losses/"
+    load("mmdet.models.losses.utils", lp + "utils.py")
+    acc = load("mmdet.models.losses.accuracy", lp + "accuracy.py")
+    load("mmdet.models.losses.cross_entropy_loss", lp + "cross_entropy_loss.py")
+    load("mmdet.models.losses.dice_loss", lp + "dice_loss.py")
+    load("mmdet.models.losses.focal_loss", lp + "focal_loss.py")
+    R._mod("polyphonic.losses")
+    load("polyphonic.losses.depth_loss", "polyphonic/losses/depth_loss.py")
+    mb.LOSSES = saved
+    return reg, acc.accuracy
+
+
+LOSS_CFG = dict(
+    loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+    loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+    loss_dice=dict(type="DiceLoss", loss_weight=4.0),
+    loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+    loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid", si_weight=1.0, sq_rel_weight=1.0,
+                    abs_rel_weight=1.0))
+
+
+def make_case(seed, B, Nq, n_thing, n_stuff, H, W, gts):
+    """crafted inputs of one stage: predictions at the assign stride, ground truth, an assignment with positives"""
+    g = torch.Generator().manual_seed(seed)
+    N, L = Nq + n_stuff, n_thing + n_stuff
+    case = dict(mask_pred=torch.randn(B, N, H, W, generator=g) * 2, cls_score=torch.randn(B, N, L, generator=g),
+                depth_pred=torch.randn(B, N, H, W, generator=g), gt=[])
+    for b in range(B):
+        G = gts[b]
+        gm = (torch.rand(G, H, W, generator=g) > 0.7).float()
+        gl = torch.randint(0, n_thing, (G,), generator=g)
+        present = torch.randperm(n_stuff, generator=g)[: max(1, n_stuff // 2 + b)].sort()[0]
+        sem_cls = present + n_thing
+        sem_seg = (torch.rand(len(present), H, W, generator=g) > 0.6).float()
+        depth = torch.rand(H, W, generator=g) * 90.0                      # some pixels beyond max_depth = 80
+        depth[torch.rand(H, W, generator=g) < 0.1] = 0.0                  # and some without ground truth
+        gt_inds = torch.zeros(Nq, dtype=torch.long)
+        if G:
+            rows = torch.randperm(Nq, generator=g)[:G]
+            gt_inds[rows] = torch.arange(1, G + 1)
+        labels = torch.full((Nq,), -1, dtype=torch.long)
+        labels[gt_inds > 0] = gl[gt_inds[gt_inds > 0] - 1]
+        case["gt"].append(dict(masks=gm, labels=gl, sem_seg=sem_seg, sem_cls=sem_cls, depth=depth, gt_inds=gt_inds,
+                               assigned_labels=labels))
+    return case
+
+
+def main():
+    ns = R.load_reference()
+    reg, accuracy = load_real_losses(ns)
+    kuh = sys.modules["polyphonic.kernel_update_head"]
+    kuh.accuracy = accuracy                                   # the module imported the stand-in at load time
+    Sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler
+    cfgs = [("a", 21, 2, 20, 8, 11, 24, 40, [5, 3]), ("b", 22, 2, 100, 8, 11, 32, 64, [12, 0]), ("c", 23, 1, 37, 3, 4, 17, 29, [6])]
+    out = {}
+    for tag, seed, B, Nq, n_thing, n_stuff, H, W, gts in cfgs:
+        L = n_thing + n_stuff
+        head = ns.MODELS.build(dict(R.stage_cfg(32, 64, 4, L, n_thing, n_stuff), **{}))
+        for k, c in LOSS_CFG.items():                              # the real loss modules in place of the stand-ins
+            setattr(head, k, reg.build(dict(c)))
+        case = make_case(seed, B, Nq, n_thing, n_stuff, H, W, gts)
+        mask_pred = case["mask_pred"].clone().requires_grad_(True)
+        cls_score = case["cls_score"].clone().requires_grad_(True)
+        depth_pred = case["depth_pred"].clone().requires_grad_(True)
+        AR = type("AR", (), {})
+        sampling = []
+        for b in range(B):
+            gt = case["gt"][b]
+            ar = AR()
+            ar.gt_inds, ar.labels, ar.num_gts = gt["gt_inds"], gt["assigned_labels"], len(gt["labels"])
+            sr = Sampler().sample(ar, mask_pred[b].detach(), gt["masks"], depth=depth_pred[b].detach())
+            # kernel_update.py:238: every ground-truth or stuff pixel is valid
+            sr.valid_mask = torch.cat((gt["masks"], gt["sem_seg"]), 0).sum(0).bool().float()
+            sampling.append(sr)
+        train_cfg = ns.ConfigDict(pos_weight=1)
+        tg = head.get_targets(sampling, [g_["masks"] for g_ in case["gt"]], [g_["labels"] for g_ in case["gt"]], train_cfg, True,
+                              gt_sem_seg=[g_["sem_seg"] for g_ in case["gt"]], gt_sem_cls=[g_["sem_cls"] for g_ in case["gt"]],
+                              gt_depth=[g_["depth"] for g_ in case["gt"]])
+        losses = head.loss(None, cls_score, mask_pred, depth_pred, *tg)
+        total = sum(v for k, v in losses.items() if k.startswith("loss"))
+        total.backward()
+        meta = dict(B=B, Nq=Nq, n_thing=n_thing, n_stuff=n_stuff, H=H, W=W, gts=gts, seed=seed)
+        out[f"{tag}_meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        for k, v in (("mask_pred", case["mask_pred"]), ("cls_score", case["cls_score"]), ("depth_pred", case["depth_pred"])):
+            out[f"{tag}_{k}"] = v.numpy()
+        for b in range(B):
+            for k, v in case["gt"][b].items():
+                out[f"{tag}_gt{b}_{k}"] = v.numpy()
+            out[f"{tag}_valid{b}"] = sampling[b].valid_mask.numpy()
+        for k, v in zip(("labels", "label_weights", "mask_targets", "mask_weights", "depth_targets", "depth_weights"), tg):
+            out[f"{tag}_t_{k}"] = v.numpy()
+        for k, v in losses.items():
+            out[f"{tag}_l_{k}"] = np.asarray(v.detach().numpy(), dtype=np.float64)
+        out[f"{tag}_g_mask_pred"] = mask_pred.grad.numpy()
+        out[f"{tag}_g_cls_score"] = cls_score.grad.numpy()
+        out[f"{tag}_g_depth_pred"] = depth_pred.grad.numpy()
+        print(tag, {k: float(v) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    print("bytes:", os.path.getsize(os.path.join(OUT, "loss.npz")))
+
+
+if __name__ == "__main__":
+    main()

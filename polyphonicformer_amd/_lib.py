@@ -50,6 +50,17 @@ SIGNATURES = {
     "ph_match_nsplit": (C.c_int, [_L, _I]),
     "ph_match_sums": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "ph_mask_loss_sums": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
+    "ph_mask_loss_grad": (C.c_int, [_P, _P, _P, _P, _I, _L, _P, _P, _P]),
+    "ph_rank_loss_blocks": (C.c_int, [_L]),
+    "ph_rank_loss_sum": (C.c_int, [_P, _P, _I, _I, _L, _I, _P, _P]),
+    "ph_rank_loss_grad": (C.c_int, [_P, _P, _I, _I, _L, _I, C.c_float, _P, _P]),
+    "ph_depth_loss_blocks": (C.c_int, [_L]),
+    "ph_depth_loss_sums": (C.c_int, [_P, _P, _P, _L, _I, _P, _P]),
+    "ph_depth_loss_grad": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "ph_focal_loss_blocks": (C.c_int, [_L]),
+    "ph_focal_loss_sum": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
+    "ph_focal_loss_grad": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, _P, _P]),
     "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ph_panoptic_argmax": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32), _I, _P, _P, _P]),
     "ph_panoptic_paste": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), _I, _P, _P, _P, _P]),

@@ -1,0 +1,284 @@
+// SURVEY.md 8f row N4 -- the pixel passes of one stage's training losses (polyphonic/kernel_update_head.py:355-441):
+//   ph_mask_loss_sums / _grad : loss_mask (BCE with logits, mmdet cross_entropy_loss.py:74-113) and loss_dice (dice_loss.py:9-46)
+//                               over the valid pixels of the POSITIVE prediction rows
+//   ph_rank_loss_sum  / _grad : loss_rank, a softmax cross entropy over the N mask channels per pixel (:9-47, ignore_index)
+//   ph_depth_loss_sums / _grad: DepthLoss (polyphonic/losses/depth_loss.py:9-65): scale-invariant, squared-relative and
+//                               absolute-relative error over the pixels with 0 < target < 80 and a non-zero weight
+//   ph_focal_loss_sum / _grad : FocalLoss (focal_loss.py:12-60) on the [rows][classes] scores
+// The reference evaluates these as ~40 ATen launches per stage with boolean-mask gathers (pred[weights] copies of every
+// positive mask); here each loss is ONE pass that produces fixed-order partial sums (fp64 accumulators, one record per
+// workgroup, combined in index order by the caller: bit-reproducible) and ONE pass that writes d loss / d logits, the
+// first step of the backward pass.  Pure HBM streaming kernels, 16 bytes per lane where the layout allows.
+#include "ph_common.h"
+
+constexpr int LOSS_T = 256;
+
+// block-wide sum of K doubles per thread -> thread 0 holds the totals (fixed order: lanes by xor-butterfly, waves ascending)
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* lds /* [4][K] */) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = lds[k] + lds[K + k] + lds[2 * K + k] + lds[3 * K + k];
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+// binary_cross_entropy_with_logits: max(z, 0) - z t + log1p(exp(-|z|))
+__device__ __forceinline__ float bce_logits(float z, float t) { return fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z))); }
+
+// ---- mask: BCE + dice over the weighted pixels of the positive rows -----------------------------------------------------
+// out [P][nsplit][5] doubles: sum bce, count, a = sum sig*t, b = sum sig^2, c = sum t^2
+__global__ __launch_bounds__(LOSS_T) void k_mask_loss_sums(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                           const float* __restrict__ wgt, const int* __restrict__ rows, int64_t HW,
+                                                           int nsplit, double* __restrict__ out) {
+    __shared__ double lds[4 * 5];
+    const int p = blockIdx.y, sp = blockIdx.x;
+    const int64_t base = (int64_t)rows[p] * HW;
+    const int64_t i0 = HW * sp / nsplit, i1 = HW * (sp + 1) / nsplit;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += LOSS_T) {
+        if (wgt[base + i] == 0.f) continue;                  // mask_weights[pos_inds].bool()   (:413)
+        const float z = pred[base + i], t = tgt[base + i], s = sigmoidf_(z);
+        v[0] += (double)bce_logits(z, t);
+        v[1] += 1.0;
+        v[2] += (double)(s * t);
+        v[3] += (double)(s * s);
+        v[4] += (double)(t * t);
+    }
+    block_sum<5>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[((int64_t)p * nsplit + sp) * 5 + k] = v[k];
+}
+
+// grad[row][i] += w * ( c_bce (sig - t) + dice_row terms ); coef [P][3] floats: bce scale, dice A = -2 lw / (P (b + c)),
+// dice B = 4 lw a / (P (b + c)^2):  d dice / dz = (A t + B sig) sig (1 - sig)
+__global__ __launch_bounds__(LOSS_T) void k_mask_loss_grad(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                           const float* __restrict__ wgt, const int* __restrict__ rows, int64_t HW,
+                                                           const float* __restrict__ coef, float* __restrict__ grad) {
+    const int p = blockIdx.y;
+    const int64_t base = (int64_t)rows[p] * HW;
+    const float cb = coef[p * 3], cA = coef[p * 3 + 1], cB = coef[p * 3 + 2];
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < HW; i += (int64_t)gridDim.x * LOSS_T) {
+        if (wgt[base + i] == 0.f) continue;
+        const float z = pred[base + i], t = tgt[base + i], s = sigmoidf_(z);
+        grad[base + i] += cb * (s - t) + (cA * t + cB * s) * s * (1.f - s);
+    }
+}
+
+// ---- rank: softmax cross entropy over the N channels of every pixel -------------------------------------------------------
+// out [B * nblk] doubles: sum over the non-ignored pixels of (logsumexp - z_target)
+__global__ __launch_bounds__(LOSS_T) void k_rank_loss_sum(const float* __restrict__ pred, const int* __restrict__ target, int N,
+                                                          int64_t HW, int ignore, double* __restrict__ out) {
+    __shared__ double lds[4];
+    const int b = blockIdx.y;
+    const float* pb = pred + (int64_t)b * N * HW;
+    double v[1] = {0};
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < HW; i += (int64_t)gridDim.x * LOSS_T) {
+        const int t = target[(int64_t)b * HW + i];
+        if (t == ignore) continue;
+        float mx = -INFINITY;
+        for (int n = 0; n < N; ++n) mx = fmaxf(mx, pb[(int64_t)n * HW + i]);
+        float se = 0.f;
+        for (int n = 0; n < N; ++n) se += expf(pb[(int64_t)n * HW + i] - mx);
+        v[0] += (double)(mx + logf(se) - pb[(int64_t)t * HW + i]);
+    }
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) out[(int64_t)b * gridDim.x + blockIdx.x] = v[0];
+}
+
+// grad[b][n][i] = scale * (softmax_n - [n == target]) on the non-ignored pixels, 0 elsewhere (OVERWRITES grad)
+__global__ __launch_bounds__(LOSS_T) void k_rank_loss_grad(const float* __restrict__ pred, const int* __restrict__ target, int N,
+                                                           int64_t HW, int ignore, float scale, float* __restrict__ grad) {
+    const int b = blockIdx.y;
+    const float* pb = pred + (int64_t)b * N * HW;
+    float* gb = grad + (int64_t)b * N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < HW; i += (int64_t)gridDim.x * LOSS_T) {
+        const int t = target ? target[(int64_t)b * HW + i] : ignore;
+        if (t == ignore) {
+            for (int n = 0; n < N; ++n) gb[(int64_t)n * HW + i] = 0.f;
+            continue;
+        }
+        float mx = -INFINITY;
+        for (int n = 0; n < N; ++n) mx = fmaxf(mx, pb[(int64_t)n * HW + i]);
+        float se = 0.f;
+        for (int n = 0; n < N; ++n) se += expf(pb[(int64_t)n * HW + i] - mx);
+        const float inv = scale / se;
+        for (int n = 0; n < N; ++n) gb[(int64_t)n * HW + i] = inv * expf(pb[(int64_t)n * HW + i] - mx) - (n == t ? scale : 0.f);
+    }
+}
+
+// ---- depth ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float depth_act_f(float z, int mode) {
+    const float s = sigmoidf_(z);
+    if (mode == 0) return s * (80.f - 0.01f) + 0.01f;                    // funcs/depth_utils.py 'sigmoid'
+    const float mn = 1.f / 80.f, mxd = 1.f / 0.01f;
+    return 1.f / (mn + (mxd - mn) * s);                                  // 'monodepth'
+}
+// d depth_act / dz
+__device__ __forceinline__ float depth_act_df(float z, int mode) {
+    const float s = sigmoidf_(z), ds = s * (1.f - s);
+    if (mode == 0) return (80.f - 0.01f) * ds;
+    const float mn = 1.f / 80.f, mxd = 1.f / 0.01f, q = mn + (mxd - mn) * s;
+    return -(mxd - mn) * ds / (q * q);
+}
+// out [nblk][5] doubles: n, sum lm^2, sum lm, sum (m / t)^2, sum |m / t|   (lm = (log p - log t) w, m = (p - t) w)
+__global__ __launch_bounds__(LOSS_T) void k_depth_loss_sums(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                            const float* __restrict__ wgt, int64_t total, int mode,
+                                                            double* __restrict__ out) {
+    __shared__ double lds[4 * 5];
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < total; i += (int64_t)gridDim.x * LOSS_T) {
+        const float t = tgt[i], w = wgt[i];
+        if (!(t > 0.f && t < 80.f && w != 0.f)) continue;
+        const float p = depth_act_f(pred[i], mode);
+        const float lm = (logf(p) - logf(t)) * w, r = (p - t) * w / t;
+        v[0] += 1.0;
+        v[1] += (double)(lm * lm);
+        v[2] += (double)lm;
+        v[3] += (double)(r * r);
+        v[4] += (double)fabsf(r);
+    }
+    block_sum<5>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[(int64_t)blockIdx.x * 5 + k] = v[k];
+}
+// grad = [ c0 lm (w / p) + c1 (w / p) + c2 r (w / t) + c3 sign(r) (w / t) ] * d depth_act / dz   (OVERWRITES grad)
+__global__ __launch_bounds__(LOSS_T) void k_depth_loss_grad(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                            const float* __restrict__ wgt, int64_t total, int mode, float c0, float c1,
+                                                            float c2, float c3, float* __restrict__ grad) {
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < total; i += (int64_t)gridDim.x * LOSS_T) {
+        const float t = tgt[i], w = wgt[i];
+        float g = 0.f;
+        if (t > 0.f && t < 80.f && w != 0.f) {
+            const float z = pred[i], p = depth_act_f(z, mode);
+            const float lm = (logf(p) - logf(t)) * w, r = (p - t) * w / t;
+            const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
+            g = ((c0 * lm + c1) * (w / p) + (c2 * r + c3 * sg) * (w / t)) * depth_act_df(z, mode);
+        }
+        grad[i] = g;
+    }
+}
+
+// ---- focal ------------------------------------------------------------------------------------------------------------------
+// pred [R][L], labels [R] (class index; >= L = background), weight [R][L]; out [nblk] doubles / grad [R][L]
+template <bool GRAD>
+__global__ __launch_bounds__(LOSS_T) void k_focal(const float* __restrict__ pred, const int64_t* __restrict__ labels,
+                                                  const float* __restrict__ wgt, int64_t R, int L, float gamma, float alpha, float scale,
+                                                  double* __restrict__ out, float* __restrict__ grad) {
+    __shared__ double lds[4];
+    double v[1] = {0};
+    const int64_t total = R * L;
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < total; i += (int64_t)gridDim.x * LOSS_T) {
+        const int64_t r = i / L;
+        const int c = (int)(i - r * L);
+        const float z = pred[i], t = labels[r] == c ? 1.f : 0.f, p = sigmoidf_(z), w = wgt[i];
+        const float pt = (1.f - p) * t + p * (1.f - t);
+        const float at = alpha * t + (1.f - alpha) * (1.f - t);
+        const float bce = bce_logits(z, t);
+        if (!GRAD) {
+            v[0] += (double)(bce * at * powf(pt, gamma) * w);
+        } else {
+            // d/dz [ at pt^g bce ] = at ( g pt^(g-1) dpt bce + pt^g (p - t) ),  dpt/dz = (1 - 2 t) p (1 - p)
+            const float dpt = (1.f - 2.f * t) * p * (1.f - p);
+            grad[i] = scale * w * at * (gamma * powf(pt, gamma - 1.f) * dpt * bce + powf(pt, gamma) * (p - t));
+        }
+    }
+    if (!GRAD) {
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) out[blockIdx.x] = v[0];
+    }
+}
+
+// =================================================================================================================================
+static int loss_grid(int64_t n, int cap) {
+    int64_t g = (n + LOSS_T - 1) / LOSS_T;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int ph_mask_loss_sums(const float* pred, const float* target, const float* weight, const int32_t* pos_rows, int P,
+                                 int64_t HW, int nsplit, double* out, void* stream) {
+    PH_CHECK_ARG(pred && target && weight && pos_rows && out && P > 0 && HW > 0 && nsplit >= 1 && nsplit <= 1024, "bad pointer or size");
+    hipLaunchKernelGGL(k_mask_loss_sums, dim3(nsplit, P), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, weight, pos_rows, HW,
+                       nsplit, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_mask_loss_grad(const float* pred, const float* target, const float* weight, const int32_t* pos_rows, int P,
+                                 int64_t HW, const float* coef, float* grad, void* stream) {
+    PH_CHECK_ARG(pred && target && weight && pos_rows && coef && grad && P > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_mask_loss_grad, dim3(loss_grid(HW, 64), P), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, weight,
+                       pos_rows, HW, coef, grad);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_rank_loss_blocks(int64_t HW) { return loss_grid(HW, 256); }
+
+extern "C" int ph_rank_loss_sum(const float* pred, const int32_t* rank_target, int B, int N, int64_t HW, int ignore_index,
+                                double* out /* [B * ph_rank_loss_blocks(HW)] */, void* stream) {
+    PH_CHECK_ARG(pred && rank_target && out && B > 0 && N > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_rank_loss_sum, dim3(loss_grid(HW, 256), B), dim3(LOSS_T), 0, (hipStream_t)stream, pred, rank_target, N, HW,
+                       ignore_index, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_rank_loss_grad(const float* pred, const int32_t* rank_target /* NULL: all zero */, int B, int N, int64_t HW,
+                                 int ignore_index, float scale, float* grad, void* stream) {
+    PH_CHECK_ARG(pred && grad && B > 0 && N > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_rank_loss_grad, dim3(loss_grid(HW, 256), B), dim3(LOSS_T), 0, (hipStream_t)stream, pred, rank_target, N, HW,
+                       ignore_index, scale, grad);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_depth_loss_blocks(int64_t total) { return loss_grid(total, 1024); }
+
+extern "C" int ph_depth_loss_sums(const float* pred, const float* target, const float* weight, int64_t total, int depth_mode,
+                                  double* out /* [ph_depth_loss_blocks(total)][5] */, void* stream) {
+    PH_CHECK_ARG(pred && target && weight && out && total > 0 && (depth_mode == 0 || depth_mode == 1), "bad pointer, size or mode");
+    hipLaunchKernelGGL(k_depth_loss_sums, dim3(loss_grid(total, 1024)), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, weight,
+                       total, depth_mode, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_depth_loss_grad(const float* pred, const float* target, const float* weight, int64_t total, int depth_mode,
+                                  float c0, float c1, float c2, float c3, float* grad, void* stream) {
+    PH_CHECK_ARG(pred && target && weight && grad && total > 0 && (depth_mode == 0 || depth_mode == 1), "bad pointer, size or mode");
+    hipLaunchKernelGGL(k_depth_loss_grad, dim3(loss_grid(total, 2048)), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, weight,
+                       total, depth_mode, c0, c1, c2, c3, grad);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_focal_loss_blocks(int64_t total) { return loss_grid(total, 256); }
+
+extern "C" int ph_focal_loss_sum(const float* pred, const int64_t* labels, const float* weight, int64_t R, int L, float gamma,
+                                 float alpha, double* out /* [ph_focal_loss_blocks(R * L)] */, void* stream) {
+    PH_CHECK_ARG(pred && labels && weight && out && R > 0 && L > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_focal<false>, dim3(loss_grid(R * L, 256)), dim3(LOSS_T), 0, (hipStream_t)stream, pred, labels, weight, R, L,
+                       gamma, alpha, 0.f, out, (float*)nullptr);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_focal_loss_grad(const float* pred, const int64_t* labels, const float* weight, int64_t R, int L, float gamma,
+                                  float alpha, float scale, float* grad, void* stream) {
+    PH_CHECK_ARG(pred && labels && weight && grad && R > 0 && L > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_focal<true>, dim3(loss_grid(R * L, 256)), dim3(LOSS_T), 0, (hipStream_t)stream, pred, labels, weight, R, L,
+                       gamma, alpha, scale, (double*)nullptr, grad);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

@@ -8,6 +8,7 @@ from . import _lib, engine as E
 from .bricks import (ConvModuleParams, FFNParams, MultiheadAttentionParams, bias_init_with_prob,
                      build_norm_layer)
 from .registry import build_loss, build_transformer_layer, register_everywhere
+from . import losses as _losses          # registers FocalLoss / CrossEntropyLoss / DiceLoss / DepthLoss under the reference's names
 
 
 class KernelUpdateHead(nn.Module):
@@ -136,10 +137,28 @@ class KernelUpdateHead(nn.Module):
         E.dynconv(dp, o["kern"], o["kbias"], 1, N, HW, mode.conv, logits_out=new_depth)
         return (o["cls"], new_mask, o["obj"].reshape(B, N, 256, 1, 1), new_depth, o["dobj"].reshape(B, N, 256, 1, 1))
 
-    def loss(self, *a, **k):
-        raise NotImplementedError("training (kernel_update_head.py:355-591) is outside the implemented hot path")
+    def loss(self, object_feats, cls_score, mask_pred, depth_pred, labels, label_weights, mask_targets, mask_weights,
+             depth_targets, depth_weights, imgs_whwh=None, reduction_override=None, with_grads=False, **kwargs):
+        """kernel_update_head.py:355-441: the stage's losses from its predictions at the assign stride and the targets of
+        `get_targets` -- `loss_depth`, `loss_cls`, `pos_acc`, `loss_rpn_mask`, `loss_rpn_dice`, `loss_rank` (the reference's
+        keys).  `with_grads=True` additionally returns d(sum of the losses) / d(mask_pred, cls_score, depth_pred)
+        (csrc/ph_loss.hip); no autograd graph is built."""
+        if reduction_override is not None:
+            raise NotImplementedError("libpolyhead: reduction_override is not used by the reference's training loop")
+        return _losses.stage_losses(self, cls_score, mask_pred, depth_pred, labels, label_weights, mask_targets, mask_weights,
+                                    depth_targets, depth_weights, with_grads=with_grads)
 
-    get_targets = loss
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
+                           pos_depth, neg_depth, gt_depth, gt_valid, cfg):
+        """kernel_update_head.py:443-531"""
+        return _losses.target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg,
+                                     gt_sem_cls, pos_depth, neg_depth, gt_depth, gt_valid, cfg)
+
+    def get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None,
+                    gt_depth=None):
+        """kernel_update_head.py:533-591"""
+        return _losses.get_targets(self, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat, gt_sem_seg, gt_sem_cls,
+                                   gt_depth)
 
 
 register_everywhere(KernelUpdateHead)

@@ -1,0 +1,324 @@
+"""Training-side losses of the hot path on libpolyhead's loss kernels (csrc/ph_loss.hip).
+
+Registry names, constructor kwargs and attributes are the reference's: `FocalLoss`, `CrossEntropyLoss`, `DiceLoss`
+(vendored mmdet, mmdet/models/losses/*.py) and `DepthLoss` (polyphonic/losses/depth_loss.py).  The modules hold the
+configuration; `stage_losses` is what `KernelUpdateHead.loss` (kernel_update_head.py:355-441) runs: four `*_sums` passes
+(mask BCE + dice, rank, depth, focal), a handful of scalars combined on the device in fp64 in a fixed order, and -- when
+asked -- four `*_grad` passes that write d(sum of the stage's losses) / d(mask_pred, cls_score, depth_pred), the first
+step of the backward pass.  The reference does the same arithmetic as ~40 ATen launches with boolean-mask gathers.
+No autograd graph is built (the backward of the kernels upstream is not part of this build yet)."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .registry import LOSSES
+
+DEPTH_MODES = {"sigmoid": 0, "monodepth": 1}
+
+
+def _gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.PolyheadError(f"{name} must live on the GPU: libpolyhead has no CPU path")
+
+
+def _f32(t):
+    return t.detach().contiguous().float()
+
+
+# ---- the four passes --------------------------------------------------------------------------------------------------------
+def mask_loss_sums(pred, target, weight, pos_rows, nsplit=None):
+    """pred / target / weight [R, HW] fp32, pos_rows int32 [P] -> float64 [P, 5] (BCE sum, count, a, b, c), fixed order"""
+    P, HW = pos_rows.numel(), pred.shape[1]
+    nsplit = nsplit or max(1, min(64, 2048 // max(P, 1)))
+    out = torch.empty((P, nsplit, 5), dtype=torch.float64, device=pred.device)
+    lib = _lib.load()
+    _lib.check(lib.ph_mask_loss_sums(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weight), _lib.ptr(pos_rows), P, HW, nsplit,
+                                     _lib.ptr(out), _lib.stream_ptr()), "ph_mask_loss_sums")
+    return out.sum(1)
+
+
+def rank_loss_sum(pred, rank_target, ignore):
+    B, N, H, W = pred.shape
+    lib = _lib.load()
+    out = torch.empty((B * lib.ph_rank_loss_blocks(H * W),), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.ph_rank_loss_sum(_lib.ptr(pred), _lib.ptr(rank_target), B, N, H * W, ignore, _lib.ptr(out), _lib.stream_ptr()),
+               "ph_rank_loss_sum")
+    return out.sum()
+
+
+def depth_loss_sums(pred, target, weight, mode):
+    lib = _lib.load()
+    total = pred.numel()
+    out = torch.empty((lib.ph_depth_loss_blocks(total), 5), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.ph_depth_loss_sums(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weight), total, mode, _lib.ptr(out),
+                                      _lib.stream_ptr()), "ph_depth_loss_sums")
+    return out.sum(0)
+
+
+def focal_loss_sum(pred, labels, weight, gamma, alpha):
+    lib = _lib.load()
+    R, L = pred.shape
+    out = torch.empty((lib.ph_focal_loss_blocks(R * L),), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.ph_focal_loss_sum(_lib.ptr(pred), _lib.ptr(labels), _lib.ptr(weight), R, L, gamma, alpha, _lib.ptr(out),
+                                     _lib.stream_ptr()), "ph_focal_loss_sum")
+    return out.sum()
+
+
+# ---- loss modules (configuration holders with the reference's names) -----------------------------------------------------------
+class _Loss(nn.Module):
+    def __init__(self, use_sigmoid=False, loss_weight=1.0, reduction="mean", **kw):
+        super().__init__()
+        self.use_sigmoid, self.loss_weight, self.reduction = use_sigmoid, loss_weight, reduction
+        self.cfg = dict(kw)
+
+
+class FocalLoss(_Loss):
+    """mmdet FocalLoss (focal_loss.py:160-244), the sigmoid form: forward(pred [R, L], target [R], weight [R, L], avg_factor)"""
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0, activated=False, **kw):
+        super().__init__(use_sigmoid, loss_weight, reduction, **kw)
+        if not use_sigmoid or activated:
+            raise NotImplementedError("libpolyhead: sigmoid focal loss on logits only (the shipped configs)")
+        self.gamma, self.alpha = gamma, alpha
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        _gpu(pred, "pred")
+        pred = _f32(pred)
+        w = torch.ones_like(pred) if weight is None else _f32(weight).expand_as(pred).contiguous()
+        s = focal_loss_sum(pred, target.long().contiguous(), w, self.gamma, self.alpha)
+        red = reduction_override or self.reduction
+        if avg_factor is not None:
+            s = s / avg_factor
+        elif red == "mean":
+            s = s / pred.numel()
+        return (self.loss_weight * s).float()
+
+
+class CrossEntropyLoss(_Loss):
+    """mmdet CrossEntropyLoss (cross_entropy_loss.py:163-251): the stage uses the sigmoid form on selected pixels (loss_mask)
+    and the softmax form over the mask channels (loss_rank); both are evaluated inside `stage_losses`"""
+
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction="mean", class_weight=None, ignore_index=None,
+                 loss_weight=1.0, **kw):
+        super().__init__(use_sigmoid, loss_weight, reduction, **kw)
+        if use_mask or class_weight is not None:
+            raise NotImplementedError("libpolyhead: use_mask / class_weight are not part of the shipped configs")
+        self.ignore_index = ignore_index
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("evaluated by KernelUpdateHead.loss / KernelHead.loss (losses.stage_losses)")
+
+
+class DiceLoss(_Loss):
+    """mmdet DiceLoss (dice_loss.py:49-136), sigmoid activation inside, eps 1e-3"""
+
+    def __init__(self, use_sigmoid=True, activate=True, reduction="mean", loss_weight=1.0, eps=1e-3, **kw):
+        super().__init__(use_sigmoid, loss_weight, reduction, **kw)
+        if not (use_sigmoid and activate):
+            raise NotImplementedError("libpolyhead: DiceLoss with the sigmoid inside (the shipped configs)")
+        self.eps, self.activate = eps, activate
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("evaluated by KernelUpdateHead.loss / KernelHead.loss (losses.stage_losses)")
+
+
+def _depth_from_sums(s, loss_weight, w3):
+    """DepthLoss from the five sums (depth_loss.py:19-32): returns (loss fp64 scalar tensor, coefficients of the grad pass)"""
+    n = s[0]
+    if float(n) == 0.0:
+        return s[0] * 0.0, (0.0, 0.0, 0.0, 0.0)
+    si = s[1] / n - s[2] / (n * n)                      # as the reference writes it: sum(log_minus) / n^2, not its square
+    sq = torch.sqrt(s[3] / n)
+    ab = s[4] / n
+    K = loss_weight / 3.0
+    loss = K * (w3[0] * si + w3[1] * sq + w3[2] * ab)
+    nf, sqf = float(n), float(sq)
+    coef = (K * w3[0] * 2.0 / nf, -K * w3[0] / (nf * nf), (K * w3[1] / (nf * sqf)) if sqf > 0 else 0.0, K * w3[2] / nf)
+    return loss, coef
+
+
+class DepthLoss(_Loss):
+    """polyphonic/losses/depth_loss.py:36-65: forward(pred logits, target, mask_weight) -> loss_weight * mean(weight * (si, sq_rel, abs_rel))"""
+
+    def __init__(self, loss_weight=1.0, depth_act_mode="monodepth", si_weight=1.0, sq_rel_weight=1.0, abs_rel_weight=1.0, **kw):
+        super().__init__(False, loss_weight, "mean", **kw)
+        self.depth_act_mode = depth_act_mode
+        self.weight = torch.tensor([si_weight, sq_rel_weight, abs_rel_weight], dtype=torch.float32)
+
+    def forward(self, pred, target, mask_weight, reduction_override="mean", **kwargs):
+        if not torch.any(self.weight > 0):
+            return (pred * 0).sum()
+        _gpu(pred, "pred")
+        s = depth_loss_sums(_f32(pred), _f32(target), _f32(mask_weight), DEPTH_MODES[self.depth_act_mode])
+        loss, _ = _depth_from_sums(s, self.loss_weight, [float(v) for v in self.weight])
+        if reduction_override == "sum":
+            loss = loss * 3.0
+        return loss.float()
+
+
+for _n, _c in (("FocalLoss", FocalLoss), ("CrossEntropyLoss", CrossEntropyLoss), ("DiceLoss", DiceLoss), ("DepthLoss", DepthLoss)):
+    LOSSES.register_module(name=_n, module=_c, force=True)
+
+
+# ---- one stage -----------------------------------------------------------------------------------------------------------------
+def stage_losses(head, cls_score, mask_pred, depth_pred, labels, label_weights, mask_targets, mask_weights, depth_targets,
+                 depth_weights, with_grads=False):
+    """KernelUpdateHead.loss (kernel_update_head.py:355-441).  cls_score [B, N, L], mask_pred / depth_pred [B, N, H, W] (at the
+    assign stride), targets as `get_targets` returns them.  Returns the reference's dict of losses (+ 'pos_acc'); with
+    `with_grads` also dict(mask_pred=, cls_score=, depth_pred=) = d(sum of the losses) / d(prediction)."""
+    _gpu(mask_pred, "mask_pred")
+    lib, dev = _lib.load(), mask_pred.device
+    B, N, H, W = mask_pred.shape
+    R, HW, L = B * N, H * W, head.num_classes
+    mp, dp, cs = _f32(mask_pred).reshape(R, HW), _f32(depth_pred).reshape(R, HW), _f32(cls_score).reshape(R, -1)
+    labels = labels.to(dev).long().contiguous()
+    pos = (labels >= 0) & (labels < L)                                                        # :375
+    num_pos = int(pos.sum())
+    avg = max(float(num_pos), 1.0)                                                            # :376-377 (single process: reduce_mean = id)
+    losses, grads = {}, None
+    if with_grads:
+        grads = dict(mask_pred=torch.empty((R, HW), dtype=torch.float32, device=dev),
+                     cls_score=torch.empty_like(cs), depth_pred=torch.empty((R, HW), dtype=torch.float32, device=dev))
+    # ---- depth (:383-391)
+    ld = head.loss_depth
+    mode = DEPTH_MODES[ld.depth_act_mode]
+    dt, dw = _f32(depth_targets).reshape(R, HW), _f32(depth_weights).reshape(R, HW)
+    w3 = [float(v) for v in ld.weight]
+    loss_d, dcoef = _depth_from_sums(depth_loss_sums(dp, dt, dw, mode), ld.loss_weight, w3)
+    losses["loss_depth"] = loss_d.float()
+    if with_grads:
+        _lib.check(lib.ph_depth_loss_grad(_lib.ptr(dp), _lib.ptr(dt), _lib.ptr(dw), R * HW, mode, *dcoef, _lib.ptr(grads["depth_pred"]),
+                                          _lib.stream_ptr()), "ph_depth_loss_grad")
+    # ---- classification (:393-402)
+    lc = head.loss_cls
+    lw = _f32(label_weights).reshape(R, -1)
+    losses["loss_cls"] = (lc.loss_weight * focal_loss_sum(cs, labels, lw, lc.gamma, lc.alpha) / avg).float()
+    if num_pos:
+        losses["pos_acc"] = (cs[pos].argmax(1) == labels[pos]).float().sum() * (100.0 / num_pos)       # mmdet accuracy, top-1
+    else:
+        losses["pos_acc"] = torch.zeros((), device=dev)
+    if with_grads:
+        _lib.check(lib.ph_focal_loss_grad(_lib.ptr(cs), _lib.ptr(labels), _lib.ptr(lw), R, cs.shape[1], lc.gamma, lc.alpha,
+                                          lc.loss_weight / avg, _lib.ptr(grads["cls_score"]), _lib.stream_ptr()), "ph_focal_loss_grad")
+    # ---- masks (:404-437)
+    ignore = head.ignore_label
+    lr = head.loss_rank
+    if num_pos:
+        mt, mw = _f32(mask_targets).reshape(R, HW), _f32(mask_weights).reshape(R, HW)
+        rows = pos.nonzero().flatten().to(torch.int32).contiguous()
+        s = mask_loss_sums(mp, mt, mw, rows)                                                   # [P, 5] fp64
+        ntot = s[:, 1].sum()
+        lm, ldice = head.loss_mask, head.loss_dice
+        losses["loss_rpn_mask"] = (lm.loss_weight * s[:, 0].sum() / ntot).float()              # BCE mean over the selected pixels
+        bc = s[:, 3] + s[:, 4] + 2 * ldice.eps
+        losses["loss_rpn_dice"] = (ldice.loss_weight * (1 - 2 * s[:, 2] / bc).mean()).float()
+        rank_target = None
+        if lr is not None:
+            # rank target (:420-432): pixel -> index (within its image) of the LAST positive row whose target covers it
+            rank_target = torch.full((B, HW), ignore, dtype=torch.int32, device=dev)
+            mtb = mt.reshape(B, N, HW) > 0
+            pb = pos.reshape(B, N)
+            for b, j in pb.nonzero(as_tuple=False).tolist():
+                rank_target[b][mtb[b, j]] = j
+            losses["loss_rank"] = (lr.loss_weight * rank_loss_sum(mp.reshape(B, N, H, W), rank_target, ignore) / (B * HW)).float()
+        if with_grads:
+            g = grads["mask_pred"]
+            if lr is not None:
+                _lib.check(lib.ph_rank_loss_grad(_lib.ptr(mp), _lib.ptr(rank_target), B, N, HW, ignore, lr.loss_weight / (B * HW),
+                                                 _lib.ptr(g), _lib.stream_ptr()), "ph_rank_loss_grad")
+            else:
+                g.zero_()
+            P = rows.numel()
+            coef = torch.stack([torch.full((P,), lm.loss_weight, dtype=torch.float64, device=dev) / ntot,
+                                -2.0 * ldice.loss_weight / (P * bc), 4.0 * ldice.loss_weight * s[:, 2] / (P * bc * bc)], 1)
+            coef = coef.float().contiguous()
+            _lib.check(lib.ph_mask_loss_grad(_lib.ptr(mp), _lib.ptr(mt), _lib.ptr(mw), _lib.ptr(rows), P, HW, _lib.ptr(coef),
+                                             _lib.ptr(g), _lib.stream_ptr()), "ph_mask_loss_grad")
+    else:                                                                                      # :438-441 (the reference's key names)
+        z = torch.zeros((), device=dev)
+        losses["loss_mask"], losses["loss_dice"] = z, z.clone()
+        if lr is not None:
+            losses["loss_rank"] = z.clone()
+        if with_grads:
+            grads["mask_pred"].zero_()
+    if with_grads:
+        grads = dict(mask_pred=grads["mask_pred"].reshape(B, N, H, W), cls_score=grads["cls_score"].reshape(B, N, -1),
+                     depth_pred=grads["depth_pred"].reshape(B, N, H, W))
+        return losses, grads
+    return losses
+
+
+# ---- targets (kernel_update_head.py:443-591) ------------------------------------------------------------------------------------
+def target_single(head, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, pos_depth,
+                  neg_depth, gt_depth, gt_valid, cfg):
+    """_get_target_single (:443-531): labels / weights / mask and depth targets of ONE image, tensors stay on their device"""
+    dev = pos_mask.device
+    num_pos, num_neg = pos_mask.shape[0], neg_mask.shape[0]
+    R = num_pos + num_neg
+    H, W = pos_mask.shape[-2:]
+    L, ns, nt = head.num_classes, head.num_stuff_classes, head.num_thing_classes
+    pw = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+    valid = gt_valid.to(dev).float()
+    labels = torch.full((R,), L, dtype=torch.long, device=dev)
+    label_weights = torch.zeros((R, L), device=dev)
+    mask_targets = torch.zeros((R, H, W), device=dev)
+    mask_weights = valid[None].expand(R, H, W).clone()                    # 1 on the valid pixels of every row
+    if num_pos:
+        labels[pos_inds] = pos_gt_labels
+        label_weights[pos_inds] = pw
+        mask_targets[pos_inds] = pos_gt_mask.float()
+    if num_neg:
+        label_weights[neg_inds] = 1.0
+    sem_rows = None
+    if gt_sem_cls is not None and gt_sem_seg is not None:
+        sem_labels = torch.full((ns,), L, dtype=torch.long, device=dev)
+        sem_targets = torch.zeros((ns, H, W), device=dev)
+        sem_weights = torch.zeros((ns, H, W), device=dev)
+        sem_label_weights = torch.cat([torch.zeros((ns, nt), device=dev), torch.eye(ns, device=dev)], -1)
+        if len(gt_sem_cls) > 0:
+            sem_rows = (gt_sem_cls - nt).long()
+            sem_labels[sem_rows] = gt_sem_cls.long()
+            sem_targets[sem_rows] = gt_sem_seg.float()
+            sem_weights[sem_rows] = 1
+        sem_weights = sem_weights * valid
+        label_weights[:, nt:] = 0
+        labels = torch.cat([labels, sem_labels])
+        label_weights = torch.cat([label_weights, sem_label_weights])
+        mask_targets = torch.cat([mask_targets, sem_targets])
+        mask_weights = torch.cat([mask_weights, sem_weights])
+    depth_targets = depth_weights = None
+    if pos_depth is not None:
+        assert neg_depth is not None and gt_depth is not None
+        Rd = R + ns
+        gd = gt_depth.to(dev).float()
+        depth_targets = torch.zeros((Rd, H, W), device=dev)
+        depth_weights = torch.zeros((Rd, H, W), device=dev)
+        if num_pos:
+            depth_targets[pos_inds] = gd
+            depth_weights[pos_inds] = pw * pos_gt_mask.float()
+        if sem_rows is not None:
+            depth_targets[sem_rows + R] = gd
+            depth_weights[sem_rows + R] = gt_sem_seg.float() * pw
+        depth_targets[-1] = gd                                            # the direct depth row (:525-528)
+        depth_weights[-1] = 1.0
+        depth_weights = depth_weights * (gd > 0.0).float()
+    return labels, label_weights, mask_targets, mask_weights, depth_targets, depth_weights
+
+
+def get_targets(head, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None,
+                gt_depth=None):
+    """KernelUpdateHead.get_targets (:533-591)"""
+    n = len(sampling_results)
+    if gt_sem_seg is None:
+        gt_sem_seg, gt_sem_cls = [None] * n, [None] * n
+    has_depth = gt_depth is not None
+    outs = []
+    for i, res in enumerate(sampling_results):
+        outs.append(target_single(head, res.pos_inds, res.neg_inds, res.pos_masks, res.neg_masks, res.pos_gt_masks, res.pos_gt_labels,
+                                  gt_sem_seg[i], gt_sem_cls[i], res.pos_depth if has_depth else None,
+                                  res.neg_depth if has_depth else None, gt_depth[i] if has_depth else None, res.valid_mask,
+                                  rcnn_train_cfg))
+    cols = list(zip(*outs))
+    if concat:
+        cols = [torch.cat(c, 0) if c[0] is not None else None for c in cols]
+    return tuple(cols)

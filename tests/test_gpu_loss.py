@@ -1,0 +1,89 @@
+"""GPU: the training-side targets and losses of one stage -- `KernelUpdateHead.get_targets` / `.loss` on the
+loss kernels (csrc/ph_loss.hip) against the REFERENCE's own outputs (tests/golden/loss.npz: the reference classes with the
+vendored mmdet losses and the project's DepthLoss, oracle/gen_golden_loss.py): targets bit for bit, every loss value,
+and d(sum of losses) / d(predictions) against the reference's autograd gradients."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from polyphonicformer_amd import assigner as A
+from polyphonicformer_amd.registry import HEADS, ConfigDict
+import polyphonicformer_amd.kernel_update_head  # noqa: F401
+import polyphonicformer_amd.kernel_updator  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _case(tag, gpu):
+    z = Hh.load_golden("loss.npz")
+    m = json.loads(bytes(z[f"{tag}_meta"]).decode())
+    L = m["n_thing"] + m["n_stuff"]
+    head = HEADS.build(Hh.stage_cfg(256, 2048, 8, L, m["n_thing"], m["n_stuff"]))
+    d = lambda k: torch.from_numpy(z[k]).to(gpu)
+    mask_pred, cls_score, depth_pred = d(f"{tag}_mask_pred"), d(f"{tag}_cls_score"), d(f"{tag}_depth_pred")
+    sampling, gts = [], []
+    for b in range(m["B"]):
+        g = {k: d(f"{tag}_gt{b}_{k}") for k in ("masks", "labels", "sem_seg", "sem_cls", "depth", "gt_inds", "assigned_labels")}
+        gts.append(g)
+        ar = A.AssignResult(len(g["labels"]), g["gt_inds"], None, labels=g["assigned_labels"])
+        sr = A.MaskPseudoSampler().sample(ar, mask_pred[b], g["masks"], depth=depth_pred[b])
+        sr.valid_mask = d(f"{tag}_valid{b}")
+        sampling.append(sr)
+    return z, m, head, mask_pred, cls_score, depth_pred, sampling, gts
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stage_targets_and_losses_vs_reference(gpu, tag):
+    z, m, head, mask_pred, cls_score, depth_pred, sampling, gts = _case(tag, gpu)
+    tg = head.get_targets(sampling, [g["masks"] for g in gts], [g["labels"] for g in gts], ConfigDict(pos_weight=1), True,
+                          gt_sem_seg=[g["sem_seg"] for g in gts], gt_sem_cls=[g["sem_cls"] for g in gts],
+                          gt_depth=[g["depth"] for g in gts])
+    for k, t in zip(("labels", "label_weights", "mask_targets", "mask_weights", "depth_targets", "depth_weights"), tg):
+        assert t.is_cuda and np.array_equal(t.cpu().numpy(), z[f"{tag}_t_{k}"]), k
+    losses, grads = head.loss(None, cls_score, mask_pred, depth_pred, *tg, with_grads=True)
+    want_keys = {k[len(tag) + 3:] for k in z.files if k.startswith(f"{tag}_l_")}
+    assert set(losses) == want_keys
+    for k, v in losses.items():
+        want = float(np.asarray(z[f"{tag}_l_{k}"]).reshape(-1)[0])
+        assert abs(float(v) - want) <= 2e-5 * max(1.0, abs(want)), (k, float(v), want)
+    for name in ("mask_pred", "cls_score", "depth_pred"):
+        e = Hh.rel_err(grads[name].cpu(), z[f"{tag}_g_{name}"])
+        assert e < 1e-4, (name, e)
+    # bit-reproducible: fixed-order partial sums
+    losses2 = head.loss(None, cls_score, mask_pred, depth_pred, *tg)
+    assert all(torch.equal(losses[k], losses2[k]) for k in losses)
+
+
+def test_stage_loss_without_positives(gpu):
+    """no matched prediction (kernel_update_head.py:438-441): zero mask losses under the reference's key names"""
+    z, m, head, mask_pred, cls_score, depth_pred, sampling, gts = _case("c", gpu)
+    R = mask_pred.shape[0] * mask_pred.shape[1]
+    L = head.num_classes
+    H, W = mask_pred.shape[-2:]
+    labels = torch.full((R,), L, dtype=torch.long, device=gpu)
+    zeros = torch.zeros((R, H, W), device=gpu)
+    losses, grads = head.loss(None, cls_score, mask_pred, depth_pred, labels, torch.ones((R, L), device=gpu), zeros, zeros + 1,
+                              zeros, zeros, with_grads=True)
+    assert float(losses["loss_mask"]) == 0 and float(losses["loss_dice"]) == 0 and float(losses["loss_rank"]) == 0
+    assert float(losses["loss_depth"]) == 0 and float(losses["pos_acc"]) == 0 and float(losses["loss_cls"]) > 0
+    assert not grads["mask_pred"].any() and not grads["depth_pred"].any() and grads["cls_score"].any()
+
+
+def test_depth_and_focal_modules(gpu):
+    """the loss modules called on their own, as the reference's other call sites do (kernel_head.py:456-569)"""
+    from polyphonicformer_amd import losses as Lo
+    from oracle import loss_oracle as LO
+    g = torch.Generator().manual_seed(3)
+    pred, tgt = torch.randn(5, 20, 30, generator=g), torch.rand(5, 20, 30, generator=g) * 90
+    w = (torch.rand(5, 20, 30, generator=g) > 0.3).float() * 0.7
+    for mode in ("sigmoid", "monodepth"):
+        got = Lo.DepthLoss(loss_weight=5.0, depth_act_mode=mode)(pred.to(gpu), tgt.to(gpu), w.to(gpu))
+        assert abs(float(got) - float(LO.depth_loss(pred, tgt, w, mode))) < 2e-5 * abs(float(got))
+    cs, lab = torch.randn(50, 19, generator=g), torch.randint(0, 20, (50,), generator=g)
+    lw = torch.rand(50, 19, generator=g)
+    got = Lo.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0)(cs.to(gpu), lab.to(gpu), lw.to(gpu), avg_factor=7.0)
+    assert abs(float(got) - float(LO.focal_loss(cs, lab, lw, 7.0))) < 2e-5 * abs(float(got))
