@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, HERE)
 import helpers as Hh                     # noqa: E402
 from oracle import ref_loader as R       # noqa: E402
 
@@ -149,5 +150,69 @@ def main():
     print("bytes:", os.path.getsize(os.path.join(OUT, "loss.npz")))
 
 
+def train_gt(seed, B, H, W, n_thing, n_stuff, gts):
+    """ground truth of a training step at the assign stride (H x W = the x2-upsampled mask size), shared with the tests"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for b in range(B):
+        G = gts[b]
+        masks = (torch.rand(G, H, W, generator=g) > 0.75).float()
+        labels = torch.randint(0, n_thing, (G,), generator=g)
+        present = torch.randperm(n_stuff, generator=g)[: n_stuff // 2 + 1].sort()[0]
+        sem_cls = present + n_thing
+        sem_seg = (torch.rand(len(present), H, W, generator=g) > 0.6).float()
+        depth = torch.rand(H, W, generator=g) * 90.0
+        depth[torch.rand(H, W, generator=g) < 0.1] = 0.0
+        out.append(dict(masks=masks, labels=labels, sem_seg=sem_seg, sem_cls=sem_cls, depth=depth))
+    return out
+
+
+def forward_train_fixture():
+    """KernelUpdateIterHead.forward_train (polyphonic/kernel_update.py:159-280) of the reference: S = 3 stages at the FULL
+    channel sizes, the reference's Hungarian assigner (funcs/assigner.py + mmdet FocalLossCost), MaskPseudoSampler,
+    get_targets and the real losses.  Weights / inputs are regenerated from seeds by the tests (helpers.seeded_fill,
+    helpers.iter_inputs); the ground truth is stored.  -> tests/golden/train.npz"""
+    import copy
+    import gen_golden as G
+    ns = R.load_reference()
+    reg, accuracy = load_real_losses(ns)
+    sys.modules["polyphonic.kernel_update_head"].accuracy = accuracy
+    na = R.load_reference_assigner()
+    cfg = Hh.FULL
+    B, H, W, S = 2, 8, 16, cfg["S"]
+    ih, kh, sd, shapes = G.build(ns, cfg)
+    N = cfg["Nq"] + cfg["n_stuff"]
+    acfg = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True),
+                depth_cost=dict(type='DepthCost', weight=0., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.),
+                                depth_act_mode='sigmoid'))
+    Sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler
+    ih.mask_assigner = [na.Assigner(**copy.deepcopy(acfg)) for _ in range(S)]
+    ih.mask_sampler = [Sampler() for _ in range(S)]
+    ih.train_cfg = [ns.ConfigDict(pos_weight=1.0) for _ in range(S)]
+    for st in ih.mask_head:
+        for k, c in LOSS_CFG.items():
+            setattr(st, k, reg.build(dict(c)))
+    ih.train()
+    inp = Hh.iter_inputs(G.ISEED, B, N, cfg["C"], H, W)
+    gts = train_gt(31, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], [6, 9])
+    metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
+    with torch.no_grad():
+        losses = ih.forward_train(inp["x"], inp["k0"], inp["m0"], None, metas, [g["masks"] for g in gts], [g["labels"] for g in gts],
+                                  gt_depth=[g["depth"] for g in gts], depth_preds=inp["depth_pred"], depth_feats=inp["dfe"],
+                                  depth_proposal=inp["q0"], gt_sem_seg=[g["sem_seg"] for g in gts],
+                                  gt_sem_cls=[g["sem_cls"] for g in gts])
+    out = {"meta_json": np.frombuffer(json.dumps(dict(B=B, H=H, W=W, S=S, N=N, iseed=G.ISEED, wseed=G.WSEED, gt_seed=31, gts=[6, 9])).encode(),
+                                      dtype=np.uint8)}
+    for b, g in enumerate(gts):
+        for k, v in g.items():
+            out[f"gt{b}_{k}"] = v.numpy()
+    for k, v in losses.items():
+        out[f"l_{k}"] = np.asarray(float(v), dtype=np.float64)
+    print({k: round(float(v), 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    forward_train_fixture()

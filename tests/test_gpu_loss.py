@@ -87,3 +87,42 @@ def test_depth_and_focal_modules(gpu):
     lw = torch.rand(50, 19, generator=g)
     got = Lo.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0)(cs.to(gpu), lab.to(gpu), lw.to(gpu), avg_factor=7.0)
     assert abs(float(got) - float(LO.focal_loss(cs, lab, lw, 7.0))) < 2e-5 * abs(float(got))
+
+
+def test_forward_train_vs_reference(gpu):
+    """KernelUpdateIterHead.forward_train (kernel_update.py:159-280), forward side, S = 3 at the full channel sizes: stage
+    forwards on libpolyhead, Hungarian assignment (ph_match_sums + scipy), pseudo sampling, get_targets, stage losses --
+    all 18 `s{stage}_{loss}` values against the REFERENCE's (tests/golden/train.npz: the reference head with its own
+    assigner, sampler and the real loss modules).  Free running over three stages and three discrete assignments."""
+    from test_gpu_parity import _full_weights
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_update  # noqa: F401
+    z = Hh.load_golden("train.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    B, H, W, S, N = m["B"], m["H"], m["W"], m["S"], m["N"]
+    assigner = dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                    dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True),
+                    depth_cost=dict(type='DepthCost', weight=0., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.), depth_act_mode='sigmoid'))
+    head = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=S, assign_stages=S, stage_loss_weights=[1] * S, num_proposals=100,
+                            num_thing_classes=8, num_stuff_classes=11, do_panoptic=True, merge_joint=True,
+                            mask_head=Hh.stage_cfg(256, 2048, 8, 19, 8, 11),
+                            train_cfg=dict(assigner=assigner, sampler=dict(type='MaskPseudoSampler'), pos_weight=1.)))
+    sd = _full_weights()
+    head.load_state_dict({k[len("roi_head."):]: v for k, v in sd.items() if k.startswith("roi_head.")})
+    head.to(gpu).eval()
+    head.set_precision("fp32")
+    inp = {k: v.to(gpu) for k, v in Hh.iter_inputs(m["iseed"], B, N, 256, H, W).items()}
+    gts = [{k: torch.from_numpy(z[f"gt{b}_{k}"]).to(gpu) for k in ("masks", "labels", "sem_seg", "sem_cls", "depth")} for b in range(B)]
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    losses = head.forward_train(inp["x"], inp["k0"], inp["m0"], None, metas, [g["masks"] for g in gts], [g["labels"] for g in gts],
+                                gt_depth=[g["depth"] for g in gts], depth_preds=inp["depth_pred"], depth_feats=inp["dfe"],
+                                depth_proposal=inp["q0"], gt_sem_seg=[g["sem_seg"] for g in gts], gt_sem_cls=[g["sem_cls"] for g in gts],
+                                with_grads=True)
+    grads = losses.pop("_grads")
+    want = {k[2:]: float(np.asarray(z[k]).reshape(-1)[0]) for k in z.files if k.startswith("l_")}
+    assert set(losses) == set(want) and len(want) == 6 * S
+    err = {k: abs(float(losses[k]) - want[k]) / max(1.0, abs(want[k])) for k in want}
+    print("forward_train losses vs reference, max rel err", max(err.values()), {k: round(float(v), 4) for k, v in losses.items()})
+    assert max(err.values()) < 1e-3, err
+    assert len(grads) == S and grads[0]["mask_pred"].shape == (B, N, 2 * H, 2 * W) and grads[0]["cls_score"].shape == (B, N, 19)
+    assert not head.training            # the training flag is restored
