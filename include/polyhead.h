@@ -246,6 +246,12 @@ int ph_focal_loss_sum(const float* pred, const int64_t* labels, const float* wei
                       double* out, void* stream);
 int ph_focal_loss_grad(const float* pred, const int64_t* labels, const float* weight, int64_t R, int L, float gamma, float alpha,
                        float scale, float* grad, void* stream);
+/* the same focal loss over a class-major map: pred [B][L][HW], target int32 [B][HW] (== L: pixel not selected) -- KernelHead's
+ * loss_rpn_seg, kernel_head.py:538-551; out [B * ph_rank_loss_blocks(HW)], grad [B][L][HW] (overwritten) */
+int ph_seg_focal_sum(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha, double* out,
+                     void* stream);
+int ph_seg_focal_grad(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha, float scale,
+                      float* grad, void* stream);
 
 /* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
  * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.

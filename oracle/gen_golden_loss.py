@@ -150,21 +150,7 @@ def main():
     print("bytes:", os.path.getsize(os.path.join(OUT, "loss.npz")))
 
 
-def train_gt(seed, B, H, W, n_thing, n_stuff, gts):
-    """ground truth of a training step at the assign stride (H x W = the x2-upsampled mask size), shared with the tests"""
-    g = torch.Generator().manual_seed(seed)
-    out = []
-    for b in range(B):
-        G = gts[b]
-        masks = (torch.rand(G, H, W, generator=g) > 0.75).float()
-        labels = torch.randint(0, n_thing, (G,), generator=g)
-        present = torch.randperm(n_stuff, generator=g)[: n_stuff // 2 + 1].sort()[0]
-        sem_cls = present + n_thing
-        sem_seg = (torch.rand(len(present), H, W, generator=g) > 0.6).float()
-        depth = torch.rand(H, W, generator=g) * 90.0
-        depth[torch.rand(H, W, generator=g) < 0.1] = 0.0
-        out.append(dict(masks=masks, labels=labels, sem_seg=sem_seg, sem_cls=sem_cls, depth=depth))
-    return out
+train_gt = Hh.train_gt
 
 
 def forward_train_fixture():
@@ -213,6 +199,60 @@ def forward_train_fixture():
     np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
 
 
+RPN_LOSS_CFG = dict(
+    loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+    loss_seg=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+    loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+    loss_dice=dict(type="DiceLoss", loss_weight=4.0),
+    loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid", si_weight=1.0, sq_rel_weight=1.0, abs_rel_weight=1.0))
+
+
+def rpn_train_fixture():
+    """KernelHead.forward_train (polyphonic/kernel_head.py:349-454) of the reference: post-neck decode in training mode (no
+    stuff rows), x2 upsample of the mask / seg / depth predictions, the rpn Hungarian assignment, get_targets (:572-698),
+    loss (:456-569: loss_depth, loss_rpn_mask, loss_rpn_dice, loss_rpn_rank, loss_rpn_seg) and depth_dense.
+    -> tests/golden/train_rpn.npz (losses + the tensors the method hands to the roi head)"""
+    import copy
+    import gen_golden as G
+    ns = R.load_reference()
+    reg, accuracy = load_real_losses(ns)
+    sys.modules["polyphonic.kernel_head"].accuracy = accuracy
+    na = R.load_reference_assigner()
+    cfg = Hh.FULL
+    B, H, W = 2, 8, 16
+    ih, kh, sd, shapes = G.build(ns, cfg)
+    acfg = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    kh.assigner = na.Assigner(**copy.deepcopy(acfg))
+    kh.sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler()
+    kh.train_cfg = ns.ConfigDict(pos_weight=1.0)
+    for k, c in RPN_LOSS_CFG.items():
+        setattr(kh, k, reg.build(dict(c)))
+    kh.train()
+    feats = Hh.neck_inputs(G.NSEED, B, cfg["C"], H, W)
+    gts = train_gt(41, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], [7, 4])
+    metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
+    with torch.no_grad():
+        r = kh.forward_train(feats, metas, [g["masks"] for g in gts], [g["labels"] for g in gts], gt_sem_seg=[g["sem_seg"] for g in gts],
+                             gt_sem_cls=[g["sem_cls"] for g in gts], gt_depth=torch.stack([g["depth"][None] for g in gts]))
+    losses, proposal_feats, x_feats, mask_preds, cls_scores, depth_feats, depth_proposal, depth_pred, aspp = r
+    assert cls_scores is None and aspp is None
+    N = cfg["Nq"] + cfg["n_stuff"]
+    out = {"meta_json": np.frombuffer(json.dumps(dict(B=B, H=H, W=W, N=N, nseed=G.NSEED, wseed=G.WSEED, gt_seed=41, gts=[7, 4])).encode(),
+                                      dtype=np.uint8)}
+    for b, g in enumerate(gts):
+        for k, v in g.items():
+            out[f"gt{b}_{k}"] = v.numpy()
+    for k, v in losses.items():
+        out[f"l_{k}"] = np.asarray(float(v), dtype=np.float64)
+    out["proposal_feats"] = proposal_feats.reshape(B, N, -1).numpy()
+    out["mask_preds"] = mask_preds.numpy()
+    out["depth_proposal"] = depth_proposal.reshape(B, N, -1).numpy()
+    print({k: round(float(v), 5) for k, v in losses.items()}, tuple(mask_preds.shape), tuple(depth_proposal.shape))
+    np.savez_compressed(os.path.join(OUT, "train_rpn.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
     forward_train_fixture()
+    rpn_train_fixture()

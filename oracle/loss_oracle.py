@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement (the *oracle*) of the training-side targets and losses of one
-KernelUpdateHead stage.  Plain fp32 torch on the CPU, functional; every function cites the reference lines it follows.
+KernelUpdateHead stage and of KernelHead (the rpn side).  Plain fp32 torch on the CPU, functional; every function cites the reference lines it follows.
 Pinned by tests/golden/loss.npz, which `oracle/gen_golden_loss.py` produced with the reference's own
 `KernelUpdateHead.get_targets` / `.loss`, the vendored mmdet FocalLoss / CrossEntropyLoss / DiceLoss / accuracy and the
-project's DepthLoss (tests/test_loss_oracle.py).  Only tests may import this file."""
+project's DepthLoss and by tests/golden/train_rpn.npz (the reference's KernelHead.forward_train) (tests/test_loss_oracle.py).  Only tests may
+import this file."""
 import torch
 import torch.nn.functional as F
 
@@ -160,3 +161,88 @@ def stage_loss(num_classes, cls_score, mask_pred, depth_pred, labels, label_weig
         losses["loss_dice"] = mask_pred.sum() * 0
         losses["loss_rank"] = mask_pred.sum() * 0
     return losses
+
+
+# ---- KernelHead._get_target_single / get_targets / loss (kernel_head.py:456-698) --------------------------------------------
+def rpn_target_single(num_classes, n_thing, n_stuff, pos_inds, neg_inds, num_samples, H, W, pos_gt_mask, pos_gt_labels, gt_sem_seg,
+                      gt_sem_cls, gt_depth, gt_valid, pos_weight=1.0):
+    labels = torch.full((num_samples,), num_classes, dtype=torch.long)                       # :583-586
+    label_weights = torch.zeros(num_samples)
+    mask_targets = torch.zeros((num_samples, H, W))
+    mask_weights = torch.zeros((num_samples, H, W))
+    mask_weights[..., gt_valid.bool()] = 1.0                                                 # :589
+    seg_targets = torch.full((H, W), num_classes, dtype=torch.long)
+    for sem_mask, sem_cls in zip(gt_sem_seg.bool(), gt_sem_cls):                             # :594-597
+        seg_targets[sem_mask] = sem_cls.long()
+    pw = 1.0 if pos_weight <= 0 else pos_weight
+    if len(pos_inds):                                                                        # :599-605
+        labels[pos_inds] = pos_gt_labels
+        label_weights[pos_inds] = pw
+        mask_targets[pos_inds] = pos_gt_mask
+        for i in range(len(pos_inds)):
+            seg_targets[pos_gt_mask[i].bool()] = pos_gt_labels[i]
+    if len(neg_inds):
+        label_weights[neg_inds] = 1.0
+    R = num_samples + n_stuff                                                                # :610-640
+    depth_targets = torch.zeros((R, H, W))
+    depth_weights = torch.zeros((R, H, W))
+    depth_valid = (gt_depth.reshape(1, H, W).repeat(R, 1, 1) > 0.0).float()
+    if len(pos_inds):
+        depth_targets[pos_inds] = gt_depth.reshape(1, H, W).repeat(len(pos_inds), 1, 1)
+        depth_weights[pos_inds] = pw * pos_gt_mask
+    if len(gt_sem_cls) > 0:
+        rows = (gt_sem_cls - n_thing).long() + num_samples
+        depth_targets[rows] = gt_depth.reshape(H, W)
+        depth_weights[rows] = gt_sem_seg * pw
+    depth_weights = depth_weights * depth_valid
+    return labels, label_weights, mask_targets, mask_weights, seg_targets, depth_targets, depth_weights
+
+
+def rpn_get_targets(num_classes, n_thing, n_stuff, Nq, H, W, gts, valids):
+    """as `get_targets` above; seg_targets are stacked (kernel_head.py:688)"""
+    outs = []
+    for g, v in zip(gts, valids):
+        pos = (g["gt_inds"] > 0).nonzero().flatten()
+        neg = (g["gt_inds"] == 0).nonzero().flatten()
+        pos_gt = g["masks"][g["gt_inds"][pos] - 1] if len(g["masks"]) else g["masks"][:0]
+        outs.append(rpn_target_single(num_classes, n_thing, n_stuff, pos, neg, Nq, H, W, pos_gt, g["assigned_labels"][pos], g["sem_seg"],
+                                      g["sem_cls"], g["depth"], v))
+    return tuple(torch.stack([o[k] for o in outs], 0) if k == 4 else torch.cat([o[k] for o in outs], 0) for k in range(7))
+
+
+def rpn_loss(num_classes, mask_pred, seg_preds, depth_pred, labels, label_weights, mask_targets, mask_weights, seg_targets,
+             depth_targets, depth_weights, ignore_label=255):
+    """KernelHead.loss with the shipped losses (polyphonic_former.py:66-97): cls_scores and semantic_aspp are None"""
+    losses = {}
+    pos = (labels >= 0) & (labels < num_classes)                                             # :475
+    B, N, H, W = mask_pred.shape
+    R = B * N
+    Rd = depth_targets.shape[0]                      # B * (proposals + stuff rows): forward_train expands the one map (:386)
+    losses["loss_depth"] = depth_loss(depth_pred.expand(B, Rd // B, H, W).reshape(Rd, H, W), depth_targets, depth_weights)   # :478-486
+    if pos.any():                                                                            # :503-531
+        pm = mask_pred.reshape(R, H, W)[pos]
+        pt = mask_targets[pos]
+        pw = mask_weights[pos].bool()
+        losses["loss_rpn_mask"] = bce_mean(pm[pw], pt[pw])
+        losses["loss_rpn_dice"] = torch.stack([dice_one(pm[i][pw[i]], pt[i][pw[i]]) for i in range(pm.shape[0])]).mean()
+        rank_target = torch.full((B, H, W), ignore_label, dtype=torch.long)
+        mt = mask_targets.view(B, -1, H, W).bool()
+        for b, j in pos.view(B, -1).nonzero(as_tuple=False).tolist():
+            rank_target[b][mt[b][j]] = j
+        losses["loss_rpn_rank"] = rank_loss(mask_pred, rank_target, ignore_label)
+    else:                                                                                    # :533-537
+        losses["loss_rpn_mask"] = mask_pred.sum() * 0
+        losses["loss_rpn_dice"] = mask_pred.sum() * 0
+        losses["loss_rank"] = mask_pred.sum() * 0
+    L = seg_preds.shape[1]                                                                   # :539-551
+    sel = seg_targets != L
+    flat = seg_preds.permute(1, 0, 2, 3)[..., sel].permute(1, 0)
+    ft = seg_targets[sel]
+    nd = ((ft >= 0) & (ft < num_classes)).sum().float().clamp(min=1.0)
+    losses["loss_rpn_seg"] = focal_loss(flat, ft, torch.ones(()), nd, loss_weight=1.0)
+    return losses
+
+
+def dense_depth(depth_pred, gt_depth):
+    """losses['depth_dense'] (kernel_head.py:438-442)"""
+    return depth_loss(depth_pred, gt_depth, (gt_depth > 0).float())

@@ -199,6 +199,42 @@ __global__ __launch_bounds__(LOSS_T) void k_focal(const float* __restrict__ pred
     }
 }
 
+// ---- focal loss over a class-major map: pred [B][L][HW], target [B][HW] (class index; == L: pixel not selected) -------------
+// KernelHead's loss_rpn_seg (kernel_head.py:538-551): the pixels with seg_targets != L, all L classes of each
+template <bool GRAD>
+__global__ __launch_bounds__(LOSS_T) void k_seg_focal(const float* __restrict__ pred, const int* __restrict__ target, int L, int64_t HW,
+                                                      float gamma, float alpha, float scale, double* __restrict__ out,
+                                                      float* __restrict__ grad) {
+    __shared__ double lds[4];
+    const int b = blockIdx.y;
+    const float* pb = pred + (int64_t)b * L * HW;
+    double v[1] = {0};
+    for (int64_t i = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; i < HW; i += (int64_t)gridDim.x * LOSS_T) {
+        const int tg = target[(int64_t)b * HW + i];
+        const bool sel = tg != L;
+        for (int c = 0; c < L; ++c) {
+            const int64_t idx = (int64_t)c * HW + i;
+            if (!sel) {
+                if (GRAD) grad[(int64_t)b * L * HW + idx] = 0.f;
+                continue;
+            }
+            const float z = pb[idx], t = tg == c ? 1.f : 0.f, p = sigmoidf_(z);
+            const float pt = (1.f - p) * t + p * (1.f - t);
+            const float at = alpha * t + (1.f - alpha) * (1.f - t);
+            const float bce = bce_logits(z, t);
+            if (!GRAD) v[0] += (double)(bce * at * powf(pt, gamma));
+            else {
+                const float dpt = (1.f - 2.f * t) * p * (1.f - p);
+                grad[(int64_t)b * L * HW + idx] = scale * at * (gamma * powf(pt, gamma - 1.f) * dpt * bce + powf(pt, gamma) * (p - t));
+            }
+        }
+    }
+    if (!GRAD) {
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) out[(int64_t)b * gridDim.x + blockIdx.x] = v[0];
+    }
+}
+
 // =================================================================================================================================
 static int loss_grid(int64_t n, int cap) {
     int64_t g = (n + LOSS_T - 1) / LOSS_T;
@@ -279,6 +315,24 @@ extern "C" int ph_focal_loss_grad(const float* pred, const int64_t* labels, cons
     PH_CHECK_ARG(pred && labels && weight && grad && R > 0 && L > 0, "bad pointer or size");
     hipLaunchKernelGGL(k_focal<true>, dim3(loss_grid(R * L, 256)), dim3(LOSS_T), 0, (hipStream_t)stream, pred, labels, weight, R, L,
                        gamma, alpha, scale, (double*)nullptr, grad);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_seg_focal_sum(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha,
+                                double* out /* [B * ph_rank_loss_blocks(HW)] */, void* stream) {
+    PH_CHECK_ARG(pred && target && out && B > 0 && L > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_seg_focal<false>, dim3(loss_grid(HW, 256), B), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, L, HW, gamma,
+                       alpha, 0.f, out, (float*)nullptr);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_seg_focal_grad(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha,
+                                 float scale, float* grad, void* stream) {
+    PH_CHECK_ARG(pred && target && grad && B > 0 && L > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_seg_focal<true>, dim3(loss_grid(HW, 256), B), dim3(LOSS_T), 0, (hipStream_t)stream, pred, target, L, HW, gamma,
+                       alpha, scale, (double*)nullptr, grad);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

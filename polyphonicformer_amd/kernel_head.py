@@ -1,12 +1,13 @@
-"""KernelHead -- drop-in for polyphonic/kernel_head.py:11-347,700-706 (inference side).
+"""KernelHead -- drop-in for polyphonic/kernel_head.py:11-706.
 Same registry name, constructor kwargs, attribute and state_dict names.  Everything after
-`localization_fpn(img)` (kernel_head.py:243) runs in libpolyhead."""
+`localization_fpn(img)` (kernel_head.py:243) runs in libpolyhead; `forward_train` is the forward side of
+the training step (predictions, assignment, targets, losses and their gradients w.r.t. the predictions)."""
 import torch
 import torch.nn as nn
 
 from . import _lib, engine as E
 from .bricks import ConvModuleParams, bias_init_with_prob
-from .registry import NECKS, build_loss, build_neck, register_everywhere
+from .registry import NECKS, ConfigDict, build_loss, build_neck, register_everywhere
 
 
 class KernelHead(nn.Module):
@@ -69,6 +70,13 @@ class KernelHead(nn.Module):
         self.precision = "fp32"
         self.emit_fp32_features = True     # the reference API returns x_feats / depth_feats as fp32 NCHW tensors
         self._pack, self._plans = None, {}
+        self.assigner = self.sampler = None
+        if self.train_cfg:                 # kernel_head.py:134-140
+            from . import assigner as A
+            if isinstance(self.train_cfg, dict) and not isinstance(self.train_cfg, ConfigDict):
+                self.train_cfg = ConfigDict(self.train_cfg)
+            self.assigner = A.build_assigner(dict(self.train_cfg.assigner))
+            self.sampler = A.build_sampler(dict(self.train_cfg.get('sampler', None) or dict(type='MaskPseudoSampler')))
 
     def init_weights(self):
         """kernel_head.py:213-238"""
@@ -108,10 +116,8 @@ class KernelHead(nn.Module):
         return self._pack[1]
 
     def _decode_init_proposals(self, img, img_metas, train_tracking=False):
-        """kernel_head.py:240-347 (eval).  `img`: the FPN tuple when `localization_fpn` is a module,
-        otherwise the three post-neck maps [B,256,H,W]."""
-        if self.training:
-            raise NotImplementedError("training is outside the implemented hot path")
+        """kernel_head.py:240-347.  `img`: the FPN tuple when `localization_fpn` is a module, otherwise the three post-neck
+        maps [B,256,H,W].  In training mode the stuff rows are not appended here (:329) -- `forward_train` does it (:444-451)."""
         neck = self.localization_fpn
         handoff = neck is not None and hasattr(neck, "forward_planes") and getattr(neck, "num_aux_convs", 0) == 2 \
             and E.PREC.get(getattr(neck, "precision", None)) == E.PREC[self.precision]      # codes: 'split' == 'fp32'
@@ -158,10 +164,81 @@ class KernelHead(nn.Module):
     def forward_dummy(self, img, img_metas):
         return self._decode_init_proposals(img, img_metas)
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError("training (kernel_head.py:349-698) is outside the implemented hot path")
+    def forward_train(self, img, img_metas, gt_masks, gt_labels, gt_sem_seg=None, gt_sem_cls=None, gt_depth=None, with_grads=False):
+        """kernel_head.py:349-454, FORWARD side: the decode in training mode, the x`feat_downsample_stride` upsample of the
+        mask / seg / depth predictions (ph_upsample2x), the Hungarian assignment on the detached masks (`assigner.py`),
+        pseudo sampling, `get_targets`, `loss` and `depth_dense`; returns the reference's 9-tuple, the stuff rows appended
+        when `cat_stuff_mask`.  `gt_depth`: [B, 1, H, W] at the scaled size, as the dataset pipeline delivers it.
+        `with_grads=True` adds losses['_grads'] = d(sum of the losses) / d(scaled mask, seg and direct depth predictions).
+        No autograd graph: this evaluates the objective, it does not train."""
+        from . import losses as Lo
+        if self.assigner is None:
+            raise ValueError("forward_train needs train_cfg (assigner / sampler)")
+        num_imgs = len(img_metas)
+        was_training, self.training = self.training, True
+        try:
+            results = self._decode_init_proposals(img, img_metas)
+        finally:
+            self.training = was_training
+        proposal_feats, x_feats, mask_preds, cls_scores, seg_preds, depth_feats, depth_proposal, depth_pred, aspp = results
+        up = self.feat_downsample_stride
+        if up not in (1, 2):
+            raise NotImplementedError("libpolyhead: feat_downsample_stride must be 1 or 2")
+        scale = (lambda t: E.upsample2x(t.float().contiguous())) if up > 1 else (lambda t: t.float())
+        scaled_mask_preds, scaled_seg_preds, scaled_depth_pred_0 = scale(mask_preds), scale(seg_preds), scale(depth_pred)     # :364-398
+        N = self.num_proposals + self.num_stuff_classes
+        scaled_depth_pred = scaled_depth_pred_0.expand(-1, N, -1, -1)
+        if self.hard_target:
+            gt_masks = [m.bool().float() for m in gt_masks]
+        sampling_results = []
+        for i in range(num_imgs):                                                             # :411-426
+            valid_mask = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
+            ar = self.assigner.assign(scaled_mask_preds[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i],
+                                      depth_pred=scaled_depth_pred[i], gt_depth=gt_depth[i], gt_valid=valid_mask)
+            sr = self.sampler.sample(ar, scaled_mask_preds[i], gt_masks[i], depth=scaled_depth_pred[i])
+            sr.valid_mask = valid_mask
+            sampling_results.append(sr)
+        targets = self.get_targets(sampling_results, gt_masks, self.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                   gt_depth=gt_depth)
+        out = self.loss(scaled_mask_preds, cls_scores, scaled_seg_preds, scaled_depth_pred, proposal_feats, None, *targets,
+                        with_grads=with_grads)
+        losses, grads = out if with_grads else (out, None)
+        dd = Lo.dense_depth_loss(self, scaled_depth_pred_0, gt_depth, with_grad=with_grads)                                  # :438-442
+        if with_grads:
+            losses['depth_dense'], g = dd
+            grads["depth_pred"] = grads["depth_pred"] + g
+            losses["_grads"] = grads
+        else:
+            losses['depth_dense'] = dd
+        if self.cat_stuff_mask:                                                               # :444-451
+            nt, L = self.num_thing_classes, self.num_classes
+            mask_preds = torch.cat([mask_preds, seg_preds[:, nt:L]], dim=1)
+            stuff_kernels = self.conv_seg.weight[nt:L].detach().to(proposal_feats)
+            proposal_feats = torch.cat([proposal_feats, stuff_kernels[None].expand(num_imgs, *stuff_kernels.size())], dim=1)
+            depth_proposal = depth_proposal.expand(-1, proposal_feats.shape[1], -1, -1, -1)
+        return losses, proposal_feats, x_feats, mask_preds, cls_scores, depth_feats, depth_proposal, depth_pred, aspp
 
-    loss = forward_train
+    def loss(self, mask_pred, cls_scores, seg_preds, depth_pred, proposal_feats, semantic_aspp_out, labels, label_weights,
+             mask_targets, mask_weights, seg_targets, depth_targets, depth_weights, reduction_override=None, with_grads=False, **kwargs):
+        """kernel_head.py:456-569 (`losses.rpn_losses`)"""
+        from . import losses as Lo
+        if cls_scores is not None or semantic_aspp_out is not None:
+            raise NotImplementedError("libpolyhead: the shipped KernelHead has no cls_scores / semantic_aspp (kernel_head.py:291,318)")
+        return Lo.rpn_losses(self, mask_pred, seg_preds, depth_pred, labels, label_weights, mask_targets, mask_weights, seg_targets,
+                             depth_targets, depth_weights, with_grads=with_grads)
+
+    def _get_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
+                           pos_depth, neg_depth, gt_depth, gt_valid, cfg):
+        """kernel_head.py:571-647"""
+        from . import losses as Lo
+        return Lo.rpn_target_single(self, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls,
+                                    pos_depth, neg_depth, gt_depth, gt_valid, cfg)
+
+    def get_targets(self, sampling_results, gt_mask, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None, gt_depth=None):
+        """kernel_head.py:649-698"""
+        from . import losses as Lo
+        return Lo.rpn_get_targets(self, sampling_results, gt_mask, rpn_train_cfg, concat, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                  gt_depth=gt_depth)
 
 
 register_everywhere(KernelHead)

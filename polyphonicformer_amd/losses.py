@@ -55,6 +55,17 @@ def depth_loss_sums(pred, target, weight, mode):
     return out.sum(0)
 
 
+def seg_focal_sum(pred, target, gamma, alpha):
+    """pred [B, L, HW] fp32 (class-major, as conv_seg writes it), target int32 [B, HW] (== L: pixel not selected)"""
+    lib = _lib.load()
+    B, L, HW = pred.shape
+    nb = lib.ph_rank_loss_blocks(HW)
+    out = torch.empty((B * nb,), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.ph_seg_focal_sum(_lib.ptr(pred), _lib.ptr(target), B, L, HW, gamma, alpha, _lib.ptr(out), _lib.stream_ptr()),
+               "ph_seg_focal_sum")
+    return out.sum()
+
+
 def focal_loss_sum(pred, labels, weight, gamma, alpha):
     lib = _lib.load()
     R, L = pred.shape
@@ -160,6 +171,53 @@ for _n, _c in (("FocalLoss", FocalLoss), ("CrossEntropyLoss", CrossEntropyLoss),
     LOSSES.register_module(name=_n, module=_c, force=True)
 
 
+def _mask_terms(head, mp, mask_targets, mask_weights, pos, B, N, H, W, losses, grad, keys, empty_keys):
+    """The mask part both heads share (kernel_update_head.py:404-441, kernel_head.py:503-536): BCE mean over the selected
+    pixels of the positive rows, the mean of the per-row dice losses, the rank cross-entropy.  mp [R, HW] fp32; `grad` (or
+    None) [R, HW] receives d(sum of the three) / d(mask_pred).  `keys` / `empty_keys` name the entries with / without
+    positives (the reference's names differ between the two cases)."""
+    lib, dev = _lib.load(), mp.device
+    R, HW = B * N, H * W
+    ignore, lr = head.ignore_label, head.loss_rank
+    num_pos = int(pos.sum())
+    if not num_pos:
+        z = torch.zeros((), device=dev)
+        losses[empty_keys[0]], losses[empty_keys[1]] = z, z.clone()
+        if lr is not None:
+            losses[empty_keys[2]] = z.clone()
+        if grad is not None:
+            grad.zero_()
+        return
+    mt, mw = _f32(mask_targets).reshape(R, HW), _f32(mask_weights).reshape(R, HW)
+    rows = pos.nonzero().flatten().to(torch.int32).contiguous()
+    s = mask_loss_sums(mp, mt, mw, rows)                                                       # [P, 5] fp64
+    ntot = s[:, 1].sum()
+    lm, ldice = head.loss_mask, head.loss_dice
+    losses[keys[0]] = (lm.loss_weight * s[:, 0].sum() / ntot).float()                          # BCE mean over the selected pixels
+    bc = s[:, 3] + s[:, 4] + 2 * ldice.eps
+    losses[keys[1]] = (ldice.loss_weight * (1 - 2 * s[:, 2] / bc).mean()).float()
+    rank_target = None
+    if lr is not None:
+        # rank target: pixel -> index (within its image) of the LAST positive row whose target covers it
+        rank_target = torch.full((B, HW), ignore, dtype=torch.int32, device=dev)
+        mtb = mt.reshape(B, N, HW) > 0
+        for b, j in pos.reshape(B, N).nonzero(as_tuple=False).tolist():
+            rank_target[b][mtb[b, j]] = j
+        losses[keys[2]] = (lr.loss_weight * rank_loss_sum(mp.reshape(B, N, H, W), rank_target, ignore) / (B * HW)).float()
+    if grad is not None:
+        if lr is not None:
+            _lib.check(lib.ph_rank_loss_grad(_lib.ptr(mp), _lib.ptr(rank_target), B, N, HW, ignore, lr.loss_weight / (B * HW),
+                                             _lib.ptr(grad), _lib.stream_ptr()), "ph_rank_loss_grad")
+        else:
+            grad.zero_()
+        P = rows.numel()
+        coef = torch.stack([torch.full((P,), lm.loss_weight, dtype=torch.float64, device=dev) / ntot,
+                            -2.0 * ldice.loss_weight / (P * bc), 4.0 * ldice.loss_weight * s[:, 2] / (P * bc * bc)], 1)
+        coef = coef.float().contiguous()
+        _lib.check(lib.ph_mask_loss_grad(_lib.ptr(mp), _lib.ptr(mt), _lib.ptr(mw), _lib.ptr(rows), P, HW, _lib.ptr(coef),
+                                         _lib.ptr(grad), _lib.stream_ptr()), "ph_mask_loss_grad")
+
+
 # ---- one stage -----------------------------------------------------------------------------------------------------------------
 def stage_losses(head, cls_score, mask_pred, depth_pred, labels, label_weights, mask_targets, mask_weights, depth_targets,
                  depth_weights, with_grads=False):
@@ -201,46 +259,8 @@ def stage_losses(head, cls_score, mask_pred, depth_pred, labels, label_weights, 
         _lib.check(lib.ph_focal_loss_grad(_lib.ptr(cs), _lib.ptr(labels), _lib.ptr(lw), R, cs.shape[1], lc.gamma, lc.alpha,
                                           lc.loss_weight / avg, _lib.ptr(grads["cls_score"]), _lib.stream_ptr()), "ph_focal_loss_grad")
     # ---- masks (:404-437)
-    ignore = head.ignore_label
-    lr = head.loss_rank
-    if num_pos:
-        mt, mw = _f32(mask_targets).reshape(R, HW), _f32(mask_weights).reshape(R, HW)
-        rows = pos.nonzero().flatten().to(torch.int32).contiguous()
-        s = mask_loss_sums(mp, mt, mw, rows)                                                   # [P, 5] fp64
-        ntot = s[:, 1].sum()
-        lm, ldice = head.loss_mask, head.loss_dice
-        losses["loss_rpn_mask"] = (lm.loss_weight * s[:, 0].sum() / ntot).float()              # BCE mean over the selected pixels
-        bc = s[:, 3] + s[:, 4] + 2 * ldice.eps
-        losses["loss_rpn_dice"] = (ldice.loss_weight * (1 - 2 * s[:, 2] / bc).mean()).float()
-        rank_target = None
-        if lr is not None:
-            # rank target (:420-432): pixel -> index (within its image) of the LAST positive row whose target covers it
-            rank_target = torch.full((B, HW), ignore, dtype=torch.int32, device=dev)
-            mtb = mt.reshape(B, N, HW) > 0
-            pb = pos.reshape(B, N)
-            for b, j in pb.nonzero(as_tuple=False).tolist():
-                rank_target[b][mtb[b, j]] = j
-            losses["loss_rank"] = (lr.loss_weight * rank_loss_sum(mp.reshape(B, N, H, W), rank_target, ignore) / (B * HW)).float()
-        if with_grads:
-            g = grads["mask_pred"]
-            if lr is not None:
-                _lib.check(lib.ph_rank_loss_grad(_lib.ptr(mp), _lib.ptr(rank_target), B, N, HW, ignore, lr.loss_weight / (B * HW),
-                                                 _lib.ptr(g), _lib.stream_ptr()), "ph_rank_loss_grad")
-            else:
-                g.zero_()
-            P = rows.numel()
-            coef = torch.stack([torch.full((P,), lm.loss_weight, dtype=torch.float64, device=dev) / ntot,
-                                -2.0 * ldice.loss_weight / (P * bc), 4.0 * ldice.loss_weight * s[:, 2] / (P * bc * bc)], 1)
-            coef = coef.float().contiguous()
-            _lib.check(lib.ph_mask_loss_grad(_lib.ptr(mp), _lib.ptr(mt), _lib.ptr(mw), _lib.ptr(rows), P, HW, _lib.ptr(coef),
-                                             _lib.ptr(g), _lib.stream_ptr()), "ph_mask_loss_grad")
-    else:                                                                                      # :438-441 (the reference's key names)
-        z = torch.zeros((), device=dev)
-        losses["loss_mask"], losses["loss_dice"] = z, z.clone()
-        if lr is not None:
-            losses["loss_rank"] = z.clone()
-        if with_grads:
-            grads["mask_pred"].zero_()
+    _mask_terms(head, mp, mask_targets, mask_weights, pos, B, N, H, W, losses, grads["mask_pred"] if with_grads else None,
+                ("loss_rpn_mask", "loss_rpn_dice", "loss_rank"), ("loss_mask", "loss_dice", "loss_rank"))
     if with_grads:
         grads = dict(mask_pred=grads["mask_pred"].reshape(B, N, H, W), cls_score=grads["cls_score"].reshape(B, N, -1),
                      depth_pred=grads["depth_pred"].reshape(B, N, H, W))
@@ -321,4 +341,140 @@ def get_targets(head, sampling_results, gt_mask, gt_labels, rcnn_train_cfg, conc
     cols = list(zip(*outs))
     if concat:
         cols = [torch.cat(c, 0) if c[0] is not None else None for c in cols]
+    return tuple(cols)
+
+
+
+# ---- KernelHead (the rpn side): kernel_head.py:456-698 --------------------------------------------------------------------------
+def rpn_losses(head, mask_pred, seg_preds, depth_pred, labels, label_weights, mask_targets, mask_weights, seg_targets,
+               depth_targets, depth_weights, with_grads=False):
+    """KernelHead.loss (kernel_head.py:456-569) for the shipped configuration (no cls_scores, no semantic_aspp): loss_depth on
+    the direct depth map broadcast over the N rows, loss_rpn_mask / loss_rpn_dice / loss_rpn_rank on the positive rows,
+    loss_rpn_seg = sigmoid focal loss of conv_seg's map over the labelled pixels.  mask_pred [B, N, H, W], seg_preds
+    [B, L, H, W], depth_pred [B, 1 or N + stuff rows, H, W].  With `with_grads`: dict(mask_pred=, seg_preds=, depth_pred= [B, 1, H, W])."""
+    _gpu(mask_pred, "mask_pred")
+    lib, dev = _lib.load(), mask_pred.device
+    B, N, H, W = mask_pred.shape
+    R, HW, L = B * N, H * W, head.num_classes
+    mp = _f32(mask_pred).reshape(R, HW)
+    labels = labels.to(dev).long().contiguous()
+    pos = (labels >= 0) & (labels < L)                                                        # :475
+    losses, grads = {}, None
+    if with_grads:
+        grads = dict(mask_pred=torch.empty((R, HW), dtype=torch.float32, device=dev))
+    if depth_pred is not None:                                                                # :478-486
+        ld = head.loss_depth
+        mode = DEPTH_MODES[ld.depth_act_mode]
+        Rd = depth_targets.shape[0]               # B * (proposals + stuff rows): one broadcast map per image (:386,482)
+        dp = _f32(depth_pred.expand(B, Rd // B, H, W)).reshape(Rd, HW)
+        dt, dw = _f32(depth_targets).reshape(Rd, HW), _f32(depth_weights).reshape(Rd, HW)
+        loss_d, dcoef = _depth_from_sums(depth_loss_sums(dp, dt, dw, mode), ld.loss_weight, [float(v) for v in ld.weight])
+        losses["loss_depth"] = loss_d.float()
+        if with_grads:
+            g = torch.empty((Rd, HW), dtype=torch.float32, device=dev)
+            _lib.check(lib.ph_depth_loss_grad(_lib.ptr(dp), _lib.ptr(dt), _lib.ptr(dw), Rd * HW, mode, *dcoef, _lib.ptr(g),
+                                              _lib.stream_ptr()), "ph_depth_loss_grad")
+            grads["depth_pred"] = g.reshape(B, Rd // B, H, W).sum(1, keepdim=True)           # the rows are one broadcast map
+    _mask_terms(head, mp, mask_targets, mask_weights, pos, B, N, H, W, losses, grads["mask_pred"] if with_grads else None,
+                ("loss_rpn_mask", "loss_rpn_dice", "loss_rpn_rank"), ("loss_rpn_mask", "loss_rpn_dice", "loss_rank"))
+    if seg_preds is not None:                                                                 # :538-551
+        ls = head.loss_seg
+        if not ls.use_sigmoid:
+            raise NotImplementedError("libpolyhead: loss_seg is the shipped sigmoid FocalLoss (polyphonic_former.py:73-78)")
+        sp = _f32(seg_preds).reshape(B, seg_preds.shape[1], HW)
+        st = seg_targets.to(dev).reshape(B, HW)
+        nd = max(float(((st >= 0) & (st < L)).sum()), 1.0)                                    # num_dense_pos.clamp(min=1)
+        st = st.to(torch.int32).contiguous()
+        losses["loss_rpn_seg"] = (ls.loss_weight * seg_focal_sum(sp, st, ls.gamma, ls.alpha) / nd).float()
+        if with_grads:
+            g = torch.empty_like(sp)
+            _lib.check(lib.ph_seg_focal_grad(_lib.ptr(sp), _lib.ptr(st), B, sp.shape[1], HW, ls.gamma, ls.alpha, ls.loss_weight / nd,
+                                             _lib.ptr(g), _lib.stream_ptr()), "ph_seg_focal_grad")
+            grads["seg_preds"] = g.reshape(seg_preds.shape)
+    if with_grads:
+        grads["mask_pred"] = grads["mask_pred"].reshape(B, N, H, W)
+        return losses, grads
+    return losses
+
+
+def dense_depth_loss(head, depth_pred, gt_depth, with_grad=False):
+    """losses['depth_dense'] (kernel_head.py:438-442): DepthLoss of the direct depth map against the ground truth, weight = gt > 0"""
+    ld = head.loss_depth
+    mode = DEPTH_MODES[ld.depth_act_mode]
+    dp, gd = _f32(depth_pred).reshape(-1), _f32(gt_depth.to(depth_pred.device)).reshape(-1)
+    if dp.numel() != gd.numel():
+        raise ValueError(f"depth_dense: prediction {tuple(depth_pred.shape)} and gt_depth {tuple(gt_depth.shape)} differ in size")
+    w = (gd > 0).float()
+    loss, coef = _depth_from_sums(depth_loss_sums(dp, gd, w, mode), ld.loss_weight, [float(v) for v in ld.weight])
+    if not with_grad:
+        return loss.float()
+    g = torch.empty_like(dp)
+    _lib.check(_lib.load().ph_depth_loss_grad(_lib.ptr(dp), _lib.ptr(gd), _lib.ptr(w), dp.numel(), mode, *coef, _lib.ptr(g),
+                                              _lib.stream_ptr()), "ph_depth_loss_grad")
+    return loss.float(), g.reshape(depth_pred.shape)
+
+
+def rpn_target_single(head, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos_gt_labels, gt_sem_seg, gt_sem_cls, pos_depth,
+                      neg_depth, gt_depth, gt_valid, cfg):
+    """KernelHead._get_target_single (kernel_head.py:571-647): ONE image.  Unlike the update heads there are no stuff rows in
+    labels / masks (label_weights is per row), a dense `seg_targets` map [H, W] (stuff classes first, then the assigned thing
+    masks painted over them in order) and depth rows for the N proposals + the stuff rows, without a direct-depth row."""
+    dev = pos_mask.device
+    num_pos, num_neg = pos_mask.shape[0], neg_mask.shape[0]
+    R = num_pos + num_neg
+    H, W = pos_mask.shape[-2:]
+    L, ns, nt = head.num_classes, head.num_stuff_classes, head.num_thing_classes
+    pw = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+    valid = gt_valid.to(dev).float()
+    labels = torch.full((R,), L, dtype=torch.long, device=dev)
+    label_weights = torch.zeros((R,), device=dev)
+    mask_targets = torch.zeros((R, H, W), device=dev)
+    mask_weights = valid[None].expand(R, H, W).clone()
+    seg_targets = torch.full((H, W), L, dtype=torch.long, device=dev)
+    has_sem = gt_sem_cls is not None and gt_sem_seg is not None
+    if has_sem:
+        sem = gt_sem_seg.to(dev).bool()
+        for m, c in zip(sem, gt_sem_cls.tolist()):                                            # later classes overwrite (:594-597)
+            seg_targets[m] = int(c)
+    if num_pos:
+        labels[pos_inds] = pos_gt_labels
+        label_weights[pos_inds] = pw
+        mask_targets[pos_inds] = pos_gt_mask.float()
+        pgl = pos_gt_labels.tolist()
+        for i in range(num_pos):
+            seg_targets[pos_gt_mask[i].bool()] = pgl[i]
+    if num_neg:
+        label_weights[neg_inds] = 1.0
+    depth_targets = depth_weights = None
+    if pos_depth is not None:                                                                 # :610-640
+        assert neg_depth is not None and gt_depth is not None
+        gd = gt_depth.to(dev).float().reshape(H, W)
+        depth_targets = torch.zeros((R + ns, H, W), device=dev)
+        depth_weights = torch.zeros((R + ns, H, W), device=dev)
+        if num_pos:
+            depth_targets[pos_inds] = gd
+            depth_weights[pos_inds] = pw * pos_gt_mask.float()
+        if has_sem and len(gt_sem_cls) > 0:
+            rows = (gt_sem_cls - nt).long() + R
+            depth_targets[rows] = gd
+            depth_weights[rows] = gt_sem_seg.float() * pw
+        depth_weights = depth_weights * (gd > 0.0).float()
+    return labels, label_weights, mask_targets, mask_weights, seg_targets, depth_targets, depth_weights
+
+
+def rpn_get_targets(head, sampling_results, gt_mask, rpn_train_cfg, concat=True, gt_sem_seg=None, gt_sem_cls=None, gt_depth=None):
+    """KernelHead.get_targets (kernel_head.py:649-698): per image, concatenated (seg_targets stacked)"""
+    n = len(sampling_results)
+    if gt_sem_seg is None:
+        gt_sem_seg, gt_sem_cls = [None] * n, [None] * n
+    has_depth = gt_depth is not None
+    outs = []
+    for i, res in enumerate(sampling_results):
+        outs.append(rpn_target_single(head, res.pos_inds, res.neg_inds, res.pos_masks, res.neg_masks, res.pos_gt_masks,
+                                      res.pos_gt_labels, gt_sem_seg[i], gt_sem_cls[i], res.pos_depth if has_depth else None,
+                                      res.neg_depth if has_depth else None, gt_depth[i] if has_depth else None, res.valid_mask,
+                                      rpn_train_cfg))
+    cols = list(zip(*outs))
+    if concat:
+        cols = [None if c[0] is None else (torch.stack(c, 0) if k == 4 else torch.cat(c, 0)) for k, c in enumerate(cols)]
     return tuple(cols)

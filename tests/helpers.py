@@ -218,3 +218,20 @@ def stage_cfg(C=256, F=2048, heads=8, L=19, n_thing=8, n_stuff=11):
         loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
         loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid"),
         depth_act_mode="sigmoid")
+
+
+def train_gt(seed, B, H, W, n_thing, n_stuff, gts):
+    """ground truth of a training step at the assign stride (H x W = the x2-upsampled mask size), shared with the tests"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for b in range(B):
+        G = gts[b]
+        masks = (torch.rand(G, H, W, generator=g) > 0.75).float()
+        labels = torch.randint(0, n_thing, (G,), generator=g)
+        present = torch.randperm(n_stuff, generator=g)[: n_stuff // 2 + 1].sort()[0]
+        sem_cls = present + n_thing
+        sem_seg = (torch.rand(len(present), H, W, generator=g) > 0.6).float()
+        depth = torch.rand(H, W, generator=g) * 90.0
+        depth[torch.rand(H, W, generator=g) < 0.1] = 0.0
+        out.append(dict(masks=masks, labels=labels, sem_seg=sem_seg, sem_cls=sem_cls, depth=depth))
+    return out

@@ -126,3 +126,118 @@ def test_forward_train_vs_reference(gpu):
     assert max(err.values()) < 1e-3, err
     assert len(grads) == S and grads[0]["mask_pred"].shape == (B, N, 2 * H, 2 * W) and grads[0]["cls_score"].shape == (B, N, 19)
     assert not head.training            # the training flag is restored
+
+
+def _rpn_head(gpu, cat_stuff_mask=True):
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    from test_gpu_parity import _full_weights
+    assigner = dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                    dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    head = HEADS.build(dict(
+        type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11, cat_stuff_mask=cat_stuff_mask,
+        feat_downsample_stride=2, feat_refine=False, use_binary=True, proposal_feats_with_obj=True, localization_fpn=None,
+        loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+        loss_seg=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+        loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0), loss_dice=dict(type="DiceLoss", loss_weight=4.0),
+        loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid"),
+        train_cfg=dict(assigner=assigner, sampler=dict(type='MaskPseudoSampler'), pos_weight=1.)))
+    sd = _full_weights()
+    head.load_state_dict({k[len("rpn_head."):]: v for k, v in sd.items() if k.startswith("rpn_head.")})
+    return head.to(gpu).eval().set_precision("fp32"), sd
+
+
+def test_rpn_forward_train_vs_reference(gpu):
+    """KernelHead.forward_train (kernel_head.py:349-454), forward side: post-neck decode in training mode on libpolyhead, x2
+    upsample, Hungarian assignment, rpn targets, the six losses -- against the REFERENCE's own forward_train
+    (tests/golden/train_rpn.npz), and the tensors handed to the roi head (stuff rows appended).  The gradients w.r.t. the
+    scaled predictions are checked against autograd through the oracle's restatement of the loss."""
+    from oracle import loss_oracle as LO
+    head, sd = _rpn_head(gpu)
+    z = Hh.load_golden("train_rpn.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    B, H, W, N = m["B"], m["H"], m["W"], m["N"]
+    feats = [f.to(gpu) for f in Hh.neck_inputs(m["nseed"], B, 256, H, W)]
+    gts = [{k: torch.from_numpy(z[f"gt{b}_{k}"]).to(gpu) for k in ("masks", "labels", "sem_seg", "sem_cls", "depth")} for b in range(B)]
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    gd = torch.stack([g["depth"][None] for g in gts])
+    out = head.forward_train(feats, metas, [g["masks"] for g in gts], [g["labels"] for g in gts], gt_sem_seg=[g["sem_seg"] for g in gts],
+                             gt_sem_cls=[g["sem_cls"] for g in gts], gt_depth=gd, with_grads=True)
+    losses, proposal_feats, x_feats, mask_preds, cls_scores, depth_feats, depth_proposal, depth_pred, aspp = out
+    grads = losses.pop("_grads")
+    want = {k[2:]: float(np.asarray(z[k]).reshape(-1)[0]) for k in z.files if k.startswith("l_")}
+    assert set(losses) == set(want) and len(want) == 6
+    err = {k: abs(float(losses[k]) - want[k]) / max(1.0, abs(want[k])) for k in want}
+    print("rpn forward_train losses vs reference, max rel err", max(err.values()), {k: round(float(v), 4) for k, v in losses.items()})
+    assert max(err.values()) < 1e-3, err
+    assert cls_scores is None and aspp is None and not head.training
+    assert Hh.rel_err(mask_preds.cpu(), z["mask_preds"]) < 1e-3 and mask_preds.shape == (B, N, H, W)
+    assert Hh.rel_err(proposal_feats.reshape(B, N, -1).cpu(), z["proposal_feats"]) < 1e-3
+    assert Hh.rel_err(depth_proposal.reshape(B, N, -1).cpu(), z["depth_proposal"]) < 1e-3
+    # gradients: the device's own scaled predictions through the oracle's loss with autograd, same discrete targets
+    from oracle import assign_oracle as AO
+    up = lambda t: torch.nn.functional.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+    nt, L = 8, 19
+    o = head.simple_test_rpn(feats, metas)         # eval decode: same maps, stuff rows appended
+    smask = up(o[2][:, :100].float().cpu()).requires_grad_(True)
+    sseg = up(o[4].float().cpu()).requires_grad_(True)
+    sdep = up(o[7].float().cpu()).requires_grad_(True)
+    cg = [{k: v.cpu() for k, v in g.items()} for g in gts]
+    valids = []
+    for b, g in enumerate(cg):
+        v = torch.cat((g["masks"], g["sem_seg"]), 0).sum(0).bool().float()
+        g["gt_inds"], g["assigned_labels"] = AO.assign(smask[b].detach(), None, g["masks"], g["labels"], v)
+        valids.append(v)
+    tg = LO.rpn_get_targets(L, nt, 11, 100, 2 * H, 2 * W, cg, valids)
+    with torch.enable_grad():
+        lo = LO.rpn_loss(L, smask, sseg, sdep, *tg)
+        lo["depth_dense"] = LO.dense_depth(sdep, gd.cpu())
+        sum(lo.values()).backward()
+    for name, t in (("mask_pred", smask), ("seg_preds", sseg), ("depth_pred", sdep)):
+        e = Hh.rel_err(grads[name].cpu(), t.grad)
+        print("rpn grad", name, e)
+        assert grads[name].shape == t.shape and e < 1e-3, (name, e)
+
+
+def test_rpn_targets_vs_oracle_and_no_gt(gpu):
+    """KernelHead.get_targets on the device against the oracle's restatement (bit for bit), and an image without any ground
+    truth instance: every row negative, the reference's key names for that case (kernel_head.py:533-537)."""
+    from oracle import loss_oracle as LO
+    from polyphonicformer_amd import assigner as A
+    head, _ = _rpn_head(gpu)
+    g = torch.Generator().manual_seed(3)
+    B, N, H, W, nt, ns = 2, 100, 16, 32, 8, 11
+    gts = Hh.train_gt(5, B, H, W, nt, ns, [5, 0])
+    mask_pred = torch.randn(B, N, H, W, generator=g)
+    gi = []
+    srs, valids = [], []
+    for b, gt in enumerate(gts):
+        inds = torch.zeros(N, dtype=torch.long)
+        k = gt["masks"].shape[0]
+        perm = torch.randperm(N, generator=g)[:k]
+        inds[perm] = torch.arange(1, k + 1)
+        labels = torch.full((N,), -1, dtype=torch.long)
+        labels[perm] = gt["labels"]
+        gt["gt_inds"], gt["assigned_labels"] = inds, labels
+        v = torch.cat((gt["masks"], gt["sem_seg"]), 0).sum(0).bool().float()
+        valids.append(v)
+        ar = A.AssignResult(k, inds.to(gpu), None, labels=labels.to(gpu))
+        sr = A.MaskPseudoSampler().sample(ar, mask_pred[b].to(gpu), gt["masks"].to(gpu), depth=torch.zeros(N + ns, H, W, device=gpu))
+        sr.valid_mask = v.to(gpu)
+        srs.append(sr)
+    got = head.get_targets(srs, [x["masks"].to(gpu) for x in gts], head.train_cfg, True, gt_sem_seg=[x["sem_seg"].to(gpu) for x in gts],
+                           gt_sem_cls=[x["sem_cls"].to(gpu) for x in gts], gt_depth=torch.stack([x["depth"][None] for x in gts]).to(gpu))
+    want = LO.rpn_get_targets(nt + ns, nt, ns, N, H, W, gts, valids)
+    for name, a, b in zip(("labels", "label_weights", "mask_targets", "mask_weights", "seg_targets", "depth_targets", "depth_weights"), got, want):
+        assert torch.equal(a.cpu(), b), name
+    # only image 1 (no instances)
+    seg = torch.randn(1, nt + ns, H, W, generator=g)
+    dpr = torch.randn(1, 1, H, W, generator=g)
+    one = head.get_targets(srs[1:], None, head.train_cfg, True, gt_sem_seg=[gts[1]["sem_seg"].to(gpu)], gt_sem_cls=[gts[1]["sem_cls"].to(gpu)],
+                           gt_depth=gts[1]["depth"][None, None].to(gpu))
+    losses = head.loss(mask_pred[1:].to(gpu), None, seg.to(gpu), dpr.to(gpu).expand(-1, N + ns, -1, -1), None, None, *one)
+    w1 = LO.rpn_get_targets(nt + ns, nt, ns, N, H, W, gts[1:], valids[1:])
+    lo = LO.rpn_loss(nt + ns, mask_pred[1:], seg, dpr, *w1)
+    assert set(losses) == set(lo) == {"loss_depth", "loss_rpn_mask", "loss_rpn_dice", "loss_rank", "loss_rpn_seg"}
+    for k in lo:
+        assert abs(float(losses[k]) - float(lo[k])) <= 1e-5 * max(1.0, abs(float(lo[k]))), k

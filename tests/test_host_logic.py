@@ -90,8 +90,10 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(NotImplementedError):
         HEADS.build(cfg)
     ih, kh = _heads()
-    with pytest.raises(NotImplementedError):
-        ih.forward_train()
+    with pytest.raises(ValueError):             # heads built without train_cfg cannot assign
+        ih.forward_train(None, None, None, None, [], [], [], depth_proposal=torch.zeros(1, 1))
+    with pytest.raises(ValueError):
+        kh.forward_train(None, [], [], [])
     with pytest.raises(NotImplementedError):
         ih.aug_test(None, None, None)
 
