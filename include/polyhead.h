@@ -253,6 +253,21 @@ int ph_seg_focal_sum(const float* pred, const int32_t* target, int B, int L, int
 int ph_seg_focal_grad(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha, float scale,
                       float* grad, void* stream);
 
+/* ---- N4, backward: the map-sized products on fp32 NCHW maps (csrc/ph_train.hip); hi+lo bf16 MFMA, fp32 grade ----------------
+ * rows_x_map : Y[b][m][p] = sum_k A[b][m][k] X[b][k][p].  A [B or 1][Mpad][lda] zero padded (Mpad % 16 == 0, lda % 8 == 0),
+ *              a_batch_stride in elements (0: one A for every image).  binarize_x: X is used as (X > 1.5 * 2^-24) ? 1 : 0.
+ *              Replaces F.conv2d with 1x1 static / dynamic kernels (kernel_head.py:250-295, kernel_update_head.py:317-329)
+ *              and autograd's grad_input of those and of the einsum pooling (kernel_update_head.py:241-242).
+ * map_x_mapT : O[b][m][k] = sum_p G[b][m][p] X[b][k][p], K <= 256.  nsplit from ph_map_x_map_t_nsplit; partial holds
+ *              B * nsplit * M * K floats, summed in a fixed order.  binarize_g as above (the hard-mask pooling forward).
+ * upsample2x_bwd : transpose of ph_upsample2x (F.interpolate x2 bilinear, align_corners=False). */
+int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B, int64_t HW,
+                  int binarize_x, void* stream);
+int ph_map_x_map_t_nsplit(int B, int M, int64_t HW);
+int ph_map_x_map_t(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
+                  int binarize_g, void* stream);
+int ph_upsample2x_bwd(const float* grad_out, float* grad_in, int64_t planes, int H, int W, void* stream);
+
 /* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
  * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.
  * activate: act_mask[k] = sigmoid(mask_up[q_idx[k]]), act_depth[k] = depth_act(depth_up[q_idx[k]]),

@@ -252,7 +252,87 @@ def rpn_train_fixture():
     np.savez_compressed(os.path.join(OUT, "train_rpn.npz"), **out)
 
 
+def grad_digest(t, n=64):
+    """a compact record of a gradient tensor: its L2 norm, its sum and `n` entries at fixed strided positions"""
+    f = t.detach().double().flatten()
+    idx = (torch.arange(n, dtype=torch.int64) * 2654435761) % f.numel()
+    return np.concatenate([[float(f.norm()), float(f.sum())], f[idx].numpy()])
+
+
+def train_step_fixture():
+    """One whole training step of the path as PolyphonicFormer.forward_train runs it after extract_feat
+    (polyphonic/polyphonic_former.py:96-129): rpn_head.forward_train -> roi_head.forward_train on the rpn's outputs, the
+    objective = sum of the entries whose key contains 'loss' (mmdet BaseDetector._parse_losses,
+    mmdet/models/detectors/base.py:198-199), torch autograd backward through the reference.  Stored: every loss value, the
+    objective, a digest (norm, sum, 64 strided entries) of the gradient of each of the 303 parameters and of the three
+    post-neck input maps.  -> tests/golden/train_step.npz"""
+    import copy
+    import gen_golden as G
+    ns = R.load_reference()
+    reg, accuracy = load_real_losses(ns)
+    sys.modules["polyphonic.kernel_update_head"].accuracy = accuracy
+    sys.modules["polyphonic.kernel_head"].accuracy = accuracy
+    na = R.load_reference_assigner()
+    cfg = Hh.FULL
+    B, H, W, S = 2, 8, 16, cfg["S"]
+    ih, kh, sd, shapes = G.build(ns, cfg)
+    Sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler
+    rpn_a = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                 mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    roi_a = dict(rpn_a, depth_cost=dict(type='DepthCost', weight=0., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.),
+                                        depth_act_mode='sigmoid'))
+    kh.assigner, kh.sampler, kh.train_cfg = na.Assigner(**copy.deepcopy(rpn_a)), Sampler(), ns.ConfigDict(pos_weight=1.0)
+    for k, c in RPN_LOSS_CFG.items():
+        setattr(kh, k, reg.build(dict(c)))
+    ih.mask_assigner = [na.Assigner(**copy.deepcopy(roi_a)) for _ in range(S)]
+    ih.mask_sampler = [Sampler() for _ in range(S)]
+    ih.train_cfg = [ns.ConfigDict(pos_weight=1.0) for _ in range(S)]
+    for st in ih.mask_head:
+        for k, c in LOSS_CFG.items():
+            setattr(st, k, reg.build(dict(c)))
+    kh.train()
+    ih.train()
+    feats = [f.requires_grad_(True) for f in Hh.neck_inputs(G.NSEED, B, cfg["C"], H, W)]
+    gts = train_gt(51, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], [5, 8])
+    metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
+    gt_masks, gt_labels = [g["masks"] for g in gts], [g["labels"] for g in gts]
+    gt_sem_seg, gt_sem_cls = [g["sem_seg"] for g in gts], [g["sem_cls"] for g in gts]
+    gt_depth = torch.stack([g["depth"][None] for g in gts])
+    with torch.enable_grad():
+        r = kh.forward_train(feats, metas, gt_masks, gt_labels, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls, gt_depth=gt_depth)
+        rpn_losses, proposal_feats, x_feats, mask_preds, cls_scores, depth_feats, depth_proposal, depth_pred, _ = r
+        losses = ih.forward_train(x=x_feats, proposal_feats=proposal_feats, mask_preds=mask_preds, cls_score=cls_scores, img_metas=metas,
+                                  gt_masks=gt_masks, gt_labels=gt_labels, gt_depth=gt_depth, depth_preds=depth_pred,
+                                  depth_feats=depth_feats, depth_proposal=depth_proposal, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                  imgs_whwh=None)
+        losses.update(rpn_losses)
+        total = sum(v.mean() for k, v in losses.items() if "loss" in k)
+        total.backward()
+    out = {"meta_json": np.frombuffer(json.dumps(dict(B=B, H=H, W=W, S=S, nseed=G.NSEED, wseed=G.WSEED, gt_seed=51, gts=[5, 8])).encode(),
+                                      dtype=np.uint8)}
+    for b, g in enumerate(gts):
+        for k, v in g.items():
+            out[f"gt{b}_{k}"] = v.numpy()
+    for k, v in losses.items():
+        out[f"l_{k}"] = np.asarray(float(v), dtype=np.float64)
+    out["total"] = np.asarray(float(total), dtype=np.float64)
+    none = []
+    for pre, mod in (("rpn_head.", kh), ("roi_head.", ih)):
+        for n, p in mod.named_parameters():
+            if p.grad is None:
+                none.append(pre + n)
+            else:
+                out["g_" + pre + n] = grad_digest(p.grad)
+    for i, f in enumerate(feats):
+        out[f"gfeat{i}"] = grad_digest(f.grad, 4096)
+    out["no_grad_json"] = np.frombuffer(json.dumps(none).encode(), dtype=np.uint8)
+    print("total", float(total), "params with grad", sum(k.startswith("g_") for k in out), "without", none)
+    print({k: round(float(v), 4) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
     forward_train_fixture()
     rpn_train_fixture()
+    train_step_fixture()

@@ -1,0 +1,294 @@
+// libpolyhead, training side: the map-sized products of the backward pass and of the
+// fp32 training forward, on fp32 NCHW maps as autograd hands them over.
+//
+//   ph_rows_x_map  : Y[b][m][p] = sum_k A[b][m][k] * X[b][k][p]      rows x map   -> map
+//                    forward of every 1x1 convolution of the path (static or dynamic kernels: kernel_head.py:250-295,
+//                    kernel_update_head.py:317-329) and, with A transposed by the caller, the gradient w.r.t. the feature
+//                    map of the dynamic convolution (A = kernels^T, X = dL/dlogits) and of the hard-mask pooling
+//                    (A = dL/dpooled^T, X = mask logits binarised on the fly).
+//   ph_map_x_map_t  : O[b][m][k] = sum_p G[b][m][p] * X[b][k][p]      map x map^T  -> rows
+//                    the hard-mask pooling forward (G = mask logits binarised on the fly, kernel_update_head.py:236-242),
+//                    and the gradient w.r.t. the kernels of a 1x1 convolution (G = dL/dlogits, X = features).
+//   ph_upsample2x_bwd : the transpose of the x2 bilinear upsample (kernel_update.py:131-143).
+//
+// Arithmetic: every fp32 operand is split in registers into hi + lo bf16 and a product is three MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulation): ~2^-17 relative per operand, the grade of the inference path's
+// PH_PREC_SPLIT.  Both products are HBM-bound (K, M <= 320 against maps of 10^4..10^5 pixels): one pass over the
+// map operand(s), no LDS -- the MFMA fragment maps let every lane read its operands straight from global memory
+// (32 contiguous bytes along the contraction for the row operands; for the map operand of ph_rows_x_map, whose
+// contiguous axis is the OUTPUT pixel, eight 4-byte loads that a 16-lane group coalesces into 64-byte segments).
+#include "ph_common.h"
+
+namespace {
+
+struct Frag {
+    uint4 hi, lo;
+};
+
+__device__ __forceinline__ Frag split8(const float* v) {
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f2bf_split(v[e], h[e], l[e]);
+    Frag f;
+    f.hi = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+    f.lo = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+    return f;
+}
+
+__device__ __forceinline__ f32x4_t mfma3(const Frag& a, const Frag& b, f32x4_t c) {
+    c = mfma16(a.lo, b.hi, c);
+    c = mfma16(a.hi, b.lo, c);
+    return mfma16(a.hi, b.hi, c);
+}
+
+__device__ __forceinline__ float binz(float z) { return z > PH_BIN_THR ? 1.f : 0.f; }
+
+// ---- rows x map --------------------------------------------------------------------------------------------------------------
+// grid (ceil(HW / 256), B, m-passes); 4 waves, each 64 pixels (4 column tiles) x RT row tiles of 16 rows.
+// A: [B or 1][Mpad][lda] fp32, Mpad % 16 == 0, lda % 8 == 0, zero padded (the caller pads: it is a few hundred KB).
+constexpr int RXM_RT = 10;
+
+template <bool BIN>
+__global__ __launch_bounds__(256) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
+                                                    const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    if (p0 >= HW) return;
+    const int mt0 = blockIdx.z * RXM_RT;
+    const int nrt = min(RXM_RT, Mpad / 16 - mt0);
+    const float* Ab = A + b * a_batch_stride + (int64_t)mt0 * 16 * lda;
+    const float* Xb = X + (int64_t)b * K * HW;
+    f32x4_t acc[RXM_RT][4];
+#pragma unroll
+    for (int r = 0; r < RXM_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        Frag xb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int64_t p = p0 + t * 16 + c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + g * 8 + e;
+                const bool ok = k < K && p < HW;
+                const float z = ok ? Xb[(int64_t)k * HW + p] : 0.f;
+                v[e] = BIN ? (ok ? binz(z) : 0.f) : z;
+            }
+            xb[t] = split8(v);
+        }
+#pragma unroll
+        for (int r = 0; r < RXM_RT; ++r) {
+            if (r < nrt) {
+                const int k = k0 + g * 8;
+                float v[8];
+                if (k < lda) {
+                    const float4* src = (const float4*)(Ab + (int64_t)(r * 16 + c) * lda + k);
+                    const float4 q0 = src[0], q1 = src[1];
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
+                const Frag a = split8(v);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
+            }
+        }
+    }
+    float* Yb = Y + (int64_t)b * M * HW;
+#pragma unroll
+    for (int r = 0; r < RXM_RT; ++r) {
+        if (r < nrt) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t p = p0 + t * 16 + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = (mt0 + r) * 16 + g * 4 + i;
+                    if (m < M && p < HW) Yb[(int64_t)m * HW + p] = acc[r][t][i];
+                }
+            }
+        }
+    }
+}
+
+// ---- map x map^T ---------------------------------------------------------------------------------------------------------------
+// grid (nsplit, B, m-passes); 4 waves, each MXM_RT row tiles (m) x 4 column tiles (64 of the K <= 256 columns).
+// partial [B][nsplit][M][K]; a fixed-order second pass sums the splits.
+constexpr int MXM_RT = 8;
+
+template <bool VEC, bool BIN>
+__device__ __forceinline__ Frag load_along_p(const float* row, bool row_ok, int64_t p, int64_t p_end) {
+    float v[8];
+    if (VEC) {
+        if (row_ok && p < p_end) {      // p_end and HW are multiples of 8 here
+            const float4 q0 = ((const float4*)(row + p))[0], q1 = ((const float4*)(row + p))[1];
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+            if (BIN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = binz(v[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = row_ok && p + e < p_end;
+            const float z = ok ? row[p + e] : 0.f;
+            v[e] = BIN ? (ok ? binz(z) : 0.f) : z;
+        }
+    }
+    return split8(v);
+}
+
+template <bool VEC, bool BIN>
+__global__ __launch_bounds__(256) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
+                                                    int M, int K, int64_t HW, int64_t chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int s = blockIdx.x, nsplit = gridDim.x, b = blockIdx.y;
+    const int mt0 = blockIdx.z * MXM_RT;
+    const int64_t pa = s * chunk, pe = min(HW, pa + chunk);
+    const float* Gb = G + (int64_t)b * M * HW;
+    const float* Xb = X + (int64_t)b * K * HW;
+    f32x4_t acc[MXM_RT][4];
+#pragma unroll
+    for (int r = 0; r < MXM_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = pa; p < pe; p += 32) {
+        Frag xb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = wave * 64 + t * 16 + c;
+            xb[t] = load_along_p<VEC, false>(Xb + (int64_t)k * HW, k < K, p + g * 8, pe);
+        }
+#pragma unroll
+        for (int r = 0; r < MXM_RT; ++r) {
+            const int m = (mt0 + r) * 16 + c;
+            if ((mt0 + r) * 16 < M) {       // wave-uniform
+                const Frag a = load_along_p<VEC, BIN>(Gb + (int64_t)m * HW, m < M, p + g * 8, pe);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
+            }
+        }
+    }
+    float* out = partial + ((int64_t)b * nsplit + s) * M * K;
+#pragma unroll
+    for (int r = 0; r < MXM_RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = wave * 64 + t * 16 + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (mt0 + r) * 16 + g * 4 + i;
+                if (m < M && k < K) out[(int64_t)m * K + k] = acc[r][t][i];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_sum_splits(const float* __restrict__ partial, float* __restrict__ out, int nsplit, int64_t MK, int B) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MK * B) return;
+    const int64_t b = i / MK, j = i - b * MK;
+    const float* p = partial + b * nsplit * MK + j;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += p[(int64_t)s * MK];       // fixed order: run-to-run identical
+    out[i] = acc;
+}
+
+// ---- transpose of the x2 bilinear upsample -----------------------------------------------------------------------------------------
+// forward (align_corners=False): out[2j] = .25 in[j-1] + .75 in[j] (out[0] = in[0]), out[2j+1] = .75 in[j] + .25 in[j+1] (clamped).
+// Hence d in[j] gathers output rows 2j-1 .. 2j+2 with weights (.25, .75, .75, .25); at the borders the tap that falls outside
+// folds onto its neighbour (j = 0: (0, 1, .75, .25); j = H-1: (.25, .75, 1, 0)).  Separable in y and x.
+__device__ __forceinline__ void taps(int j, int n, float w[4]) {
+    w[0] = j > 0 ? 0.25f : 0.f;
+    w[1] = j > 0 ? 0.75f : 1.f;
+    w[2] = j < n - 1 ? 0.75f : 1.f;
+    w[3] = j < n - 1 ? 0.25f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict__ g, float* __restrict__ out, int64_t planes, int H, int W) {
+    const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int64_t pl = i / ((int64_t)W * H);
+        float wy[4], wx[4];
+        taps(y, H, wy);
+        taps(x, W, wx);
+        const float* gp = g + pl * 4 * H * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int Y = 2 * y - 1 + a;
+            if (wy[a] == 0.f) continue;
+            float row = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int X = 2 * x - 1 + c;
+                if (wx[c] != 0.f) row += wx[c] * gp[(int64_t)Y * 2 * W + X];
+            }
+            acc += wy[a] * row;
+        }
+        out[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
+                             int64_t HW, int binarize_x, void* stream) {
+    PH_CHECK_ARG(A && X && Y && B > 0 && M > 0 && K > 0 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(Mpad % 16 == 0 && Mpad >= M && lda % 8 == 0 && lda >= K && (a_batch_stride % 4) == 0, "A must be zero padded: rows to 16, row stride to 8");
+    PH_CHECK_ARG(((uintptr_t)A & 15) == 0, "A must be 16-byte aligned");
+    const dim3 grid((unsigned)((HW + 255) / 256), B, (Mpad / 16 + RXM_RT - 1) / RXM_RT);
+    if (binarize_x) hipLaunchKernelGGL(k_rows_x_map<true>, grid, dim3(256), 0, (hipStream_t)stream, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+    else hipLaunchKernelGGL(k_rows_x_map<false>, grid, dim3(256), 0, (hipStream_t)stream, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_map_x_map_t_nsplit(int B, int M, int64_t HW) {
+    const int passes = ((M + 15) / 16 + MXM_RT - 1) / MXM_RT;
+    int64_t want = 1024 / ((int64_t)B * passes);
+    const int64_t most = (HW + 255) / 256;          // at least 256 pixels per split
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial /* [B][nsplit][M][K] */, float* out /* [B][M][K] */, int B,
+                             int M, int K, int64_t HW, int nsplit, int binarize_g, void* stream) {
+    PH_CHECK_ARG(G && X && partial && out && B > 0 && M > 0 && K > 0 && K <= 256 && HW > 0 && nsplit >= 1, "bad pointer or size (K <= 256)");
+    int64_t chunk = (HW + nsplit - 1) / nsplit;
+    chunk = (chunk + 31) / 32 * 32;
+    const bool vec = (HW % 8) == 0 && (((uintptr_t)G | (uintptr_t)X) & 15) == 0;
+    const dim3 grid(nsplit, B, ((M + 15) / 16 + MXM_RT - 1) / MXM_RT);
+    hipStream_t s = (hipStream_t)stream;
+#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(256), 0, s, G, X, partial, M, K, HW, chunk)
+    if (vec) { if (binarize_g) PH_MXM(true, true); else PH_MXM(true, false); }
+    else { if (binarize_g) PH_MXM(false, true); else PH_MXM(false, false); }
+#undef PH_MXM
+    PH_CHECK_LAUNCH();
+    const int64_t MK = (int64_t)M * K;
+    hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((MK * B + 255) / 256)), dim3(256), 0, s, partial, out, nsplit, MK, B);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_upsample2x_bwd(const float* grad_out /* [planes][2H][2W] */, float* grad_in /* [planes][H][W] */, int64_t planes, int H,
+                                 int W, void* stream) {
+    PH_CHECK_ARG(grad_out && grad_in && planes > 0 && H > 0 && W > 0, "bad pointer or size");
+    const int64_t total = planes * H * W;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_upsample2x_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_out, grad_in, planes, H, W);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

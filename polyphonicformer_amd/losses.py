@@ -310,7 +310,7 @@ def target_single(head, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask, pos
     if pos_depth is not None:
         assert neg_depth is not None and gt_depth is not None
         Rd = R + ns
-        gd = gt_depth.to(dev).float()
+        gd = gt_depth.to(dev).float().reshape(H, W)           # [H, W] or [1, H, W] (the batched gt_depth of forward_train)
         depth_targets = torch.zeros((Rd, H, W), device=dev)
         depth_weights = torch.zeros((Rd, H, W), device=dev)
         if num_pos:

@@ -1,0 +1,364 @@
+"""One training step of the path: forward in training mode, the objective, backward.
+
+What `PolyphonicFormer.forward_train` runs after `extract_feat` (polyphonic_former.py:96-129) and what mmdet's
+`BaseDetector._parse_losses` + `loss.backward()` do with its result (mmdet/models/detectors/base.py:176-199):
+
+    rpn_head.forward_train -> roi_head.forward_train -> objective = sum of the entries whose key contains 'loss' -> backward
+
+How the work is split on the MI355X:
+
+  * everything that is map-sized runs in libpolyhead, forward AND backward: every 1x1 convolution (static or
+    dynamic kernels), the hard-mask pooling, the x2 upsamples (`ph_rows_x_map`, `ph_map_x_map_t`, `ph_upsample2x`,
+    `ph_upsample2x_bwd`, csrc/ph_train.hip) and the losses with their gradients w.r.t. the predictions
+    (csrc/ph_loss.hip).  They are `torch.autograd.Function`s here, each with a hand-written backward.
+    `feat_transform` is folded as in the inference path (pooling and the dynamic convolution are linear in it),
+    so a stage makes two pooling and two dynamic-convolution passes over the maps and nothing else.
+  * the query side -- [B * N, 256] rows: KernelUpdator, attention, FFN, the fc towers -- is expressed with the
+    library's dense GEMMs and row-wise ops under autograd.  It is 4 MB of weights against a few thousand rows;
+    the fused inference kernels (csrc/ph_query.hip) keep no intermediates, so the training forward re-evaluates
+    it op by op.  GroupNorm + ReLU of the three KernelHead towers likewise.
+  * the discrete parts (Hungarian assignment, sampling, targets) are the ones `forward_train` already uses.
+
+The result is checked against the reference's own forward + autograd backward (tests/golden/train_step.npz:
+every loss, the objective and the gradient of every parameter and of the three input maps)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, engine as E, losses as Lo
+
+LN_EPS = 1e-5
+BIN_THR = 1.5 * 2.0 ** -24          # sigmoid(z) > 0.5 in fp32 (csrc/ph_common.h PH_BIN_THR)
+
+
+def _gpu32(t, name):
+    if not t.is_cuda:
+        raise _lib.PolyheadError(f"{name} must live on the GPU: libpolyhead has no CPU path")
+    return t.detach().contiguous().float()
+
+
+# ---- raw calls -------------------------------------------------------------------------------------------------------------
+def rows_x_map(A, X, binarize_x=False):
+    """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p];  A [B or 1, M, K], X [B, K, *spatial] -> [B, M, *spatial]"""
+    X = _gpu32(X, "X")
+    B, K = X.shape[:2]
+    HW = X[0, 0].numel()
+    Ab, M, Ka = A.shape
+    assert Ka == K and Ab in (1, B), (A.shape, X.shape)
+    Mpad, lda = (M + 15) // 16 * 16, (K + 7) // 8 * 8
+    Ap = torch.zeros((Ab, Mpad, lda), dtype=torch.float32, device=X.device)
+    Ap[:, :M, :K] = A.detach()
+    Y = torch.empty((B, M) + tuple(X.shape[2:]), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.load().ph_rows_x_map(_lib.ptr(Ap), Mpad * lda if Ab > 1 else 0, lda, Mpad, M, K, _lib.ptr(X), _lib.ptr(Y), B, HW,
+                                         int(binarize_x), _lib.stream_ptr()), "ph_rows_x_map")
+    return Y
+
+
+def map_x_mapT(G, X, binarize_g=False):
+    """O[b, m, k] = sum_p G[b, m, p] X[b, k, p];  G [B, M, *spatial], X [B, K, *spatial] -> [B, M, K]"""
+    G, X = _gpu32(G, "G"), _gpu32(X, "X")
+    B, M = G.shape[:2]
+    K = X.shape[1]
+    HW = X[0, 0].numel()
+    assert G[0, 0].numel() == HW and X.shape[0] == B
+    lib = _lib.load()
+    ns = lib.ph_map_x_map_t_nsplit(B, M, HW)
+    part = torch.empty((B, ns, M, K), dtype=torch.float32, device=X.device)
+    out = torch.empty((B, M, K), dtype=torch.float32, device=X.device)
+    _lib.check(lib.ph_map_x_map_t(_lib.ptr(G), _lib.ptr(X), _lib.ptr(part), _lib.ptr(out), B, M, K, HW, ns, int(binarize_g),
+                                 _lib.stream_ptr()), "ph_map_x_map_t")
+    return out
+
+
+# ---- differentiable map-sized operations -------------------------------------------------------------------------------------
+class _Conv1x1(torch.autograd.Function):
+    """Y = A . X per image (F.conv2d with 1x1 kernels: static when A has batch 1, dynamic otherwise)"""
+
+    @staticmethod
+    def forward(ctx, A, X):
+        ctx.save_for_backward(A, X)
+        return rows_x_map(A, X)
+
+    @staticmethod
+    def backward(ctx, gY):
+        A, X = ctx.saved_tensors
+        gA = gX = None
+        if ctx.needs_input_grad[0]:
+            gA = map_x_mapT(gY, X)                                   # [B, M, K]: dL/dA[m, k] = sum_p gY[m, p] X[k, p]
+            if A.shape[0] == 1:
+                gA = gA.sum(0, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            gX = rows_x_map(A.transpose(1, 2), gY)                   # dL/dX[k, p] = sum_m A[m, k] gY[m, p]
+        return gA, gX
+
+
+class _PoolHard(torch.autograd.Function):
+    """O[b, n, c] = sum_p [sigmoid(logits[b, n, p]) > 0.5] X[b, c, p]; no gradient through the hard mask
+    (kernel_update_head.py:236-242, kernel_head.py:314-320)"""
+
+    @staticmethod
+    def forward(ctx, logits, X):
+        ctx.save_for_backward(logits)
+        return map_x_mapT(logits, X, binarize_g=True)
+
+    @staticmethod
+    def backward(ctx, gO):
+        (logits,) = ctx.saved_tensors
+        return None, rows_x_map(gO.transpose(1, 2), logits, binarize_x=True)   # dL/dX[c, p] = sum_n gO[n, c] M[n, p]
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return E.upsample2x(_gpu32(t, "t"))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _gpu32(g, "g")
+        B, N, H2, W2 = g.shape
+        out = torch.empty((B, N, H2 // 2, W2 // 2), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().ph_upsample2x_bwd(_lib.ptr(g), _lib.ptr(out), B * N, H2 // 2, W2 // 2, _lib.stream_ptr()),
+                   "ph_upsample2x_bwd")
+        return out
+
+
+class _Objective(torch.autograd.Function):
+    """The loss kernels as one differentiable scalar: forward evaluates `fn(*preds)` -> (dict of losses, dict of
+    d(sum of the 'loss' entries) / d(pred)); backward hands the stored gradients on, scaled by the incoming one."""
+
+    @staticmethod
+    def forward(ctx, fn, box, *preds):
+        losses, grads = fn(*[p.detach() for p in preds])
+        box.update(losses)
+        ctx.save_for_backward(*grads)
+        total = sum(v.double() for k, v in losses.items() if "loss" in k)
+        return total.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g * t for t in ctx.saved_tensors)
+
+
+def conv1x1(X, weight, bias=None):
+    """F.conv2d(X, weight [O, C, 1, 1], bias) on libpolyhead"""
+    Y = _Conv1x1.apply(weight.reshape(1, weight.shape[0], -1), X)
+    return Y if bias is None else Y + bias.reshape(1, -1, 1, 1)
+
+
+def dynconv(kernels, X):
+    """per-image 1x1 convolution with predicted kernels [B, N, C] (kernel_update_head.py:317-329)"""
+    return _Conv1x1.apply(kernels, X)
+
+
+pool_hard = _PoolHard.apply
+upsample2x = _Upsample2x.apply
+
+
+def hard_count(logits):
+    """number of foreground pixels of each hard mask, [B, N] (the bias term of the folded feat_transform)"""
+    return (logits.detach() > BIN_THR).flatten(2).sum(-1).float()
+
+
+# ---- the query side (rows), under autograd -------------------------------------------------------------------------------------
+def _lin(P, name, x, bias=True):
+    return F.linear(x, P[name + ".weight"], P[name + ".bias"] if bias else None)
+
+
+def _ln(P, name, x):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], LN_EPS)
+
+
+def _updator(P, name, u, k):
+    """KernelUpdator.forward (funcs/kernel_updator.py:55-93), conv_kernel_size = 1"""
+    Cf = P[name + ".input_gate.weight"].shape[0]
+    p = _lin(P, name + ".dynamic_layer", u)
+    i = _lin(P, name + ".input_layer", k)
+    gate = i[..., :Cf] * p[..., :Cf]
+    ig = _ln(P, name + ".input_norm_in", _lin(P, name + ".input_gate", gate)).sigmoid()
+    ug = _ln(P, name + ".norm_in", _lin(P, name + ".update_gate", gate)).sigmoid()
+    f = ug * _ln(P, name + ".norm_out", p[..., -Cf:]) + ig * _ln(P, name + ".input_norm_out", i[..., -Cf:])
+    return F.relu(_ln(P, name + ".fc_norm", _lin(P, name + ".fc_layer", f)))
+
+
+def _self_attention(P, name, t, heads):
+    """mmcv MultiheadAttention (identity added) around nn.MultiheadAttention with q = k = v (kernel_update_head.py:259)"""
+    B, N, C = t.shape
+    d = C // heads
+    q, k, v = F.linear(t, P[name + ".attn.in_proj_weight"], P[name + ".attn.in_proj_bias"]).split(C, dim=-1)
+    q = q.view(B, N, heads, d).transpose(1, 2) * (1.0 / math.sqrt(d))
+    k, v = k.view(B, N, heads, d).transpose(1, 2), v.view(B, N, heads, d).transpose(1, 2)
+    a = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B, N, C)
+    return t + F.linear(a, P[name + ".attn.out_proj.weight"], P[name + ".attn.out_proj.bias"])
+
+
+def _ffn(P, name, t):
+    return t + _lin(P, name + ".layers.1", F.relu(_lin(P, name + ".layers.0.0", t)))
+
+
+def stage_forward(head, x, dfe, k, m, q):
+    """KernelUpdateHead.forward (kernel_update_head.py:212-353) in training form.  x, dfe [B, C, H, W] (gradients flow),
+    k / q [B, N, C] kernels and depth kernels, m [B, N, H, W] mask logits (used through the hard mask only).
+    -> cls [B, N, L], mask [B, N, H, W], obj [B, N, C], depth [B, N, H, W], dobj [B, N, C]"""
+    P = dict(head.named_parameters())
+    Wt, bt = P["feat_transform.conv.weight"].flatten(1), P["feat_transform.conv.bias"]
+    Wd, bd = P["feat_depth_transform.conv.weight"].flatten(1), P["feat_depth_transform.conv.bias"]
+    cnt = hard_count(m)[..., None]
+    u = pool_hard(m, x) @ Wt.t() + cnt * bt               # = einsum(hard mask, feat_transform(x)) (:225,241)
+    ud = pool_hard(m, dfe) @ Wd.t() + cnt * bd
+    q = q + k.detach()                                    # :250
+    o = _updator(P, "kernel_update_conv", u, k)
+    od = _updator(P, "kernel_update_conv_depth", ud, q)
+    heads = head.attention.attn.num_heads
+    o = _ln(P, "attention_norm", _self_attention(P, "attention", o, heads))
+    od = _ln(P, "attention_norm_depth", _self_attention(P, "attention_depth", od, heads))
+    o = _ln(P, "ffn_norm", _ffn(P, "ffn", o))
+    od = _ln(P, "ffn_norm_depth", _ffn(P, "ffn_depth", od))
+    cls_feat = F.relu(_ln(P, "cls_fcs.1", _lin(P, "cls_fcs.0", o, bias=False)))
+    mask_feat = F.relu(_ln(P, "mask_fcs.1", _lin(P, "mask_fcs.0", o, bias=False)))
+    dep_feat = _ln(P, "depth_regs.1", _lin(P, "depth_regs.0", od, bias=False))
+    cls = _lin(P, "fc_cls", cls_feat)
+    kmask, kdep = _lin(P, "fc_mask", mask_feat), _lin(P, "fc_depth", dep_feat)
+    mask = dynconv(kmask @ Wt, x) + (kmask @ bt)[..., None, None]         # = conv(feat_transform(x), kmask) (:317-322)
+    depth = dynconv(kdep @ Wd, dfe) + (kdep @ bd)[..., None, None]
+    return cls, mask, o, depth, od
+
+
+def _tower(P, name, f, groups):
+    y = conv1x1(f, P[name + ".conv.weight"])
+    return F.relu(F.group_norm(y, groups, P[name + ".gn.weight"], P[name + ".gn.bias"], 1e-5))
+
+
+def rpn_forward(head, feats):
+    """KernelHead._decode_init_proposals after the neck (kernel_head.py:245-336), training form (no stuff rows)"""
+    P = dict((n, p) for n, p in head.named_parameters() if not n.startswith("localization_fpn."))
+    groups = head.norm_cfg.get("num_groups", 32)
+    loc = _tower(P, "loc_convs.0", feats[0], groups)
+    sem = _tower(P, "seg_convs.0", feats[1], groups)
+    dfe = _tower(P, "depth_convs.0", feats[2], groups)
+    W_init = P["init_kernels.weight"]
+    mask_preds = conv1x1(loc, W_init)
+    depth_pred = conv1x1(dfe, P["conv_direct_depth.weight"], P["conv_direct_depth.bias"])
+    seg_preds = conv1x1(sem, P["conv_seg.weight"], P["conv_seg.bias"])
+    x = sem + loc
+    B = x.shape[0]
+    proposal = W_init.flatten(1)[None] + pool_hard(mask_preds, x)                              # :299-300,314-326
+    depth_proposal = P["conv_direct_depth.weight"].flatten(1)[None].expand(B, 1, -1)           # :286-289
+    return dict(proposal=proposal, x=x, mask_preds=mask_preds, seg_preds=seg_preds, dfe=dfe, depth_proposal=depth_proposal,
+                depth_pred=depth_pred)
+
+
+# ---- the step ------------------------------------------------------------------------------------------------------------------
+def parse_losses(losses):
+    """mmdet BaseDetector._parse_losses (base.py:188-199): the objective is the sum of the entries with 'loss' in the key"""
+    return sum(v.mean() for k, v in losses.items() if "loss" in k and torch.is_tensor(v))
+
+
+class TrainStep:
+    """rpn_head: KernelHead, roi_head: KernelUpdateIterHead, both built with train_cfg.  `forward_backward` evaluates one
+    step on the three post-neck maps and leaves `.grad` on every parameter of the two heads (accumulating, like autograd)
+    and returns (losses, objective, gradients of the three maps)."""
+
+    def __init__(self, rpn_head, roi_head):
+        self.rpn, self.roi = rpn_head, roi_head
+        if rpn_head.assigner is None or not roi_head.mask_assigner:
+            raise ValueError("TrainStep needs heads built with train_cfg (assigner / sampler)")
+
+    def parameters(self):
+        return [p for n, p in self.rpn.named_parameters() if not n.startswith("localization_fpn.")] + list(self.roi.parameters())
+
+    # -- rpn side: kernel_head.py:349-454
+    def _rpn(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses):
+        h = self.rpn
+        r = rpn_forward(h, feats)
+        up = (lambda t: upsample2x(t)) if h.feat_downsample_stride == 2 else (lambda t: t)
+        smask, sseg, sdep0 = up(r["mask_preds"]), up(r["seg_preds"]), up(r["depth_pred"])
+        N = h.num_proposals + h.num_stuff_classes
+        sdep = sdep0.detach().expand(-1, N, -1, -1)
+        srs = []
+        for i in range(len(img_metas)):
+            valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
+            ar = h.assigner.assign(smask[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i], depth_pred=sdep[i],
+                                   gt_depth=gt_depth[i], gt_valid=valid)
+            sr = h.sampler.sample(ar, smask[i].detach(), gt_masks[i], depth=sdep[i])
+            sr.valid_mask = valid
+            srs.append(sr)
+        targets = h.get_targets(srs, gt_masks, h.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls, gt_depth=gt_depth)
+
+        def fn(mp, sp, dp):
+            ls, g = Lo.rpn_losses(h, mp, sp, dp.expand(-1, N, -1, -1), *targets, with_grads=True)
+            return ls, (g["mask_pred"], g["seg_preds"], g["depth_pred"])
+
+        total = _Objective.apply(fn, losses, smask, sseg, sdep0)
+        losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)             # logged, not in the objective
+        return total, r
+
+    # -- roi side: kernel_update.py:159-280
+    def _roi(self, r, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses):
+        ih, rp = self.roi, self.rpn
+        B = r["x"].shape[0]
+        nt, L = rp.num_thing_classes, rp.num_classes
+        mask_preds, k, q = r["mask_preds"], r["proposal"], r["depth_proposal"]
+        if rp.cat_stuff_mask:                                                                 # kernel_head.py:444-451
+            mask_preds = torch.cat([mask_preds, r["seg_preds"][:, nt:L]], dim=1)
+            stuff = dict(rp.named_parameters())["conv_seg.weight"][nt:L].flatten(1)
+            k = torch.cat([k, stuff[None].expand(B, -1, -1)], dim=1)
+        N = k.shape[1]
+        q = q.expand(B, N, -1)
+        up = ih.mask_head[0].mask_upsample_stride
+        scale = (lambda t: upsample2x(t)) if up == 2 else (lambda t: t)
+        prev_mask = scale(mask_preds.detach()).detach()
+        prev_depth = scale(r["depth_pred"].detach().expand(-1, N, -1, -1).contiguous()).detach()
+        prev_cls = [None] * B
+        if ih.hard_target:
+            gt_masks = [m.bool().float() for m in gt_masks]
+        total, m, assign = 0.0, mask_preds, []
+        for s in range(ih.num_stages):
+            head = ih.mask_head[s]
+            cls, m, k, depth, q = stage_forward(head, r["x"], r["dfe"], k, m, q)
+            smask, sdepth = scale(m), scale(depth)
+            srs = []
+            if s < ih.assign_stages:
+                assign = []
+            for i in range(B):
+                valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
+                if s < ih.assign_stages:
+                    c = None if prev_cls[i] is None else prev_cls[i][:ih.num_proposals, :ih.num_thing_classes]
+                    assign.append(ih.mask_assigner[s].assign(prev_mask[i][:ih.num_proposals], c, gt_masks[i], gt_labels[i], img_metas[i],
+                                                             depth_pred=prev_depth[i][:ih.num_proposals], gt_depth=gt_depth[i],
+                                                             gt_valid=valid))
+                sr = ih.mask_sampler[s].sample(assign[i], smask[i].detach(), gt_masks[i], depth=sdepth[i].detach())
+                sr.valid_mask = valid
+                srs.append(sr)
+            targets = head.get_targets(srs, gt_masks, gt_labels, ih.train_cfg[s], True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                       gt_depth=gt_depth)
+
+            def fn(cs, mp, dp, head=head, targets=targets):
+                ls, g = Lo.stage_losses(head, cs, mp, dp, *targets, with_grads=True)
+                return ls, (g["cls_score"], g["mask_pred"], g["depth_pred"])
+
+            box = {}
+            w = ih.stage_loss_weights[s]
+            total = total + w * _Objective.apply(fn, box, cls, smask, sdepth)
+            for key, v in box.items():
+                losses[f"s{s}_{key}"] = v * w
+            prev_mask, prev_cls, prev_depth = smask.detach(), cls.detach(), sdepth.detach()
+        return total
+
+    def forward_backward(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, backward=True):
+        feats = [f.detach().float().contiguous().requires_grad_(True) for f in feats]
+        for f in feats:
+            if not f.is_cuda:
+                raise _lib.PolyheadError("the post-neck maps must live on the GPU: libpolyhead has no CPU path")
+        if self.rpn.hard_target:
+            gt_masks = [m.bool().float() for m in gt_masks]
+        losses = {}
+        with torch.enable_grad():
+            rpn_losses = {}
+            t_rpn, r = self._rpn(feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, rpn_losses)
+            t_roi = self._roi(r, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses)
+            losses.update(rpn_losses)
+            total = t_rpn + t_roi
+            if backward:
+                total.backward()
+        return losses, total.detach(), [f.grad for f in feats]
