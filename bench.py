@@ -418,6 +418,85 @@ def video_leg(dev, precision="bf16", frames=6):
             "wall time incl. the D2H of the id / depth maps and the host-side tracker"}
 
 
+def train_leg(wl, dev, world, B=2, steps=4):
+    """secondary number: one TRAINING step of the path per image batch -- both heads forward in training mode
+    from the three post-neck maps, Hungarian assignment (host, scipy), targets, losses, backward to every parameter and to the
+    maps (polyphonicformer_amd/train.py), gradient all-reduce over the process group when there is more than one rank."""
+    from polyphonicformer_amd.registry import HEADS
+    from polyphonicformer_amd import train as T
+    import polyphonicformer_amd.kernel_head, polyphonicformer_amd.kernel_update  # noqa: F401,E401
+    import polyphonicformer_amd.kernel_update_head, polyphonicformer_amd.kernel_updator  # noqa: F401,E401
+    L, nt, ns, H, W = wl["n_thing"] + wl["n_stuff"], wl["n_thing"], wl["n_stuff"], wl["H"], wl["W"]
+    cost = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
+                mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    tc = lambda extra: dict(assigner=dict(type='MaskHungarianAssignerWithDepth', **cost, **extra), sampler=dict(type='MaskPseudoSampler'),
+                            pos_weight=1.)
+    torch.manual_seed(2)
+    rpn = HEADS.build(dict(type="KernelHead", num_proposals=wl["Nq"], num_classes=L, num_thing_classes=nt, num_stuff_classes=ns,
+                           cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False, use_binary=True, proposal_feats_with_obj=True,
+                           loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+                           loss_seg=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                           loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+                           loss_dice=dict(type="DiceLoss", loss_weight=4.0),
+                           loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid"), train_cfg=tc({})))
+    scfg = stage_cfg(L, nt, ns, wl["F"])
+    scfg.update(loss_rank=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.1),
+                loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+                loss_dice=dict(type="DiceLoss", loss_weight=4.0), loss_depth=dict(type="DepthLoss", loss_weight=5.0, depth_act_mode="sigmoid"))
+    depth_cost = dict(depth_cost=dict(type='DepthCost', weight=0., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.), depth_act_mode='sigmoid'))
+    roi = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=wl["S"], assign_stages=wl["S"], stage_loss_weights=[1] * wl["S"],
+                           num_proposals=wl["Nq"], num_thing_classes=nt, num_stuff_classes=ns, mask_head=scfg, train_cfg=tc(depth_cost)))
+    rpn.init_weights()
+    roi.init_weights()
+    rpn.to(dev)
+    roi.to(dev)
+    step = T.TrainStep(rpn, roi)
+    g = torch.Generator().manual_seed(11)
+    feats = [torch.randn(B, 256, H, W, generator=g).relu().to(dev) for _ in range(3)]
+    H2, W2 = 2 * H, 2 * W
+    gts = []
+    for b in range(B):                       # ~20 instances and half of the stuff classes per image, at the assign stride
+        G = 20
+        cy, cx = torch.rand(G, generator=g) * H2, torch.rand(G, generator=g) * W2
+        r = 8 + torch.rand(G, generator=g) * 40
+        yy, xx = torch.arange(H2)[None, :, None], torch.arange(W2)[None, None, :]
+        masks = (((yy - cy[:, None, None]) ** 2 + (xx - cx[:, None, None]) ** 2) < r[:, None, None] ** 2).float()
+        present = torch.randperm(ns, generator=g)[: ns // 2].sort()[0]
+        sem = (torch.rand(len(present), H2 // 16, W2 // 16, generator=g) > 0.6).float()
+        sem = torch.nn.functional.interpolate(sem[None], size=(H2, W2), mode="nearest")[0]
+        depth = torch.rand(H2, W2, generator=g) * 79.0 + 0.5
+        gts.append(dict(masks=masks.to(dev), labels=torch.randint(0, nt, (G,), generator=g).to(dev), sem_seg=sem.to(dev),
+                        sem_cls=(present + nt).to(dev), depth=depth.to(dev)))
+    metas = [dict(img_shape=(H * 8, W * 8, 3), ori_shape=(H * 8, W * 8, 3), batch_input_shape=(H * 8, W * 8))] * B
+    gd = torch.stack([x["depth"][None] for x in gts])
+    args = (feats, metas, [x["masks"] for x in gts], [x["labels"] for x in gts], [x["sem_seg"] for x in gts], [x["sem_cls"] for x in gts], gd)
+
+    def one(backward=True):
+        for p in step.parameters():
+            p.grad = None
+        return step.forward_backward(*args, backward=backward)
+
+    one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses, total, _ = one()
+    torch.cuda.synchronize(dev)
+    full = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(backward=False)
+    torch.cuda.synchronize(dev)
+    fwd = (time.perf_counter() - t0) / steps
+    nparam = sum(p.numel() for p in step.parameters())
+    return {"images_per_step_per_gpu": B, "ms_per_step": round(full * 1e3, 2), "forward_only_ms": round(fwd * 1e3, 2),
+            "images_per_s": round(world * B / full, 2), "objective": round(float(total), 3), "parameters": nparam,
+            "grad_allreduce": f"{len(step.buckets.buckets)} bucket(s) over {world} rank(s)" + ("" if world > 1 else " (nothing sent)"),
+            "workload": f"{H * 8}x{W * 8}, stride-8 maps {H}x{W}, losses at stride 4, N={wl['Nq']}+{ns}, S={wl['S']}, 20 instances / image",
+            "note": "forward (training mode) + Hungarian assignment on the host + targets + losses + backward to all parameters and "
+                    "the three post-neck maps; fp32, wall time incl. host work"}
+
+
 def panoptic_leg(wl, head, plan, dev):
     """get_panoptic (a7, SURVEY 8d: reported separately) on ONE frame of the step's outputs; host wall time,
     including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
@@ -809,6 +888,11 @@ def main():
                 res["hungarian_assign"] = assign_leg(dev)
             except Exception as e:
                 res["hungarian_assign"] = {"error": repr(e)}
+        if world == 1 and not args.no_neck:
+            try:
+                res["train_step"] = train_leg(wl, dev, world)
+            except Exception as e:
+                res["train_step"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, head)
         os.write(json_fd, (json.dumps(res) + "\n").encode())

@@ -232,7 +232,8 @@ def stage_losses(head, cls_score, mask_pred, depth_pred, labels, label_weights, 
     labels = labels.to(dev).long().contiguous()
     pos = (labels >= 0) & (labels < L)                                                        # :375
     num_pos = int(pos.sum())
-    avg = max(float(num_pos), 1.0)                                                            # :376-377 (single process: reduce_mean = id)
+    from .dist import reduce_mean
+    avg = max(float(reduce_mean(pos.sum().float())), 1.0)                                     # :376-377 (mean over ranks, clamp)
     losses, grads = {}, None
     if with_grads:
         grads = dict(mask_pred=torch.empty((R, HW), dtype=torch.float32, device=dev),

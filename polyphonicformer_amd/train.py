@@ -256,13 +256,17 @@ def parse_losses(losses):
 
 class TrainStep:
     """rpn_head: KernelHead, roi_head: KernelUpdateIterHead, both built with train_cfg.  `forward_backward` evaluates one
-    step on the three post-neck maps and leaves `.grad` on every parameter of the two heads (accumulating, like autograd)
-    and returns (losses, objective, gradients of the three maps)."""
+    step on the three post-neck maps and leaves `.grad` on every parameter of the two heads (accumulating, like autograd; averaged over the ranks
+    when torch.distributed runs with more than one) and returns (losses, objective, gradients of the three maps)."""
 
-    def __init__(self, rpn_head, roi_head):
+    def __init__(self, rpn_head, roi_head, bucket_bytes=32 << 20, group=None):
         self.rpn, self.roi = rpn_head, roi_head
         if rpn_head.assigner is None or not roi_head.mask_assigner:
             raise ValueError("TrainStep needs heads built with train_cfg (assigner / sampler)")
+        # data parallel: one process per GPU, gradients averaged by bucketed all-reduces (RCCL over xGMI) that start while
+        # backward is still running (dist.GradBuckets); on one rank nothing is sent
+        from .dist import GradBuckets
+        self.buckets = GradBuckets(self.parameters(), bucket_bytes=bucket_bytes, group=group)
 
     def parameters(self):
         return [p for n, p in self.rpn.named_parameters() if not n.startswith("localization_fpn.")] + list(self.roi.parameters())
@@ -360,5 +364,7 @@ class TrainStep:
             losses.update(rpn_losses)
             total = t_rpn + t_roi
             if backward:
+                self.buckets.start()
                 total.backward()
+                self.buckets.finish()
         return losses, total.detach(), [f.grad for f in feats]

@@ -111,3 +111,75 @@ def test_single_process_gather_is_identity():
     r, n = D.pack_track_records(*_frame_records(3))
     out = D.allgather_track_records([3], [r], [n], 1)
     assert out[0][0] == 3 and torch.equal(out[0][3], _frame_records(3)[2])
+
+
+# ---- data-parallel training: bucketed gradient all-reduce overlapped with backward (dist.GradBuckets) ---------------------------
+def _toy(seed=0):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+
+
+def _toy_data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(16, 32, generator=g), torch.randn(16, 8, generator=g)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _toy()
+    unused = torch.nn.Parameter(torch.ones(5))                 # takes no part in the backward: reduced as zeros
+    params = list(net.parameters()) + [unused]
+    gb = D.GradBuckets(params, bucket_bytes=2048)              # several buckets
+    out = []
+    for step in range(2):                                      # the buckets re-arm
+        for p in params:
+            p.grad = None
+        gb.start()
+        x, y = _toy_data(rank)
+        with torch.enable_grad():
+            ((net(x) - y) ** 2).mean().backward()
+        gb.finish()
+        out.append([p.grad.numpy().copy() for p in params])      # by value: the worker exits before the parent reads
+    n = torch.tensor(3.0 + rank)
+    q.put((rank, len(gb.buckets), out, float(D.reduce_mean(n))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_world2_match_mean_of_rank_gradients():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+    want = []
+    for r in range(world):
+        net = _toy()
+        x, y = _toy_data(r)
+        with torch.enable_grad():
+            ((net(x) - y) ** 2).mean().backward()
+        want.append([p.grad for p in net.parameters()])
+    mean = [(a + b) / 2 for a, b in zip(*want)]
+    for rank, nb, out, rm in res:
+        assert nb >= 2 and rm == 3.5
+        for grads in out:
+            for g, w in zip(grads[:-1], mean):
+                assert torch.allclose(torch.from_numpy(g), w, atol=1e-6)
+            assert not grads[-1].any()
+
+
+def test_grad_buckets_single_process_leaves_gradients_alone():
+    net = _toy()
+    gb = D.GradBuckets(net.parameters(), bucket_bytes=1024)
+    x, y = _toy_data(0)
+    with torch.enable_grad():
+        ((net(x) - y) ** 2).mean().backward()
+    before = [p.grad.clone() for p in net.parameters()]
+    gb.finish()
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
+    gb.remove()
