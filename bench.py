@@ -784,8 +784,8 @@ def main():
             try:
                 with open(os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")) as f:
                     pt = json.load(f)
-                if pt["frames_per_launch"] == kplan.B and args.workload == "cfg2" and args.precision == "bf16" \
-                        and dom in pt["kernels"]:
+                if pt["frames_per_launch"] == kplan.B and args.workload == "cfg2" \
+                        and args.precision == pt.get("mode", "bf16") and dom in pt["kernels"]:
                     traffic = pt["kernels"][dom].get("hbm_bytes_per_launch")
                     traffic_src = f"profiles/{rnd}/pmc_traffic.json (rocprofv3 --pmc passes of this command, not measured in this run)"
                     break
