@@ -63,8 +63,8 @@ class MultiheadAttentionParams(nn.Module):
 
 
 class _LossStub(nn.Module):
-    """Training losses are out of scope; the heads only read `.use_sigmoid`
-    (kernel_head.py:152,226, kernel_update_head.py:169,203, kernel_update.py:333)."""
+    """Placeholder for the TRACK head's loss configs (its training is out of scope, track_head.py); the path's own losses
+    are real classes (losses.py)."""
 
     def __init__(self, use_sigmoid=False, **kw):
         super().__init__()
@@ -74,10 +74,6 @@ class _LossStub(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("training losses are outside the hot path this package implements")
 
-
-for _n in ("FocalLoss", "CrossEntropyLoss", "DiceLoss", "DepthLoss"):
-    if _n not in LOSSES:
-        LOSSES.register_module(name=_n, module=type(_n, (_LossStub,), {}))
 
 
 def bias_init_with_prob(p):

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from . import _lib, engine as E
 from .bricks import ConvModuleParams, bias_init_with_prob
+from . import losses as _losses  # noqa: F401  registers FocalLoss / CrossEntropyLoss / DiceLoss / DepthLoss
 from .registry import NECKS, ConfigDict, build_loss, build_neck, register_everywhere
 
 
