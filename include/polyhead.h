@@ -124,8 +124,11 @@ typedef struct {
  * Outputs obj, dobj fp32 [B][N][256]; cls fp32 [B][N][L]; kern planes [P][2][B][Npad][256] and
  *         kbias fp32 [2][B][Npad]: the dynamic 1x1 conv kernels already folded with
  *         feat_transform, i.e. new_mask_logits = kern[0] . x + kbias[0]  (kernel_update_head.py:317-329).
- * Workspace (ph_query_workspace_bytes): q/k/v planes + residual. */
-enum { PH_QUERY_PRE = 1, PH_QUERY_POST = 2, PH_QUERY_BOTH = 3 };
+ * Workspace (ph_query_workspace_bytes): q/k/v planes + residual.
+ * phases: PH_QUERY_PRE | PH_QUERY_POST, optionally | PH_QUERY_WIDE: as many rows per workgroup as divide the padded row
+ *         count (fewest CU-seconds; for launches that share the GPU with other streams).  Without it the launch is shaped
+ *         to fill the chip by itself (lowest latency of a single launch). */
+enum { PH_QUERY_PRE = 1, PH_QUERY_POST = 2, PH_QUERY_BOTH = 3, PH_QUERY_WIDE = 0x100 };
 size_t ph_query_workspace_bytes(int B, int N, int prec);
 /* byte offset, inside the workspace, of the fp32 [B][2][Npad][256] KernelUpdator outputs
  * (funcs/kernel_updator.py:93) that the PRE phase leaves behind for the POST phase. */

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
 PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16 = 1, 2, 3, 5
+PH_QUERY_WIDE = 0x100            # ph_query_stage phases flag: most rows per workgroup (launches that share the GPU)
 PH_OUT_F32, PH_OUT_BF16, PH_OUT_F16 = 0, 1, 2
 PH_KERN_BF16_PLANES, PH_KERN_F16 = 0, 1
 PH_GN_TO_PLANES, PH_GN_UP2_PLANES, PH_GN_ACCUM, PH_GN_TO_NCHW, PH_GN_TO_CPLANES = 0, 1, 2, 3, 4

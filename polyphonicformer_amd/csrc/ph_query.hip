@@ -1667,7 +1667,8 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
                               float* cls, int cls_sigmoid, uint16_t* kern, float* kbias, void* workspace,
                               size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format, int phases,
                               void* stream) {
-    PH_CHECK_ARG(phases >= 1 && phases <= 3, "phases must be PH_QUERY_PRE | PH_QUERY_POST");
+    PH_CHECK_ARG((phases & ~(PH_QUERY_BOTH | PH_QUERY_WIDE)) == 0 && (phases & PH_QUERY_BOTH) != 0,
+                 "phases must be PH_QUERY_PRE | PH_QUERY_POST [| PH_QUERY_WIDE]");
     PH_CHECK_ARG(partial && bits && k_in && q_in && wb && wf && layout && obj && dobj && cls && kern && kbias && workspace,
                  "null pointer");
     PH_CHECK_ARG(B > 0 && N > 0 && N <= 256 && HW > 0 && nsplit >= 1, "bad size");
@@ -1676,6 +1677,8 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
     PH_CHECK_ARG(layout->ffn_dim > 0 && layout->ffn_dim % 256 == 0, "ffn_dim must be a multiple of 256");
     PH_CHECK_ARG(layout->num_classes > 0 && layout->num_classes <= 1024, "bad num_classes");
     const int PA = prec == PH_PREC_SPLIT ? 2 : 1, Npad = ph_n_padded(N);
+    const bool wide = (phases & PH_QUERY_WIDE) != 0;
+    phases &= PH_QUERY_BOTH;
     if (workspace_bytes < q_ws_bytes(B, Npad, PA)) {
         ph_set_error("ph_query_stage: workspace too small (%zu < %zu)", workspace_bytes, q_ws_bytes(B, Npad, PA));
         return PH_EWORKSPACE;
@@ -1702,11 +1705,27 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
         }();
         a2.tl = tl;
         a2.pi = a.o1 + (size_t)B * 2 * Npad * 256;
-        // rows per workgroup: the largest of 80 / 64 / 48 / 32 / 16 that divides the padded row count
+        // rows per workgroup (16 * nrt, nrt | Npad / 16).  Two regimes, measured at cfg2 (tools/query_time.py, split
+        // precision, pre + post): 24 frames alone on the GPU 306 us at 80 rows (96 workgroups) against 166 us at 32 rows (240
+        // workgroups) -- a launch that has the chip to itself wants the chip FILLED; inside the multi-stream step the 80-row
+        // form costs 34 CU-ms per launch against 48 and leaves 160 CUs to the other parts' HBM kernels (8.16 against 8.58 ms per
+        // 96-frame step) -- PH_QUERY_WIDE asks for that one.  Default: the largest divisor that still gives >= 200 workgroups,
+        // else the smallest one above 16 rows.
         const int t = Npad / 16;
-        int nrt = t % 5 == 0 ? 5 : (t % 4 == 0 ? 4 : (t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1)));
+        int nrt = 1;
+        if (wide) {
+            nrt = t % 5 == 0 ? 5 : (t % 4 == 0 ? 4 : (t % 3 == 0 ? 3 : (t % 2 == 0 ? 2 : 1)));
+        } else {
+            int smallest = 1;
+            for (int c = 5; c >= 2; --c) {
+                if (t % c) continue;
+                smallest = c;
+                if (nrt == 1 && (int64_t)B * 2 * (t / c) >= 200) nrt = c;
+            }
+            if (nrt == 1) nrt = smallest;
+        }
         static const int cap = [] { const char* e = getenv("PH_QUERY_NRT"); return e ? atoi(e) : 0; }();   // tuning knob
-        if (cap > 0) { nrt = cap < nrt ? cap : nrt; while (t % nrt) --nrt; }
+        if (cap > 0) { nrt = cap; while (t % nrt) --nrt; }
 #define PH_Q2(P, R) launch_query2<P, R>(a2, phases, s)
         if (PA == 1) { switch (nrt) { case 5: PH_Q2(1, 5); break; case 4: PH_Q2(1, 4); break; case 3: PH_Q2(1, 3); break; case 2: PH_Q2(1, 2); break; default: PH_Q2(1, 1); } }
         else { switch (nrt) { case 5: PH_Q2(2, 5); break; case 4: PH_Q2(2, 4); break; case 3: PH_Q2(2, 3); break; case 2: PH_Q2(2, 2); break; default: PH_Q2(2, 1); } }

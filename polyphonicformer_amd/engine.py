@@ -280,7 +280,8 @@ class DecodePlan:
             last = s == self.S - 1
             pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
-                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt)
+                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt,
+                            phases=3 | (_lib.PH_QUERY_WIDE if getattr(self, "shares_gpu", False) else 0))
             cv = self.mode.conv
             if not last:
                 dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
@@ -584,6 +585,8 @@ class DualDecodePlan:
         base, rem = divmod(B, parts)
         self.sizes = [base + (1 if i < rem else 0) for i in range(parts)]
         self.halves = [DecodePlan(packs, n, N, H, W, prec, out_dtype, device) for n in self.sizes]
+        for p in self.halves:
+            p.shares_gpu = True          # query launches with the most rows per workgroup: the other parts' kernels run beside them
         self.graph = None
 
     def set_inputs(self, x, dfe, k0, q0, m0):
