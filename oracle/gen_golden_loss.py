@@ -259,7 +259,7 @@ def grad_digest(t, n=64):
     return np.concatenate([[float(f.norm()), float(f.sum())], f[idx].numpy()])
 
 
-def train_step_fixture():
+def train_step_fixture(name="train_step.npz", B=2, H=8, W=16, gt_counts=(5, 8), gt_seed=51):
     """One whole training step of the path as PolyphonicFormer.forward_train runs it after extract_feat
     (polyphonic/polyphonic_former.py:96-129): rpn_head.forward_train -> roi_head.forward_train on the rpn's outputs, the
     objective = sum of the entries whose key contains 'loss' (mmdet BaseDetector._parse_losses,
@@ -274,7 +274,7 @@ def train_step_fixture():
     sys.modules["polyphonic.kernel_head"].accuracy = accuracy
     na = R.load_reference_assigner()
     cfg = Hh.FULL
-    B, H, W, S = 2, 8, 16, cfg["S"]
+    S = cfg["S"]
     ih, kh, sd, shapes = G.build(ns, cfg)
     Sampler = sys.modules["polyphonic.funcs.sampler"].MaskPseudoSampler
     rpn_a = dict(cls_cost=dict(type='FocalLossCost', weight=2.0), dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True),
@@ -293,7 +293,7 @@ def train_step_fixture():
     kh.train()
     ih.train()
     feats = [f.requires_grad_(True) for f in Hh.neck_inputs(G.NSEED, B, cfg["C"], H, W)]
-    gts = train_gt(51, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], [5, 8])
+    gts = train_gt(gt_seed, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], list(gt_counts))
     metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
     gt_masks, gt_labels = [g["masks"] for g in gts], [g["labels"] for g in gts]
     gt_sem_seg, gt_sem_cls = [g["sem_seg"] for g in gts], [g["sem_cls"] for g in gts]
@@ -308,7 +308,7 @@ def train_step_fixture():
         losses.update(rpn_losses)
         total = sum(v.mean() for k, v in losses.items() if "loss" in k)
         total.backward()
-    out = {"meta_json": np.frombuffer(json.dumps(dict(B=B, H=H, W=W, S=S, nseed=G.NSEED, wseed=G.WSEED, gt_seed=51, gts=[5, 8])).encode(),
+    out = {"meta_json": np.frombuffer(json.dumps(dict(B=B, H=H, W=W, S=S, nseed=G.NSEED, wseed=G.WSEED, gt_seed=gt_seed, gts=list(gt_counts))).encode(),
                                       dtype=np.uint8)}
     for b, g in enumerate(gts):
         for k, v in g.items():
@@ -328,7 +328,7 @@ def train_step_fixture():
     out["no_grad_json"] = np.frombuffer(json.dumps(none).encode(), dtype=np.uint8)
     print("total", float(total), "params with grad", sum(k.startswith("g_") for k in out), "without", none)
     print({k: round(float(v), 4) for k, v in losses.items()})
-    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name), **out)
 
 
 if __name__ == "__main__":
@@ -336,3 +336,5 @@ if __name__ == "__main__":
     forward_train_fixture()
     rpn_train_fixture()
     train_step_fixture()
+    # ragged map (7 x 11: no 16-byte rows), three images, one of them without any instance
+    train_step_fixture("train_step_b.npz", B=3, H=7, W=11, gt_counts=(4, 0, 7), gt_seed=52)

@@ -284,10 +284,12 @@ __global__ __launch_bounds__(LOSS_T) void k_seg_focal(const float* __restrict__ 
             const float pt = (1.f - p) * t + p * (1.f - t);
             const float at = alpha * t + (1.f - alpha) * (1.f - t);
             const float bce = bce_logits(z, t);
-            if (!GRAD) v[0] += (double)(bce * at * powf(pt, gamma));
+            // gamma == 2 (every shipped config): two multiplies instead of two powf
+            const float ptg = gamma == 2.f ? pt * pt : powf(pt, gamma), ptg1 = gamma == 2.f ? pt : powf(pt, gamma - 1.f);
+            if (!GRAD) v[0] += (double)(bce * at * ptg);
             else {
                 const float dpt = (1.f - 2.f * t) * p * (1.f - p);
-                grad[(int64_t)b * L * HW + idx] = scale * at * (gamma * powf(pt, gamma - 1.f) * dpt * bce + powf(pt, gamma) * (p - t));
+                grad[(int64_t)b * L * HW + idx] = scale * at * (gamma * ptg1 * dpt * bce + ptg * (p - t));
             }
         }
     }

@@ -280,16 +280,18 @@ def test_map_products_vs_torch(gpu):
         assert Hh.rel_err(d.grad.cpu(), t.grad) < 1e-6, (B, N, H, W)
 
 
-def test_train_step_vs_reference(gpu):
+@pytest.mark.parametrize("golden", ["train_step.npz", "train_step_b.npz"])
+def test_train_step_vs_reference(gpu, golden):
     """One whole training step -- KernelHead.forward_train -> KernelUpdateIterHead.forward_train -> objective (the entries
     with 'loss' in the key, mmdet _parse_losses) -> backward -- against the REFERENCE's forward + torch autograd
     (tests/golden/train_step.npz): all 24 loss values, the objective, and the gradient of every parameter of both heads and
     of the three post-neck maps (norm, sum and 64 / 4096 strided entries each).  Three Hungarian assignments and every
-    hard mask must come out as in the reference for this to hold."""
+    hard mask must come out as in the reference for this to hold.  Second fixture: three images on a ragged 7 x 11 map (no
+    16-byte aligned rows anywhere), one image without any instance."""
     from test_gpu_parity import _full_weights
     from polyphonicformer_amd import train as T
     import polyphonicformer_amd.kernel_update  # noqa: F401
-    z = Hh.load_golden("train_step.npz")
+    z = Hh.load_golden(golden)
     m = json.loads(bytes(z["meta_json"]).decode())
     B, H, W, S = m["B"], m["H"], m["W"], m["S"]
     rpn, sd = _rpn_head(gpu)
