@@ -139,10 +139,14 @@ constexpr int conv_dma_waves(int nw, int pieces) {
 // 32-pixel half of the tile) and owns the whole LDS of its CU: a ring of NBUF tile buffers, NBUF-1 tiles of DMA
 // in flight while one is consumed (96 KiB at cfg2), plus -- logits output, single-plane precision -- a per-wave
 // transposition patch.
-template <int PF, int PK, int NRT, bool BITS, typename OutT> struct ConvCfg {
+template <int PF, int PK, int NRT, bool BITS, typename OutT, bool F2 = false> struct ConvCfg {
     // 32-pixel halves per wave: one (two waves per row block) while that keeps <= 3 waves per SIMD (168 VGPRs for
-    // the 64-VGPR A operand + fragments); two for wide N and for two kernel planes (A operand = 128 VGPRs)
-    static constexpr int HPW = (PK == 1 && NRT <= 6) ? 1 : 2;
+    // the 64-VGPR A operand + fragments); two for wide N.  Two kernel planes over one feature plane (A operand = 128
+    // VGPRs, the `mixed` mode): a wave that walks both halves is a serial chain of 2 x 16 k-steps with nothing else on its
+    // SIMD (113 us per 24 frames whether it has 2, 3 or 4 row blocks); one half per wave fits 2 waves per SIMD up to 4
+    // row blocks (86 / 95 / 103 us) and, for the bits output, 3 waves per SIMD at 5-6 row blocks (131 -> 120 us at cfg2;
+    // the logits variants would spill 40+ VGPRs there and stay on two halves per wave)
+    static constexpr int HPW = (PK == 1 && NRT <= 6) || (!F2 && PF == 1 && PK == 2 && (NRT <= 4 || (BITS && NRT <= 6))) ? 1 : 2;
     static constexpr int NW = 2 * NRT / HPW;
     static constexpr int TILE = 256 * CONV_T;                                  // elements per plane per buffer
     static constexpr int TILEB = PF * TILE * 2;                                // bytes per ring stage
@@ -157,14 +161,14 @@ template <int PF, int PK, int NRT, bool BITS, typename OutT> struct ConvCfg {
     static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
 };
 
-template <int PF, int PK, int E, int NRT, bool BITS, typename OutT>
-__global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
+template <int PF, int PK, int E, int NRT, bool BITS, typename OutT, bool F2 = false>
+__global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT, F2>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
                                                           const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
                                                           int64_t kern_batch_stride, const float* __restrict__ kbias,
                                                           int64_t kbias_batch_stride, uint32_t* __restrict__ bits_out,
                                                           OutT* __restrict__ logits_out, int64_t out_batch_stride, int B,
                                                           int N, int64_t HW, int64_t HWp) {
-    using C = ConvCfg<PF, PK, NRT, BITS, OutT>;
+    using C = ConvCfg<PF, PK, NRT, BITS, OutT, F2>;
     constexpr int Npad = NRT * 32, TILE = C::TILE, NBUF = C::NBUF;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][PF][256][64] | patch[NW][32][PATCH_LD]
 
@@ -416,24 +420,35 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     if (const char* e = getenv("PH_CONV_WGS")) wgs = atoi(e);   // tuning knob
     if (wgs > total) wgs = (int)total;
     if (wgs < 1) wgs = 1;
-    const dim3 grid(wgs), block(ConvCfg<PF, PK, NRT, true, float>::NW * 64);
-#define PH_CONV_LAUNCH(BITS, T)                                                                                      \
+    const dim3 grid(wgs);
+    // tuning knob: PH_CONV_TWO_HALVES=1 forces the two-halves-per-wave form of the two-kernel-plane kernels (A/B measurements)
+    static const bool two_halves = [] { const char* e = getenv("PH_CONV_TWO_HALVES"); return e && atoi(e) != 0; }();
+#define PH_CONV_LAUNCH_(BITS, T, F2)                                                                                 \
     do {                                                                                                             \
-        constexpr int lds = ConvCfg<PF, PK, NRT, BITS, T>::LDSB;                                                     \
-        static const bool once = [&] {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_dynconv<PF, PK, E, NRT, BITS, T>,                                      \
+        constexpr int lds = ConvCfg<PF, PK, NRT, BITS, T, F2>::LDSB;                                                 \
+        const dim3 block(ConvCfg<PF, PK, NRT, BITS, T, F2>::NW * 64);                                                \
+        static const bool once = [&] {                                                                               \
+            (void)hipFuncSetAttribute((const void*)k_dynconv<PF, PK, E, NRT, BITS, T, F2>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
             return true;                                                                                             \
-        }();                                                                                             \
-        (void)once;                                                                                                            \
-        hipLaunchKernelGGL((k_dynconv<PF, PK, E, NRT, BITS, T>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs,   \
+        }();                                                                                                         \
+        (void)once;                                                                                                  \
+        hipLaunchKernelGGL((k_dynconv<PF, PK, E, NRT, BITS, T, F2>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs, \
                            bits_out, (T*)logits_out, obs, B, N, HW, HWp);                                            \
+    } while (0)
+#define PH_CONV_LAUNCH(BITS, T)                                                                                      \
+    do {                                                                                                             \
+        if constexpr (PF == 1 && PK == 2) {                                                                          \
+            if (two_halves) PH_CONV_LAUNCH_(BITS, T, true);                                                          \
+            else PH_CONV_LAUNCH_(BITS, T, false);                                                                    \
+        } else PH_CONV_LAUNCH_(BITS, T, false);                                                                      \
     } while (0)
     if (bits_out) PH_CONV_LAUNCH(true, float);
     else if (out_dtype == PH_OUT_F32) PH_CONV_LAUNCH(false, float);
     else if (out_dtype == PH_OUT_F16) PH_CONV_LAUNCH(false, ph_h16);
     else PH_CONV_LAUNCH(false, uint16_t);
 #undef PH_CONV_LAUNCH
+#undef PH_CONV_LAUNCH_
     return 0;
 }
 
