@@ -256,6 +256,12 @@ int ph_seg_focal_sum(const float* pred, const int32_t* target, int B, int L, int
 int ph_seg_focal_grad(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha, float scale,
                       float* grad, void* stream);
 
+/* DepthCost (funcs/assigner.py:17-80): out[n][g] = { sum lm^2, sum lm, sum r^2, sum |r| } over the pixels with
+ * gt_depth * gt_masks[g] > 0, lm = log(depth_act(z_n) + eps) - log(gt_depth * gt_masks[g] + eps), r = (d - t) / t;
+ * nvalid[g] = number of those pixels.  depth_mode: 0 'sigmoid', 1 'monodepth' (funcs/depth_utils.py). */
+int ph_depth_cost_sums(const float* depth_logits, const float* gt_depth, const float* gt_masks, int N, int G, int64_t HW,
+                       int depth_mode, float eps, float* out, float* nvalid, void* stream);
+
 /* ---- N4, backward: the map-sized products on fp32 NCHW maps (csrc/ph_train.hip); hi+lo bf16 MFMA, fp32 grade ----------------
  * rows_x_map : Y[b][m][p] = sum_k A[b][m][k] X[b][k][p].  A [B or 1][Mpad][lda] zero padded (Mpad % 16 == 0, lda % 8 == 0),
  *              a_batch_stride in elements (0: one A for every image).  binarize_x: X is used as (X > 1.5 * 2^-24) ? 1 : 0.

@@ -40,6 +40,23 @@ def mask_cost(mask_logits, gt_masks, gt_valid=None, weight=1.0):
     return c * weight
 
 
+def depth_cost(depth_logits, gt_depth, gt_masks, mode="sigmoid", weight=1.0, loss_weight=1.0, eps=1e-5):
+    """DepthCost.__call__ + DepthMatchLoss.__call__ (assigner.py:17-80): every (prediction, ground truth) pair over the
+    pixels where gt_depth * gt_mask > 0; the eps-shifted zeros outside them cancel."""
+    from .poly_oracle import depth_act
+    d = depth_act(depth_logits, mode)                                             # [n, H, W]   :68
+    t = gt_depth.reshape(1, *gt_masks.shape[-2:]) * gt_masks                      # [m, H, W]   :70
+    v = (t > 0).float()                                                           # :75
+    di = d[:, None] * v[None] + eps                                               # :76, :33
+    ti = (t[None] + eps).expand_as(di)                                            # :34
+    nv = v.sum((-1, -2)).clamp(min=0.001)[None]                                   # :77
+    lm, mi = torch.log(di) - torch.log(ti), di - ti                               # :35-36
+    si = (lm ** 2).sum((-1, -2)) / nv - lm.sum((-1, -2)) / nv ** 2                # :38-39
+    sq = torch.sqrt(((mi / ti) ** 2).sum((-1, -2)) / nv)                          # :41
+    ab = (mi / ti).abs().sum((-1, -2)) / nv                                       # :43
+    return loss_weight * (si + sq + ab) * weight                                  # :45-46, :80
+
+
 def cost_matrix(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid=None, w_cls=2.0, w_dice=4.0, w_mask=1.0):
     c = dice_cost(mask_logits, gt_masks, gt_valid, w_dice) + mask_cost(mask_logits, gt_masks, gt_valid, w_mask)
     if cls_logits is not None:
@@ -47,7 +64,7 @@ def cost_matrix(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid=None, w_c
     return c                                                                      # :506
 
 
-def assign(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid=None, **w):
+def assign(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid=None, extra_cost=None, **w):
     """-> (assigned_gt_inds [N] (0 = background, k = gt k-1), assigned_labels [N] (-1 = none))   assigner.py:463-541"""
     N, G = mask_logits.shape[0], gt_masks.shape[0]
     inds = torch.full((N,), -1, dtype=torch.long)
@@ -56,7 +73,10 @@ def assign(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid=None, **w):
         if G == 0:
             inds[:] = 0
         return inds, labels
-    rows, cols = linear_sum_assignment(cost_matrix(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid, **w).numpy())
+    cost = cost_matrix(mask_logits, cls_logits, gt_masks, gt_labels, gt_valid, **w)
+    if extra_cost is not None:                                                    # the depth cost (:497-504)
+        cost = cost + extra_cost
+    rows, cols = linear_sum_assignment(cost.numpy())
     inds[:] = 0
     inds[torch.from_numpy(rows)] = torch.from_numpy(cols) + 1
     labels[torch.from_numpy(rows)] = gt_labels[torch.from_numpy(cols)]

@@ -39,6 +39,21 @@ def main():
         out[f"c{i}_pos_gt_masks_sum"] = sr.pos_gt_masks.sum((1, 2)).numpy().astype(np.float32)
         out[f"c{i}_pos_depth_sum"] = sr.pos_depth.sum((1, 2)).numpy().astype(np.float32)
         print(i, case, "matched", int((r.gt_inds > 0).sum()))
+    # DepthCost with a non-zero weight (assigner.py:17-80, :497-502), both depth activations
+    for i in Hh.DEPTH_COST_CASES:
+        case = Hh.ASSIGN_CASES[i]
+        c = Hh.assign_case(**case)
+        z, gd = Hh.assign_depth_inputs(case["seed"], case["N"], case["H"], case["W"])
+        for mode in ("sigmoid", "monodepth"):
+            cfg = dict(CFG, depth_cost=dict(type='DepthCost', weight=0.5, loss_fn=dict(type='DepthMatchLoss', loss_weight=1.),
+                                            depth_act_mode=mode))
+            ad = ns.Assigner(**cfg)
+            r = ad.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, depth_pred=z, gt_depth=gd,
+                          gt_valid=c["gt_valid"])
+            out[f"d{i}_{mode}_depth_cost"] = ad.depth_cost(inputs=z, depth_gt=gd, target_masks=c["gt_masks"]).numpy().astype(np.float32)
+            out[f"d{i}_{mode}_gt_inds"], out[f"d{i}_{mode}_labels"] = r.gt_inds.numpy(), r.labels.numpy()
+            print("depth cost", i, mode, "matched", int((r.gt_inds > 0).sum()),
+                  "differs from the depth-free assignment at", int((r.gt_inds.numpy() != out[f"c{i}_gt_inds"]).sum()), "rows")
     # empty ground truth (assigner.py:469-475)
     c = Hh.assign_case(seed=16, N=10, G=0, L=8, H=8, W=8)
     r = a.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, gt_valid=c["gt_valid"])

@@ -7,8 +7,8 @@ names, constructor kwargs, `assign(...)` signature and `AssignResult` fields.  W
 the three `einsum`s over all pixels and the four row sums of one image (DiceCost.dice_loss :113-129, MaskCost.__call__
 :178-194) are ONE pass of `ph_match_sums` (csrc/ph_match.hip: bf16 hi/lo MFMA contraction over the pixel axis with the
 sigmoid fused in); the [N, G] cost algebra and `scipy.optimize.linear_sum_assignment` stay on the host, as in the
-reference (:511-519).  `DepthCost` is accepted with weight 0 (the shipped configs; :165-173 of the config) and refused
-otherwise -- it is not part of this widening step.  No CPU fallback: tensors must live on the GPU."""
+reference (:511-519).  `DepthCost` (weight 0 in the shipped configs) is one direct pass of `ph_depth_cost_sums` when its weight
+is not zero.  No CPU fallback: tensors must live on the GPU."""
 import numpy as np
 import torch
 
@@ -137,19 +137,46 @@ class MaskCost:
 
 
 @MATCH_COST.register_module()
-class DepthCost:
-    """assigner.py:49-77: accepted for config compatibility with weight 0 (what the shipped configs set)"""
+class DepthMatchLoss:
+    """assigner.py:17-46: loss_weight * (loss_si * si + loss_sq_rel * sq_rel + loss_abs_rel * abs_rel) from the pixel sums"""
 
-    def __init__(self, weight=1., loss_fn=None, depth_act_mode='monodepth'):
-        self.weight = weight
-        if weight != 0:
-            raise NotImplementedError("DepthCost with a non-zero weight is outside this build's scope (SURVEY.md 8f N4)")
+    def __init__(self, loss_weight=1., loss_si=1., loss_sq_rel=1., loss_abs_rel=1.):
+        self.loss_weight, self.loss_si, self.loss_sq_rel, self.loss_abs_rel = loss_weight, loss_si, loss_sq_rel, loss_abs_rel
+        self.eps = 1.e-5
+
+    def from_sums(self, s, num_valid):
+        """s [N, G, 4] = sum lm^2, sum lm, sum r^2, sum |r|; num_valid [G] already clamped"""
+        si = s[..., 0] / num_valid - s[..., 1] / torch.square(num_valid)
+        sq = torch.sqrt(s[..., 2] / num_valid)
+        ab = s[..., 3] / num_valid
+        return self.loss_weight * (self.loss_si * si + self.loss_sq_rel * sq + self.loss_abs_rel * ab)
 
 
 @MATCH_COST.register_module()
-class DepthMatchLoss:
-    def __init__(self, **kw):
-        pass
+class DepthCost:
+    """assigner.py:49-80: the DepthMatchLoss of every (predicted depth map, ground-truth instance) pair over the instance's
+    pixels with a depth label -- one pass of `ph_depth_cost_sums` (csrc/ph_match.hip)"""
+
+    def __init__(self, weight=1., loss_fn=dict(type='DepthMatchLoss', loss_weight=1.), depth_act_mode='monodepth'):
+        self.weight = weight
+        self.loss_fn = build_match_cost(dict(loss_fn))
+        self.depth_act_mode = depth_act_mode
+
+    def __call__(self, inputs, depth_gt, target_masks):
+        if not inputs.is_cuda:
+            raise _lib.PolyheadError("DepthCost: tensors must live on the GPU (libpolyhead has no CPU path)")
+        n, m = inputs.shape[0], target_masks.shape[0]
+        HW = inputs[0].numel()
+        z = inputs.detach().contiguous().float()
+        gd = depth_gt.detach().to(z.device).contiguous().float().reshape(-1)
+        tm = target_masks.detach().contiguous().float()
+        assert gd.numel() == HW and tm[0].numel() == HW
+        out = torch.empty((n, m, 4), dtype=torch.float32, device=z.device)
+        nv = torch.empty((m,), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().ph_depth_cost_sums(_lib.ptr(z), _lib.ptr(gd), _lib.ptr(tm), n, m, HW,
+                                                  {"sigmoid": 0, "monodepth": 1}[self.depth_act_mode], self.loss_fn.eps,
+                                                  _lib.ptr(out), _lib.ptr(nv), _lib.stream_ptr()), "ph_depth_cost_sums")
+        return self.loss_fn.from_sums(out, nv.clamp(min=0.001)[None]) * self.weight       # :77-80
 
 
 def _need_sigmoid(c):
@@ -188,9 +215,11 @@ class _MaskAssignerBase:
             if c.weight != 0:
                 _need_sigmoid(c)
 
-    def costs(self, sums, i, cls_pred, gt_labels):
+    def costs(self, sums, i, cls_pred, gt_labels, depth_pred=None, gt_depth=None, gt_masks=None):
         """weighted cost matrix [N, G] of image i of a `MatchSums` batch (assigner.py:478-506)"""
         cost = 0
+        if self.depth_cost is not None and self.depth_cost.weight != 0 and gt_depth is not None and depth_pred is not None:
+            cost = cost + self.depth_cost(inputs=depth_pred, depth_gt=gt_depth, target_masks=gt_masks)           # :497-502
         if self.cls_cost.weight != 0 and cls_pred is not None:
             cost = cost + self.cls_cost(cls_pred, gt_labels)
         if self.mask_cost.weight != 0:
@@ -199,7 +228,7 @@ class _MaskAssignerBase:
             cost = cost + self.dice_cost.from_sums(sums, i)
         return cost
 
-    def _assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid, gt_pids=None):
+    def _assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid, gt_pids=None, depth_pred=None, gt_depth=None):
         num_gts, num_bboxes = gt_bboxes.size(0), bbox_pred.size(0)
         gt_inds = bbox_pred.new_full((num_bboxes,), -1, dtype=torch.long)                      # :463-468
         labels = bbox_pred.new_full((num_bboxes,), -1, dtype=torch.long)
@@ -208,7 +237,7 @@ class _MaskAssignerBase:
                 gt_inds[:] = 0
             return AssignResult(num_gts, gt_inds, None, labels=labels)
         sums = MatchSums(bbox_pred[None], gt_bboxes[None], None if gt_valid is None else gt_valid[None])
-        cost = self.costs(sums, 0, cls_pred, gt_labels)
+        cost = self.costs(sums, 0, cls_pred, gt_labels, depth_pred, gt_depth, gt_bboxes)
         rows, cols = _hungarian(cost, self.topk)
         rows = torch.from_numpy(rows).to(bbox_pred.device)
         cols = torch.from_numpy(cols).to(bbox_pred.device)
@@ -230,7 +259,7 @@ class MaskHungarianAssignerWithDepth(_MaskAssignerBase):
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta=None, gt_bboxes_ignore=None, depth_pred=None,
                gt_depth=None, gt_valid=None, eps=1e-7):
         assert gt_bboxes_ignore is None, 'Only case when gt_bboxes_ignore is None is supported.'
-        return self._assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid)
+        return self._assign(bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_valid, depth_pred=depth_pred, gt_depth=gt_depth)
 
 
 @BBOX_ASSIGNERS.register_module()

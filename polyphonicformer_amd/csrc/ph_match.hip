@@ -249,3 +249,65 @@ extern "C" int ph_match_sums(const float* logits, const float* gt, const float* 
     ph_set_error("ph_match_sums: unsupported tile combination");
     return PH_EINVAL;
 }
+
+// ---- DepthCost (polyphonic/funcs/assigner.py:17-80): per (prediction n, ground truth g) the DepthMatchLoss sums over the
+// pixels where gt_depth * gt_mask[g] > 0 -- with d = depth_act(z_n) + eps and t = gt_depth * gt_mask[g] + eps:
+//   out[n][g] = { sum (log d - log t)^2, sum (log d - log t), sum ((d - t) / t)^2, sum |(d - t) / t| },  nvalid[g] = #pixels.
+// The absolute value does not factor into a GEMM, so this is a direct pass: one workgroup per (n, g), pixels strided over
+// the threads, pixels outside the (small) instance mask skipped before any transcendental; fixed-order reduction.
+// (Outside the valid pixels the reference's eps-shifted zeros cancel exactly: log(eps) - log(eps), eps - eps.)
+namespace {
+constexpr int DC_T = 256;
+__global__ __launch_bounds__(DC_T) void k_depth_cost(const float* __restrict__ z, const float* __restrict__ gt_depth,
+                                                     const float* __restrict__ gt_masks, int G, int64_t HW, int mode, float eps,
+                                                     float* __restrict__ out, float* __restrict__ nvalid) {
+    __shared__ double lds[4][5];
+    const int g = blockIdx.x, n = blockIdx.y;
+    const float* zn = z + (int64_t)n * HW;
+    const float* mg = gt_masks + (int64_t)g * HW;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int64_t p = threadIdx.x; p < HW; p += DC_T) {
+        const float tm = gt_depth[p] * mg[p];
+        if (!(tm > 0.f)) continue;
+        const float s = 1.f / (1.f + expf(-zn[p]));
+        float d;
+        if (mode == 0) d = s * (80.f - 0.01f) + 0.01f;
+        else d = 1.f / (1.f / 80.f + (1.f / 0.01f - 1.f / 80.f) * s);
+        d += eps;
+        const float t = tm + eps;
+        const float lm = logf(d) - logf(t), r = (d - t) / t;
+        v[0] += (double)(lm * lm);
+        v[1] += (double)lm;
+        v[2] += (double)(r * r);
+        v[3] += (double)fabsf(r);
+        v[4] += 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) lds[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] = lds[0][k] + lds[1][k] + lds[2][k] + lds[3][k];
+        float* o = out + ((int64_t)n * G + g) * 4;
+        o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3];
+        if (n == 0) nvalid[g] = (float)t[4];
+    }
+}
+}  // namespace
+
+extern "C" int ph_depth_cost_sums(const float* depth_logits /* [N][HW] */, const float* gt_depth /* [HW] */,
+                                  const float* gt_masks /* [G][HW] */, int N, int G, int64_t HW, int depth_mode, float eps,
+                                  float* out /* [N][G][4] */, float* nvalid /* [G] */, void* stream) {
+    PH_CHECK_ARG(depth_logits && gt_depth && gt_masks && out && nvalid, "null pointer");
+    PH_CHECK_ARG(N > 0 && N <= 65535 && G > 0 && HW > 0 && (depth_mode == 0 || depth_mode == 1), "bad size or mode");
+    hipLaunchKernelGGL(k_depth_cost, dim3(G, N), dim3(DC_T), 0, (hipStream_t)stream, depth_logits, gt_depth, gt_masks, G, HW, depth_mode,
+                       eps, out, nvalid);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

@@ -193,6 +193,17 @@ def assign_case(seed, N, G, L, H, W, with_valid=True, with_cls=True):
     return dict(mask_logits=logits, cls_logits=cls, gt_masks=gt, gt_labels=labels, gt_valid=valid)
 
 
+def assign_depth_inputs(seed, N, H, W):
+    """depth logits [N, H, W] and a ground-truth depth map [1, H, W] (10 % unlabelled = 0) for the DepthCost cases"""
+    g = torch.Generator().manual_seed(seed + 1000)
+    z = torch.randn(N, H, W, generator=g)
+    d = torch.rand(1, H, W, generator=g) * 70.0 + 1.0
+    d[torch.rand(1, H, W, generator=g) < 0.1] = 0.0
+    return z, d
+
+
+DEPTH_COST_CASES = [0, 2]          # indices into ASSIGN_CASES that also have a golden with DepthCost weight 1
+
 ASSIGN_CASES = [dict(seed=11, N=100, G=7, L=8, H=24, W=40, with_valid=True),
                 dict(seed=12, N=100, G=33, L=8, H=16, W=24, with_valid=True),
                 dict(seed=13, N=37, G=3, L=8, H=7, W=13, with_valid=False),

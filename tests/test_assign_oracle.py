@@ -23,6 +23,19 @@ def test_oracle_costs_and_assignment_match_reference(gold, i):
     assert np.array_equal(labels.numpy(), gold[f"c{i}_labels"])
 
 
+@pytest.mark.parametrize("i", Hh.DEPTH_COST_CASES)
+@pytest.mark.parametrize("mode", ["sigmoid", "monodepth"])
+def test_oracle_depth_cost_matches_reference(gold, i, mode):
+    """DepthCost with weight 0.5 (assigner.py:17-80): the cost matrix and the assignment it leads to"""
+    case = Hh.ASSIGN_CASES[i]
+    c = Hh.assign_case(**case)
+    z, gd = Hh.assign_depth_inputs(case["seed"], case["N"], case["H"], case["W"])
+    dc = AO.depth_cost(z, gd, c["gt_masks"], mode, weight=0.5)
+    assert Hh.rel_err(dc, gold[f"d{i}_{mode}_depth_cost"]) < 1e-5
+    inds, labels = AO.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"], extra_cost=dc)
+    assert np.array_equal(inds.numpy(), gold[f"d{i}_{mode}_gt_inds"]) and np.array_equal(labels.numpy(), gold[f"d{i}_{mode}_labels"])
+
+
 def test_oracle_empty_ground_truth(gold):
     c = Hh.assign_case(seed=16, N=10, G=0, L=8, H=8, W=8)
     inds, labels = AO.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], c["gt_valid"])
@@ -44,8 +57,8 @@ def test_product_assigner_registry_and_guards():
     c = Hh.assign_case(**Hh.ASSIGN_CASES[2])
     with pytest.raises(_lib.PolyheadError):                                                      # CPU tensors: refuse
         a.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, gt_valid=c["gt_valid"])
-    with pytest.raises(NotImplementedError):
-        A.build_match_cost(dict(type='DepthCost', weight=1.0))
+    dc = A.build_match_cost(dict(type='DepthCost', weight=1.0))                                  # built; evaluated on the GPU only
+    assert dc.loss_fn.eps == 1e-5 and dc.depth_act_mode == 'monodepth'
     # FocalLossCost is host arithmetic: identical to the oracle's restatement
     cls, lab = torch.randn(9, 5), torch.tensor([0, 4, 2])
     assert torch.allclose(A.FocalLossCost(weight=2.0)(cls, lab), AO.focal_cost(cls, lab, 2.0))

@@ -43,6 +43,26 @@ def test_assigner_vs_reference_golden(gpu, i):
     assert np.array_equal(r.labels.cpu().numpy(), gold[f"c{i}_labels"])
 
 
+@pytest.mark.parametrize("i", Hh.DEPTH_COST_CASES)
+@pytest.mark.parametrize("mode", ["sigmoid", "monodepth"])
+def test_depth_cost_vs_reference_golden(gpu, i, mode):
+    """DepthCost with a non-zero weight (funcs/assigner.py:17-80) on ph_depth_cost_sums: the cost matrix against the
+    reference's and the assignment it leads to (it differs from the depth-free one on three of the four fixtures)"""
+    from polyphonicformer_amd import assigner as A
+    gold = Hh.load_golden("assign.npz")
+    case = Hh.ASSIGN_CASES[i]
+    c = _dev(Hh.assign_case(**case), gpu)
+    z, gd = (t.to(gpu) for t in Hh.assign_depth_inputs(case["seed"], case["N"], case["H"], case["W"]))
+    cfg = dict(CFG, depth_cost=dict(type='DepthCost', weight=0.5, loss_fn=dict(type='DepthMatchLoss', loss_weight=1.), depth_act_mode=mode))
+    a = A.build_assigner(cfg)
+    dc = a.depth_cost(inputs=z, depth_gt=gd, target_masks=c["gt_masks"])
+    e = Hh.rel_err(dc.cpu(), gold[f"d{i}_{mode}_depth_cost"])
+    assert e < 1e-4, e
+    r = a.assign(c["mask_logits"], c["cls_logits"], c["gt_masks"], c["gt_labels"], None, depth_pred=z, gt_depth=gd, gt_valid=c["gt_valid"])
+    assert np.array_equal(r.gt_inds.cpu().numpy(), gold[f"d{i}_{mode}_gt_inds"])
+    assert np.array_equal(r.labels.cpu().numpy(), gold[f"d{i}_{mode}_labels"])
+
+
 def test_pixel_sums_vs_einsum(gpu):
     """every sum of the record against fp64 torch, ragged sizes (HW % 4 != 0), batch of 3 with zero-padded gt rows"""
     from polyphonicformer_amd import assigner as A
