@@ -37,8 +37,11 @@ enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWOR
  *   PH_PREC_BF16_KSPLIT  ph_dynconv only: bf16 features in ONE plane, the dynamic kernels as hi + lo planes (2 MFMAs):
  *                        exact for features that ARE bf16 values, kernels to 2^-17
  *   PH_PREC_SPLIT        bf16, hi + lo planes of both operands, a.b ~= ah.bh + ah.bl + al.bh (3 MFMAs, ~2^-16)
- *   PH_PREC_F16          IEEE fp16, one plane each (1 MFMA, ~2^-12 per operand; |values| < 65504) */
-enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5 };
+ *   PH_PREC_F16          IEEE fp16, one plane each (1 MFMA, ~2^-12 per operand; |values| < 65504)
+ *   PH_PREC_BF16_KF16    ph_dynconv only: bf16 features in ONE plane, the dynamic kernels as ONE fp16 plane (PH_KERN_F16); the
+ *                        feature fragments are converted to fp16 in registers (exact inside fp16's normal range) and the
+ *                        product is one f16 MFMA: ~2^-12 on the kernels only -- 2.5e-4 per stage, single-plane speed. */
+enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5, PH_PREC_BF16_KF16 = 6 };
 enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1, PH_OUT_F16 = 2 };
 enum { PH_KERN_BF16_PLANES = 0, PH_KERN_F16 = 1 };   /* ph_query_stage: format of the dynamic conv kernels it emits */
 enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3, PH_GN_TO_CPLANES = 4 };   /* ph_gn_apply modes */
@@ -148,7 +151,7 @@ int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits,
  * Either writes the mask bits the next stage pools with (bits_out != NULL; the logits of a
  * non-final stage are consumed only through `> 0`, kernel_update_head.py:236-238) or the logits
  * themselves (logits_out, dtype out_dtype = PH_OUT_F32 / BF16 / F16).  `prec` = PH_PREC_BF16 (1 feature plane, 1 kernel
- * plane), PH_PREC_BF16_KSPLIT (1, 2), PH_PREC_SPLIT (2, 2) or PH_PREC_F16 (fp16 planes, 1, 1).
+ * plane), PH_PREC_BF16_KSPLIT (1, 2), PH_PREC_SPLIT (2, 2), PH_PREC_F16 (fp16 planes, 1, 1) or PH_PREC_BF16_KF16 (bf16 plane, one fp16 kernel plane).
  * `kern` is planes [P][..][Npad][256] (plane stride
  * given), `kern_batch_stride` / `kbias_batch_stride` / `out_batch_stride` are the element distances
  * between frames: Npad*256 / Npad / N*HW for per-frame dynamic kernels; 0 / 0 / rows*HW when the

@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- MUST precede dlopen: libpolyhead has to bind to t
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
-PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16 = 1, 2, 3, 5
+PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16, PH_PREC_BF16_KF16 = 1, 2, 3, 5, 6
 PH_QUERY_WIDE = 0x100            # ph_query_stage phases flag: most rows per workgroup (launches that share the GPU)
 PH_OUT_F32, PH_OUT_BF16, PH_OUT_F16 = 0, 1, 2
 PH_KERN_BF16_PLANES, PH_KERN_F16 = 0, 1

@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t pack2(uint32_t a, uint32_t b) { return a | (
 // ---- 16-bit element formats of feature planes / dynamic kernels / outputs: bf16 (8-bit mantissa, fp32 range) or IEEE
 // fp16 (11-bit mantissa, |x| < 65504).  A bf16 value is exactly representable in fp16 when it is inside fp16's normal
 // range, so an fp16 plane carries bf16-rounded inputs unchanged and fp32 inputs with 8x finer rounding.
-enum { PH_E_BF16 = 0, PH_E_F16 = 1 };
+enum { PH_E_BF16 = 0, PH_E_F16 = 1, PH_E_F16_FROM_BF16 = 2 /* conv only: bf16 feature fragments converted to fp16 in registers */ };
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t f2h(float x) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)x); }
@@ -106,8 +106,12 @@ __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// two bf16 in a dword -> two fp16 (exact whenever the value is inside fp16's normal range; bf16 has 8 significand bits)
+__device__ __forceinline__ uint32_t bf2h_pk(uint32_t w) { return f2h_pk(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)); }
+__device__ __forceinline__ uint4 bf2h_x8(uint4 v) { return make_uint4(bf2h_pk(v.x), bf2h_pk(v.y), bf2h_pk(v.z), bf2h_pk(v.w)); }
+
 template <int E> __device__ __forceinline__ f32x16_t mfma32e(uint4 a, uint4 b, f32x16_t c) {
-    if constexpr (E == PH_E_F16)
+    if constexpr (E == PH_E_F16 || E == PH_E_F16_FROM_BF16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else
         return mfma32(a, b, c);

@@ -93,7 +93,10 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][
             uint4 bf[PF];
 #pragma unroll
             for (int p = 0; p < PF; ++p)
+            {
                 bf[p] = make_uint4(bq[BI & 1][p][k][0].x, bq[BI & 1][p][k][0].y, bq[BI & 1][p][k][1].x, bq[BI & 1][p][k][1].y);
+                if constexpr (E == PH_E_F16_FROM_BF16) bf[p] = bf2h_x8(bf[p]);      // 12 VALU ops under the previous MFMA
+            }
             acc = mfma32e<E>(af[0][BI * KB + k], bf[0], acc);
             if (PF == 2) acc = mfma32e<E>(af[0][BI * KB + k], bf[PF - 1], acc);
             if (PK == 2) acc = mfma32e<E>(af[PK - 1][BI * KB + k], bf[0], acc);
@@ -458,7 +461,8 @@ extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t 
                           void* stream) {
     PH_CHECK_ARG(planes && kern && kbias && B > 0 && N > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG((bits_out != nullptr) != (logits_out != nullptr), "exactly one of bits_out / logits_out");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_BF16_KSPLIT || prec == PH_PREC_F16, "bad prec");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_BF16_KSPLIT || prec == PH_PREC_F16 ||
+                 prec == PH_PREC_BF16_KF16, "bad prec");
     PH_CHECK_ARG(out_dtype == PH_OUT_F32 || out_dtype == PH_OUT_BF16 || out_dtype == PH_OUT_F16, "bad out_dtype");
     PH_CHECK_ARG(N <= 256, "at most 256 queries");
     const int nrt = ph_n_padded(N) / 32;
@@ -470,6 +474,7 @@ extern "C" int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t 
         if (prec == PH_PREC_BF16) launch_conv<1, 1, PH_E_BF16, R>(PH_CONV_ARGS);                                \
         else if (prec == PH_PREC_F16) launch_conv<1, 1, PH_E_F16, R>(PH_CONV_ARGS);                             \
         else if (prec == PH_PREC_BF16_KSPLIT) launch_conv<1, 2, PH_E_BF16, R>(PH_CONV_ARGS);                    \
+        else if (prec == PH_PREC_BF16_KF16) launch_conv<1, 1, PH_E_F16_FROM_BF16, R>(PH_CONV_ARGS);             \
         else launch_conv<2, 2, PH_E_BF16, R>(PH_CONV_ARGS);                                                     \
         break;
     switch (nrt) {

@@ -28,6 +28,9 @@ MODES = {
     # bf16 feature planes as they are (cfg2's input dtype), everything computed FROM them at fp32 grade: exact 0/1 x bf16
     # pooling, hi/lo split query GEMMs, hi/lo dynamic kernels x one feature plane (<= 1e-3 on identical inputs)
     "mixed": Mode("mixed", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KSPLIT, _lib.PH_KERN_BF16_PLANES, 1, 2, torch.bfloat16),
+    # as `mixed`, but the dynamic kernels as ONE fp16 plane: the conv converts its bf16 feature fragments to fp16 in registers
+    # (exact) and runs one f16 MFMA -- the single-plane conv speed at 2.5e-4 per stage (kernel rounding 2^-12)
+    "mixed16": Mode("mixed16", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KF16, _lib.PH_KERN_F16, 1, 1, torch.bfloat16),
     # fp16 feature planes / kernels / outputs (cfg5), fp32-grade query side
     "fp16": Mode("fp16", _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_F16, _lib.PH_KERN_F16, 1, 1, torch.float16),
     # parity grade: every operand hi + lo (1.6e-5 per stage)
@@ -36,7 +39,7 @@ MODES = {
 MODES["split"] = MODES["fp32"]
 # arithmetic of the kernels that know two grades only (KernelHead, the neck, the track head): fast or fp32 grade
 PREC = {"bf16": _lib.PH_PREC_BF16, "split": _lib.PH_PREC_SPLIT, "fp32": _lib.PH_PREC_SPLIT,
-        "mixed": _lib.PH_PREC_SPLIT, "fp16": _lib.PH_PREC_SPLIT}
+        "mixed": _lib.PH_PREC_SPLIT, "mixed16": _lib.PH_PREC_SPLIT, "fp16": _lib.PH_PREC_SPLIT}
 OUT_CODE = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}
 
 

@@ -236,11 +236,12 @@ def test_pool_fp16_planes(gpu, N, H, W, nsplit):
     assert Hh.rel_err(got, ref32) < 5e-4              # 2^-12 per element, 8x finer than a bf16 plane
 
 
-@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16_KSPLIT, _lib.PH_PREC_F16])
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16_KSPLIT, _lib.PH_PREC_F16, _lib.PH_PREC_BF16_KF16])
 @pytest.mark.parametrize("N,H,W", [(111, 8, 16), (153, 16, 32), (40, 6, 13), (253, 8, 48), (20, 4, 32)])
 def test_dynconv_ksplit_and_fp16(gpu, prec, N, H, W):
-    """PH_PREC_BF16_KSPLIT: hi + lo kernel planes x ONE bf16 feature plane (2 MFMAs); PH_PREC_F16: fp16 x fp16.  Products
-    of the stored operands are exact in fp32 accumulation; outputs fp32 / fp16 / bits"""
+    """PH_PREC_BF16_KSPLIT: hi + lo kernel planes x ONE bf16 feature plane (2 MFMAs); PH_PREC_F16: fp16 x fp16;
+    PH_PREC_BF16_KF16: ONE fp16 kernel plane x a bf16 feature plane whose fragments are converted to fp16 in registers
+    (exact).  Products of the stored operands are exact in fp32 accumulation; outputs fp32 / fp16 / bits"""
     g = torch.Generator().manual_seed(41)
     B, HW = 2, H * W
     Npad = E.n_padded(N)
@@ -252,6 +253,11 @@ def test_dynconv_ksplit_and_fp16(gpu, prec, N, H, W):
         kq = kern_f.half().double()
         xp = E.ingest(x.to(gpu), _lib.PH_PREC_F16)
         xq = x.half().double().reshape(B, 256, HW)
+    elif prec == _lib.PH_PREC_BF16_KF16:
+        kern = _planes16(kern_f, torch.float16)[None].contiguous().to(gpu)
+        kq = kern_f.half().double()
+        xp = E.ingest(x.to(gpu), _lib.PH_PREC_BF16)
+        xq = x.bfloat16().double().reshape(B, 256, HW)
     else:
         hi = kern_f.to(torch.bfloat16)
         lo = (kern_f - hi.float()).to(torch.bfloat16)

@@ -1,10 +1,10 @@
 """runs only the pooling + conv kernels at the cfg2 shape in the launch geometry of the headline step (24 frames per launch),
-for the rocprofv3 --pmc passes.  usage: python tools/pool_only.py [mode = mixed | bf16 | fp16]"""
+for the rocprofv3 --pmc passes.  usage: python tools/pool_only.py [mode = mixed16 | mixed | bf16 | fp16]"""
 import sys, torch
 sys.path.insert(0, ".")
 from polyphonicformer_amd import _lib, engine as E
 dev = torch.device("cuda:0")
-mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed"]
+mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed16"]
 N, B, H, W = 153, 24, 128, 256
 HW = H * W
 xp = torch.randint(-2**15, 2**15, (1, B, 256, E.hw_padded(HW)), dtype=torch.int16, device=dev) & 0x3BFF      # finite in bf16 and fp16
