@@ -399,16 +399,21 @@ def video_leg(dev, precision="bf16", frames=6):
     base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(dev) for s in (4, 8, 16, 32)]
     meta = [dict(img_shape=(H8, W8, 3), ori_shape=(H8, W8, 3), batch_input_shape=(H8, W8))]
     t_heads, t_assoc, nthing = [], [], []
-    for f in range(frames + 2):
-        x = tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base)
+    # the clip runs twice: the first pass pays every one-time cost (weight packs, kernel attributes, the host library's
+    # first-call initialisation of the tracker's CPU ops: 90-250 ms spikes on single frames), the second one is timed
+    for f in range(2 * frames):
+        x = tuple(torch.roll(t, (f % frames, 2 * (f % frames)), dims=(2, 3)) for t in base)
+        if f == frames:
+            pipe.assoc.init_tracker()          # a new clip (polyphonic_former_video.py:59-61)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = pipe.heads(x, meta)[0]
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         pipe.assoc.step(x, res[2][0], res[2][1], res[4])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if f >= 2:
+        if f >= frames:
             t_heads.append(t1 - t0), t_assoc.append(t2 - t1)
             nthing.append(sum(1 for s_ in res[2][1] if s_["isthing"]))
     med = lambda v: sorted(v)[len(v) // 2]
