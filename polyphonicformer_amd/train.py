@@ -274,6 +274,8 @@ class TrainStep:
     # -- rpn side: kernel_head.py:349-454
     def _rpn(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses):
         h = self.rpn
+        if h.hard_target:                     # local to the rpn side, as in the reference (kernel_head.py:400-403)
+            gt_masks = [m.bool().float() for m in gt_masks]
         r = rpn_forward(h, feats)
         up = (lambda t: upsample2x(t)) if h.feat_downsample_stride == 2 else (lambda t: t)
         smask, sseg, sdep0 = up(r["mask_preds"]), up(r["seg_preds"]), up(r["depth_pred"])
@@ -354,8 +356,6 @@ class TrainStep:
         for f in feats:
             if not f.is_cuda:
                 raise _lib.PolyheadError("the post-neck maps must live on the GPU: libpolyhead has no CPU path")
-        if self.rpn.hard_target:
-            gt_masks = [m.bool().float() for m in gt_masks]
         losses = {}
         with torch.enable_grad():
             rpn_losses = {}

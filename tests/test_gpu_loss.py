@@ -346,3 +346,38 @@ def test_train_step_vs_reference(gpu, golden):
         print("d objective / d post-neck map", i, e)
         assert e[0] < 1e-3 and e[1] < 1e-3 and e[2] < 1e-2, (i, e)
     print("parameter gradients vs reference autograd: worst", worst, "over", len(named), "tensors")
+
+
+def test_training_steps_reduce_the_objective(gpu):
+    """the step is usable as a training step: AdamW + gradient clipping (the reference's optimizer_config: grad_clip
+    max_norm = 1, configs/_base_/schedules) on ONE fixed batch for a few iterations -- the objective goes down"""
+    from test_gpu_parity import _full_weights
+    from polyphonicformer_amd import train as T
+    import polyphonicformer_amd.kernel_update  # noqa: F401
+    rpn, sd = _rpn_head(gpu)
+    roi_a = dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                 dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    roi = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=3, assign_stages=3, stage_loss_weights=[1] * 3, num_proposals=100,
+                           num_thing_classes=8, num_stuff_classes=11, mask_head=Hh.stage_cfg(256, 2048, 8, 19, 8, 11),
+                           train_cfg=dict(assigner=roi_a, sampler=dict(type='MaskPseudoSampler'), pos_weight=1.)))
+    roi.load_state_dict({k[len("roi_head."):]: v for k, v in sd.items() if k.startswith("roi_head.")})
+    roi.to(gpu)
+    step = T.TrainStep(rpn, roi)
+    B, H, W = 2, 8, 16
+    feats = [f.to(gpu) for f in Hh.neck_inputs(77, B, 256, H, W)]
+    gts = [{k: v.to(gpu) for k, v in g.items()} for g in Hh.train_gt(78, B, 2 * H, 2 * W, 8, 11, [4, 6])]
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    gd = torch.stack([g["depth"][None] for g in gts])
+    args = (feats, metas, [g["masks"] for g in gts], [g["labels"] for g in gts], [g["sem_seg"] for g in gts], [g["sem_cls"] for g in gts], gd)
+    opt = torch.optim.AdamW(step.parameters(), lr=1e-4, weight_decay=0.05)
+    hist = []
+    for it in range(8):
+        opt.zero_grad(set_to_none=True)
+        losses, total, _ = step.forward_backward(*args)
+        assert all(torch.isfinite(p.grad).all() for p in step.parameters())
+        torch.nn.utils.clip_grad_norm_(step.parameters(), max_norm=1.0, norm_type=2)
+        with torch.enable_grad():
+            opt.step()
+        hist.append(float(total))
+    print("objective over 8 AdamW steps on one batch:", [round(h, 2) for h in hist])
+    assert hist[-1] < 0.9 * hist[0], hist
