@@ -259,6 +259,14 @@ int ph_seg_focal_sum(const float* pred, const int32_t* target, int B, int L, int
 int ph_seg_focal_grad(const float* pred, const int32_t* target, int B, int L, int64_t HW, float gamma, float alpha, float scale,
                       float* grad, void* stream);
 
+/* target assembly of the losses above.  rank_target: out[b][p] = the last j with pos[b*N + j] and mask_targets[b*N + j][p] != 0,
+ * else ignore_index (kernel_update_head.py:420-432).  seg_target (one image): L, then sem_cls[s] where sem_seg[s] != 0 in order,
+ * then pos_labels[i] where pos_masks[i] != 0 in order (kernel_head.py:590-605). */
+int ph_rank_target(const float* mask_targets, const uint8_t* pos, int B, int N, int64_t HW, int ignore_index, int32_t* out,
+                   void* stream);
+int ph_seg_target(const float* sem_seg, const int64_t* sem_cls, int S, const float* pos_masks, const int64_t* pos_labels, int P,
+                  int L, int64_t HW, int64_t* out, void* stream);
+
 /* DepthCost (funcs/assigner.py:17-80): out[n][g] = { sum lm^2, sum lm, sum r^2, sum |r| } over the pixels with
  * gt_depth * gt_masks[g] > 0, lm = log(depth_act(z_n) + eps) - log(gt_depth * gt_masks[g] + eps), r = (d - t) / t;
  * nvalid[g] = number of those pixels.  depth_mode: 0 'sigmoid', 1 'monodepth' (funcs/depth_utils.py). */

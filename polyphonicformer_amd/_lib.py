@@ -64,6 +64,8 @@ SIGNATURES = {
     "ph_focal_loss_grad": (C.c_int, [_P, _P, _P, _L, _I, C.c_float, C.c_float, C.c_float, _P, _P]),
     "ph_seg_focal_sum": (C.c_int, [_P, _P, _I, _I, _L, C.c_float, C.c_float, _P, _P]),
     "ph_seg_focal_grad": (C.c_int, [_P, _P, _I, _I, _L, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "ph_rank_target": (C.c_int, [_P, _P, _I, _I, _L, _I, _P, _P]),
+    "ph_seg_target": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _L, _P, _P]),
     "ph_depth_cost_sums": (C.c_int, [_P, _P, _P, _I, _I, _L, _I, C.c_float, _P, _P, _P]),
     "ph_rows_x_map": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _I, _L, _I, _P]),
     "ph_map_x_map_t_nsplit": (C.c_int, [_I, _I, _L]),

@@ -408,3 +408,52 @@ extern "C" int ph_seg_focal_grad(const float* pred, const int32_t* target, int B
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
+
+// ---- target assembly -----------------------------------------------------------------------------------------------------------
+// rank target (kernel_update_head.py:420-432, kernel_head.py:516-528): pixel -> index, within its image, of the LAST positive
+// row whose mask target covers it (the reference paints the rows one after the other), `ignore` where none does.
+__global__ __launch_bounds__(LOSS_T) void k_rank_target(const float* __restrict__ mask_targets, const uint8_t* __restrict__ pos, int N,
+                                                        int64_t HW, int ignore, int* __restrict__ out) {
+    const int b = blockIdx.y;
+    for (int64_t p = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; p < HW; p += (int64_t)gridDim.x * LOSS_T) {
+        int t = ignore;
+        for (int j = 0; j < N; ++j)
+            if (pos[b * N + j] && mask_targets[((int64_t)b * N + j) * HW + p] != 0.f) t = j;      // .bool()
+        out[(int64_t)b * HW + p] = t;
+    }
+}
+
+// dense semantic target of ONE image (kernel_head.py:590-605): background L, then the stuff masks in order, then the assigned
+// thing masks in order, each painting its class over what is there
+__global__ __launch_bounds__(LOSS_T) void k_seg_target(const float* __restrict__ sem_seg, const int64_t* __restrict__ sem_cls, int S,
+                                                       const float* __restrict__ pos_masks, const int64_t* __restrict__ pos_labels, int P,
+                                                       int L, int64_t HW, int64_t* __restrict__ out) {
+    for (int64_t p = blockIdx.x * (int64_t)LOSS_T + threadIdx.x; p < HW; p += (int64_t)gridDim.x * LOSS_T) {
+        int64_t t = L;
+        for (int s = 0; s < S; ++s)
+            if (sem_seg[(int64_t)s * HW + p] != 0.f) t = sem_cls[s];
+        for (int i = 0; i < P; ++i)
+            if (pos_masks[(int64_t)i * HW + p] != 0.f) t = pos_labels[i];
+        out[p] = t;
+    }
+}
+
+extern "C" int ph_rank_target(const float* mask_targets /* [B*N][HW] */, const uint8_t* pos /* [B*N] */, int B, int N, int64_t HW,
+                              int ignore_index, int32_t* out /* [B][HW] */, void* stream) {
+    PH_CHECK_ARG(mask_targets && pos && out && B > 0 && N > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_rank_target, dim3(loss_grid(HW, 1024), B), dim3(LOSS_T), 0, (hipStream_t)stream, mask_targets, pos, N, HW,
+                       ignore_index, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_seg_target(const float* sem_seg /* [S][HW], may be NULL when S == 0 */, const int64_t* sem_cls, int S,
+                             const float* pos_masks /* [P][HW], may be NULL when P == 0 */, const int64_t* pos_labels, int P, int L,
+                             int64_t HW, int64_t* out /* [HW] */, void* stream) {
+    PH_CHECK_ARG(out && S >= 0 && P >= 0 && HW > 0 && (S == 0 || (sem_seg && sem_cls)) && (P == 0 || (pos_masks && pos_labels)),
+                 "bad pointer or size");
+    hipLaunchKernelGGL(k_seg_target, dim3(loss_grid(HW, 1024)), dim3(LOSS_T), 0, (hipStream_t)stream, sem_seg, sem_cls, S, pos_masks,
+                       pos_labels, P, L, HW, out);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

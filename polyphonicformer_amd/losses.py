@@ -199,10 +199,9 @@ def _mask_terms(head, mp, mask_targets, mask_weights, pos, B, N, H, W, losses, g
     rank_target = None
     if lr is not None:
         # rank target: pixel -> index (within its image) of the LAST positive row whose target covers it
-        rank_target = torch.full((B, HW), ignore, dtype=torch.int32, device=dev)
-        mtb = mt.reshape(B, N, HW) > 0
-        for b, j in pos.reshape(B, N).nonzero(as_tuple=False).tolist():
-            rank_target[b][mtb[b, j]] = j
+        rank_target = torch.empty((B, HW), dtype=torch.int32, device=dev)
+        _lib.check(lib.ph_rank_target(_lib.ptr(mt), _lib.ptr(pos.to(torch.uint8).contiguous()), B, N, HW, ignore, _lib.ptr(rank_target),
+                                      _lib.stream_ptr()), "ph_rank_target")
         losses[keys[2]] = (lr.loss_weight * rank_loss_sum(mp.reshape(B, N, H, W), rank_target, ignore) / (B * HW)).float()
     if grad is not None:
         if lr is not None:
@@ -420,6 +419,7 @@ def rpn_target_single(head, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask,
     """KernelHead._get_target_single (kernel_head.py:571-647): ONE image.  Unlike the update heads there are no stuff rows in
     labels / masks (label_weights is per row), a dense `seg_targets` map [H, W] (stuff classes first, then the assigned thing
     masks painted over them in order) and depth rows for the N proposals + the stuff rows, without a direct-depth row."""
+    _gpu(pos_mask, "sampling result")
     dev = pos_mask.device
     num_pos, num_neg = pos_mask.shape[0], neg_mask.shape[0]
     R = num_pos + num_neg
@@ -431,19 +431,20 @@ def rpn_target_single(head, pos_inds, neg_inds, pos_mask, neg_mask, pos_gt_mask,
     label_weights = torch.zeros((R,), device=dev)
     mask_targets = torch.zeros((R, H, W), device=dev)
     mask_weights = valid[None].expand(R, H, W).clone()
-    seg_targets = torch.full((H, W), L, dtype=torch.long, device=dev)
     has_sem = gt_sem_cls is not None and gt_sem_seg is not None
-    if has_sem:
-        sem = gt_sem_seg.to(dev).bool()
-        for m, c in zip(sem, gt_sem_cls.tolist()):                                            # later classes overwrite (:594-597)
-            seg_targets[m] = int(c)
+    S = len(gt_sem_cls) if has_sem else 0
     if num_pos:
         labels[pos_inds] = pos_gt_labels
         label_weights[pos_inds] = pw
         mask_targets[pos_inds] = pos_gt_mask.float()
-        pgl = pos_gt_labels.tolist()
-        for i in range(num_pos):
-            seg_targets[pos_gt_mask[i].bool()] = pgl[i]
+    # the dense semantic target in one pass: stuff classes in order, then the assigned thing masks in order (:590-605)
+    seg_targets = torch.empty((H, W), dtype=torch.long, device=dev)
+    sem_f = gt_sem_seg.to(dev).float().contiguous() if S else None
+    sem_c = gt_sem_cls.to(dev).long().contiguous() if S else None
+    pgm = pos_gt_mask.float().contiguous() if num_pos else None
+    pgl = pos_gt_labels.to(dev).long().contiguous() if num_pos else None
+    _lib.check(_lib.load().ph_seg_target(_lib.ptr(sem_f), _lib.ptr(sem_c), S, _lib.ptr(pgm), _lib.ptr(pgl), num_pos, L, H * W,
+                                         _lib.ptr(seg_targets), _lib.stream_ptr()), "ph_seg_target")
     if num_neg:
         label_weights[neg_inds] = 1.0
     depth_targets = depth_weights = None
