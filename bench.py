@@ -90,27 +90,59 @@ def time_op(fn, iters, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def kernel_breakdown(plan, iters=10):
-    """average duration (ms) of every launch class of one step, each timed on its own with HIP
-    events on the launch stream (torch's current stream = the stream the C ABI launches on)."""
+def kernel_breakdown(plan, iters=4):
+    """average duration (ms) of every launch class of one step, measured INSIDE the step: the plan's own launch sequence
+    (binarize, S x (pool, query pre, query post, conv), x2 upsamples) runs `iters` times on the launch stream (torch's
+    current stream = the stream the C ABI launches on) with a HIP event between consecutive launches, so every kernel
+    sees the cache / DRAM state its predecessor leaves -- what a single-stream rocprofv3 trace of the step records
+    (profiles/r02/e_single_stream_B24_kernel_stats.csv)."""
     from polyphonicformer_amd import engine as E
     p = plan
-    o = p.stage_out[-1]
-    t = {}
-    t["ingest"] = time_op(lambda: E.ingest(p.x, p.prec, out=p.xp), iters)
-    t["binarize"] = time_op(lambda: E.binarize(p.m0, out=p.bits), iters)
-    t["pool"] = time_op(lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial), iters)
-    for name, ph in (("query_pre", 1), ("query_post", 2)):
-        t[name] = time_op(lambda ph=ph: E.query_stage(p.partial, p.bits, p.k0, p.q0, p.packs[0], p.N, p.HW,
-                                                      outs=p.stage_out[0], workspace=p.ws, phases=ph,
-                                                      kern_fmt=p.mode.kern_fmt), iters)
-    t["dynconv_bits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits), iters)
-    t["dynconv_logits"] = time_op(lambda: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv,
-                                                    logits_out=p.mask, out_dtype=p.out_code), iters)
-    t["upsample2x"] = time_op(lambda: E.upsample2x(p.mask, out=p.mask_up), iters)
+    seq = []                                    # (class name, launch)
+    seq.append(("binarize", lambda: E.binarize(p.m0, out=p.bits)))
+    k, q = p.k0, p.q0
+    for s in range(p.S):
+        last = s == p.S - 1
+        o = p.stage_out[s]
+        seq.append(("pool", lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial)))
+        for name, ph in (("query_pre", 1), ("query_post", 2)):
+            seq.append((name, lambda ph=ph, k=k, q=q, s=s, last=last: E.query_stage(
+                p.partial, p.bits, k, q, p.packs[s], p.N, p.HW, cls_sigmoid=last, outs=p.stage_out[s], workspace=p.ws,
+                phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt)))
+        if not last:
+            seq.append(("dynconv_bits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits)))
+        else:
+            seq.append(("dynconv_logits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv,
+                                                                logits_out=p.mask, out_dtype=p.out_code)))
+            seq.append(("dynconv_logits", lambda o=o: E.dynconv(p.dp, o["kern"], o["kbias"], 1, p.N, p.HW, p.mode.conv,
+                                                                logits_out=p.depth, out_dtype=p.out_code)))
+        k, q = o["obj"], o["dobj"]
+    seq.append(("upsample2x", lambda: E.upsample2x(p.mask, out=p.mask_up)))
+    seq.append(("upsample2x", lambda: E.upsample2x(p.depth, out=p.depth_up)))
+    for _, fn in seq:                           # one untimed pass
+        fn()
+    tot, cnt = {}, {}
+    for _ in range(iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i, (_, fn) in enumerate(seq):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        for i, (name, _) in enumerate(seq):
+            tot[name] = tot.get(name, 0.0) + ev[i].elapsed_time(ev[i + 1])
+            cnt[name] = cnt.get(name, 0) + 1
+    t = {name: tot[name] / cnt[name] for name in tot}
+    t["ingest"] = time_op(lambda: E.ingest(p.x, p.prec, out=p.xp), 4) if getattr(p, "x", None) is not None else 0.0
     counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
                   dynconv_logits=2, upsample2x=2)
     return t, counts
+
+
+def _lib_wide():
+    from polyphonicformer_amd import _lib
+    return _lib.PH_QUERY_WIDE
 
 
 def algorithmic_bytes(plan, kernel):
