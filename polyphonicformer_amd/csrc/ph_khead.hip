@@ -85,9 +85,16 @@ __device__ __forceinline__ void kh_load_tile(float (&v)[8][4], const float* __re
     }
 }
 
-template <int PA>
+// element format of the tile / weights: bf16 (hi [+ lo] planes) or ONE IEEE fp16 plane (PH_PREC_F16: 2^-12 per operand,
+// one MFMA per product -- the grade of the decode's `fp16` mode)
+template <int E> __device__ __forceinline__ void kh_split(float x, uint32_t& hi, uint32_t& lo) {
+    if constexpr (E == PH_E_F16) { hi = f2h(x); lo = 0; }
+    else f2bf_split(x, hi, lo);
+}
+
+template <int PA, int E>
 __device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* lds, int tid, int64_t HW, int64_t px0) {
-    // fp32 -> bf16 plane(s) in LDS; columns past the map are zero
+    // fp32 -> bf16 plane(s) (or ONE fp16 plane, E = PH_E_F16) in LDS; columns past the map are zero
     const int row_in = tid >> 4, p4 = (tid & 15) * 4;
     bool ok[4];
 #pragma unroll
@@ -97,7 +104,7 @@ __device__ __forceinline__ void kh_store_tile(const float (&v)[8][4], uint16_t* 
         const int row = q * 32 + row_in;
         uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f2bf_split(ok[e] ? v[q][e] : 0.f, hi[e], lo[e]);
+        for (int e = 0; e < 4; ++e) kh_split<E>(ok[e] ? v[q][e] : 0.f, hi[e], lo[e]);
         *(uint2*)(lds + row * KH_LDT + p4) = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
         if (PA == 2) *(uint2*)(lds + 256 * KH_LDT + row * KH_LDT + p4) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
     }
@@ -125,14 +132,14 @@ __device__ __forceinline__ void kh_store_tile_planes(const uint4 (&q)[PA][4], ui
             *(uint4*)(lds + p * 256 * KH_LDT + (it * 64 + (tid >> 3)) * KH_LDT + (tid & 7) * 8) = q[p][it];
 }
 // staging registers of one tile in either input format
-template <int PA, int INFMT> struct KhStage {
+template <int PA, int INFMT, int E> struct KhStage {
     float v[8][4];
     __device__ __forceinline__ void load(const KHArgs& a, int m, int b, int64_t px0, int tid, bool more) {
         kh_load_tile<INFMT == 1>(v, a.f[m] + (int64_t)b * 256 * a.HW, a.HW, px0, tid, more);
     }
-    __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t HW, int64_t px0) const { kh_store_tile<PA>(v, lds, tid, HW, px0); }
+    __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t HW, int64_t px0) const { kh_store_tile<PA, E>(v, lds, tid, HW, px0); }
 };
-template <int PA> struct KhStage<PA, 2> {
+template <int PA, int E> struct KhStage<PA, 2, E> {
     uint4 q[PA][4];
     __device__ __forceinline__ void load(const KHArgs& a, int m, int b, int64_t px0, int tid, bool more) {
         kh_load_tile_planes<PA>(q, a.fp[m] + (int64_t)b * 256 * a.HWp, (int64_t)a.B * 256 * a.HWp, a.HWp, px0, tid, more);
@@ -152,7 +159,7 @@ __device__ __forceinline__ void kh_load_a(uint4 (&af)[PA][16], const uint16_t* _
 }
 
 // acc[32 rows of A][32 px of column tile ct] over K = 256 channels of the LDS tile
-template <int PA>
+template <int PA, int E>
 __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uint16_t* lds, int ct, int lane) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
     f32x16_t acc;
@@ -168,10 +175,10 @@ __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uin
             const uint2 hi = lds_read_tr16(a0 + 4 * KH_LDT);
             bf[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        acc = mfma32(af[0][ks], bf[0], acc);
+        acc = mfma32e<E>(af[0][ks], bf[0], acc);
         if (PA == 2) {
-            acc = mfma32(af[0][ks], bf[PA - 1], acc);
-            acc = mfma32(af[PA - 1][ks], bf[0], acc);
+            acc = mfma32e<E>(af[0][ks], bf[PA - 1], acc);
+            acc = mfma32e<E>(af[PA - 1][ks], bf[0], acc);
         }
         if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bounds how many B fragments are read ahead (registers)
     }
@@ -179,7 +186,7 @@ __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uin
 }
 
 // ---- pass 1: per-channel sum / sum of squares of the conv output; the three maps in one launch (blockIdx.z) ------
-template <int PA, int INFMT>
+template <int PA, int INFMT, int E = PH_E_BF16>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-    KhStage<PA, INFMT> stg;
+    KhStage<PA, INFMT, E> stg;
     stg.load(a, m, b, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
         stg.load(a, m, b, (int64_t)(t + 1) * KH_T, tid, t + 1 < t1);   // in flight during the MFMAs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
+            const f32x16_t acc = kh_gemm<PA, E>(af, lds, ct, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s1[r] += acc[r]; s2[r] += acc[r] * acc[r]; }
         }
@@ -286,7 +293,7 @@ __device__ __forceinline__ void kh_flush_rows(const uint16_t* rows, uint16_t* ds
     }
 }
 // vals (fp32, D layout of the two 32x32 tiles) -> bf16 plane(s) in this wave's rows of the LDS tile
-template <int PA>
+template <int PA, int E>
 __device__ __forceinline__ void kh_vals_to_rows(const float (&vals)[2][16], uint16_t* rows, int lane) {
     const int g = lane >> 5;
 #pragma unroll
@@ -295,13 +302,13 @@ __device__ __forceinline__ void kh_vals_to_rows(const float (&vals)[2][16], uint
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
             uint32_t hi, lo;
-            f2bf_split(vals[ct][r], hi, lo);
+            kh_split<E>(vals[ct][r], hi, lo);
             rows[rl * KH_LDT + ct * 32 + (lane & 31)] = (uint16_t)hi;
             if (PA == 2) rows[256 * KH_LDT + rl * KH_LDT + ct * 32 + (lane & 31)] = (uint16_t)lo;
         }
 }
 
-template <int PA, int ADD, int INFMT>
+template <int PA, int ADD, int INFMT, int E = PH_E_BF16>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     const int ntiles = (int)(a.HWp / KH_T);
     const int t0 = blockIdx.x * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
-    KhStage<PA, INFMT> stg;
+    KhStage<PA, INFMT, E> stg;
     stg.load(a, 0, b, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         const int64_t px0 = (int64_t)t * KH_T;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
         float vals[2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x16_t acc = kh_gemm<PA>(af, lds, ct, lane);
+            const f32x16_t acc = kh_gemm<PA, E>(af, lds, ct, lane);
             const int64_t px = px0 + ct * 32 + (lane & 31);
             const bool inside = px < a.HW;
 #pragma unroll
@@ -389,8 +396,8 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
 #pragma unroll
                 for (int rp = 0; rp < 8; ++rp) {
                     uint32_t h0, l0, h1, l1;
-                    f2bf_split(vals[ct][2 * rp], h0, l0);
-                    f2bf_split(vals[ct][2 * rp + 1], h1, l1);
+                    kh_split<E>(vals[ct][2 * rp], h0, l0);
+                    kh_split<E>(vals[ct][2 * rp + 1], h1, l1);
                     *(uint32_t*)(a.blocks_out + blk + ((ct * 8 + rp) * 64 + lane) * 2) = pack2(h0, h1);
                     if (PA == 2) *(uint32_t*)(a.blocks_out + oplane + blk + ((ct * 8 + rp) * 64 + lane) * 2) = pack2(l0, l1);
                 }
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = ((r & 3) + 8 * (r >> 2) + 4 * g) * KH_LDT + ct * 32 + (lane & 31);
-                        float s = vals[ct][r] + bf2f(rows[o]);
+                        float s = vals[ct][r] + e2f<E>(rows[o]);
                         if (PA == 2) s += bf2f(rows[256 * KH_LDT + o]);
                         sumv[ct][r] = s;
                     }
@@ -426,8 +433,8 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                         float s0 = vals[ct][2 * rp], s1 = vals[ct][2 * rp + 1];
 #pragma unroll
                         for (int p = 0; p < PA; ++p) {
-                            s0 += bf2f(addb[p][ct][rp] & 0xFFFFu);
-                            s1 += __uint_as_float(addb[p][ct][rp] & 0xFFFF0000u);
+                            s0 += e2f<E>(addb[p][ct][rp] & 0xFFFFu);
+                            s1 += e2f<E>(addb[p][ct][rp] >> 16);
                         }
                         sumv[ct][2 * rp] = s0;
                         sumv[ct][2 * rp + 1] = s1;
@@ -445,13 +452,13 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                         }
                 }
             }
-            kh_vals_to_rows<PA>(sumv, rows, lane);
+            kh_vals_to_rows<PA, E>(sumv, rows, lane);
             kh_wave_sync();
 #pragma unroll
             for (int p = 0; p < PA; ++p) kh_flush_rows(rows + p * 256 * KH_LDT, a.sum_planes + p * oplane, row0, a.HWp, lane);
             kh_wave_sync();
         }
-        kh_vals_to_rows<PA>(vals, rows, lane);
+        kh_vals_to_rows<PA, E>(vals, rows, lane);
         if (a.planes) {
             kh_wave_sync();
 #pragma unroll
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                     for (int ks = 0; ks < 16; ++ks)
                         a2[p][ks] = (PA == 1 && a.w2_lds) ? *(const uint4*)(w2l + ((rt * 16 + ks) * 64 + lane) * 8)
                                             : *(const uint4*)(a.w2 + p * a.w2_plane + ((int64_t)(rt * 16 + ks) * 64 + lane) * 8);
-                const f32x16_t acc = kh_gemm<PA>(a2, lds, ct, lane);
+                const f32x16_t acc = kh_gemm<PA, E>(a2, lds, ct, lane);
                 const int64_t px = px0 + ct * 32 + (lane & 31);
                 const bool inside = px < a.HW;
 #pragma unroll
@@ -543,7 +550,11 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
                   const KhFused* fu, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream,
                   const char* fn) {
     if (!(B > 0 && HW > 0 && groups > 0 && 256 % groups == 0)) { ph_set_error("%s: bad size", fn); return PH_EINVAL; }
-    if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT)) { ph_set_error("%s: prec must be PH_PREC_BF16 or PH_PREC_SPLIT", fn); return PH_EINVAL; }
+    if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16)) {
+        ph_set_error("%s: prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16", fn);
+        return PH_EINVAL;
+    }
+    const bool f16 = prec == PH_PREC_F16;      // ONE fp16 plane of everything (weights packed as fp16 by the caller; plane inputs must be fp16)
     if (B > 65535) { ph_set_error("%s: B must be <= 65535", fn); return PH_EINVAL; }
     if (workspace_bytes < ph_khead_workspace_bytes(B, HW, groups)) {
         ph_set_error("%s: workspace too small", fn);
@@ -563,7 +574,11 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
 #define KH_ALL(F) (const void*)k_khead_stats<1, F>, (const void*)k_khead_stats<2, F>, (const void*)k_khead_apply<1, 0, F>, \
     (const void*)k_khead_apply<1, 1, F>, (const void*)k_khead_apply<1, 2, F>, (const void*)k_khead_apply<2, 0, F>,         \
     (const void*)k_khead_apply<2, 1, F>, (const void*)k_khead_apply<2, 2, F>
-            KH_ALL(0), KH_ALL(1), KH_ALL(2)
+            KH_ALL(0), KH_ALL(1), KH_ALL(2),
+#define KH_F16(F) (const void*)k_khead_stats<1, F, PH_E_F16>, (const void*)k_khead_apply<1, 0, F, PH_E_F16>, \
+    (const void*)k_khead_apply<1, 1, F, PH_E_F16>, (const void*)k_khead_apply<1, 2, F, PH_E_F16>
+            KH_F16(0), KH_F16(1), KH_F16(2)
+#undef KH_F16
 #undef KH_ALL
         };
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -583,7 +598,10 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     const int fmt = in_planes ? 2 : ((HW % 4) == 0 ? 1 : 0);      // kernel input format: fp32 scalar / fp32 x4 / bf16 planes
 #define KH_LAUNCH(K, G, L, ...)                                                                      \
     do {                                                                                             \
-        if (PA == 1 && fmt == 0) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 0>), G, block, L, s, a);    \
+        if (f16 && fmt == 0) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 0, PH_E_F16>), G, block, L, s, a);      \
+        else if (f16 && fmt == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 1, PH_E_F16>), G, block, L, s, a); \
+        else if (f16) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 2, PH_E_F16>), G, block, L, s, a);             \
+        else if (PA == 1 && fmt == 0) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 0>), G, block, L, s, a);    \
         else if (PA == 1 && fmt == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 1>), G, block, L, s, a); \
         else if (PA == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 2>), G, block, L, s, a);           \
         else if (fmt == 0) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 0>), G, block, L, s, a);          \

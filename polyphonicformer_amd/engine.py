@@ -40,6 +40,9 @@ MODES["split"] = MODES["fp32"]
 # arithmetic of the kernels that know two grades only (KernelHead, the neck, the track head): fast or fp32 grade
 PREC = {"bf16": _lib.PH_PREC_BF16, "split": _lib.PH_PREC_SPLIT, "fp32": _lib.PH_PREC_SPLIT,
         "mixed": _lib.PH_PREC_SPLIT, "mixed16": _lib.PH_PREC_SPLIT, "fp16": _lib.PH_PREC_SPLIT}
+# KernelHead's post-neck part (a1) has a third grade: "fp16" = ONE fp16 plane of the maps and weights (2^-12 per operand, one
+# MFMA per product), whose planes and mask bits the decode's `fp16` mode adopts as they are
+KHEAD_PREC = dict(PREC, fp16=_lib.PH_PREC_F16)
 OUT_CODE = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}
 
 
@@ -333,9 +336,11 @@ class DecodePlan:
 
 
 # ---- KernelHead (a1) ---------------------------------------------------------------------------------
-def _planes_of(w64, P):
-    """float64 [..] -> int16 [P, ...] bf16 hi(/lo) planes"""
+def _planes_of(w64, P, fp16=False):
+    """float64 [..] -> int16 [P, ...] bf16 hi(/lo) planes, or ONE fp16 plane"""
     w = w64.to(torch.float32)
+    if fp16:
+        return w.to(torch.float16).view(torch.int16)[None].contiguous()
     hi = w.to(torch.bfloat16)
     out = [hi.view(torch.int16)]
     if P == 2:
@@ -353,18 +358,19 @@ class KernelHeadPack:
 
     def __init__(self, sd, prec, device, groups):
         P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+        h = prec == _lib.PH_PREC_F16                                         # one fp16 plane of every weight
         g = lambda k: sd[k].detach().to("cpu", torch.float64)
         convs = torch.stack([g(f"{n}_convs.0.conv.weight").reshape(256, 256) for n in ("loc", "seg", "depth")], 0)
-        self.wplanes = _planes_of(convs, P).to(device)                       # [P,3,256,256]
+        self.wplanes = _planes_of(convs, P, h).to(device)                    # [P,3,256,256]
         self.gn = torch.stack([torch.stack([g(f"{n}_convs.0.gn.weight"), g(f"{n}_convs.0.gn.bias")], 0)
                                for n in ("loc", "seg", "depth")], 0).float().contiguous().to(device)   # [3,2,256]
         w_init = g("init_kernels.weight").reshape(-1, 256)
         w_seg = g("conv_seg.weight").reshape(-1, 256)
         w_dd = g("conv_direct_depth.weight").reshape(1, 256)
         self.n_init, self.n_seg = w_init.shape[0], w_seg.shape[0]
-        self.init_planes = _planes_of(_pad_rows32(w_init), P).to(device)
-        self.seg_planes = _planes_of(_pad_rows32(w_seg), P).to(device)
-        self.dd_planes = _planes_of(_pad_rows32(w_dd), P).to(device)
+        self.init_planes = _planes_of(_pad_rows32(w_init), P, h).to(device)
+        self.seg_planes = _planes_of(_pad_rows32(w_seg), P, h).to(device)
+        self.dd_planes = _planes_of(_pad_rows32(w_dd), P, h).to(device)
         z = lambda n: torch.zeros(n, dtype=torch.float32)
         sb = z(self.seg_planes.shape[1]); sb[:self.n_seg] = g("conv_seg.bias").float()
         self.seg_bias = sb.to(device)

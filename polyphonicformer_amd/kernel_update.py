@@ -109,7 +109,7 @@ class KernelUpdateIterHead(nn.Module):
         plan = self._plan(B, N, H, W, x.device)
         plan.renew_outputs()         # results are the caller's: an earlier call's tensors are never overwritten
         ho = getattr(x, "_ph_handoff", None)
-        if (ho is not None and ho["prec"] == plan.prec and plan.mode.name in ("bf16", "fp32") and ho["mask_preds"] is mask_preds
+        if (ho is not None and ho["prec"] == plan.prec and plan.mode.name in ("bf16", "fp32", "fp16") and ho["mask_preds"] is mask_preds
                 and ho["depth_feats"] is depth_feats and tuple(ho["xp"].shape) == tuple(plan.xp.shape)
                 and tuple(ho["bits"].shape) == tuple(plan.bits.shape)):
             # inputs come straight from this package's KernelHead: its bf16 planes and mask bits are reused

@@ -297,6 +297,36 @@ def test_whole_path_a1_a6(gpu, weights):
     assert Hh.rel_err(mask_up.cpu(), ref["mask_up"]) < tol
 
 
+def test_kernel_head_fp16_grade_and_handoff(gpu, weights):
+    """KernelHead's third grade (`set_precision("fp16")`: ONE fp16 plane of the maps and weights, one MFMA per product):
+    every output of the post-neck part within 1e-3 of the REFERENCE golden, and the fp16 planes + mask bits it hands to a
+    KernelUpdateIterHead in `fp16` mode decode to exactly what the fp32 tensors of the same call decode to."""
+    z = Hh.load_golden("full_khead.npz")
+    m = json.loads(bytes(z["meta_json"]).decode())
+    B, N, H, W = m["B"], m["N"], m["H"], m["W"]
+    feats = [f.to(gpu) for f in Hh.neck_inputs(m["nseed"], B, 256, H, W)]
+    kh = _kernel_head(weights, "fp16")
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    (pf, xf, mp, cs, seg, df, dp, dpr, _) = kh.simple_test_rpn(feats, metas)
+    for name, t in (("x_feats", xf), ("mask_preds", mp), ("seg_preds", seg), ("depth_feats", df), ("depth_pred", dpr)):
+        e = Hh.rel_err(t.cpu(), z[name])
+        print("KernelHead fp16 grade", name, e)
+        assert e < 1e-3, (name, e)
+    flips = int(((mp.cpu() > 0) != (torch.from_numpy(z["mask_preds"]) > 0)).sum())
+    assert flips <= 8, flips
+    if flips == 0:
+        assert Hh.rel_err(pf.cpu().reshape(B, N, 256), z["proposal_feats"]) < 1e-3
+    ih = _iter_head(weights, 3, precision="fp16")
+    a = ih.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
+    plan = next(iter(ih._plans.values()))
+    assert plan.handoff_runs == 1                   # fp16 planes and bits adopted, no ingest / binarize
+    a = [t.clone() for t in a]
+    b = ih.simple_test_mask_preds(xf.clone(), pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)   # no hand-off
+    assert plan.handoff_runs == 1
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+
+
 def test_bf16_feature_inputs_skip_ingest(gpu, weights):
     """bf16 NCHW feature tensors are the plane format: same result as fp32 inputs rounded by the ingest kernel"""
     B, N, H, W, S = 1, 111, 8, 16, 2
