@@ -70,6 +70,11 @@ __device__ __forceinline__ uint32_t f2h_pk(float a, float b) {
 }
 template <int E> __device__ __forceinline__ uint32_t f2e(float x) { return E == PH_E_F16 ? f2h(x) : f2bf(x); }
 template <int E> __device__ __forceinline__ float e2f(uint32_t h) { return E == PH_E_F16 ? h2f(h) : bf2f(h); }
+// x -> (hi, lo) planes of format E: bf16 hi + lo (lo unused by one-plane callers), or ONE fp16 value (lo = 0)
+template <int E> __device__ __forceinline__ void f2e_split(float x, uint32_t& hi, uint32_t& lo) {
+    if constexpr (E == PH_E_F16) { hi = f2h(x); lo = 0; }
+    else f2bf_split(x, hi, lo);
+}
 template <int E> __device__ __forceinline__ uint32_t f2e_pk(float a, float b) { return E == PH_E_F16 ? f2h_pk(a, b) : f2bf_pk(a, b); }
 
 // ---- streaming (non-temporal) 16-byte accesses for data that is written or read exactly once per kernel: the x2

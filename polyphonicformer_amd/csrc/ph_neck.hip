@@ -18,7 +18,7 @@
 // fp32 NCHW [B][256][HW] (+ add[256][HW], nullable) -> bf16 NHWC planes [PA][B][HW][256]; 64 channels x 64 pixels per
 // block (256-byte runs in, whole 128-byte lines out).  A 256-channel x 32-pixel variant that writes whole 512-byte
 // pixel vectors was 50 % slower at the stride-4 level (256 rows 512 KB apart per block).
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ src, const float* __restrict__ add,
                                                      uint16_t* __restrict__ dst, int B, int64_t HW) {
     __shared__ float t[64][65];                       // [channel][pixel] tile
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ s
     for (int p = ty; p < 64; p += 4) {
         if (p0 + p >= HW) continue;
         uint32_t hi, lo;
-        f2bf_split(t[tx][p], hi, lo);
+        f2e_split<E>(t[tx][p], hi, lo);
         const int64_t o = ((int64_t)b * HW + p0 + p) * 256 + c0 + tx;
         dst[o] = (uint16_t)hi;
         if (PA == 2) dst[o + plane] = (uint16_t)lo;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ s
 
 // the same tile with 16-byte accesses on both sides (HW % 4 == 0): 4 x float4 per thread in, 2 x 16 bytes (8 channels of
 // one pixel) per thread out -- a quarter / an eighth of the memory instructions of the scalar kernel above
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict__ src, const float* __restrict__ add,
                                                         uint16_t* __restrict__ dst, int B, int64_t HW) {
     __shared__ float t[64][65];                       // [channel][pixel] tile
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict_
         if (p0 + px >= HW) continue;
         uint32_t hi[8], lo[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f2bf_split(t[piece * 8 + e][px], hi[e], lo[e]);
+        for (int e = 0; e < 8; ++e) f2e_split<E>(t[piece * 8 + e][px], hi[e], lo[e]);
         uint16_t* d = dst + ((int64_t)b * HW + p0 + px) * 256 + c0 + piece * 8;
         *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
         if (PA == 2) *(uint4*)(d + plane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
@@ -93,9 +93,12 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict_
 
 extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst, int B, int64_t HW, int prec, void* stream) {
     PH_CHECK_ARG(src && dst && B > 0 && HW > 0, "bad pointer or size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     const dim3 grid((unsigned)((HW + 63) / 64), 4, B);
-    if ((HW & 3) == 0) {
+    if (prec == PH_PREC_F16) {
+        if ((HW & 3) == 0) hipLaunchKernelGGL((k_nhwc_ingest_v4<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
+        else hipLaunchKernelGGL((k_nhwc_ingest<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
+    } else if ((HW & 3) == 0) {
         if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_nhwc_ingest_v4<1>, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
         else hipLaunchKernelGGL(k_nhwc_ingest_v4<2>, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
     } else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_nhwc_ingest<1>, grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
@@ -133,7 +136,7 @@ template <int KS, int S, int PA> struct ConvGeo {
     static constexpr int PLANE = IR * ICS * LDP;                                   // elements per precision plane
 };
 
-template <int PA, int KS, int S>
+template <int PA, int KS, int S, int E = PH_E_BF16>
 __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ X, int64_t x_plane,
                                                    const uint16_t* __restrict__ Wp, int64_t w_plane, float* __restrict__ Y,
                                                    float* __restrict__ partial, int B, int H, int W, int Ho, int Wo) {
@@ -252,10 +255,10 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
                 }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = mfma32(a[0][mt], bcur[0], acc[mt]);
+                acc[mt] = mfma32e<E>(a[0][mt], bcur[0], acc[mt]);
                 if (PA == 2) {
-                    acc[mt] = mfma32(a[0][mt], bcur[PA - 1], acc[mt]);
-                    acc[mt] = mfma32(a[PA - 1][mt], bcur[0], acc[mt]);
+                    acc[mt] = mfma32e<E>(a[0][mt], bcur[PA - 1], acc[mt]);
+                    acc[mt] = mfma32e<E>(a[PA - 1][mt], bcur[0], acc[mt]);
                 }
             }
             if (MT > 4) __builtin_amdgcn_sched_barrier(0);   // 128 accumulator VGPRs: keep the A fragments of later k-steps out
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     }
 }
 
-static int conv_th(int ksize, int stride, int prec) { return prec == PH_PREC_BF16 ? 4 : 2; }
+static int conv_th(int ksize, int stride, int prec) { return prec == PH_PREC_SPLIT ? 2 : 4; }      // one-plane formats: 4-row tiles
 
 // workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
 extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {
@@ -312,29 +315,31 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
                             int stride, int B, int H, int W, int prec, void* stream) {
     PH_CHECK_ARG(X && Wp && Y && partial && B > 0 && H > 0 && W > 0, "bad pointer or size");
     PH_CHECK_ARG((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "supported: 3x3 stride 1/2, 1x1 stride 1");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const int th = conv_th(ksize, stride, prec);
     const dim3 grid((Wo + CV_TW - 1) / CV_TW, (Ho + th - 1) / th, B);
     const int64_t x_plane = (int64_t)B * H * W * 256;
     hipStream_t s = (hipStream_t)stream;
-#define PH_CV(PA, KS, S)                                                                                                 \
+#define PH_CV(PA, KS, S, EE)                                                                                             \
     do {                                                                                                                 \
-        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                                        \
-        static const bool once = [&] {                                                                                                     \
-            (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                \
+        static const bool once = [&] {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                         \
             return true;                                                                                                 \
-        }();                                                                                                 \
-        (void)once;                                                                                                                \
-        hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
+        }();                                                                                                             \
+        (void)once;                                                                                                      \
+        hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S, EE>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
                            B, H, W, Ho, Wo);                                                                             \
     } while (0)
     if (prec == PH_PREC_BF16) {
-        if (ksize == 1) PH_CV(1, 1, 1); else if (stride == 1) PH_CV(1, 3, 1); else PH_CV(1, 3, 2);
+        if (ksize == 1) PH_CV(1, 1, 1, PH_E_BF16); else if (stride == 1) PH_CV(1, 3, 1, PH_E_BF16); else PH_CV(1, 3, 2, PH_E_BF16);
+    } else if (prec == PH_PREC_F16) {
+        if (ksize == 1) PH_CV(1, 1, 1, PH_E_F16); else if (stride == 1) PH_CV(1, 3, 1, PH_E_F16); else PH_CV(1, 3, 2, PH_E_F16);
     } else {
-        if (ksize == 1) PH_CV(2, 1, 1); else if (stride == 1) PH_CV(2, 3, 1); else PH_CV(2, 3, 2);
+        if (ksize == 1) PH_CV(2, 1, 1, PH_E_BF16); else if (stride == 1) PH_CV(2, 3, 1, PH_E_BF16); else PH_CV(2, 3, 2, PH_E_BF16);
     }
 #undef PH_CV
     PH_CHECK_LAUNCH();
@@ -354,15 +359,15 @@ __device__ __forceinline__ float4 gn_relu4(float4 v, float4 sc, float4 sh, bool 
     return o;
 }
 
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __device__ __forceinline__ void st_planes4(uint16_t* dst, int64_t plane, float4 o) {
     uint32_t h[4], l[4];
-    f2bf_split(o.x, h[0], l[0]); f2bf_split(o.y, h[1], l[1]); f2bf_split(o.z, h[2], l[2]); f2bf_split(o.w, h[3], l[3]);
+    f2e_split<E>(o.x, h[0], l[0]); f2e_split<E>(o.y, h[1], l[1]); f2e_split<E>(o.z, h[2], l[2]); f2e_split<E>(o.w, h[3], l[3]);
     *(uint2*)dst = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
     if (PA == 2) *(uint2*)(dst + plane) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
 }
 
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int groups,
                                                   int mode, int accumulate, uint16_t* __restrict__ planes,
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, c
                     o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
                     o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
                     o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
-                    st_planes4<PA>(planes + ((int64_t)b * Ho * Wo + (int64_t)oy * Wo + ox) * 256 + c4, plane, o);
+                    st_planes4<PA, E>(planes + ((int64_t)b * Ho * Wo + (int64_t)oy * Wo + ox) * 256 + c4, plane, o);
                 }
         }
         return;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ y, c
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < HW; p += (int64_t)gridDim.x * 4) {
         const float4 o = gn_relu4(*(const float4*)(yb + p * 256 + c4), sc, sh, act);
         if (mode == PH_GN_TO_PLANES) {
-            st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, o);
+            st_planes4<PA, E>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, o);
         } else if (mode == PH_GN_ACCUM) {
             float4* d = (float4*)(outf + ((int64_t)b * HW + p) * 256 + c4);
             if (accumulate) {
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(256) void k_gn_to_nchw(const float* __restrict__ y,
 // split precision), zero in [HW, HWp) -- what KernelHead's kernels take directly (ph_khead_fused, PH_IN_PLANES), so the
 // neck's three outputs cross HBM once at 2 bytes instead of 4 and are never converted again.  A block takes 64 pixels x
 // 256 channels: whole 1 KiB pixel vectors in, 128-byte runs of 64 pixels per channel row out.
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __global__ __launch_bounds__(256) void k_gn_to_cplanes(const float* __restrict__ y, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int groups, uint16_t* __restrict__ planes, int64_t HW, int64_t HWp,
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void k_gn_to_cplanes(const float* __restrict__
             const int row = ps * 32 + r0;
             uint32_t hi[8], lo[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f2bf_split(tt[row * 65 + piece * 8 + e], hi[e], lo[e]);
+            for (int e = 0; e < 8; ++e) f2e_split<E>(tt[row * 65 + piece * 8 + e], hi[e], lo[e]);
             uint16_t* d = planes + ((int64_t)b * 256 + row) * HWp + p0 + piece * 8;
             *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
             if (PA == 2) *(uint4*)(d + oplane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
@@ -554,7 +559,7 @@ struct GnSumArgs {
     const float* beta[4];
 };
 
-template <int PA>
+template <int PA, int E = PH_E_BF16>
 __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nlev, int groups, uint16_t* __restrict__ planes,
                                                        int B, int64_t HW) {
     const int b = blockIdx.z;
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nl
                 acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
             }
         }
-        st_planes4<PA>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, acc);
+        st_planes4<PA, E>(planes + ((int64_t)b * HW + p) * 256 + c4, plane, acc);
     }
 }
 
@@ -598,7 +603,7 @@ extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stat
                                 void* stream) {
     PH_CHECK_ARG(ys && stats && gammas && betas && planes && nlev >= 1 && nlev <= 4 && B > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG(groups > 0 && 256 % groups == 0, "bad group count");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     GnSumArgs a;
     for (int l = 0; l < 4; ++l) {
         const int k = l < nlev ? l : 0;
@@ -607,7 +612,8 @@ extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stat
     int gx = 1024;                     // several pixels per workgroup: its per-channel affine set-up (4 levels) is amortised
     if (const char* e = getenv("PH_GNSUM_WGS")) gx = atoi(e);
     if ((HW + 3) / 4 < gx) gx = (int)((HW + 3) / 4);
-    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_planes<1>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
+    if (prec == PH_PREC_F16) hipLaunchKernelGGL((k_gn_sum_planes<1, PH_E_F16>), dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
+    else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_planes<1>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
     else hipLaunchKernelGGL(k_gn_sum_planes<2>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
     PH_CHECK_LAUNCH();
     return PH_OK;
@@ -621,7 +627,7 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
     PH_CHECK_ARG(((mode == PH_GN_TO_PLANES || mode == PH_GN_UP2_PLANES || mode == PH_GN_TO_CPLANES) && planes) ||
                      ((mode == PH_GN_ACCUM || mode == PH_GN_TO_NCHW) && outf),
                  "output pointer missing for this mode");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     if (mode == PH_GN_TO_CPLANES) {
         PH_CHECK_ARG(stats && B <= 65535, "PH_GN_TO_CPLANES needs statistics (and B <= 65535)");
         const int64_t HW = (int64_t)H * W, HWp = ph_hw_padded(HW);
@@ -634,10 +640,12 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
         static const bool once = [&] {
             (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_gn_to_cplanes<1, PH_E_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             return true;
         }();
         (void)once;
-        if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_to_cplanes<1>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
+        if (prec == PH_PREC_F16) hipLaunchKernelGGL((k_gn_to_cplanes<1, PH_E_F16>), grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
+        else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_to_cplanes<1>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
         else hipLaunchKernelGGL(k_gn_to_cplanes<2>, grid, dim3(256), lds, (hipStream_t)stream, y, stats, gamma, beta, groups, planes, HW, HWp, B, tpw);
         PH_CHECK_LAUNCH();
         return PH_OK;
@@ -653,7 +661,8 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
     int gx = (int)((npix + 3) / 4 < 2048 ? (npix + 3) / 4 : 2048);
     const dim3 grid(gx, 1, B);
     if (!groups) groups = 1;
-    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_apply<1>, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
+    if (prec == PH_PREC_F16) hipLaunchKernelGGL((k_gn_apply<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
+    else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_apply<1>, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
     else hipLaunchKernelGGL(k_gn_apply<2>, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gamma, beta, groups, mode, accumulate, planes, outf, B, H, W);
     PH_CHECK_LAUNCH();
     return PH_OK;

@@ -40,7 +40,7 @@ MODES["split"] = MODES["fp32"]
 # arithmetic of the kernels that know two grades only (KernelHead, the neck, the track head): fast or fp32 grade
 PREC = {"bf16": _lib.PH_PREC_BF16, "split": _lib.PH_PREC_SPLIT, "fp32": _lib.PH_PREC_SPLIT,
         "mixed": _lib.PH_PREC_SPLIT, "mixed16": _lib.PH_PREC_SPLIT, "fp16": _lib.PH_PREC_SPLIT}
-# KernelHead's post-neck part (a1) has a third grade: "fp16" = ONE fp16 plane of the maps and weights (2^-12 per operand, one
+# KernelHead's post-neck part (a1) and the neck have a third grade: "fp16" = ONE fp16 plane of the maps and weights (2^-12 per operand, one
 # MFMA per product), whose planes and mask bits the decode's `fp16` mode adopts as they are
 KHEAD_PREC = dict(PREC, fp16=_lib.PH_PREC_F16)
 OUT_CODE = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}

@@ -121,7 +121,7 @@ class KernelHead(nn.Module):
         maps [B,256,H,W].  In training mode the stuff rows are not appended here (:329) -- `forward_train` does it (:444-451)."""
         neck = self.localization_fpn
         handoff = neck is not None and hasattr(neck, "forward_planes") and getattr(neck, "num_aux_convs", 0) == 2 \
-            and E.PREC.get(getattr(neck, "precision", None)) == E.KHEAD_PREC[self.precision]   # codes: 'split' == 'fp32'; never fp16
+            and E.KHEAD_PREC.get(getattr(neck, "precision", None)) == E.KHEAD_PREC[self.precision]   # codes: 'split' == 'fp32'
         if handoff:
             # this build's neck: its three maps come over as bf16 planes (half the bytes, no conversion pass in front of
             # the GEMMs; bit-identical in bf16 precision because the first use of the fp32 maps is that same rounding)

@@ -98,13 +98,13 @@ class SemanticFPNWrapper(nn.Module):
         key = (str(dev), self.precision, tuple(p._version for p in self.parameters()))
         if key not in self._packs:
             self._packs.clear()
-            prec = E.PREC[self.precision]
+            prec = E.KHEAD_PREC[self.precision]             # 'fp16': one fp16 plane of weights and activations (f16 MFMA)
             P = 2 if prec == _lib.PH_PREC_SPLIT else 1
 
             def one(m):
                 w = m.conv.weight.detach().to("cpu", torch.float64)                   # [out][in][kh][kw]
                 w2 = w.permute(0, 2, 3, 1).reshape(256, -1)                           # K order (tap, channel)
-                planes = E._planes_of(w2, P)                                          # [P][256][K]
+                planes = E._planes_of(w2, P, prec == _lib.PH_PREC_F16)                                          # [P][256][K]
                 wp = torch.stack([pack_b32(planes[p]) for p in range(P)], 0).contiguous().to(dev)
                 return dict(wp=wp, gamma=m.gn.weight.detach().float().contiguous().to(dev),
                             beta=m.gn.bias.detach().float().contiguous().to(dev), k=m.ksize, s=m.stride)
@@ -132,7 +132,7 @@ class SemanticFPNWrapper(nn.Module):
         x0 = inputs[0]
         E._require_gpu(x0, "inputs[0]")
         dev, B = x0.device, x0.shape[0]
-        pk, prec, G = self._pack(dev), E.PREC[self.precision], self.groups
+        pk, prec, G = self._pack(dev), E.KHEAD_PREC[self.precision], self.groups
         shapes = tuple(tuple(t.shape[-2:]) for t in inputs[:4])
         plan = self._plans.get((B, shapes, str(dev), self.precision))
         if plan is None:
