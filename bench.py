@@ -949,9 +949,11 @@ def main():
             torch.cuda.empty_cache()
         if world == 1 and not args.no_neck:
             try:
-                res["video_cfg3"] = video_leg(dev)
+                res["video_cfg3"] = video_leg(dev, precision="fp16")      # fp16 grade in neck / heads, split-grade track head
+                fast = video_leg(dev, precision="bf16")
+                res["video_cfg3"]["fast_bf16"] = {k: fast[k] for k in ("ms_per_frame", "heads_and_merge_ms", "association_ms")}
             except Exception as e:
-                res["video_cfg3"] = {"error": repr(e)}
+                res.setdefault("video_cfg3", {})["error"] = repr(e)
         if world == 1 and not args.no_neck:
             try:
                 res["hungarian_assign"] = assign_leg(dev)

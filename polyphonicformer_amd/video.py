@@ -90,6 +90,22 @@ class _TrackTable:
             self.backdrops = []
 
 
+class _OneHostThread:
+    """The tracker's host arithmetic is a few [n <= 100, 256] products and softmaxes: on the GPU box's 256 hardware threads
+    the host BLAS / OpenMP pool turns each of them into a 256-way fork-join (measured: 100 - 250 ms per frame when the pool
+    is contended, 2.5 ms with one thread).  Intra-op threading is switched off for the duration of `match` only."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 @TRACKERS.register_module()
 class QuasiDenseEmbedTracker(object):
     """Quasi-dense embedding tracker with the constructor kwargs, `match` signature and integer-id semantics of
@@ -162,6 +178,10 @@ class QuasiDenseEmbedTracker(object):
     def match(self, bboxes, labels, track_feats, frame_id, asso_tau=-1):
         """bboxes [n,5] (x1,y1,x2,y2,score), labels [n], track_feats [n,256] -> (bboxes, labels, ids) of the kept
         detections in descending-score order; ids >= 0 track, -1 unmatched, -2 suppressed."""
+        with _OneHostThread():
+            return self._match(bboxes, labels, track_feats, frame_id)
+
+    def _match(self, bboxes, labels, track_feats, frame_id):
         box, lab, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().cpu().float()
         order = box[:, 4].sort(descending=True)[1]
         box, lab, emb = box[order], lab[order], emb[order]
