@@ -388,6 +388,48 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
         del keep, graph
     except Exception as e:
         out["hip_graph"] = {"error": repr(e)}
+    try:        # two module pipelines on two streams, the second one a phase behind: its neck (matrix-pipe bound) runs under
+        #         the first one's KernelHead + decode (HBM bound) -- what a serving loop with two frame batches in flight does
+        import copy
+        kh2, head2 = copy.deepcopy(kh), copy.deepcopy(head)
+        for m_ in (kh2, head2, getattr(kh2, "localization_fpn", None)):
+            if m_ is not None:
+                for attr in ("_plans", ):
+                    if hasattr(m_, attr):
+                        setattr(m_, attr, {})
+        kh2._pack = None
+        feats2 = tuple(f.clone() for f in feats)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def one(k_, h_, f_):
+            (pf, xf, mp, cs, seg, df, dp, dpr, aspp) = k_.simple_test_rpn(f_, metas)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return ev, h_.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
+
+        def issue():
+            cur = torch.cuda.current_stream()
+            sa.wait_stream(cur)
+            sb.wait_stream(cur)
+            with torch.cuda.stream(sa):
+                skew, ra = one(kh, head, feats)
+            with torch.cuda.stream(sb):
+                sb.wait_event(skew)
+                _, rb = one(kh2, head2, feats2)
+            cur.wait_stream(sa)
+            cur.wait_stream(sb)
+            return ra, rb
+
+        issue()
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            keep2 = issue()
+        t2 = time_op(g2.replay, steps)
+        out["two_streams"] = {"frames_per_step": 2 * B, "frames_per_s": round(2 * B / (t2 * 1e-3), 1), "ms_per_step": round(t2, 4)}
+        del keep2, g2, kh2, head2
+    except Exception as e:
+        out["two_streams"] = {"error": repr(e)}
     return out
 
 
