@@ -178,3 +178,24 @@ def test_api_outputs_survive_the_next_call(gpu):
     d1b = ih.simple_test_mask_preds(r1[1], r1[0], r1[2], r1[3], m8, depth_preds=r1[7], depth_feats=r1[5], depth_proposal=r1[6])
     for a, b in zip(d1, d1b):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+def test_cfg2_full_size_kernel_head_vs_oracle(gpu, precision):
+    """a1 at cfg2's full stride-8 size (128 x 256, one frame, 100 + 11 rows) against the oracle, in its three grades: GroupNorm
+    statistics over 32768 pixels, the static convs, x = sem + loc.  'fp16' is the grade that feeds the decode's fp16 mode."""
+    from test_gpu_parity import _full_weights, _kernel_head
+    w = _full_weights()
+    sd = {k[len("rpn_head."):]: v for k, v in w.items() if k.startswith("rpn_head.")}
+    H, W = 128, 256
+    feats = Hh.neck_inputs(57, 1, 256, H, W)
+    ref = O.kernel_head_post_neck(sd, *feats, 8, 19, 32)
+    kh = _kernel_head(w, precision)
+    out = kh.simple_test_rpn([f.to(gpu) for f in feats], [Hh.img_meta(H * 8, W * 8)])
+    tol = {"fp32": 1e-3, "fp16": 1e-3, "bf16": 3e-2}[precision]
+    errs = {name: Hh.rel_err(t.float().cpu(), ref[name]) for name, t in (("x_feats", out[1]), ("mask_preds", out[2]), ("seg_preds", out[4]),
+                                                                         ("depth_feats", out[5]), ("depth_pred", out[7]))}
+    print("KernelHead full size", precision, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < tol, errs
+    flips = ((out[2][:, :100].cpu() > 0) != (ref["mask_preds"][:, :100] > 0)).float().mean().item()
+    assert flips < (1e-3 if precision != "bf16" else 2e-2), flips
