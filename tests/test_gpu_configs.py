@@ -117,7 +117,7 @@ def test_cfg3_video_head_size_two_frames(gpu, precision):
     _teacher_forced(head, sd, CFG3, inp, gpu, TOL[precision])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "mixed16", "mixed"])
 def test_cfg5_teacher_forced_and_free_running(gpu, precision):
     """cfg5's shape (48x156: HW = 7488 is not a multiple of 128, N = 253 -> 8 row tiles), all three stages"""
     wl = CFG5
@@ -139,6 +139,8 @@ def test_cfg5_teacher_forced_and_free_running(gpu, precision):
     if precision in ("fp32", "fp16"):      # fp16 = cfg5 as specified: fp16 planes / kernels / logits, S = 3, N = 253
         assert flips < (1e-3 if precision == "fp32" else 5e-3)
         assert max(e.values()) < (1e-3 if flips == 0 else 5e-2)
+    elif precision in ("mixed", "mixed16"):      # fp32 inputs are rounded to one bf16 plane by the ingest: input rounding, not arithmetic
+        assert flips < 2e-2 and e["obj"] < 0.1
     else:
         assert flips < 0.05 and e["obj"] < 0.1
 

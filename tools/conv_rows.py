@@ -1,7 +1,8 @@
 """dynamic-conv time against the number of query rows (waves per workgroup), modes bf16 and mixed: is the mixed mode's 2-MFMA form
 bound by the SIMD that hosts two of its five waves?  usage: python tools/conv_rows.py"""
 import sys, json, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from polyphonicformer_amd import _lib, engine as E
 dev = torch.device("cuda:0")

@@ -1,6 +1,7 @@
 """GPU: the neck leg and the whole-head leg (bench.neck_leg / full_head_leg) in the fp16 and bf16 grades"""
 import sys, json, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS["cfg2"]

@@ -1,6 +1,7 @@
 """GPU: the a1 + a6 leg (bench.kernel_head_leg) in the three grades.  usage: python tools/khead_leg.py"""
 import sys, json, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS["cfg2"]
