@@ -756,7 +756,7 @@ def main():
                     help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
                          "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4, 6, 8],
                     help="n > 1: n part-batches on n skewed HIP streams, one HIP graph (engine.DualDecodePlan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-head", action="store_true")
