@@ -49,7 +49,7 @@ __device__ __forceinline__ float binz(float z) { return z > PH_BIN_THR ? 1.f : 0
 constexpr int RXM_RT = 10;
 
 template <bool BIN>
-__global__ __launch_bounds__(256) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
+__global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
                                                     const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -148,7 +148,7 @@ __device__ __forceinline__ Frag load_along_p(const float* row, bool row_ok, int6
 }
 
 template <bool VEC, bool BIN>
-__global__ __launch_bounds__(256) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
+__global__ __launch_bounds__(256, 2) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
                                                     int M, int K, int64_t HW, int64_t chunk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
