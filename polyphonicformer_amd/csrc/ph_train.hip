@@ -44,31 +44,31 @@ __device__ __forceinline__ f32x4_t mfma3(const Frag& a, const Frag& b, f32x4_t c
 __device__ __forceinline__ float binz(float z) { return z > PH_BIN_THR ? 1.f : 0.f; }
 
 // ---- rows x map --------------------------------------------------------------------------------------------------------------
-// grid (ceil(HW / 256), B, m-passes); 4 waves, each 64 pixels (4 column tiles) x RT row tiles of 16 rows.
+// grid (ceil(HW / (64 * CT)), B, m-passes); 4 waves, each CT column tiles of 16 pixels x RT row tiles of 16 rows: (CT, RT) =
+// (4, 10), one pass per 160 rows; (2, 20) = all of up to 320 rows in one pass for the binarised map operand (160 accumulator
+// registers either way).
 // A: [B or 1][Mpad][lda] fp32, Mpad % 16 == 0, lda % 8 == 0, zero padded (the caller pads: it is a few hundred KB).
-constexpr int RXM_RT = 10;
-
-template <bool BIN>
+template <bool BIN, int CT, int RT>
 __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
-                                                    const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
+                                                       const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const int64_t p0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int64_t p0 = (int64_t)blockIdx.x * (64 * CT) + wave * (16 * CT);
     if (p0 >= HW) return;
-    const int mt0 = blockIdx.z * RXM_RT;
-    const int nrt = min(RXM_RT, Mpad / 16 - mt0);
+    const int mt0 = blockIdx.z * RT;
+    const int nrt = min(RT, Mpad / 16 - mt0);
     const float* Ab = A + b * a_batch_stride + (int64_t)mt0 * 16 * lda;
     const float* Xb = X + (int64_t)b * K * HW;
-    f32x4_t acc[RXM_RT][4];
+    f32x4_t acc[RT][CT];
 #pragma unroll
-    for (int r = 0; r < RXM_RT; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < CT; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < K; k0 += 32) {
-        Frag xb[4];
+        Frag xb[CT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < CT; ++t) {
             const int64_t p = p0 + t * 16 + c;
             float v[8];
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
             xb[t] = split8(v);
         }
 #pragma unroll
-        for (int r = 0; r < RXM_RT; ++r) {
+        for (int r = 0; r < RT; ++r) {
             if (r < nrt) {
                 const int k = k0 + g * 8;
                 float v[8];
@@ -95,16 +95,16 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
                 }
                 const Frag a = split8(v);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
+                for (int t = 0; t < CT; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
             }
         }
     }
     float* Yb = Y + (int64_t)b * M * HW;
 #pragma unroll
-    for (int r = 0; r < RXM_RT; ++r) {
+    for (int r = 0; r < RT; ++r) {
         if (r < nrt) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < CT; ++t) {
                 const int64_t p = p0 + t * 16 + c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -117,63 +117,93 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
 }
 
 // ---- map x map^T ---------------------------------------------------------------------------------------------------------------
-// grid (nsplit, B, m-passes); 4 waves, each MXM_RT row tiles (m) x 4 column tiles (64 of the K <= 256 columns).
+// grid (nsplit, B, m-passes); 8 waves = 2 row halves (MXM_RT / 2 row tiles of m each) x 4 column groups (64 of the K <= 256 columns).
+// Both operands are contraction-contiguous, so a 32-pixel step of (up to 160 G rows + 256 X rows) is staged ONCE per workgroup:
+// global fp32 -> registers (the next step's loads are in flight during the MFMAs) -> hi / lo bf16 -> LDS rows of 32 pixels
+// (80-byte pitch: the 16 rows x 16 bytes of a fragment read hit 16 distinct bank groups) -> fragments by ds_read_b128.
+// (First version: every wave converted its own fragments straight from global memory, G four times over: 1.1 - 1.5 TB/s.)
 // partial [B][nsplit][M][K]; a fixed-order second pass sums the splits.
-constexpr int MXM_RT = 8;
+constexpr int MXM_RT = 10;                 // 160 rows of G per pass
+constexpr int MXM_ROWS = 448;               // 160 rows of G + 256 rows of X, rounded up to the 64 rows one staging pass covers
+constexpr int MXM_PITCH = 40;              // uint16 elements per LDS row: 32 pixels + 16 bytes of padding
+constexpr int MXM_LOADS = MXM_ROWS / 64;   // float4 loads per thread and step (row = tid / 8 + 64 j, 4 pixels at (tid % 8) * 4)
 
 template <bool VEC, bool BIN>
-__device__ __forceinline__ Frag load_along_p(const float* row, bool row_ok, int64_t p, int64_t p_end) {
-    float v[8];
-    if (VEC) {
-        if (row_ok && p < p_end) {      // p_end and HW are multiples of 8 here
-            const float4 q0 = ((const float4*)(row + p))[0], q1 = ((const float4*)(row + p))[1];
-            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-            if (BIN) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = binz(v[e]);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = row_ok && p + e < p_end;
-            const float z = ok ? row[p + e] : 0.f;
-            v[e] = BIN ? (ok ? binz(z) : 0.f) : z;
-        }
-    }
-    return split8(v);
-}
-
-template <bool VEC, bool BIN>
-__global__ __launch_bounds__(256, 2) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
-                                                    int M, int K, int64_t HW, int64_t chunk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
+                                                       int M, int K, int64_t HW, int64_t chunk) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2][MXM_ROWS][MXM_PITCH];     // [hi | lo][row][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int s = blockIdx.x, nsplit = gridDim.x, b = blockIdx.y;
-    const int mt0 = blockIdx.z * MXM_RT;
+    const int m0 = blockIdx.z * (MXM_RT * 16);
     const int64_t pa = s * chunk, pe = min(HW, pa + chunk);
-    const float* Gb = G + (int64_t)b * M * HW;
+    const float* Gb = G + ((int64_t)b * M + m0) * HW;
     const float* Xb = X + (int64_t)b * K * HW;
-    f32x4_t acc[MXM_RT][4];
+    const int r0 = tid >> 3, p4 = (tid & 7) * 4;
+    // row j of this thread: LDS row r0 + 32 j; rows < 160 are G rows m0 + .., the others X rows
+    float4 st[MXM_LOADS];
+    auto fetch = [&](int64_t p) {
 #pragma unroll
-    for (int r = 0; r < MXM_RT; ++r)
+        for (int j = 0; j < MXM_LOADS; ++j) {
+            const int row = r0 + 64 * j;
+            const bool isg = row < MXM_RT * 16;
+            const int rr = isg ? row : row - MXM_RT * 16;
+            const bool ok = isg ? (m0 + rr < M) : (rr < K);
+            const float* src = (isg ? Gb : Xb) + (int64_t)rr * HW + p + p4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                if (VEC) { if (p + p4 < pe) v = *(const float4*)src; }      // pe, HW multiples of 4 here
+                else {
+                    if (p + p4 + 0 < pe) v.x = src[0];
+                    if (p + p4 + 1 < pe) v.y = src[1];
+                    if (p + p4 + 2 < pe) v.z = src[2];
+                    if (p + p4 + 3 < pe) v.w = src[3];
+                }
+                if (BIN && isg) {
+                    v.x = p + p4 + 0 < pe ? binz(v.x) : 0.f; v.y = p + p4 + 1 < pe ? binz(v.y) : 0.f;
+                    v.z = p + p4 + 2 < pe ? binz(v.z) : 0.f; v.w = p + p4 + 3 < pe ? binz(v.w) : 0.f;
+                }
+            }
+            st[j] = v;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < MXM_LOADS; ++j) {
+            const int row = r0 + 64 * j;
+            uint32_t h[4], l[4];
+            f2bf_split(st[j].x, h[0], l[0]); f2bf_split(st[j].y, h[1], l[1]); f2bf_split(st[j].z, h[2], l[2]); f2bf_split(st[j].w, h[3], l[3]);
+            *(uint2*)&lds[0][row][p4] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+            *(uint2*)&lds[1][row][p4] = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+        }
+    };
+    constexpr int WRT = MXM_RT / 2;             // row tiles per wave
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x4_t acc[WRT][4];
+#pragma unroll
+    for (int r = 0; r < WRT; ++r)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nrt = min(WRT, (M - m0 + 15) / 16 - wr * WRT);      // valid row tiles of this wave (may be <= 0)
+    if (pa < pe) fetch(pa);
     for (int64_t p = pa; p < pe; p += 32) {
+        __syncthreads();                        // every wave is done with the previous step's fragments
+        stash();
+        __syncthreads();
+        if (p + 32 < pe) fetch(p + 32);         // in flight during the MFMAs
         Frag xb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int k = wave * 64 + t * 16 + c;
-            xb[t] = load_along_p<VEC, false>(Xb + (int64_t)k * HW, k < K, p + g * 8, pe);
+            const int row = MXM_RT * 16 + wc * 64 + t * 16 + c;
+            xb[t].hi = *(const uint4*)&lds[0][row][g * 8];
+            xb[t].lo = *(const uint4*)&lds[1][row][g * 8];
         }
 #pragma unroll
-        for (int r = 0; r < MXM_RT; ++r) {
-            const int m = (mt0 + r) * 16 + c;
-            if ((mt0 + r) * 16 < M) {       // wave-uniform
-                const Frag a = load_along_p<VEC, BIN>(Gb + (int64_t)m * HW, m < M, p + g * 8, pe);
+        for (int r = 0; r < WRT; ++r) {
+            if (r < nrt) {                      // wave-uniform
+                Frag a;
+                a.hi = *(const uint4*)&lds[0][(wr * WRT + r) * 16 + c][g * 8];
+                a.lo = *(const uint4*)&lds[1][(wr * WRT + r) * 16 + c][g * 8];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
             }
@@ -181,14 +211,14 @@ __global__ __launch_bounds__(256, 2) void k_map_x_mapT(const float* __restrict__
     }
     float* out = partial + ((int64_t)b * nsplit + s) * M * K;
 #pragma unroll
-    for (int r = 0; r < MXM_RT; ++r)
+    for (int r = 0; r < WRT; ++r)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int k = wave * 64 + t * 16 + c;
+            const int k = wc * 64 + t * 16 + c;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = (mt0 + r) * 16 + g * 4 + i;
-                if (m < M && k < K) out[(int64_t)m * K + k] = acc[r][t][i];
+                const int m = m0 + (wr * WRT + r) * 16 + g * 4 + i;
+                if (r < nrt && m < M && k < K) out[(int64_t)m * K + k] = acc[r][t][i];
             }
         }
 }
@@ -247,9 +277,18 @@ extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, in
     PH_CHECK_ARG(A && X && Y && B > 0 && M > 0 && K > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG(Mpad % 16 == 0 && Mpad >= M && lda % 8 == 0 && lda >= K && (a_batch_stride % 4) == 0, "A must be zero padded: rows to 16, row stride to 8");
     PH_CHECK_ARG(((uintptr_t)A & 15) == 0, "A must be 16-byte aligned");
-    const dim3 grid((unsigned)((HW + 255) / 256), B, (Mpad / 16 + RXM_RT - 1) / RXM_RT);
-    if (binarize_x) hipLaunchKernelGGL(k_rows_x_map<true>, grid, dim3(256), 0, (hipStream_t)stream, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
-    else hipLaunchKernelGGL(k_rows_x_map<false>, grid, dim3(256), 0, (hipStream_t)stream, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+    const int tiles = Mpad / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define PH_RXM(BIN, CT, RT)                                                                                               \
+    hipLaunchKernelGGL((k_rows_x_map<BIN, CT, RT>), dim3((unsigned)((HW + 64 * CT - 1) / (64 * CT)), B, (tiles + RT - 1) / RT), \
+                       dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW)
+    // more than 160 rows: one pass of (32 pixels x 320 rows) per wave when the map operand is binarised on the fly (the
+    // comparison is done once: 317 against 365 us at 8 images), two passes of (64 x 160) otherwise (200 against 245 us: the
+    // 4-byte map loads of a 32-pixel wave tile coalesce into half as many bytes per instruction)
+    if (tiles > 10 && binarize_x) PH_RXM(true, 2, 20);
+    else if (binarize_x) PH_RXM(true, 4, 10);
+    else PH_RXM(false, 4, 10);
+#undef PH_RXM
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -268,10 +307,10 @@ extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial /* 
     PH_CHECK_ARG(G && X && partial && out && B > 0 && M > 0 && K > 0 && K <= 256 && HW > 0 && nsplit >= 1, "bad pointer or size (K <= 256)");
     int64_t chunk = (HW + nsplit - 1) / nsplit;
     chunk = (chunk + 31) / 32 * 32;
-    const bool vec = (HW % 8) == 0 && (((uintptr_t)G | (uintptr_t)X) & 15) == 0;
+    const bool vec = (HW % 4) == 0 && (((uintptr_t)G | (uintptr_t)X) & 15) == 0;
     const dim3 grid(nsplit, B, ((M + 15) / 16 + MXM_RT - 1) / MXM_RT);
     hipStream_t s = (hipStream_t)stream;
-#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(256), 0, s, G, X, partial, M, K, HW, chunk)
+#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(512), 0, s, G, X, partial, M, K, HW, chunk)
     if (vec) { if (binarize_g) PH_MXM(true, true); else PH_MXM(true, false); }
     else { if (binarize_g) PH_MXM(false, true); else PH_MXM(false, false); }
 #undef PH_MXM
