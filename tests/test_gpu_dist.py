@@ -88,3 +88,78 @@ def test_bench_launches_its_own_ranks(gpu):
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     tag = res["track_allgather"]
     assert tag["2"]["world_size"] == 2 and tag["2"]["payload_round_trip_exact"] and tag["2"]["collective_us_per_step"] > 0
+
+
+# ---- data-parallel training step: two ranks, gradients averaged by dist.GradBuckets -------------------------------------------
+def _train_heads(dev):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers as Hh
+    from test_gpu_loss import _rpn_head
+    from polyphonicformer_amd.registry import HEADS
+    import polyphonicformer_amd.kernel_update  # noqa: F401
+    rpn, sd = _rpn_head(dev)
+    roi_a = dict(type='MaskHungarianAssignerWithDepth', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                 dice_cost=dict(type='DiceCost', weight=4.0, pred_act=True), mask_cost=dict(type='MaskCost', weight=1.0, pred_act=True))
+    roi = HEADS.build(dict(type="KernelUpdateIterHead", num_stages=2, assign_stages=2, stage_loss_weights=[1] * 2, num_proposals=100,
+                           num_thing_classes=8, num_stuff_classes=11, mask_head=Hh.stage_cfg(256, 2048, 8, 19, 8, 11),
+                           train_cfg=dict(assigner=roi_a, sampler=dict(type='MaskPseudoSampler'), pos_weight=1.)))
+    roi.load_state_dict({k[len("roi_head."):]: v for k, v in sd.items() if k.startswith("roi_head.") and int(k.split(".")[2]) < 2})
+    return rpn, roi.to(dev)
+
+
+def _train_batch(rank, dev):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers as Hh
+    B, H, W = 1, 8, 16
+    feats = [f.to(dev) for f in Hh.neck_inputs(300 + rank, B, 256, H, W)]
+    gts = [{k: v.to(dev) for k, v in g.items()} for g in Hh.train_gt(400 + rank, B, 2 * H, 2 * W, 8, 11, [3 + rank])]
+    gd = torch.stack([g["depth"][None] for g in gts])
+    return (feats, [Hh.img_meta(H * 8, W * 8)] * B, [g["masks"] for g in gts], [g["labels"] for g in gts], [g["sem_seg"] for g in gts],
+            [g["sem_cls"] for g in gts], gd)
+
+
+def _ddp_worker(rank, world, port, backend, q):
+    import torch.distributed as dist
+    from polyphonicformer_amd import train as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.set_grad_enabled(False)
+    rpn, roi = _train_heads(dev)
+    step = T.TrainStep(rpn, roi, bucket_bytes=8 << 20)
+    losses, total, _ = step.forward_backward(*_train_batch(rank, dev))
+    names = [n for n, _ in rpn.named_parameters()] + [n for n, _ in roi.named_parameters()]
+    digest = {n: (float(p.grad.double().norm()), float(p.grad.double().sum())) for n, p in zip(names, step.parameters())}
+    q.put((rank, len(step.buckets.buckets), float(total), digest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_averages_gradients(gpu):
+    """two ranks (two GPUs over RCCL when there are two, else both on GPU 0 over gloo), each with its own image and its own
+    objective: after `TrainStep.forward_backward` (bucketed all-reduce started from the gradient hooks during backward,
+    focal normaliser = mean positive count over the ranks, kernel_update_head.py:376) both ranks hold the SAME gradient for
+    every one of the parameter tensors.  (That the reduced value is the mean of the ranks' gradients: tests/test_dist_gloo.py.)"""
+    world = 2
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] >= 2                                  # several buckets
+    assert abs(res[0][2] - res[1][2]) > 1e-3               # different images, different objectives
+    d0, d1 = res[0][3], res[1][3]
+    assert len(d0) > 200
+    for n in d0:                                           # both ranks hold the same averaged gradients
+        assert abs(d0[n][0] - d1[n][0]) <= 1e-6 * max(1.0, d0[n][0]), n
+        assert abs(d0[n][1] - d1[n][1]) <= 1e-5 * max(1.0, d0[n][0]), n
