@@ -109,7 +109,120 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = (mt0 + r) * 16 + g * 4 + i;
-                    if (m < M && p < HW) Yb[(int64_t)m * HW + p] = acc[r][t][i];
+                    if (m < M && p < HW) __builtin_nontemporal_store(acc[r][t][i], &Yb[(int64_t)m * HW + p]);
+                }
+            }
+        }
+    }
+}
+
+// ---- rows x map, map operand staged through LDS -------------------------------------------------------------------------------
+// The direct form above reads the map operand with 4-byte loads (its contiguous axis is the output pixel, the MFMA wants 8
+// consecutive k per lane).  Here a [32 k][256 px] step is loaded with 16-byte accesses, split to hi / lo bf16 and stored to LDS
+// as it lies ([k][px], 8-byte stores); B fragments come back through the gfx950 transposing read ds_read_b64_tr_b16 (as in
+// k_dynconv), two per plane and fragment.  One pass per 160 rows; the next step's loads are in flight during the MFMAs.
+// Measured (8 images, tools/train_kernels_time.py): better than the direct form where the map operand is binarised on the fly
+// (267 against 324 us), not otherwise (194 / 250 against 169 / 196 us) -- used for the binarised case only.  Also tried: the row
+// operand pre-split into bf16 planes by the caller (no conversions per wave and step): no gain, three more launches per call.
+constexpr int RX2_PITCH = 272;             // uint16 elements per LDS row: 256 pixels + 32 bytes (rows 0..3 of a read: disjoint bank windows)
+
+template <bool BIN, bool VEC>
+__global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
+                                                           const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2][32][RX2_PITCH];            // [hi | lo][k][px]
+    constexpr int RT = 5, CT = 4;                                  // per wave: 8 waves = 2 row halves x 4 pixel quarters
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wave = wv & 3, wr = wv >> 2;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int64_t pw = (int64_t)blockIdx.x * 256;                  // first pixel of the workgroup
+    const int mt0 = blockIdx.z * (2 * RT) + wr * RT;
+    const int nrt = min(RT, Mpad / 16 - mt0);                      // may be <= 0 for the second row half
+    const float* Ab = A + b * a_batch_stride + (int64_t)mt0 * 16 * lda;
+    const float* Xb = X + (int64_t)b * K * HW;
+    const int kr = tid >> 6, p4 = (tid & 63) * 4;                  // staging: rows kr + 8 j (j < 4), 4 pixels at p4
+    float4 st[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + kr + 8 * j;
+            const int64_t p = pw + p4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K) {
+                const float* src = Xb + (int64_t)k * HW + p;
+                if (VEC) { if (p < HW) v = *(const float4*)src; }
+                else {
+                    if (p + 0 < HW) v.x = src[0];
+                    if (p + 1 < HW) v.y = src[1];
+                    if (p + 2 < HW) v.z = src[2];
+                    if (p + 3 < HW) v.w = src[3];
+                }
+                if (BIN) {
+                    v.x = p + 0 < HW ? binz(v.x) : 0.f; v.y = p + 1 < HW ? binz(v.y) : 0.f;
+                    v.z = p + 2 < HW ? binz(v.z) : 0.f; v.w = p + 3 < HW ? binz(v.w) : 0.f;
+                }
+            }
+            st[j] = v;
+        }
+    };
+    f32x4_t acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t h[4], l[4];
+            f2bf_split(st[j].x, h[0], l[0]); f2bf_split(st[j].y, h[1], l[1]); f2bf_split(st[j].z, h[2], l[2]); f2bf_split(st[j].w, h[3], l[3]);
+            *(uint2*)&lds[0][kr + 8 * j][p4] = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+            *(uint2*)&lds[1][kr + 8 * j][p4] = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+        }
+        __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
+        Frag xb[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            // lane (g, i = c): rows g * 8 + (i >> 2) [+ 4], pixels of this wave's column tile t at (i & 3) * 4
+            const int px = wave * 64 + t * 16 + (c & 3) * 4;
+            const int row = g * 8 + (c >> 2);
+            const uint2 h0 = lds_read_tr16(&lds[0][row][px]), h1 = lds_read_tr16(&lds[0][row + 4][px]);
+            const uint2 l0 = lds_read_tr16(&lds[1][row][px]), l1 = lds_read_tr16(&lds[1][row + 4][px]);
+            xb[t].hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            xb[t].lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            if (r < nrt) {
+                const int k = k0 + g * 8;
+                float v[8];
+                if (k < lda) {
+                    const float4* src = (const float4*)(Ab + (int64_t)(r * 16 + c) * lda + k);
+                    const float4 q0 = src[0], q1 = src[1];
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                }
+                const Frag a = split8(v);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
+            }
+        }
+    }
+    float* Yb = Y + (int64_t)b * M * HW;
+    const int64_t p0 = pw + wave * 64;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (r < nrt) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int64_t p = p0 + t * 16 + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = (mt0 + r) * 16 + g * 4 + i;
+                    if (m < M && p < HW) __builtin_nontemporal_store(acc[r][t][i], &Yb[(int64_t)m * HW + p]);
                 }
             }
         }
@@ -282,12 +395,13 @@ extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, in
 #define PH_RXM(BIN, CT, RT)                                                                                               \
     hipLaunchKernelGGL((k_rows_x_map<BIN, CT, RT>), dim3((unsigned)((HW + 64 * CT - 1) / (64 * CT)), B, (tiles + RT - 1) / RT), \
                        dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW)
-    // more than 160 rows: one pass of (32 pixels x 320 rows) per wave when the map operand is binarised on the fly (the
-    // comparison is done once: 317 against 365 us at 8 images), two passes of (64 x 160) otherwise (200 against 245 us: the
-    // 4-byte map loads of a 32-pixel wave tile coalesce into half as many bytes per instruction)
-    if (tiles > 10 && binarize_x) PH_RXM(true, 2, 20);
-    else if (binarize_x) PH_RXM(true, 4, 10);
-    else PH_RXM(false, 4, 10);
+    if (binarize_x) {           // the map operand staged through LDS (one comparison per element, 16-byte loads)
+        const dim3 grid((unsigned)((HW + 255) / 256), B, (tiles + 9) / 10);
+        if ((HW % 4) == 0 && ((uintptr_t)X & 15) == 0)
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, true>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+        else
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, false>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+    } else PH_RXM(false, 4, 10);
 #undef PH_RXM
     PH_CHECK_LAUNCH();
     return PH_OK;
