@@ -159,7 +159,7 @@ def test_two_rank_training_step_averages_gradients(gpu):
     assert res[0][1] >= 2                                  # several buckets
     assert abs(res[0][2] - res[1][2]) > 1e-3               # different images, different objectives
     d0, d1 = res[0][3], res[1][3]
-    assert len(d0) > 200
+    assert len(d0) > 150                                   # every parameter tensor of the two heads (two stages here)
     for n in d0:                                           # both ranks hold the same averaged gradients
         assert abs(d0[n][0] - d1[n][0]) <= 1e-6 * max(1.0, d0[n][0]), n
         assert abs(d0[n][1] - d1[n][1]) <= 1e-5 * max(1.0, d0[n][0]), n
