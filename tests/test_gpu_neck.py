@@ -118,10 +118,11 @@ def test_neck_vs_reference_golden(gpu, precision):
         assert e < tol, (name, e)
 
 
-def test_neck_vs_oracle_ragged_sizes(gpu):
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_neck_vs_oracle_ragged_sizes(gpu, precision):
     """level sizes that are multiples of nothing (24x40 -> 12x20 -> 6x10 -> 3x5), two frames"""
     sd = _state()
-    m = _neck("fp32", gpu, sd)
+    m = _neck(precision, gpu, sd)
     feats = Hh.fpn_inputs(seed=33, B=2, C=256, H0=24, W0=40)
     outs = m([f.to(gpu) for f in feats])
     ref = NO.semantic_fpn(sd, feats, groups=32, num_feats=128)

@@ -198,12 +198,13 @@ def test_kernel_head_golden(gpu, weights, precision):
     assert Hh.rel_err(dp.cpu().reshape(B, N, 256), z["depth_proposal"]) < 1e-7
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 @pytest.mark.parametrize("H,W,B", [(6, 13, 2), (16, 24, 1)])
-def test_kernel_head_vs_oracle_ragged(gpu, weights, H, W, B):
+def test_kernel_head_vs_oracle_ragged(gpu, weights, H, W, B, precision):
     feats = Hh.neck_inputs(321, B, 256, H, W)
     sd = {k[len("rpn_head."):]: v for k, v in weights.items() if k.startswith("rpn_head.")}
     ref = O.kernel_head_post_neck(sd, *feats, 8, 19, 32)
-    kh = _kernel_head(weights, "fp32")
+    kh = _kernel_head(weights, precision)
     out = kh.simple_test_rpn([f.to(gpu) for f in feats], [Hh.img_meta(H * 8, W * 8)] * B)
     N = 111
     for name, t in (("x_feats", out[1]), ("mask_preds", out[2]), ("seg_preds", out[4]), ("depth_feats", out[5]),
@@ -215,7 +216,7 @@ def test_kernel_head_vs_oracle_ragged(gpu, weights, H, W, B):
     mp, xf = out[2].cpu(), out[1].cpu()
     flips = int(((mp[:, :100] > 0) != (ref["mask_preds"][:, :100] > 0)).sum())
     print("KernelHead binarisation flips vs oracle:", flips, "of", mp[:, :100].numel())
-    assert flips <= 4
+    assert flips <= (4 if precision == "fp32" else 16)
     own = sd["init_kernels.weight"].reshape(1, 100, 256) + torch.einsum("bnhw,bchw->bnc", (mp[:, :100] > 0).float(), xf)
     assert Hh.rel_err(out[0].cpu().reshape(B, N, 256)[:, :100], own) < 1e-3
     assert Hh.rel_err(out[0].cpu().reshape(B, N, 256)[:, 100:], ref["proposal_feats"].reshape(B, N, 256)[:, 100:]) < 1e-6
