@@ -75,6 +75,10 @@ int ph_binarize(const float* logits, int64_t logits_batch_stride /* elements; 0 
  * 256..511 = depth_feats) and are summed in fixed order by the consumer. `dplanes` may be NULL. */
 int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial,
             int B, int N, int64_t HW, int nsplit, int prec, void* stream);
+/* the same over the first ph_n_padded(N) rows of a bits tensor that has `bits_rows` (>= that) rows per frame:
+ * kernel_head.py:314-320 pools over the THING rows of the full mask tensor */
+int ph_pool_rows(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial,
+                 int B, int N, int64_t HW, int nsplit, int prec, void* stream);
 
 /* ---- packed per-stage weights -------------------------------------------------------------
  * One KernelUpdateHead stage (kernel_update_head.py:21-191 parameters) packed by the host into
@@ -203,6 +207,32 @@ int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_
                    uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
                    float* mask_preds, float* seg_preds, float* depth_pred,
                    void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
+/* ph_khead_onepass (round 3): ph_khead_fused's results from ONE read of the three maps.  The conv output of a 128-pixel
+ * slice stays in the accumulator registers of one workgroup per CU while the GroupNorm sums of the whole (frame, map)
+ * are exchanged between the workgroups inside the launch (persistent grid, bounded spins); loc waits in LDS for
+ * x = sem + loc; the mask bits of `mask_preds` (kernel_head.py:314-317; what ph_binarize would write) come from the
+ * second GEMM's accumulators.  Same arithmetic as ph_khead_fused's PH_PREC_BF16 / PH_PREC_F16 grades.
+ *   conv_frags: {loc,seg,depth}_convs.0.conv.weight as MFMA 32x32x16 A fragments [3][8][16][64][8] (one 16-bit plane);
+ *   mask_preds / seg_preds / depth_pred: fp32 or fp16 (`out_dtype` PH_OUT_F32 / PH_OUT_F16), shapes as ph_khead_fused;
+ *   bits: nullable, uint32 [B][bits_rows][HWp/32], rows >= n_init + n_stuff are cleared;
+ *   workspace: ph_khead_onepass_workspace_bytes(B, HW) bytes, cleared by the call itself (a memset node ahead of the kernel).
+ * ph_khead_onepass_supported: 1 when the geometry fits (HWp / 128 <= #CUs, 32 groups, one-plane grade, HW % 4 == 0 for
+ * fp32 inputs); otherwise callers use ph_khead_fused.  Two ph_khead_onepass launches must not run concurrently on one
+ * device (each needs every CU resident); a starved launch times out, sets a status word (ph_khead_onepass_status,
+ * synchronising) and finishes with undefined results instead of hanging. */
+int ph_khead_onepass_supported(int B, int64_t HW, int groups, int prec, int input_format);
+size_t ph_khead_onepass_workspace_bytes(int B, int64_t HW);
+int ph_khead_onepass(const void* f0, const void* f1, const void* f2, const uint16_t* conv_frags,
+                     const float* gn_affine, int groups, float eps,
+                     const uint16_t* w2_init, int n_init, const uint16_t* w2_seg, const float* bias_seg, int n_seg,
+                     const uint16_t* w2_dd, const float* bias_dd, int stuff_lo, int n_stuff,
+                     uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
+                     void* mask_preds, void* seg_preds, void* depth_pred, int out_dtype,
+                     uint32_t* bits /* nullable */, int bits_rows,
+                     void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
+int ph_khead_onepass_status(const void* workspace, int B, void* stream);
+/* debugging aid: device buffer [grid][2][3 * rounds][16] uint64 filled with s_memtime stamps by the following launches (NULL: off) */
+void ph_khead_onepass_set_timeline(void* buf);
 int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[Nq][256]*/,
                        const float* w_stuff /*[n_stuff][256]*/, float* proposal_feats,
                        int B, int n_thing_queries, int n_stuff, void* stream);

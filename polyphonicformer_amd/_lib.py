@@ -37,6 +37,7 @@ SIGNATURES = {
     "ph_ingest_features": (C.c_int, [_P, _P, _I, _L, _I, _P]),
     "ph_binarize": (C.c_int, [_P, _L, _P, _I, _I, _L, _P]),
     "ph_pool": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
+    "ph_pool_rows": (C.c_int, [_P, _P, _P, _I, _P, _I, _I, _L, _I, _I, _P]),
     "ph_query_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
                                  _P, _Z, _I, _I, _L, _I, _I, _I, _P]),
@@ -46,6 +47,12 @@ SIGNATURES = {
     "ph_khead_conv_gn": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_khead_fused": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
                                  _P, _P, _P, _P, _Z, _I, _L, _I, _I, _P]),
+    "ph_khead_onepass_supported": (C.c_int, [_I, _L, _I, _I, _I]),
+    "ph_khead_onepass_workspace_bytes": (C.c_size_t, [_I, _L]),
+    "ph_khead_onepass": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
+                                   _P, _P, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
+    "ph_khead_onepass_status": (C.c_int, [_P, _I, _P]),
+    "ph_khead_onepass_set_timeline": (None, [_P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_match_record_floats": (C.c_int64, [_I, _I]),
     "ph_match_nsplit": (C.c_int, [_L, _I]),

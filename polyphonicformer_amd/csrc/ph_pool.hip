@@ -64,7 +64,7 @@ __device__ __forceinline__ int pool_swz(int row) { return (row >> 1) & 7; }
 template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/, int E /*element format of the planes*/>
 __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
                                               const uint32_t* __restrict__ bits, float* __restrict__ partial,
-                                              int B, int64_t HWp, int nsplit) {
+                                              int B, int64_t HWp, int nsplit, int bits_rows) {
     constexpr int Npad = NRT * 32;
     constexpr int NBI = (Npad * 2 + 63) / 64;                         // DMA instructions for the mask words of a chunk
     constexpr int NBW = (NBI + 3) / 4;                                // ... issued per wave
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
     const int64_t plane_stride = (int64_t)B * PH_C * HWp;
     const uint16_t* fbase = feat + ((int64_t)b * PH_C + ch0) * HWp;
     const int64_t words_per_row = HWp / 32;
-    const uint32_t* brow = bits + (int64_t)b * Npad * words_per_row;
+    const uint32_t* brow = bits + (int64_t)b * bits_rows * words_per_row;      // bits_rows >= Npad rows per frame
 
     const int nchunks = (int)(HWp / POOL_CHUNK);
     const int c0 = (int)((int64_t)split * nchunks / nsplit), c1 = (int)((int64_t)(split + 1) * nchunks / nsplit);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
 
 template <int PA, int NRT, int E>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
-                        int nsplit, hipStream_t s) {
+                        int nsplit, int bits_rows, hipStream_t s) {
     const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
     static const bool once = [&] {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -215,30 +215,47 @@ static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bi
     }();
     (void)once;
     hipLaunchKernelGGL((k_pool<PA, NRT, E>), dim3(nsplit, d ? 4 : 2, B), dim3(256), lds, s, x, d, bits, partial, B, HWp,
-                       nsplit);
+                       nsplit, bits_rows);
 }
 
-extern "C" int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int B,
-                       int N, int64_t HW, int nsplit, int prec, void* stream) {
-    PH_CHECK_ARG(xplanes && bits && partial && B > 0 && N > 0 && HW > 0, "bad pointer or size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
-    PH_CHECK_ARG(N <= 256, "at most 256 queries");
+static int pool_run(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial, int B,
+                    int N, int64_t HW, int nsplit, int prec, void* stream, const char* fn) {
+    if (!(xplanes && bits && partial && B > 0 && N > 0 && HW > 0)) { ph_set_error("%s: bad pointer or size", fn); return PH_EINVAL; }
+    if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16)) {
+        ph_set_error("%s: prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16", fn);
+        return PH_EINVAL;
+    }
+    if (N > 256) { ph_set_error("%s: at most 256 queries", fn); return PH_EINVAL; }
     const int64_t HWp = ph_hw_padded(HW);
-    PH_CHECK_ARG(nsplit >= 1 && nsplit <= HWp / POOL_CHUNK, "nsplit out of range");
+    if (!(nsplit >= 1 && nsplit <= HWp / POOL_CHUNK)) { ph_set_error("%s: nsplit out of range", fn); return PH_EINVAL; }
     const int nrt = ph_n_padded(N) / 32;
+    if (bits_rows == 0) bits_rows = nrt * 32;
+    if (bits_rows < nrt * 32) { ph_set_error("%s: bits_rows must be >= N rounded up to 32", fn); return PH_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
 #define PH_POOL_CASE(R)                                                                         \
     case R:                                                                                     \
-        if (prec == PH_PREC_BF16) launch_pool<1, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s); \
-        else if (prec == PH_PREC_F16) launch_pool<1, R, PH_E_F16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s); \
-        else launch_pool<2, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, s);             \
+        if (prec == PH_PREC_BF16) launch_pool<1, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s); \
+        else if (prec == PH_PREC_F16) launch_pool<1, R, PH_E_F16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s); \
+        else launch_pool<2, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s);             \
         break;
     switch (nrt) {
         PH_POOL_CASE(1) PH_POOL_CASE(2) PH_POOL_CASE(3) PH_POOL_CASE(4)
         PH_POOL_CASE(5) PH_POOL_CASE(6) PH_POOL_CASE(7) PH_POOL_CASE(8)
-        default: ph_set_error("ph_pool: unsupported N"); return PH_EUNSUPPORTED;
+        default: ph_set_error("%s: unsupported N", fn); return PH_EUNSUPPORTED;
     }
 #undef PH_POOL_CASE
     PH_CHECK_LAUNCH();
     return PH_OK;
+}
+
+extern "C" int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int B,
+                       int N, int64_t HW, int nsplit, int prec, void* stream) {
+    return pool_run(xplanes, dplanes, bits, 0, partial, B, N, HW, nsplit, prec, stream, __func__);
+}
+
+// the same over the FIRST ph_n_padded(N) rows of a bits tensor with `bits_rows` rows per frame (KernelHead's object
+// pooling over the thing rows of the full mask-bit tensor, kernel_head.py:314-320: no copy of the thing rows)
+extern "C" int ph_pool_rows(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial,
+                            int B, int N, int64_t HW, int nsplit, int prec, void* stream) {
+    return pool_run(xplanes, dplanes, bits, bits_rows, partial, B, N, HW, nsplit, prec, stream, __func__);
 }

@@ -380,6 +380,8 @@ class KernelHeadPack:
         from .pack import pack_b32
         frag = lambda pl: torch.stack([pack_b32(pl[p].cpu()) for p in range(P)], 0).contiguous().to(device)
         self.init_frag, self.seg_frag, self.dd_frag = frag(self.init_planes), frag(self.seg_planes), frag(self.dd_planes)
+        # the three conv weights in the same fragment form: the A operand of ph_khead_onepass (one-plane grades)
+        self.conv_frag = torch.stack([pack_b32(self.wplanes[0, m].cpu()) for m in range(3)], 0).contiguous().to(device) if P == 1 else None
         self.w_init_f32 = w_init.float().contiguous().to(device)
         self.w_seg_f32 = w_seg.float().contiguous().to(device)
         self.w_dd_f32 = sd["conv_direct_depth.weight"].detach().float().contiguous().to(device)   # [1,256,1,1]
@@ -389,7 +391,11 @@ class KernelHeadPack:
 class KernelHeadPlan:
     """buffers + launch sequence of KernelHead's post-neck part for one (B, H, W)."""
 
-    def __init__(self, pack, B, H, W, num_thing_classes, num_classes, cat_stuff, device, want_f32=True, nsplit=None):
+    def __init__(self, pack, B, H, W, num_thing_classes, num_classes, cat_stuff, device, want_f32=True, nsplit=None,
+                 logit_dtype=torch.float32, onepass=None):
+        """`onepass`: None = ph_khead_onepass whenever the geometry / grade allows it (and PH_KHEAD_TWOPASS is unset),
+        False = always the two-pass ph_khead_fused.  `logit_dtype`: fp32 (the reference API) or fp16 (one-pass form only)
+        for mask_preds / seg_preds / depth_pred."""
         self.pack, self.B, self.H, self.W, self.HW = pack, B, H, W, H * W
         self.n_thing_cls, self.n_cls, self.cat_stuff = num_thing_classes, num_classes, cat_stuff
         self.Nq = pack.n_init
@@ -406,15 +412,28 @@ class KernelHeadPlan:
         self.xp, self.dp = e((P, B, 256, HWp), torch.int16), e((P, B, 256, HWp), torch.int16)
         self.x_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
         self.dfe_f32 = e((B, 256, H, W), torch.float32) if want_f32 else None
-        self.mask_preds = e((B, self.N, H, W), torch.float32)
-        self.seg_preds = e((B, pack.n_seg, H, W), torch.float32)
-        self.depth_pred = e((B, 1, H, W), torch.float32)
+        import os
+        lib = _lib.load()
+        self.ws1 = None
+        self.onepass = False
+        if onepass is not False and not os.environ.get("PH_KHEAD_TWOPASS") and pack.conv_frag is not None:
+            # the input format is only known at set_inputs: the fp32 form has the stricter condition (HW % 4 == 0)
+            self.onepass = bool(lib.ph_khead_onepass_supported(B, self.HW, pack.groups, prec, _lib.PH_IN_F32_NCHW))
+        if onepass and not self.onepass:
+            raise _lib.PolyheadError("ph_khead_onepass does not support this geometry / grade")
+        if logit_dtype != torch.float32 and not self.onepass:
+            raise _lib.PolyheadError("16-bit KernelHead logits need the one-pass form")
+        self.logit_dtype = logit_dtype
+        if self.onepass:
+            self.ws1 = e((lib.ph_khead_onepass_workspace_bytes(B, self.HW),), torch.uint8)
+        self.mask_preds = e((B, self.N, H, W), logit_dtype)
+        self.seg_preds = e((B, pack.n_seg, H, W), logit_dtype)
+        self.depth_pred = e((B, 1, H, W), logit_dtype)
         self.bits = e((B, n_padded(self.N), HWp // 32), torch.int32)
-        self.bits_th = torch.zeros((B, n_padded(self.Nq), HWp // 32), dtype=torch.int32, device=dev)   # padding rows stay 0
         self.nsplit = nsplit or default_nsplit(B, self.HW)
         self.partial = e((B, self.nsplit, n_padded(self.Nq), 512), torch.float32)
         self.proposal = e((B, self.N, 256), torch.float32)
-        self.ws = e((_lib.load().ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
+        self.ws = None if self.onepass else e((lib.ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
         self.w_stuff = pack.w_seg_f32[num_thing_classes:num_classes].contiguous() if self.n_stuff else None
 
     def renew_outputs(self):
@@ -452,30 +471,49 @@ class KernelHeadPlan:
     def run(self):
         lib, pk, s = _lib.load(), self.pack, _lib.stream_ptr
         B, HW, prec = self.B, self.HW, pk.prec
-        # conv1x1+GN+ReLU x3, x = sem + loc, and the static 1x1 convs on the normalised tiles (kernel_head.py:250-331):
-        # init_kernels(loc) -> thing rows of mask_preds (:256), conv_seg(sem) -> seg_preds (:295) and its stuff rows ->
-        # the remaining rows of mask_preds (:329-331), conv_direct_depth(dfe) -> depth_pred (:285)
-        _lib.check(lib.ph_khead_fused(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
-                                      _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
-                                      _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
-                                      _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
-                                      _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
-                                      _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), _lib.ptr(self.ws), self.ws.numel(),
-                                      B, HW, prec, _lib.PH_IN_PLANES if self.in_planes else _lib.PH_IN_F32_NCHW, s()),
-                   "ph_khead_fused")
-        # object features: binarise the logits once (all rows: the decode stages start from these bits), pool x over the
-        # THING rows (:314-320), add to the kernels (:324-326)
-        _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
-        if n_padded(self.Nq) == n_padded(self.N):
-            bits_th = self.bits                      # rows >= Nq are pooled too; ph_khead_proposals ignores them
+        fmt = _lib.PH_IN_PLANES if self.in_planes else _lib.PH_IN_F32_NCHW
+        if self.onepass:
+            # one read of the three maps: conv1x1+GN+ReLU x3, x = sem + loc, the static 1x1 convs AND the mask bits
+            # (kernel_head.py:250-331, :314-317) in one persistent launch; the object pooling reads the thing rows of
+            # the full bit tensor in place
+            _lib.check(lib.ph_khead_onepass(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.conv_frag),
+                                            _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
+                                            _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
+                                            _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
+                                            _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
+                                            _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), OUT_CODE[self.logit_dtype],
+                                            _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.ws1), self.ws1.numel(),
+                                            B, HW, prec, fmt, s()), "ph_khead_onepass")
+            _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
+                                        B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
         else:
-            # the thing rows are the first Nq rows of every frame: copy their words (row padding differs)
-            self.bits_th[:, :self.Nq].copy_(self.bits[:, :self.Nq])
-            bits_th = self.bits_th
-        pool(self.xp, None, bits_th, self.Nq, HW, prec, self.nsplit, out=self.partial)
+            # conv1x1+GN+ReLU x3, x = sem + loc, and the static 1x1 convs on the normalised tiles (kernel_head.py:250-331):
+            # init_kernels(loc) -> thing rows of mask_preds (:256), conv_seg(sem) -> seg_preds (:295) and its stuff rows ->
+            # the remaining rows of mask_preds (:329-331), conv_direct_depth(dfe) -> depth_pred (:285)
+            _lib.check(lib.ph_khead_fused(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
+                                          _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
+                                          _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
+                                          _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
+                                          _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
+                                          _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), _lib.ptr(self.ws), self.ws.numel(),
+                                          B, HW, prec, fmt, s()), "ph_khead_fused")
+            # object features: binarise the logits once (all rows: the decode stages start from these bits), pool x over the
+            # THING rows (:314-320)
+            _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
+            _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
+                                        B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
+        # add the pooled features to the kernels (:324-326)
         _lib.check(lib.ph_khead_proposals(_lib.ptr(self.partial), self.nsplit, _lib.ptr(pk.w_init_f32),
                                           _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
+
+    def check_status(self):
+        """one-pass form: raise if a bounded spin of the last run timed out (synchronises the stream)"""
+        if self.onepass:
+            rc = _lib.load().ph_khead_onepass_status(_lib.ptr(self.ws1), self.B, _lib.stream_ptr())
+            if rc != 0:
+                raise _lib.PolyheadError("ph_khead_onepass: the statistics hand-off timed out (two persistent launches "
+                                         "running concurrently on one device?) -- results of that run are undefined")
 
 
 # ---- SemanticFPNWrapper (N3) -------------------------------------------------------------------------------

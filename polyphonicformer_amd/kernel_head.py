@@ -70,6 +70,7 @@ class KernelHead(nn.Module):
         self.semantic_aspp = None
         self.precision = "fp32"
         self.emit_fp32_features = True     # the reference API returns x_feats / depth_feats as fp32 NCHW tensors
+        self.logit_dtype = torch.float32   # mask_preds / seg_preds / depth_pred; torch.float16 halves their bytes (one-pass form)
         self._pack, self._plans = None, {}
         self.assigner = self.sampler = None
         if self.train_cfg:                 # kernel_head.py:134-140
@@ -138,11 +139,11 @@ class KernelHead(nn.Module):
             dev = feats[0].device
         pack = self._get_pack(dev)
         cat_stuff = self.cat_stuff_mask and not self.training
-        key = (B, H, W, cat_stuff, self.emit_fp32_features)
+        key = (B, H, W, cat_stuff, self.emit_fp32_features, self.logit_dtype)
         plan = self._plans.get(key)
         if plan is None:
             self._plans = {key: E.KernelHeadPlan(pack, B, H, W, self.num_thing_classes, self.num_classes, cat_stuff, dev,
-                                                 want_f32=self.emit_fp32_features)}
+                                                 want_f32=self.emit_fp32_features, logit_dtype=self.logit_dtype)}
             plan = self._plans[key]
         plan.renew_outputs()         # the 9-tuple (and the hand-off planes) belong to the caller from here on
         plan.set_inputs(list(feats) if handoff else [f.float() for f in feats])

@@ -1,0 +1,183 @@
+"""ph_khead_onepass (round 3: KernelHead's post-neck part from ONE read of the three maps, GroupNorm statistics
+exchanged between the workgroups inside a persistent launch) against the two-pass ph_khead_fused and the oracle.
+polyphonic/kernel_head.py:245-347."""
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import poly_oracle as O
+from polyphonicformer_amd import _lib, engine as E
+from polyphonicformer_amd.registry import HEADS
+import polyphonicformer_amd.kernel_head  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(precision, Nq=100, n_thing=8, n_stuff=11, cat_stuff=True, seed=5):
+    torch.manual_seed(seed)
+    h = HEADS.build(dict(type="KernelHead", num_proposals=Nq, num_classes=n_thing + n_stuff, num_thing_classes=n_thing,
+                         num_stuff_classes=n_stuff, in_channels=256, out_channels=256, cat_stuff_mask=cat_stuff,
+                         feat_downsample_stride=2, feat_refine_stride=1, feat_refine=False, use_binary=True,
+                         conv_normal_init=True, proposal_feats_with_obj=True, xavier_init_kernel=False, kernel_init_std=1,
+                         loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=None))
+    h.init_weights()
+    with torch.no_grad():        # GroupNorm affine away from (1, 0), conv_seg bias of both signs
+        for n in ("loc", "seg", "depth"):
+            m = getattr(h, f"{n}_convs")[0].gn
+            m.weight.add_(0.2 * torch.randn_like(m.weight))
+            m.bias.add_(0.2 * torch.randn_like(m.bias))
+        h.conv_seg.weight.mul_(30.0)
+        h.conv_seg.bias.copy_(0.5 * torch.randn_like(h.conv_seg.bias))
+        h.conv_direct_depth.weight.mul_(30.0)
+        for n in ("loc", "seg", "depth"):
+            getattr(h, f"{n}_convs")[0].conv.weight.mul_(8.0)
+    sd = {k: v.detach().clone() for k, v in h.state_dict().items()}
+    h.eval().to("cuda:0")
+    h.set_precision(precision)
+    return h, sd
+
+
+def _plans(h, B, H, W, n_thing, L, cat_stuff, dev, logit_dtype=torch.float32):
+    pack = h._get_pack(dev)
+    one = E.KernelHeadPlan(pack, B, H, W, n_thing, L, cat_stuff, dev, want_f32=True, logit_dtype=logit_dtype, onepass=True)
+    two = E.KernelHeadPlan(pack, B, H, W, n_thing, L, cat_stuff, dev, want_f32=True, onepass=False)
+    assert one.onepass and not two.onepass
+    return one, two
+
+
+def _unpack_bits(bits, N, HW):
+    """int32 [B][rows][words] -> bool [B][N][HW]"""
+    b = bits.cpu().numpy().view("uint32")
+    import numpy as np
+    u = np.unpackbits(b.view("uint8"), axis=-1, bitorder="little")
+    return torch.from_numpy(u[:, :N, :HW].astype(bool))
+
+
+# (H, W, B): one slice per frame / 4 slices / cfg5's ragged 7488 pixels, 59 slices, 5 frames on 4 slots (two rounds) /
+# more slices than 64 owners need (P = 96) with three frames on two slots
+GEOMS = [(8, 16, 3), (16, 32, 2), (48, 156, 5), (96, 128, 3)]
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("H,W,B", GEOMS)
+def test_onepass_equals_twopass(gpu, precision, H, W, B):
+    h, sd = _head(precision)
+    one, two = _plans(h, B, H, W, 8, 19, True, gpu)
+    feats = [f.to(gpu) for f in Hh.neck_inputs(11 + H, B, 256, H, W)]
+    for p in (one, two):
+        p.set_inputs(feats)
+        p.run()
+    torch.cuda.synchronize()
+    one.check_status()
+    N, HW = one.N, H * W
+    tol = 2e-4 if precision == "fp16" else 4e-3        # the statistics are summed in a different order: 1-ulp plane flips
+    for name in ("mask_preds", "seg_preds", "depth_pred", "x_f32", "dfe_f32", "proposal"):
+        a, b = getattr(one, name), getattr(two, name)
+        e = Hh.rel_err(a.cpu(), b.cpu())
+        assert e < tol, (name, e)
+    dt = torch.float16 if precision == "fp16" else torch.bfloat16
+    for name in ("xp", "dp"):
+        a = getattr(one, name).view(dt).float().cpu()
+        b = getattr(two, name).view(dt).float().cpu()
+        assert a.shape == b.shape
+        assert Hh.rel_err(a, b) < (2e-3 if precision == "fp16" else 1.6e-2), name
+        frac = float((a != b).float().mean())
+        assert frac < 2e-2, (name, frac)
+        HWp = E.hw_padded(HW)
+        if HWp != HW:
+            assert float(a[..., HW:].abs().max()) == 0.0, "planes must be zero padded"
+    # the mask bits are exactly the hard threshold of the fp32 logits this launch wrote (kernel_head.py:314-317), pad rows zero
+    got = _unpack_bits(one.bits, one.bits.shape[1], E.hw_padded(HW))
+    want = (one.mask_preds.float().reshape(B, N, HW) > 1.5 * 2.0 ** -24).cpu()
+    assert torch.equal(got[:, :N, :HW], want)
+    assert not got[:, N:].any() and not got[:, :, HW:].any()
+
+
+@pytest.mark.parametrize("H,W,B", [(6, 14, 2), (48, 156, 2)])
+def test_onepass_vs_oracle(gpu, H, W, B):
+    """fp16 grade against the CPU restatement of kernel_head.py:245-347 (fp32): the 1e-3 contract"""
+    h, sd = _head("fp16")
+    feats = Hh.neck_inputs(5, B, 256, H, W)
+    ref = O.kernel_head_post_neck(sd, *feats, 8, 19, 32)
+    one, _ = _plans(h, B, H, W, 8, 19, True, gpu)
+    one.set_inputs([f.to(gpu) for f in feats])
+    one.run()
+    torch.cuda.synchronize()
+    one.check_status()
+    for name, t in (("x_feats", one.x_f32), ("mask_preds", one.mask_preds), ("seg_preds", one.seg_preds),
+                    ("depth_feats", one.dfe_f32), ("depth_pred", one.depth_pred)):
+        e = Hh.rel_err(t.cpu(), ref[name])
+        print("one-pass fp16 grade vs oracle", name, e)
+        assert e < 1e-3, (name, e)
+
+
+def test_onepass_fp16_logits_and_plane_inputs(gpu):
+    """fp16 logits = the fp32 logits rounded once; 16-bit plane inputs (the neck's hand-off) = the fp32 maps they round"""
+    H, W, B = 16, 40, 3
+    h, sd = _head("fp16")
+    pack = h._get_pack(gpu)
+    feats = [f.to(gpu) for f in Hh.neck_inputs(3, B, 256, H, W)]
+    a = E.KernelHeadPlan(pack, B, H, W, 8, 19, True, gpu, want_f32=False, onepass=True)
+    b = E.KernelHeadPlan(pack, B, H, W, 8, 19, True, gpu, want_f32=False, logit_dtype=torch.float16, onepass=True)
+    for p in (a, b):
+        p.set_inputs(feats)
+        p.run()
+    torch.cuda.synchronize()
+    for name in ("mask_preds", "seg_preds", "depth_pred"):
+        assert getattr(b, name).dtype == torch.float16
+        assert torch.equal(getattr(a, name).half(), getattr(b, name)), name
+    assert torch.equal(a.bits, b.bits) and torch.equal(a.xp, b.xp) and torch.equal(a.proposal, b.proposal)
+    # plane inputs: fp16-rounded maps, zero padded to HWp
+    HW, HWp = H * W, E.hw_padded(H * W)
+    planes = []
+    for f in feats:
+        p = torch.zeros((1, B, 256, HWp), dtype=torch.float16, device=gpu)
+        p[0, :, :, :HW] = f.reshape(B, 256, HW).half()
+        planes.append(p.view(torch.int16))
+    c = E.KernelHeadPlan(pack, B, H, W, 8, 19, True, gpu, want_f32=False, onepass=True)
+    c.set_inputs(planes)
+    c.run()
+    torch.cuda.synchronize()
+    c.check_status()
+    for name in ("mask_preds", "seg_preds", "depth_pred", "xp", "dp", "bits", "proposal"):
+        assert torch.equal(getattr(a, name), getattr(c, name)), name
+
+
+def test_onepass_without_stuff_rows_and_reproducible(gpu):
+    H, W, B = 24, 32, 4
+    h, sd = _head("fp16", Nq=37, cat_stuff=False)
+    one, two = _plans(h, B, H, W, 8, 19, False, gpu)
+    feats = [f.to(gpu) for f in Hh.neck_inputs(8, B, 256, H, W)]
+    outs = []
+    for rep in range(3):
+        one.set_inputs(feats)
+        one.run()
+        torch.cuda.synchronize()
+        one.check_status()
+        outs.append({k: getattr(one, k).clone() for k in ("mask_preds", "seg_preds", "depth_pred", "xp", "dp", "bits", "proposal")})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k      # fixed-order sums
+    two.set_inputs(feats)
+    two.run()
+    assert one.mask_preds.shape == (B, 37, H, W)
+    for name in ("mask_preds", "seg_preds", "depth_pred", "proposal"):
+        assert Hh.rel_err(getattr(one, name).cpu(), getattr(two, name).cpu()) < 2e-4, name
+
+
+def test_onepass_full_size_cfg2(gpu):
+    """1024x2048 (128x256 at stride 8): 256 slices = every CU, one frame slot, N = 100 + 53"""
+    H, W, B = 128, 256, 2
+    h, sd = _head("fp16", Nq=100, n_thing=80, n_stuff=53)
+    one, two = _plans(h, B, H, W, 80, 133, True, gpu)
+    feats = [f.to(gpu) for f in Hh.neck_inputs(2, B, 256, H, W)]
+    for p in (one, two):
+        p.set_inputs(feats)
+        p.run()
+    torch.cuda.synchronize()
+    one.check_status()
+    for name in ("mask_preds", "seg_preds", "depth_pred", "x_f32", "dfe_f32", "proposal"):
+        e = Hh.rel_err(getattr(one, name).cpu(), getattr(two, name).cpu())
+        assert e < 5e-4, (name, e)
+    got = _unpack_bits(one.bits, one.bits.shape[1], H * W)
+    want = (one.mask_preds.reshape(B, one.N, H * W) > 1.5 * 2.0 ** -24).cpu()
+    assert torch.equal(got[:, :one.N], want) and not got[:, one.N:].any()
