@@ -82,12 +82,13 @@ def barrier_and_max(value, device):
 
 
 # ---- data-parallel training (the reference wraps the detector in MMDistributedDataParallel, tools/train.py) ------
-def reduce_mean(t):
-    """mmdet.core.utils.reduce_mean (kernel_update_head.py:376-377): the mean over ranks of a scalar tensor; identity on one"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def reduce_mean(t, group=None):
+    """mmdet.core.utils.reduce_mean (kernel_update_head.py:376-377): the mean over the ranks of `group` (None: the default
+    group) of a scalar tensor; identity on one"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t
     t = t.clone()
-    dist.all_reduce(t.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    dist.all_reduce(t.div_(dist.get_world_size(group)), op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -114,17 +115,22 @@ class GradBuckets:
             self.buckets.append(cur)
         self._of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._left, self._work, self._flat = [], [], []
+        self._armed = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
-        self.start()
 
     def start(self):
-        """arm the buckets for one backward pass (call before every `backward`)"""
+        """arm the buckets for one backward pass (call before every `backward`); a backward outside start() .. finish() --
+        another TrainStep on the same heads, a fine-tuning script -- leaves the buckets alone"""
         self._left = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._flat = [None] * len(self.buckets)
+        self._armed = True
 
     def _ready(self, p):
+        if not self._armed:
+            return
         i = self._of[id(p)]
+        assert self._left[i] > 0, "a parameter's gradient arrived twice in one armed backward pass"
         self._left[i] -= 1
         if self._left[i] == 0:
             self._launch(i)
@@ -139,6 +145,7 @@ class GradBuckets:
     def finish(self):
         """wait for every bucket; parameters whose gradient never arrived (unused this step) are reduced as zeros"""
         if self.world == 1:
+            self._armed = False
             return
         for i, left in enumerate(self._left):
             if left > 0:                      # some parameter of the bucket took no part in this backward
@@ -155,6 +162,7 @@ class GradBuckets:
                 else:
                     p.grad.copy_(g)
                 o += n
+        self._armed = False
 
     def remove(self):
         for h in self._hooks:

@@ -1,7 +1,7 @@
 """KernelHead -- drop-in for polyphonic/kernel_head.py:11-706.
 Same registry name, constructor kwargs, attribute and state_dict names.  Everything after
-`localization_fpn(img)` (kernel_head.py:243) runs in libpolyhead; `forward_train` is the forward side of
-the training step (predictions, assignment, targets, losses and their gradients w.r.t. the predictions)."""
+`localization_fpn(img)` (kernel_head.py:243) runs in libpolyhead; `forward_train` trains (train.py: differentiable
+libpolyhead operations, losses attached to one autograd node)."""
 import torch
 import torch.nn as nn
 
@@ -167,58 +167,32 @@ class KernelHead(nn.Module):
         return self._decode_init_proposals(img, img_metas)
 
     def forward_train(self, img, img_metas, gt_masks, gt_labels, gt_sem_seg=None, gt_sem_cls=None, gt_depth=None, with_grads=False):
-        """kernel_head.py:349-454, FORWARD side: the decode in training mode, the x`feat_downsample_stride` upsample of the
-        mask / seg / depth predictions (ph_upsample2x), the Hungarian assignment on the detached masks (`assigner.py`),
-        pseudo sampling, `get_targets`, `loss` and `depth_dense`; returns the reference's 9-tuple, the stuff rows appended
-        when `cat_stuff_mask`.  `gt_depth`: [B, 1, H, W] at the scaled size, as the dataset pipeline delivers it.
-        `with_grads=True` adds losses['_grads'] = d(sum of the losses) / d(scaled mask, seg and direct depth predictions).
-        No autograd graph: this evaluates the objective, it does not train."""
-        from . import losses as Lo
-        if self.assigner is None:
-            raise ValueError("forward_train needs train_cfg (assigner / sampler)")
-        num_imgs = len(img_metas)
-        was_training, self.training = self.training, True
-        try:
-            results = self._decode_init_proposals(img, img_metas)
-        finally:
-            self.training = was_training
-        proposal_feats, x_feats, mask_preds, cls_scores, seg_preds, depth_feats, depth_proposal, depth_pred, aspp = results
-        up = self.feat_downsample_stride
-        if up not in (1, 2):
-            raise NotImplementedError("libpolyhead: feat_downsample_stride must be 1 or 2")
-        scale = (lambda t: E.upsample2x(t.float().contiguous())) if up > 1 else (lambda t: t.float())
-        scaled_mask_preds, scaled_seg_preds, scaled_depth_pred_0 = scale(mask_preds), scale(seg_preds), scale(depth_pred)     # :364-398
-        N = self.num_proposals + self.num_stuff_classes
-        scaled_depth_pred = scaled_depth_pred_0.expand(-1, N, -1, -1)
-        if self.hard_target:
-            gt_masks = [m.bool().float() for m in gt_masks]
-        sampling_results = []
-        for i in range(num_imgs):                                                             # :411-426
-            valid_mask = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
-            ar = self.assigner.assign(scaled_mask_preds[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i],
-                                      depth_pred=scaled_depth_pred[i], gt_depth=gt_depth[i], gt_valid=valid_mask)
-            sr = self.sampler.sample(ar, scaled_mask_preds[i], gt_masks[i], depth=scaled_depth_pred[i])
-            sr.valid_mask = valid_mask
-            sampling_results.append(sr)
-        targets = self.get_targets(sampling_results, gt_masks, self.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
-                                   gt_depth=gt_depth)
-        out = self.loss(scaled_mask_preds, cls_scores, scaled_seg_preds, scaled_depth_pred, proposal_feats, None, *targets,
-                        with_grads=with_grads)
-        losses, grads = out if with_grads else (out, None)
-        dd = Lo.dense_depth_loss(self, scaled_depth_pred_0, gt_depth, with_grad=with_grads)                                  # :438-442
-        if with_grads:
-            losses['depth_dense'], g = dd
-            grads["depth_pred"] = grads["depth_pred"] + g
-            losses["_grads"] = grads
-        else:
-            losses['depth_dense'] = dd
-        if self.cat_stuff_mask:                                                               # :444-451
-            nt, L = self.num_thing_classes, self.num_classes
-            mask_preds = torch.cat([mask_preds, seg_preds[:, nt:L]], dim=1)
-            stuff_kernels = self.conv_seg.weight[nt:L].detach().to(proposal_feats)
-            proposal_feats = torch.cat([proposal_feats, stuff_kernels[None].expand(num_imgs, *stuff_kernels.size())], dim=1)
-            depth_proposal = depth_proposal.expand(-1, proposal_feats.shape[1], -1, -1, -1)
-        return losses, proposal_feats, x_feats, mask_preds, cls_scores, depth_feats, depth_proposal, depth_pred, aspp
+        """kernel_head.py:349-454: the decode in training mode, the x`feat_downsample_stride` upsample of the mask / seg /
+        depth predictions, the Hungarian assignment on the detached masks (`assigner.py`), pseudo sampling, `get_targets`,
+        `loss` and `depth_dense`; returns the reference's 9-tuple, the stuff rows appended when `cat_stuff_mask`.
+        `gt_depth`: [B, 1, H, W] at the scaled size, as the dataset pipeline delivers it.
+        It TRAINS: the forward runs as differentiable libpolyhead operations (`train.rpn_forward_train`, hand-written
+        backward of every map-sized product), the 'loss' entries of the returned dict are attached to one autograd node, and
+        the tensors handed on to the roi head stay on the graph -- mmdet's `_parse_losses` + `backward()`
+        (mmdet/models/detectors/base.py:176-199) work on the result unchanged.  `img`: the three post-neck maps (gradients
+        flow into them when they require them) or, with this package's neck as `localization_fpn`, the FPN tuple (the neck
+        runs without a graph).  `with_grads=True` adds losses['_grads'] = d(sum of the 'loss' entries) / d(scaled mask, seg
+        and direct depth predictions)."""
+        from . import train as T
+        neck = self.localization_fpn
+        feats = neck(img) if neck is not None else list(img)
+        if not isinstance(feats, (list, tuple)) or len(feats) != 3:
+            raise NotImplementedError("with_depth needs the neck's three maps (kernel_head.py:272-276)")
+        for f in feats:
+            E._require_gpu(f, "localization feats")
+        feats = [f if f.dtype == torch.float32 and f.is_contiguous() else f.float().contiguous() for f in feats]
+        with torch.enable_grad():
+            losses, r = T.rpn_forward_train(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
+                                            want_grads=with_grads)
+            k, mask_preds, q = T.rpn_outputs(self, r)
+            B, N = k.shape[:2]
+            out = (losses, k.reshape(B, N, 256, 1, 1), r["x"], mask_preds, None, r["dfe"], q.reshape(B, N, 256, 1, 1), r["depth_pred"], None)
+        return out
 
     def loss(self, mask_pred, cls_scores, seg_preds, depth_pred, proposal_feats, semantic_aspp_out, labels, label_weights,
              mask_targets, mask_weights, seg_targets, depth_targets, depth_weights, reduction_override=None, with_grads=False, **kwargs):

@@ -148,70 +148,31 @@ class KernelUpdateIterHead(nn.Module):
     def forward_train(self, x, proposal_feats, mask_preds, cls_score, img_metas, gt_masks, gt_labels, gt_depth=None,
                       depth_preds=None, depth_feats=None, depth_proposal=None, gt_bboxes_ignore=None, imgs_whwh=None,
                       gt_bboxes=None, gt_sem_seg=None, gt_sem_cls=None, with_grads=False):
-        """kernel_update.py:159-280, FORWARD side: every stage's predictions (libpolyhead kernels), the Hungarian assignment
-        on the previous stage's detached predictions (`assigner.py`, ph_match_sums), pseudo sampling, `get_targets` and the
-        stage's losses (`losses.stage_losses`, ph_*_loss_sums) -- the dict of `s{stage}_{loss}` the reference returns (with
-        `tracking=True` also object_feats, cls_score, mask_preds, scaled_mask_preds).  `with_grads=True` adds, per stage,
-        d(stage losses) / d(its cls_score, scaled mask and depth predictions).  No autograd graph: the backward of the
-        pooling / query / conv kernels is not built yet, so this evaluates the training objective, it does not
-        train."""
-        if self.post_assign:
-            raise NotImplementedError                       # as the reference (:222-223)
-        if not self.mask_assigner:
-            raise ValueError("forward_train needs train_cfg (assigner / sampler per stage)")
-        num_imgs = len(img_metas)
-        N = depth_proposal.shape[1]
-        depth_preds = depth_preds.expand(-1, N, -1, -1)                                        # :178
-        up = self.mask_head[0].mask_upsample_stride
-        if up not in (1, 2):
-            raise NotImplementedError("libpolyhead: mask_upsample_stride must be 1 or 2")
-        scale = (lambda t: E.upsample2x(t.detach().float().contiguous())) if up > 1 else (lambda t: t.detach())
-        prev_mask_preds, prev_depth_preds_scaled = scale(mask_preds), scale(depth_preds)       # :179-191
-        prev_cls_score = cls_score.detach() if cls_score is not None else [None] * num_imgs    # :193-196
-        if self.hard_target:
-            gt_masks = [m.bool().float() for m in gt_masks]
-        was_training = self.training
-        self.training = True                                # _mask_forward upsamples at every stage when training (:131)
-        object_feats, all_stage_loss, all_grads, assign_results = proposal_feats, {}, [], []
-        try:
-            for stage in range(self.num_stages):
-                r = self._mask_forward(stage, x, object_feats, mask_preds, img_metas, depth_preds, depth_proposal, depth_feats)
-                mask_preds, scaled_mask_preds, cls_score = r['mask_preds'], r['scaled_mask_preds'], r['cls_score']
-                object_feats, depth_proposal = r['object_feats'], r['depth_proposal']
-                scaled_depth_preds, depth_preds = r['scaled_depth_preds'], r['depth_preds']
-                sampling_results = []
-                if stage < self.assign_stages:
-                    assign_results = []
-                for i in range(num_imgs):
-                    valid_mask = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()       # :238
-                    if stage < self.assign_stages:
-                        cls_for_assign = None
-                        if prev_cls_score[i] is not None:
-                            cls_for_assign = prev_cls_score[i][:self.num_proposals, :self.num_thing_classes]
-                        assign_results.append(self.mask_assigner[stage].assign(
-                            prev_mask_preds[i][:self.num_proposals], cls_for_assign, gt_masks[i], gt_labels[i], img_metas[i],
-                            depth_pred=prev_depth_preds_scaled[i][:self.num_proposals], gt_depth=gt_depth[i], gt_valid=valid_mask))
-                    sr = self.mask_sampler[stage].sample(assign_results[i], scaled_mask_preds[i], gt_masks[i],
-                                                         depth=scaled_depth_preds[i])
-                    sr.valid_mask = valid_mask
-                    sampling_results.append(sr)
-                targets = self.mask_head[stage].get_targets(sampling_results, gt_masks, gt_labels, self.train_cfg[stage], True,
-                                                            gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls, gt_depth=gt_depth)
-                out = self.mask_head[stage].loss(object_feats, cls_score, scaled_mask_preds, scaled_depth_preds, *targets,
-                                                 imgs_whwh=imgs_whwh, with_grads=with_grads)
-                single, g = out if with_grads else (out, None)
-                for key, value in single.items():
-                    all_stage_loss[f's{stage}_{key}'] = value * self.stage_loss_weights[stage]
-                all_grads.append(g)
-                prev_mask_preds, prev_cls_score = scaled_mask_preds.detach(), cls_score.detach()                 # :273-276
-                prev_depth_preds_scaled = scaled_depth_preds.detach()
-        finally:
-            self.training = was_training
-        if with_grads:
-            all_stage_loss["_grads"] = all_grads
+        """kernel_update.py:159-280: every stage's predictions, the Hungarian assignment on the previous stage's detached
+        predictions (`assigner.py`, ph_match_sums), pseudo sampling, `get_targets` and the stage's losses -- the dict of
+        `s{stage}_{loss}` the reference returns (with `tracking=True` also object_feats, cls_score, mask_preds,
+        scaled_mask_preds).  It TRAINS: `train.roi_forward_train` runs the stages as differentiable libpolyhead operations
+        and attaches the 'loss' entries to one autograd node per stage, so that `sum(losses).backward()` -- what mmdet's
+        `_parse_losses` + `backward()` do (mmdet/models/detectors/base.py:176-199) -- leaves the gradient of the objective
+        on every parameter and on whatever of x / proposal_feats / depth_feats / ... is on a graph (the tensors
+        `KernelHead.forward_train` returns are).  `with_grads=True` adds losses['_grads']: per stage d(stage losses) /
+        d(its cls_score, scaled mask and depth predictions)."""
+        from . import train as T
+        if cls_score is not None:
+            raise NotImplementedError("libpolyhead: the shipped KernelHead hands cls_scores=None to the roi head (kernel_head.py:291)")
+        E._require_gpu(x, "x")
+        B, N = proposal_feats.shape[:2]
+        with torch.enable_grad():          # also around the reshapes: a view made with autograd off is cut from the graph
+            k = proposal_feats.reshape(B, N, -1)
+            q = depth_proposal.reshape(depth_proposal.shape[0], depth_proposal.shape[1], -1).expand(B, N, -1)
+            losses, last = T.roi_forward_train(self, x.float(), depth_feats.float(), k.float(), mask_preds.float(), q.float(),
+                                               depth_preds.float(), img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
+                                               want_grads=with_grads)
+            obj, cls, m, smask = last
+            obj = obj.reshape(B, N, -1, 1, 1)
         if not self.tracking:
-            return all_stage_loss
-        return all_stage_loss, object_feats, cls_score, mask_preds, scaled_mask_preds
+            return losses
+        return losses, obj, cls, m, smask
 
 
 register_everywhere(KernelUpdateIterHead)

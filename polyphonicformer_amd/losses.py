@@ -83,6 +83,23 @@ class _Loss(nn.Module):
         self.cfg = dict(kw)
 
 
+# the process group the focal normaliser is averaged over (None: the default group); train.TrainStep(group=...) sets it for
+# the duration of its step so that a sub-group step neither averages over foreign ranks nor waits for them
+_REDUCE_GROUP = [None]
+
+
+class reduce_group:
+    def __init__(self, group):
+        self.group = group
+
+    def __enter__(self):
+        _REDUCE_GROUP.append(self.group)
+
+    def __exit__(self, *exc):
+        _REDUCE_GROUP.pop()
+        return False
+
+
 class FocalLoss(_Loss):
     """mmdet FocalLoss (focal_loss.py:160-244), the sigmoid form: forward(pred [R, L], target [R], weight [R, L], avg_factor)"""
 
@@ -95,9 +112,17 @@ class FocalLoss(_Loss):
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         _gpu(pred, "pred")
         pred = _f32(pred)
-        w = torch.ones_like(pred) if weight is None else _f32(weight).expand_as(pred).contiguous()
-        s = focal_loss_sum(pred, target.long().contiguous(), w, self.gamma, self.alpha)
         red = reduction_override or self.reduction
+        if red not in ("mean", "sum") or (red == "sum" and avg_factor is not None):
+            raise NotImplementedError("libpolyhead FocalLoss: reduction 'mean' (optionally with avg_factor) or 'sum'")
+        if weight is None:
+            w = torch.ones_like(pred)
+        else:
+            w = _f32(weight)
+            if w.dim() == 1:                   # one weight per row, as mmdet reshapes it (focal_loss.py:60-69)
+                w = w.view(-1, 1)
+            w = w.expand_as(pred).contiguous()
+        s = focal_loss_sum(pred, target.long().contiguous(), w, self.gamma, self.alpha)
         if avg_factor is not None:
             s = s / avg_factor
         elif red == "mean":
@@ -116,8 +141,29 @@ class CrossEntropyLoss(_Loss):
             raise NotImplementedError("libpolyhead: use_mask / class_weight are not part of the shipped configs")
         self.ignore_index = ignore_index
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("evaluated by KernelUpdateHead.loss / KernelHead.loss (losses.stage_losses)")
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, ignore_index=None, **kw):
+        """mmdet CrossEntropyLoss.forward on the device's loss kernels, the two forms the path uses:
+        use_sigmoid: binary cross entropy of mask logits [R, P] against soft targets [R, P] (every pixel selected) --
+          mean over all elements (cross_entropy_loss.py:56-105), what `loss_mask` evaluates;
+        softmax: cross entropy over dim 1 of [B, N, H, W] (or [B, N, P]) logits against an index map [B, H, W] with
+          `ignore_index` pixels contributing zero -- mean over all pixels (:9-53), what `loss_rank` evaluates.
+        The heads themselves go through `stage_losses` / `rpn_losses`, which fuse these with the other losses."""
+        red = reduction_override or self.reduction
+        if weight is not None or avg_factor is not None or red != "mean":
+            raise NotImplementedError("libpolyhead CrossEntropyLoss: mean reduction without weights (the shipped configs)")
+        _gpu(cls_score, "cls_score")
+        if self.use_sigmoid:
+            z, t = _f32(cls_score).reshape(cls_score.shape[0], -1), _f32(label).reshape(cls_score.shape[0], -1)
+            sel = torch.ones_like(z)
+            sums = mask_loss_sums(z, t, sel, torch.arange(z.shape[0], device=z.device, dtype=torch.int32))
+            return (self.loss_weight * sums[:, 0].sum() / z.numel()).float()
+        ii = self.ignore_index if ignore_index is None else ignore_index
+        z = _f32(cls_score)
+        B, N = z.shape[:2]
+        HW = z[0, 0].numel()
+        tgt = label.reshape(B, HW).to(torch.int32).contiguous()
+        s = rank_loss_sum(z.reshape(B, N, HW, 1), tgt, -100 if ii is None else int(ii))
+        return (self.loss_weight * s / (B * HW)).float()
 
 
 class DiceLoss(_Loss):
@@ -129,8 +175,17 @@ class DiceLoss(_Loss):
             raise NotImplementedError("libpolyhead: DiceLoss with the sigmoid inside (the shipped configs)")
         self.eps, self.activate = eps, activate
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("evaluated by KernelUpdateHead.loss / KernelHead.loss (losses.stage_losses)")
+    def forward(self, pred, target, weight=None, reduction_override=None, avg_factor=None):
+        """mmdet DiceLoss.forward (dice_loss.py:7-47,96-136): pred [R, P] logits, target [R, P]; per-row
+        1 - 2 sum(p t) / ((sum(p^2) + eps) + (sum(t^2) + eps)) with p = sigmoid(pred), mean over the rows"""
+        red = reduction_override or self.reduction
+        if weight is not None or avg_factor is not None or red != "mean":
+            raise NotImplementedError("libpolyhead DiceLoss: mean reduction without weights (the shipped configs)")
+        _gpu(pred, "pred")
+        z, t = _f32(pred).reshape(pred.shape[0], -1), _f32(target).reshape(pred.shape[0], -1)
+        sums = mask_loss_sums(z, t, torch.ones_like(z), torch.arange(z.shape[0], device=z.device, dtype=torch.int32))
+        dice = 1.0 - 2.0 * sums[:, 2] / (sums[:, 3] + sums[:, 4] + 2.0 * self.eps)          # dice_loss.py:33-38
+        return (self.loss_weight * dice.mean()).float()
 
 
 def _depth_from_sums(s, loss_weight, w3):
@@ -232,7 +287,7 @@ def stage_losses(head, cls_score, mask_pred, depth_pred, labels, label_weights, 
     pos = (labels >= 0) & (labels < L)                                                        # :375
     num_pos = int(pos.sum())
     from .dist import reduce_mean
-    avg = max(float(reduce_mean(pos.sum().float())), 1.0)                                     # :376-377 (mean over ranks, clamp)
+    avg = max(float(reduce_mean(pos.sum().float(), _REDUCE_GROUP[-1])), 1.0)                  # :376-377 (mean over ranks, clamp)
     losses, grads = {}, None
     if with_grads:
         grads = dict(mask_pred=torch.empty((R, HW), dtype=torch.float32, device=dev),

@@ -248,123 +248,215 @@ def rpn_forward(head, feats):
                 depth_pred=depth_pred)
 
 
-# ---- the step ------------------------------------------------------------------------------------------------------------------
+# ---- the two heads' training forwards (ONE implementation: the API methods and TrainStep both call these) --------------------
 def parse_losses(losses):
     """mmdet BaseDetector._parse_losses (base.py:188-199): the objective is the sum of the entries with 'loss' in the key"""
     return sum(v.mean() for k, v in losses.items() if "loss" in k and torch.is_tensor(v))
 
 
+def _attach(values, total):
+    """values: {name: detached scalar}, total: the differentiable objective these values add up to (their 'loss' entries,
+    already weighted).  Returns the dict the reference's forward_train returns, with every 'loss' entry carrying an equal
+    share of `total`'s graph, so that what mmdet forms from it -- `sum(the 'loss' entries)`, base.py:188-199 -- has exactly
+    the gradient of the objective, through ONE autograd node per head and stage.  (The loss kernels return
+    d(sum of a head's losses) / d(prediction), not one gradient per entry: only the SUM of the entries is differentiable
+    in a meaningful way, which is all the reference's runner ever differentiates.)"""
+    keys = [k for k in values if "loss" in k]
+    share = (total - total.detach()) / max(len(keys), 1)
+    return {k: (v + share if "loss" in k else v) for k, v in values.items()}
+
+
+def check_stage_topology(head):
+    """the assumptions stage_forward hard-codes (the shipped configuration, configs/_base_/models/polyphonic_former.py:111-165);
+    the constructors reject everything else, this guards modules altered after construction"""
+    bad = []
+    if len(head.cls_fcs) != 3 or len(head.mask_fcs) != 3 or len(head.depth_regs) != 2: bad.append("num_cls_fcs / num_mask_fcs != 1")
+    if head.dropout != 0.0: bad.append("dropout")
+    if head.conv_kernel_size != 1 or head.mask_transform_stride != 1 or head.feat_gather_stride != 1: bad.append("kernel size / strides")
+    if head.hard_mask_thr != 0.5: bad.append("hard_mask_thr")
+    if not head.with_ffn or len(head.ffn.layers) != 3 or len(head.ffn.layers[0]) != 3: bad.append("FFN layout")   # (Linear, act, Dropout), Linear, Dropout
+    if bad:
+        raise NotImplementedError("training forward: unsupported KernelUpdateHead topology: " + ", ".join(bad))
+
+
+def check_rpn_topology(head):
+    bad = []
+    if len(head.loc_convs) != 1 or len(head.seg_convs) != 1 or len(head.depth_convs) != 1: bad.append("num_*_convs != 1")
+    if head.conv_kernel_size != 1 or not head.use_binary or not head.proposal_feats_with_obj: bad.append("kernel size / use_binary")
+    if head.feat_downsample_stride > 1 and head.feat_refine: bad.append("feat_refine")
+    if head.feat_downsample_stride not in (1, 2): bad.append("feat_downsample_stride")
+    if bad:
+        raise NotImplementedError("training forward: unsupported KernelHead topology: " + ", ".join(bad))
+
+
+def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, want_grads=False):
+    """KernelHead.forward_train, kernel_head.py:349-454, on the three post-neck maps (gradients flow into `feats` when they
+    require them).  Returns (losses, r): `losses` = the reference's dict with the 'loss' entries attached to the graph
+    (`_attach`), `depth_dense` logged only (base.py:198 leaves it out of the objective); r = the differentiable training-
+    mode decode (no stuff rows).  want_grads: losses['_grads'] = d(sum of the 'loss' entries) / d(scaled mask, seg and
+    direct depth predictions)."""
+    check_rpn_topology(h)
+    if h.assigner is None:
+        raise ValueError("forward_train needs train_cfg (assigner / sampler)")
+    if h.hard_target:                     # local to the rpn side, as in the reference (kernel_head.py:400-403)
+        gt_masks = [m.bool().float() for m in gt_masks]
+    r = rpn_forward(h, feats)
+    up = (lambda t: upsample2x(t)) if h.feat_downsample_stride == 2 else (lambda t: t)
+    smask, sseg, sdep0 = up(r["mask_preds"]), up(r["seg_preds"]), up(r["depth_pred"])         # :364-398
+    N = h.num_proposals + h.num_stuff_classes
+    sdep = sdep0.detach().expand(-1, N, -1, -1)
+    srs = []
+    for i in range(len(img_metas)):                                                           # :411-426
+        valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
+        ar = h.assigner.assign(smask[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i], depth_pred=sdep[i],
+                               gt_depth=gt_depth[i], gt_valid=valid)
+        sr = h.sampler.sample(ar, smask[i].detach(), gt_masks[i], depth=sdep[i])
+        sr.valid_mask = valid
+        srs.append(sr)
+    targets = h.get_targets(srs, gt_masks, h.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls, gt_depth=gt_depth)
+    kept = {}
+
+    def fn(mp, sp, dp):
+        ls, g = Lo.rpn_losses(h, mp, sp, dp.expand(-1, N, -1, -1), *targets, with_grads=True)
+        kept.update(mask_pred=g["mask_pred"], seg_preds=g["seg_preds"], depth_pred=g["depth_pred"])
+        return ls, (g["mask_pred"], g["seg_preds"], g["depth_pred"])
+
+    values = {}
+    total = _Objective.apply(fn, values, smask, sseg, sdep0)
+    losses = _attach(values, total)
+    losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)                  # :438-442, logged only
+    if want_grads:
+        losses["_grads"] = kept
+    return losses, r
+
+
+def rpn_outputs(h, r):
+    """what KernelHead.forward_train hands to the roi head besides the losses (kernel_head.py:444-454): the stuff rows
+    appended when cat_stuff_mask, all tensors still on the graph"""
+    B = r["x"].shape[0]
+    nt, L = h.num_thing_classes, h.num_classes
+    mask_preds, k, q = r["mask_preds"], r["proposal"], r["depth_proposal"]
+    if h.cat_stuff_mask:
+        mask_preds = torch.cat([mask_preds, r["seg_preds"][:, nt:L]], dim=1)
+        stuff = dict(h.named_parameters())["conv_seg.weight"][nt:L].flatten(1)
+        k = torch.cat([k, stuff[None].expand(B, -1, -1)], dim=1)
+    N = k.shape[1]
+    return k, mask_preds, q.expand(B, N, -1)
+
+
+def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
+                      want_grads=False):
+    """KernelUpdateIterHead.forward_train, kernel_update.py:159-280.  x, dfe [B, C, H, W]; k / q [B, N, C] kernels and depth
+    kernels; mask_preds [B, N, H, W]; depth_pred [B, 1, H, W].  Every stage: forward in training form, the Hungarian
+    assignment on the previous stage's detached predictions, pseudo sampling, targets, the stage's losses as one autograd
+    node.  Returns (losses, last): losses = {s{stage}_{name}} weighted and attached (`_attach`), last = the final stage's
+    (object_feats, cls_score, mask_preds, scaled_mask_preds)."""
+    if ih.post_assign:
+        raise NotImplementedError                       # as the reference (:222-223)
+    if not ih.mask_assigner:
+        raise ValueError("forward_train needs train_cfg (assigner / sampler per stage)")
+    B, N = k.shape[:2]
+    up = ih.mask_head[0].mask_upsample_stride
+    if up not in (1, 2):
+        raise NotImplementedError("libpolyhead: mask_upsample_stride must be 1 or 2")
+    scale = (lambda t: upsample2x(t)) if up == 2 else (lambda t: t)
+    prev_mask = scale(mask_preds.detach()).detach()                                           # :179-191
+    prev_depth = scale(depth_pred.detach().expand(-1, N, -1, -1).contiguous()).detach()
+    prev_cls = [None] * B                                                                      # :193-196
+    if ih.hard_target:
+        gt_masks = [m.bool().float() for m in gt_masks]
+    total, m, assign, values, grads = 0.0, mask_preds, [], {}, []
+    cls = smask = None
+    for s in range(ih.num_stages):
+        head = ih.mask_head[s]
+        check_stage_topology(head)
+        cls, m, k, depth, q = stage_forward(head, x, dfe, k, m, q)
+        smask, sdepth = scale(m), scale(depth)                                                 # training: every stage (:131)
+        srs = []
+        if s < ih.assign_stages:
+            assign = []
+        for i in range(B):
+            valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()  # :238
+            if s < ih.assign_stages:
+                c = None if prev_cls[i] is None else prev_cls[i][:ih.num_proposals, :ih.num_thing_classes]
+                assign.append(ih.mask_assigner[s].assign(prev_mask[i][:ih.num_proposals], c, gt_masks[i], gt_labels[i], img_metas[i],
+                                                         depth_pred=prev_depth[i][:ih.num_proposals], gt_depth=gt_depth[i],
+                                                         gt_valid=valid))
+            sr = ih.mask_sampler[s].sample(assign[i], smask[i].detach(), gt_masks[i], depth=sdepth[i].detach())
+            sr.valid_mask = valid
+            srs.append(sr)
+        targets = head.get_targets(srs, gt_masks, gt_labels, ih.train_cfg[s], True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
+                                   gt_depth=gt_depth)
+        kept = {}
+
+        def fn(cs, mp, dp, head=head, targets=targets, kept=kept):
+            ls, g = Lo.stage_losses(head, cs, mp, dp, *targets, with_grads=True)
+            kept.update(g)
+            return ls, (g["cls_score"], g["mask_pred"], g["depth_pred"])
+
+        box = {}
+        w = ih.stage_loss_weights[s]
+        total = total + w * _Objective.apply(fn, box, cls, smask, sdepth)
+        for key, v in box.items():
+            values[f"s{s}_{key}"] = v * w
+        grads.append(kept)
+        prev_mask, prev_cls, prev_depth = smask.detach(), cls.detach(), sdepth.detach()       # :273-276
+    losses = _attach(values, total)
+    if want_grads:
+        losses["_grads"] = grads
+    return losses, (k, cls, m, smask)
+
+
+# ---- the step ------------------------------------------------------------------------------------------------------------------
 class TrainStep:
     """rpn_head: KernelHead, roi_head: KernelUpdateIterHead, both built with train_cfg.  `forward_backward` evaluates one
     step on the three post-neck maps and leaves `.grad` on every parameter of the two heads (accumulating, like autograd; averaged over the ranks
-    when torch.distributed runs with more than one) and returns (losses, objective, gradients of the three maps)."""
+    when torch.distributed runs with more than one) and returns (losses, objective, gradients of the three maps).  The
+    same two functions back the reference-named API methods (`KernelHead.forward_train`,
+    `KernelUpdateIterHead.forward_train`), whose loss dicts mmdet's `_parse_losses` + `backward()` consume unchanged; this
+    class adds the bucketed gradient all-reduce.  Use as a context manager (or call `close()`) to take the gradient hooks
+    off the parameters again."""
 
     def __init__(self, rpn_head, roi_head, bucket_bytes=32 << 20, group=None):
         self.rpn, self.roi = rpn_head, roi_head
         if rpn_head.assigner is None or not roi_head.mask_assigner:
             raise ValueError("TrainStep needs heads built with train_cfg (assigner / sampler)")
+        check_rpn_topology(rpn_head)
+        for h in roi_head.mask_head:
+            check_stage_topology(h)
         # data parallel: one process per GPU, gradients averaged by bucketed all-reduces (RCCL over xGMI) that start while
         # backward is still running (dist.GradBuckets); on one rank nothing is sent
         from .dist import GradBuckets
+        self.group = group
         self.buckets = GradBuckets(self.parameters(), bucket_bytes=bucket_bytes, group=group)
+
+    def close(self):
+        self.buckets.remove()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def parameters(self):
         return [p for n, p in self.rpn.named_parameters() if not n.startswith("localization_fpn.")] + list(self.roi.parameters())
-
-    # -- rpn side: kernel_head.py:349-454
-    def _rpn(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses):
-        h = self.rpn
-        if h.hard_target:                     # local to the rpn side, as in the reference (kernel_head.py:400-403)
-            gt_masks = [m.bool().float() for m in gt_masks]
-        r = rpn_forward(h, feats)
-        up = (lambda t: upsample2x(t)) if h.feat_downsample_stride == 2 else (lambda t: t)
-        smask, sseg, sdep0 = up(r["mask_preds"]), up(r["seg_preds"]), up(r["depth_pred"])
-        N = h.num_proposals + h.num_stuff_classes
-        sdep = sdep0.detach().expand(-1, N, -1, -1)
-        srs = []
-        for i in range(len(img_metas)):
-            valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
-            ar = h.assigner.assign(smask[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i], depth_pred=sdep[i],
-                                   gt_depth=gt_depth[i], gt_valid=valid)
-            sr = h.sampler.sample(ar, smask[i].detach(), gt_masks[i], depth=sdep[i])
-            sr.valid_mask = valid
-            srs.append(sr)
-        targets = h.get_targets(srs, gt_masks, h.train_cfg, True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls, gt_depth=gt_depth)
-
-        def fn(mp, sp, dp):
-            ls, g = Lo.rpn_losses(h, mp, sp, dp.expand(-1, N, -1, -1), *targets, with_grads=True)
-            return ls, (g["mask_pred"], g["seg_preds"], g["depth_pred"])
-
-        total = _Objective.apply(fn, losses, smask, sseg, sdep0)
-        losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)             # logged, not in the objective
-        return total, r
-
-    # -- roi side: kernel_update.py:159-280
-    def _roi(self, r, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses):
-        ih, rp = self.roi, self.rpn
-        B = r["x"].shape[0]
-        nt, L = rp.num_thing_classes, rp.num_classes
-        mask_preds, k, q = r["mask_preds"], r["proposal"], r["depth_proposal"]
-        if rp.cat_stuff_mask:                                                                 # kernel_head.py:444-451
-            mask_preds = torch.cat([mask_preds, r["seg_preds"][:, nt:L]], dim=1)
-            stuff = dict(rp.named_parameters())["conv_seg.weight"][nt:L].flatten(1)
-            k = torch.cat([k, stuff[None].expand(B, -1, -1)], dim=1)
-        N = k.shape[1]
-        q = q.expand(B, N, -1)
-        up = ih.mask_head[0].mask_upsample_stride
-        scale = (lambda t: upsample2x(t)) if up == 2 else (lambda t: t)
-        prev_mask = scale(mask_preds.detach()).detach()
-        prev_depth = scale(r["depth_pred"].detach().expand(-1, N, -1, -1).contiguous()).detach()
-        prev_cls = [None] * B
-        if ih.hard_target:
-            gt_masks = [m.bool().float() for m in gt_masks]
-        total, m, assign = 0.0, mask_preds, []
-        for s in range(ih.num_stages):
-            head = ih.mask_head[s]
-            cls, m, k, depth, q = stage_forward(head, r["x"], r["dfe"], k, m, q)
-            smask, sdepth = scale(m), scale(depth)
-            srs = []
-            if s < ih.assign_stages:
-                assign = []
-            for i in range(B):
-                valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
-                if s < ih.assign_stages:
-                    c = None if prev_cls[i] is None else prev_cls[i][:ih.num_proposals, :ih.num_thing_classes]
-                    assign.append(ih.mask_assigner[s].assign(prev_mask[i][:ih.num_proposals], c, gt_masks[i], gt_labels[i], img_metas[i],
-                                                             depth_pred=prev_depth[i][:ih.num_proposals], gt_depth=gt_depth[i],
-                                                             gt_valid=valid))
-                sr = ih.mask_sampler[s].sample(assign[i], smask[i].detach(), gt_masks[i], depth=sdepth[i].detach())
-                sr.valid_mask = valid
-                srs.append(sr)
-            targets = head.get_targets(srs, gt_masks, gt_labels, ih.train_cfg[s], True, gt_sem_seg=gt_sem_seg, gt_sem_cls=gt_sem_cls,
-                                       gt_depth=gt_depth)
-
-            def fn(cs, mp, dp, head=head, targets=targets):
-                ls, g = Lo.stage_losses(head, cs, mp, dp, *targets, with_grads=True)
-                return ls, (g["cls_score"], g["mask_pred"], g["depth_pred"])
-
-            box = {}
-            w = ih.stage_loss_weights[s]
-            total = total + w * _Objective.apply(fn, box, cls, smask, sdepth)
-            for key, v in box.items():
-                losses[f"s{s}_{key}"] = v * w
-            prev_mask, prev_cls, prev_depth = smask.detach(), cls.detach(), sdepth.detach()
-        return total
 
     def forward_backward(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, backward=True):
         feats = [f.detach().float().contiguous().requires_grad_(True) for f in feats]
         for f in feats:
             if not f.is_cuda:
                 raise _lib.PolyheadError("the post-neck maps must live on the GPU: libpolyhead has no CPU path")
-        losses = {}
-        with torch.enable_grad():
-            rpn_losses = {}
-            t_rpn, r = self._rpn(feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, rpn_losses)
-            t_roi = self._roi(r, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, losses)
-            losses.update(rpn_losses)
-            total = t_rpn + t_roi
+        with torch.enable_grad(), Lo.reduce_group(self.group):
+            rpn_losses, r = rpn_forward_train(self.rpn, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth)
+            k, mask_preds, q = rpn_outputs(self.rpn, r)
+            losses, _ = roi_forward_train(self.roi, r["x"], r["dfe"], k, mask_preds, q, r["depth_pred"], img_metas, gt_masks, gt_labels,
+                                          gt_sem_seg, gt_sem_cls, gt_depth)
+            losses.update(rpn_losses)                       # polyphonic_former.py:126
+            total = parse_losses(losses)
             if backward:
                 self.buckets.start()
                 total.backward()
                 self.buckets.finish()
-        return losses, total.detach(), [f.grad for f in feats]
+        return {k_: v.detach() for k_, v in losses.items()}, total.detach(), [f.grad for f in feats]
