@@ -245,6 +245,18 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         run()
     t_all = time_op(graph.replay, steps)
     t_a1 = time_op(run_a1, steps)
+    kplan.check_status()
+    # the same with fp16 mask / seg / depth logits out of KernelHead (the decode consumes the mask BITS; the logits are API
+    # outputs of simple_test_rpn): 19 MB per frame less
+    t_a1_h = None
+    if kplan.onepass:
+        try:
+            kplan_h = E.KernelHeadPlan(kh._get_pack(dev), B, H, W, wl["n_thing"], L, True, dev, want_f32=False, logit_dtype=torch.float16)
+            kplan_h.set_inputs(kplan.f)
+            t_a1_h = time_op(kplan_h.run, steps)
+            del kplan_h
+        except Exception as e:
+            t_a1_h = repr(e)
     # the same on two streams, a second half-batch of B frames one phase behind the first (as the headline does for a6)
     two = None
     try:
@@ -279,9 +291,16 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
     except Exception as e:
         two = {"error": repr(e)}
     return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
-            "a1_only_ms_per_step": round(t_a1, 4), "two_streams": two,
-            "note": "KernelHead post-neck (3 x conv1x1+GN+ReLU two-pass with the static 1x1 convs fused into the apply pass, "
-                    "object pooling) + 3-stage decode, 16-bit plane + mask-bit hand-off, fp32 post-neck inputs resident in HBM"}
+            "a1_only_ms_per_step": round(t_a1, 4), "a1_form": "one-pass (ph_khead_onepass)" if kplan.onepass else "two-pass (ph_khead_fused)",
+            "a1_only_ms_per_step_fp16_logits": round(t_a1_h, 4) if isinstance(t_a1_h, float) else t_a1_h, "two_streams": two,
+            "a1_alg_bytes_per_frame": int(3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2),
+            "a1_plus_a6_fraction_hbm": round(((3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2)
+                                              + algorithmic_rates(wl, N, B, 1.0, precision)["bytes_per_frame"] - N * H * W * 2) * (B / (t_all * 1e-3)) / 8e12, 4),
+            "note": "KernelHead post-neck (3 x conv1x1+GN+ReLU in ONE read of the maps: persistent kernel, GroupNorm sums exchanged between "
+                    "the workgroups inside the launch; the static 1x1 convs, x = sem + loc and the mask bits in the same launch; object "
+                    "pooling) + 3-stage decode, 16-bit plane + mask-bit hand-off, fp32 post-neck inputs resident in HBM.  "
+                    "a1_alg_bytes_per_frame = maps read once + x / dfe planes + fp32 logits + bits + the pooling's read of x; "
+                    "a1_plus_a6_fraction_hbm = (that + SURVEY 8d's B_alg less the initial logit read) x frames/s / 8 TB/s"}
 
 
 def neck_leg(wl, precision, dev, B=16, steps=5):
@@ -433,12 +452,9 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
     return out
 
 
-def video_leg(dev, precision="bf16", frames=6):
-    """BASELINE configs[2] (poly_r50_cityscapes_1x video head, 2-frame clips with tracking query match): wall time per
-    1024x2048 frame of PolyphonicVideo.simple_test after extract_feat (polyphonic_former_video.py:327-405) through the
-    module API -- neck + KernelHead + 3-stage decode + panoptic merge + things -> boxes -> FPN RoIAlign -> track head ->
-    tracker; the shipped video head (100 + 11 queries), classification biases raised so that an un-trained network
-    yields thing segments."""
+def _video_pipeline(dev, precision):
+    """the shipped video head (poly_r50_cityscapes_1x: 100 + 11 queries) with this package's neck, random-init weights;
+    classification biases raised so that an un-trained network yields thing segments"""
     from polyphonicformer_amd.registry import HEADS, ConfigDict
     from polyphonicformer_amd import video as V
     import polyphonicformer_amd.kernel_head, polyphonicformer_amd.track_head  # noqa: F401,E401
@@ -467,7 +483,92 @@ def video_leg(dev, precision="bf16", frames=6):
     cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
                memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
                match_metric="bisoftmax")
-    pipe = V.VideoFramePipeline(kh, ih, th, cfg)
+    return V.VideoFramePipeline(kh, ih, th, cfg), cfg, wl
+
+
+def _video_frame(base, f, period):
+    """synthetic FPN levels of global frame f of the video: the base levels rolled by a frame-dependent offset"""
+    return tuple(torch.roll(t, (f % period, 2 * (f % period)), dims=(2, 3)) for t in base)
+
+
+def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4, warmup=1, collect_ids=False):
+    """BASELINE configs[3]: clips sharded one per GPU, the track records all-gathered on RCCL, the tracker replayed in frame
+    order.  The video is `world * clip_frames` frames per step; rank r owns the contiguous clip r (`dist.shard_frames`,
+    SURVEY 8e).  One step per rank = polyphonic/apis/video_inference.py:8-31's loop body for its frames up to the tracker:
+    PolyphonicVideo.simple_test after extract_feat (polyphonic_former_video.py:327-389: neck, both heads, panoptic merge,
+    things -> boxes -> FPN RoIAlign -> track embeddings) with `records_only`, then ONE `dist.allgather_track_records` and
+    `video.replay_tracking` of all frames of the step in frame order with the stream's persistent tracker (:391-402).
+    Returns timings (max over ranks) and, with collect_ids, the track ids of every frame."""
+    import torch.distributed as dist
+    from polyphonicformer_amd import dist as D, video as V
+    assert dist.is_initialized() and dist.get_world_size() == world, "process group does not span --gpus ranks"
+    pipe, tcfg, wl = _video_pipeline(dev, precision)
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(31)               # the same video on every rank; each takes its own frames
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(dev) for s in (4, 8, 16, 32)]
+    meta = [dict(img_shape=(H8, W8, 3), ori_shape=(H8, W8, 3), batch_input_shape=(H8, W8))]
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    tracker = V.QuasiDenseEmbedTracker(**tcfg)
+    per_step = world * clip_frames
+    ids_log, t_heads, t_coll, t_replay, cnt = {}, [], [], [], 1
+
+    def one_step(step):
+        nonlocal cnt
+        mine = [step * per_step + f for f in D.shard_frames(per_step, rank, world)]
+        recs, cnts = [], []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in mine:
+            seg_ids, rec = pipe.simple_test(_video_frame(base, f, 6), meta, records_only=True)
+            if rec is None:
+                rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256))
+            r, n = D.pack_track_records(*[t.to(cdev) for t in rec])
+            recs.append(r)
+            cnts.append(n)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        allrec = D.allgather_track_records(mine, recs, cnts, clip_frames)
+        if cdev.type == "cuda":
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ids = V.replay_tracking([(fid, bb.cpu(), lab.cpu(), emb.cpu()) for fid, bb, lab, emb in allrec], tracker=tracker, first_count=cnt)
+        cnt += sum(1 for t in allrec if t[1].shape[0] > 0)
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2, ids
+
+    for s_ in range(warmup):
+        one_step(s_)
+    tracker = V.QuasiDenseEmbedTracker(**tcfg)           # a new video for the timed steps (polyphonic_former_video.py:59-61)
+    cnt = 1
+    dist.barrier()
+    torch.cuda.synchronize()
+    t_all0 = time.perf_counter()
+    for s_ in range(steps):
+        a, b, c, ids = one_step(warmup + s_)
+        t_heads.append(a), t_coll.append(b), t_replay.append(c)
+        if collect_ids:
+            ids_log.update({int(k): v.tolist() for k, v in ids.items()})
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = D.barrier_and_max(time.perf_counter() - t_all0, cdev)
+    med = lambda v: sorted(v)[len(v) // 2]
+    out = {"frames_per_s": round(steps * per_step / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step": per_step,
+           "clip_frames_per_rank": clip_frames, "world_size": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+           "heads_merge_records_ms_per_step": round(D.barrier_and_max(med(t_heads), cdev) * 1e3, 3),
+           "allgather_track_records_us_per_step": round(D.barrier_and_max(med(t_coll), cdev) * 1e6, 1),
+           "replay_tracking_ms_per_step": round(D.barrier_and_max(med(t_replay), cdev) * 1e3, 3), "precision": precision}
+    if collect_ids:
+        out["track_ids"] = ids_log
+    return out, pipe
+
+
+def video_leg(dev, precision="bf16", frames=6):
+    """BASELINE configs[2] (poly_r50_cityscapes_1x video head, 2-frame clips with tracking query match): wall time per
+    1024x2048 frame of PolyphonicVideo.simple_test after extract_feat (polyphonic_former_video.py:327-405) through the
+    module API -- neck + KernelHead + 3-stage decode + panoptic merge + things -> boxes -> FPN RoIAlign -> track head ->
+    tracker; the shipped video head (100 + 11 queries), classification biases raised so that an un-trained network
+    yields thing segments."""
+    pipe, cfg, wl = _video_pipeline(dev, precision)
     H8, W8 = wl["H"] * 8, wl["W"] * 8
     g = torch.Generator().manual_seed(31)
     base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(dev) for s in (4, 8, 16, 32)]
@@ -476,7 +577,7 @@ def video_leg(dev, precision="bf16", frames=6):
     # the clip runs twice: the first pass pays every one-time cost (weight packs, kernel attributes, the host library's
     # first-call initialisation of the tracker's CPU ops: 90-250 ms spikes on single frames), the second one is timed
     for f in range(2 * frames):
-        x = tuple(torch.roll(t, (f % frames, 2 * (f % frames)), dims=(2, 3)) for t in base)
+        x = _video_frame(base, f, frames)
         if f == frames:
             pipe.assoc.init_tracker()          # a new clip (polyphonic_former_video.py:59-61)
         torch.cuda.synchronize()
@@ -595,7 +696,7 @@ def panoptic_leg(wl, head, plan, dev):
     return {"ms_per_frame": round(min(ts[1:]), 3), "segments": len(r[2][1]), "output": f"int32 {H * 8}x{W * 8} id map + 2 fp32 depth maps on the host"}
 
 
-def cpu_baseline(wl, head, budget_s=16.0):
+def cpu_baseline(wl, head, budget_s=16.0, all_cores=True, workload_note="the same workload (1024x2048, N=153, S=3)"):
     """the oracle (CPU restatement of the reference path) on this box's host cores, bounded sample"""
     from oracle import poly_oracle as O
     sd = {k: v.detach().cpu() for k, v in head.state_dict().items()}
@@ -622,14 +723,14 @@ def cpu_baseline(wl, head, budget_s=16.0):
     ncores = min(16, allc)
     n, dt = timed(ncores, budget_s * 0.5)
     n1, dt1 = timed(1, budget_s * 0.25)
-    if allc != ncores:      # hundreds of threads on these small ops are pathologically slow (~45 s per frame on 256): ONE frame
+    if allc != ncores and all_cores:      # hundreds of threads on these small ops are pathologically slow (~45 s per frame on 256): ONE frame
         torch.set_num_threads(allc)
         with torch.no_grad():
             t0 = time.time()
             O.iter_head_mask_preds(sd, S, inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])
         na, dta = 1, time.time() - t0
     else:
-        na, dta = n, dt
+        na, dta = (n, dt) if allc == ncores else (0, float("inf"))
     torch.set_num_threads(ncores)
     extra = {}
     try:        # the assigner's cost matrices (SURVEY 8f N4 first part) by the oracle, same sizes as the `hungarian_assign` leg
@@ -645,11 +746,15 @@ def cpu_baseline(wl, head, budget_s=16.0):
         extra["assign_costs_ms_per_image"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
     except Exception as e:
         extra["assign_costs_ms_per_image"] = repr(e)
-    return dict(value=1.0 / dt, unit="frames/s", cores=ncores, kind="port", **extra,
-                one_thread={"value": 1.0 / dt1, "cores": 1, "frames": n1},
-                all_cores={"value": 1.0 / dta, "cores": allc, "frames": na},
-                sample=f"{n} frame(s) of the same workload (1024x2048, N=153, S=3), fp32, B=1, after 1 warm-up; "
-                       f"+ {n1} frame(s) on 1 thread and {na} on all {allc} hardware threads")
+    out = dict(value=1.0 / dt, unit="frames/s", cores=ncores, kind="port", **extra,
+               one_thread={"value": 1.0 / dt1, "cores": 1, "frames": n1},
+               sample=f"{n} frame(s) of {workload_note}, fp32, B=1, after 1 warm-up; + {n1} frame(s) on 1 thread")
+    if na:
+        out["all_cores"] = {"value": 1.0 / dta, "cores": allc, "frames": na}
+        out["sample"] += f" and {na} on all {allc} hardware threads"
+    else:
+        out["all_cores"] = f"not run by default ({allc} hardware threads take ~45 s per frame: --all-legs); profiles/r02 has 0.022 frames/s"
+    return out
 
 
 def _free_port():
@@ -739,6 +844,43 @@ def track_allgather_leg(dev, world, backend, frames_per_rank=2, iters=30):
                     "the second number adds the host-side unpack (one D2H of the meta vector) of dist.allgather_track_records"}
 
 
+def cfg4_main(args, dev, world, rank, backend, json_fd):
+    """`python bench.py --workload cfg4 --gpus N`: BASELINE configs[3] end to end (see cfg4_run); rank 0 prints the JSON line
+    with frames/s (all ranks' frames / the max-over-ranks time), the collective's time, roofline and cpu_baseline."""
+    import torch.distributed as dist
+    prec = args.precision if args.precision in ("bf16", "fp32") else "fp16"       # the contract grade of neck / heads
+    run, pipe = cfg4_run(dev, world, rank, backend, precision=prec, clip_frames=args.clip_frames, steps=args.steps, warmup=args.warmup)
+    if rank != 0:
+        return
+    wl = WORKLOADS["cfg3"]
+    N = wl["Nq"] + wl["n_stuff"]
+    plan = next(iter(pipe.roi_head._plans.values()))                 # the decode plan the frames ran on: one frame per launch
+    times, counts = kernel_breakdown(plan)
+    ab = algorithmic_bytes(plan, "pool")
+    achieved = ab / (times["pool"] * 1e-3) / 1e9
+    res = {"metric": f"frames/sec video head (heads + merge + association), {wl['H'] * 8}x{wl['W'] * 8} N={N} S={wl['S']}, clips sharded 1/GPU",
+           "value": run["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": run["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": {"fp16": "fp16 (planes, dynamic kernels, logits; hi/lo bf16 query GEMMs)", "bf16": "bf16", "fp32": "bf16x3 (fp32-grade split)"}[prec],
+           "data": "synthetic",
+           "config": {"workload": f"cfg4: poly_r50 video head, {wl['H'] * 8}x{wl['W'] * 8}, N={N}, S={wl['S']}, {args.clip_frames}-frame clip per "
+                                  f"GPU and step, one frame per launch (samples_per_gpu = 1 as in the reference), module API, random-init weights",
+                      "frames_per_step_per_gpu": args.clip_frames,
+                      "parallelism": f"clips sharded over {world} GPU(s); ONE all-gather of the track records per step on "
+                                     f"{run['backend']}, tracker replayed in frame order on every rank"},
+           "cfg4": run,
+           "roofline": {"bound": "hbm", "kernel": "pool", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": ab,
+                        "avg_launch_ms": round(times["pool"], 4), "frames_per_launch": plan.B,
+                        "note": "the path's HBM-dominant contraction at THIS workload's launch geometry: one frame per launch, i.e. "
+                                "latency bound (the reference's video loop is one frame at a time); cfg2's batched launches are the "
+                                "default workload"},
+           "kernels_ms": {k: round(v, 4) for k, v in times.items()}}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(wl, pipe.roi_head, all_cores=False, workload_note=f"the decode part, {wl['H'] * 8}x{wl['W'] * 8}, N={N}, S={wl['S']}")
+    os.write(json_fd, (json.dumps(res) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -751,13 +893,20 @@ def main():
                          "the same with ONE fp16 plane of dynamic kernels (2.4e-4 per stage: the cheapest mode inside the 1e-3 "
                          "contract on bf16 inputs, the default); fp16 = fp16 planes / "
                          "kernels / logits (cfg5), fp32-grade query side; fp32 = every operand hi + lo (parity grade)")
-    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS) + ["cfg4"],
+                    help="cfg2 (default, BASELINE's metric) / cfg3 / cfg5 / tiny: simple_test_mask_preds at that geometry; cfg4: the "
+                         "video head with clips sharded one per GPU and the track records all-gathered (configs[3])")
     ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16", "fp16"],
                     help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
                          "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4, 6, 8],
                     help="n > 1: n part-batches on n skewed HIP streams, one HIP graph (engine.DualDecodePlan)")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="also run the secondary legs (all five precision modes, cfg5, the parity / fast pairs of a1 + a6, the neck, "
+                         "the whole head from the FPN levels, video cfg3, the assigner, the training step, the 256-thread CPU "
+                         "point): ~10 minutes; the default run takes about two")
+    ap.add_argument("--clip-frames", type=int, default=2, help="cfg4: frames of a rank's clip per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-head", action="store_true")
     ap.add_argument("--no-neck", action="store_true")
@@ -795,6 +944,16 @@ def main():
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "cfg4":
+        cfg4_main(args, dev, world, rank, backend, json_fd)
+        dist.barrier()
+        dist.destroy_process_group()
+        rc = 0
+        for w in workers:
+            rc |= w.wait()
+        if rc:
+            raise SystemExit(f"a self-launched rank exited with status {rc}")
+        return
     wl = WORKLOADS[args.workload]
     B = args.frames
     out_dtype = {"bf16": torch.bfloat16, "mixed": torch.float16, "mixed16": torch.float16, "fp16": torch.float16, "fp32": torch.float32}[args.precision]
@@ -888,6 +1047,12 @@ def main():
                                    f"L={wl['n_thing'] + wl['n_stuff']}, random-init weights",
                        "frames_per_step_per_gpu": B, "hip_graph": not args.no_graph, "streams": args.streams,
                        "feature_input_dtype": in_dt, "mask_logit_input_dtype": "fp32", "output_dtype": str(out_dtype),
+                       "parity_inputs": {"bf16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads); 6.6e-3 per stage: outside the 1e-3 contract",
+                                         "mixed": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 1.2e-5 per stage",
+                                         "mixed16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 2.4e-4 per stage; "
+                                                    "against UNROUNDED fp32 features this mode is gated at 3e-3 -- the `fp16` mode (precision_modes) meets 1e-3 there",
+                                         "fp16": "unrounded fp32 features into the oracle, fp16-rounded into the device: 3.9e-4 per stage",
+                                         "fp32": "fp32 features on both sides: 1.3e-5 per stage"}[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -903,9 +1068,12 @@ def main():
                              "final_incl_upsample": round(times["pool"] + times["query_pre"] + times["query_post"] + 2 * times["dynconv_logits"] + 2 * times["upsample2x"], 4)},
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+            "kernels_ms_per_step_note": f"sum of the isolated launch durations x launches per step; the step itself runs its {nplans} part(s) on "
+                                        f"{nplans} skewed streams, whose kernels overlap (query launches beside HBM-bound ones), so this sum exceeds ms_per_step",
             "track_allgather": tag,
         }
-        if world == 1 and in_dt in ("bf16", "fp16") and not args.no_kernel_head:
+        full = args.all_legs
+        if world == 1 and full and in_dt in ("bf16", "fp16") and not args.no_kernel_head:
             # the same step when the features arrive as fp32 NCHW (the reference's dtype) and go through the ingest kernel
             try:
                 gin32 = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
@@ -926,7 +1094,7 @@ def main():
                         "fp16": "2.4e-4 per stage on identical fp16 inputs, 3.9e-4 against unrounded fp32 inputs (1e-3 contract met)",
                         "fp32": "1.3e-5 per stage against fp32 inputs (parity grade)"}
             res["precision_modes"] = {args.precision: {"value": round(fps, 2), "unit": "frames/s", "per_stage_rel_err": err_note[args.precision]}}
-            for mode in ("bf16", "mixed", "mixed16", "fp16", "fp32"):
+            for mode in (("bf16", "mixed", "mixed16", "fp16", "fp32") if full else ("fp16", "mixed16")):
                 if mode == args.precision:
                     continue
                 try:
@@ -934,7 +1102,7 @@ def main():
                                                         per_stage_rel_err=err_note[mode])
                 except Exception as e:
                     res["precision_modes"][mode] = {"error": repr(e)}
-        if world == 1 and not args.no_kernel_head and args.workload == "cfg2":
+        if world == 1 and full and not args.no_kernel_head and args.workload == "cfg2":
             try:        # BASELINE configs[4] as specified: fp16, 1242x375 (48x156 at stride 8), N = 253, S = 3
                 res["cfg5_fp16"] = mode_leg(WORKLOADS["cfg5"], "fp16", dev, 192, 4, fp32_inputs=True)
             except Exception as e:
@@ -951,7 +1119,7 @@ def main():
                 del h16
             except Exception as e:          # secondary leg: never lose the headline line
                 res["with_kernel_head"] = {"error": repr(e)}
-            for name, prec, odt in (("fast_bf16", "bf16", torch.bfloat16), ("parity_fp32", "fp32", torch.float32)):
+            for name, prec, odt in ((("fast_bf16", "bf16", torch.bfloat16), ("parity_fp32", "fp32", torch.float32)) if full else ()):
                 try:
                     hk = head if args.precision == prec else build_head(wl, prec, odt, dev)
                     r = kernel_head_leg(wl, hk, prec, odt, dev)
@@ -961,12 +1129,12 @@ def main():
                 except Exception as e:
                     res["with_kernel_head"][name] = {"error": repr(e)}
             torch.cuda.empty_cache()
-        if world == 1 and not args.no_kernel_head:
+        if world == 1 and full and not args.no_kernel_head:
             try:
                 res["panoptic_merge"] = panoptic_leg(wl, head, kplan, dev)
             except Exception as e:
                 res["panoptic_merge"] = {"error": repr(e)}
-        if world == 1 and not args.no_neck:
+        if world == 1 and full and not args.no_neck:
             # the neck and the whole head from the FPN levels: the fp16 grade (one fp16 plane of weights / activations in the
             # neck and in KernelHead, the decode's `fp16` mode: every stage inside the 1e-3 contract) first, the all-bf16 fast
             # grade (outside the contract) next to it
@@ -989,25 +1157,28 @@ def main():
             except Exception as e:
                 res.setdefault("full_head_from_fpn", {})["error"] = repr(e)
             torch.cuda.empty_cache()
-        if world == 1 and not args.no_neck:
+        if world == 1 and full and not args.no_neck:
             try:
                 res["video_cfg3"] = video_leg(dev, precision="fp16")      # fp16 grade in neck / heads, split-grade track head
                 fast = video_leg(dev, precision="bf16")
                 res["video_cfg3"]["fast_bf16"] = {k: fast[k] for k in ("ms_per_frame", "heads_and_merge_ms", "association_ms")}
             except Exception as e:
                 res.setdefault("video_cfg3", {})["error"] = repr(e)
-        if world == 1 and not args.no_neck:
+        if world == 1 and full and not args.no_neck:
             try:
                 res["hungarian_assign"] = assign_leg(dev)
             except Exception as e:
                 res["hungarian_assign"] = {"error": repr(e)}
-        if world == 1 and not args.no_neck:
+        if world == 1 and full and not args.no_neck:
             try:
                 res["train_step"] = train_leg(wl, dev, world)
             except Exception as e:
                 res["train_step"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl, head)
+        if not full:
+            res["legs_not_run"] = "secondary legs (all precision modes, cfg5, panoptic merge, neck, whole head from the FPN levels, video cfg3, " \
+                                  "assigner, training step) need --all-legs; profiles/r03/bench_all_legs.json holds this round's full line"
+        if not args.no_cpu_baseline:                       # rank 0, at every N: the line of an N-GPU run carries it too
+            res["cpu_baseline"] = cpu_baseline(wl, head, all_cores=full)
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()

@@ -179,6 +179,8 @@ class KernelHead(nn.Module):
         runs without a graph).  `with_grads=True` adds losses['_grads'] = d(sum of the 'loss' entries) / d(scaled mask, seg
         and direct depth predictions)."""
         from . import train as T
+        if self.assigner is None:
+            raise ValueError("forward_train needs train_cfg (assigner / sampler)")
         neck = self.localization_fpn
         feats = neck(img) if neck is not None else list(img)
         if not isinstance(feats, (list, tuple)) or len(feats) != 3:

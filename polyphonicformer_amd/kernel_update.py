@@ -109,11 +109,17 @@ class KernelUpdateIterHead(nn.Module):
         plan = self._plan(B, N, H, W, x.device)
         plan.renew_outputs()         # results are the caller's: an earlier call's tensors are never overwritten
         ho = getattr(x, "_ph_handoff", None)
-        if (ho is not None and ho["prec"] == plan.prec and plan.mode.name in ("bf16", "fp32", "fp16") and ho["mask_preds"] is mask_preds
-                and ho["depth_feats"] is depth_feats and tuple(ho["xp"].shape) == tuple(plan.xp.shape)
-                and tuple(ho["bits"].shape) == tuple(plan.bits.shape)):
-            # inputs come straight from this package's KernelHead: its bf16 planes and mask bits are reused
+        same_call = (ho is not None and ho["mask_preds"] is mask_preds and ho["depth_feats"] is depth_feats
+                     and tuple(ho["bits"].shape) == tuple(plan.bits.shape))
+        if same_call and ho["prec"] == plan.prec and plan.mode.name in ("bf16", "fp32", "fp16") \
+                and tuple(ho["xp"].shape) == tuple(plan.xp.shape):
+            # inputs come straight from this package's KernelHead: its planes (same format) and mask bits are reused
             plan.run_from_planes(ho["xp"], ho["dp"], ho["bits"], proposal_feats, depth_proposal)
+        elif same_call and ho["prec"] == _lib.PH_PREC_SPLIT and plan.mode.feat == _lib.PH_PREC_BF16 \
+                and tuple(ho["xp"].shape[1:]) == tuple(plan.xp.shape[1:]):
+            # KernelHead at the parity grade (hi + lo bf16 planes) in front of a mode that reads ONE bf16 plane ('mixed',
+            # 'mixed16', 'bf16'): the hi plane IS the bf16 rounding of x_feats the ingest pass would produce -- adopt it
+            plan.run_from_planes(ho["xp"][:1], ho["dp"][:1], ho["bits"], proposal_feats, depth_proposal)
         else:
             plan.set_inputs(x, depth_feats, proposal_feats, depth_proposal, mask_preds)
             plan.run()
@@ -158,6 +164,10 @@ class KernelUpdateIterHead(nn.Module):
         `KernelHead.forward_train` returns are).  `with_grads=True` adds losses['_grads']: per stage d(stage losses) /
         d(its cls_score, scaled mask and depth predictions)."""
         from . import train as T
+        if self.post_assign:
+            raise NotImplementedError                       # as the reference (:222-223)
+        if not self.mask_assigner:
+            raise ValueError("forward_train needs train_cfg (assigner / sampler per stage)")
         if cls_score is not None:
             raise NotImplementedError("libpolyhead: the shipped KernelHead hands cls_scores=None to the roi head (kernel_head.py:291)")
         E._require_gpu(x, "x")

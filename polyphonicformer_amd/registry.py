@@ -101,3 +101,48 @@ def register_everywhere(cls, kind="head"):
 def deep_cfg(cfg):
     """configs are mutated by the heads (feat_transform_cfg.pop, kernel_update_head.py:125): copy first"""
     return copy.deepcopy(cfg)
+
+
+# ---- the reference's mixed-precision hook ---------------------------------------------------------------------------------
+def wrap_fp16_model(model):
+    """mmcv.runner.wrap_fp16_model as the reference applies it (tools/test.py:202-204, tools/test_video.py: `fp16_cfg =
+    cfg.get('fp16', None); if fp16_cfg is not None: wrap_fp16_model(model)`): every module of this package under `model`
+    that has precision grades is switched to its fp16 grade -- KernelHead (and its neck) to one fp16 plane of maps and
+    weights, KernelUpdateIterHead to the `fp16` mode of engine.MODES with fp16 logits, the track head to the grade engine.PREC maps 'fp16' to.
+    `model`: a module tree (a detector holding `rpn_head` / `roi_head`, or a head), or an iterable of modules."""
+    import torch
+    mods = list(model) if isinstance(model, (list, tuple)) else [model]
+    done = []
+    for root in mods:
+        for m in root.modules():
+            if m.__class__.__name__ == "KernelUpdateIterHead" and hasattr(m, "set_precision"):
+                m.set_precision("fp16", torch.float16)
+                done.append(m)
+            elif m.__class__.__name__ == "KernelHead" and hasattr(m, "set_precision"):
+                m.set_precision("fp16")          # forwards to its SemanticFPNWrapper
+                done.append(m)
+            elif m.__class__.__name__ == "QuasiDenseMaskEmbedHeadGTMask" and hasattr(m, "precision"):
+                m.precision = "fp16"             # engine.PREC: the split grade of the track head (its embeddings feed a hard match)
+                done.append(m)
+    return done
+
+
+def build_heads_from_config(cfg):
+    """The two heads of a reference detector config (`cfg.model.rpn_head`, `cfg.model.roi_head`, with `train_cfg` /
+    `test_cfg` injected as TwoStageDetector does, mmdet/models/detectors/two_stage.py:36-49) built from this package's
+    registry, honouring the config's `fp16` key exactly as tools/test.py:202-204 does.  `cfg`: the loaded config as a
+    (nested) dict.  Returns (rpn_head, roi_head)."""
+    model = cfg["model"]
+    train_cfg, test_cfg = model.get("train_cfg"), model.get("test_cfg")
+    rpn = deep_cfg(model["rpn_head"])
+    roi = deep_cfg(model["roi_head"])
+    if train_cfg is not None:
+        rpn.setdefault("train_cfg", deep_cfg(train_cfg.get("rpn")))
+        roi.setdefault("train_cfg", deep_cfg(train_cfg.get("rcnn")))
+    if test_cfg is not None:
+        rpn.setdefault("test_cfg", deep_cfg(test_cfg.get("rpn")))
+        roi.setdefault("test_cfg", deep_cfg(test_cfg.get("rcnn")))
+    rpn_head, roi_head = build_head(rpn), build_head(roi)
+    if cfg.get("fp16", None) is not None:
+        wrap_fp16_model([rpn_head, roi_head])
+    return rpn_head, roi_head

@@ -211,13 +211,14 @@ class QuasiDenseEmbedTracker(object):
         self.table.expire(frame_id, self.memo_tracklet_frames)
 
 
-def replay_tracking(records, tracker_cfg=None, tracker=None):
+def replay_tracking(records, tracker_cfg=None, tracker=None, first_count=1):
     """records: [(frame_id, bboxes[n,5], labels[n], embeds[n,256])] of ALL frames (any order); replays `match` in
     frame order like polyphonic_former_video.py:391-402 (frame_id = running count from 1, ids + 1, -1 -> 0).
-    Returns {frame_id: ids tensor}."""
+    A stream that arrives in batches passes its persistent `tracker` and `first_count` = 1 + the number of non-empty frames
+    replayed so far.  Returns {frame_id: ids tensor}."""
     if tracker is None:
         tracker = QuasiDenseEmbedTracker(**(tracker_cfg or {}))
-    out, cnt = {}, 1
+    out, cnt = {}, first_count
     for fid, bb, lab, emb in sorted(records, key=lambda r: r[0]):
         if bb.shape[0] > 0:
             _, _, ids = tracker.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)

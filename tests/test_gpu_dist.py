@@ -90,6 +90,76 @@ def test_bench_launches_its_own_ranks(gpu):
     assert tag["2"]["world_size"] == 2 and tag["2"]["payload_round_trip_exact"] and tag["2"]["collective_us_per_step"] > 0
 
 
+# ---- cfg4: clips sharded over the ranks, ids equal to the single-process video loop ------------------------------------------
+def _cfg4_worker(rank, world, port, backend, steps, q):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.set_grad_enabled(False)
+    run, _ = bench.cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=steps, warmup=0, collect_ids=True)
+    q.put((rank, run))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _cfg4(world, backend, steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cfg4_worker, args=(r, world, port, backend, steps, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in ps)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_cfg4_sharded_clips_track_ids_equal_the_single_process_video_loop(gpu):
+    """BASELINE configs[3] (`bench.py --workload cfg4`): the video's frames sharded as one clip per rank, ONE all-gather of
+    the track records per step, the tracker replayed in frame order -- the integer track ids of every frame must equal,
+    bit for bit, what ONE process gets that walks the same frames in order (polyphonic/apis/video_inference.py:8-31).
+    Ranks = the visible GPUs over nccl (= RCCL); on a single-GPU box additionally two ranks sharing the GPU over gloo, so
+    that the sharded path (shard_frames, all-gather, replay with a persistent tracker) is crossed with world > 1."""
+    ndev = torch.cuda.device_count()
+    # the same 8 frames: world 1 walks them as 4 steps of one 2-frame clip; world 2 as 2 steps of two clips; world = ndev ...
+    one = _cfg4(1, "nccl", 4)[0]
+    assert one["world_size"] == 1 and len(one["track_ids"]) == 8
+    assert sum(len(v) for v in one["track_ids"].values()) > 0, "no thing segment was tracked: the comparison would be vacuous"
+    two = _cfg4(2, "nccl" if ndev >= 2 else "gloo", 2)
+    for r in (0, 1):
+        assert two[r]["world_size"] == 2
+        assert two[r]["track_ids"] == one["track_ids"], (r, two[r]["track_ids"], one["track_ids"])
+    if ndev >= 4 and 8 % (2 * ndev) == 0:
+        allr = _cfg4(ndev, "nccl", 8 // (2 * ndev))
+        for r in range(ndev):
+            assert allr[r]["track_ids"] == one["track_ids"]
+
+
+def test_bench_cfg4_json_line(gpu):
+    """`python bench.py --workload cfg4 --gpus N`: one JSON line with the metric, the collective's time, roofline and
+    cpu_baseline; the process group spans exactly --gpus ranks"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "cfg4", "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["unit"] == "frames/s" and res["scaling"] == "weak"
+    assert res["cfg4"]["world_size"] == 1 and res["cfg4"]["allgather_track_records_us_per_step"] > 0
+    assert res["roofline"]["kernel"] == "pool" and 0 < res["roofline"]["frac"] < 1
+
+
 # ---- data-parallel training step: two ranks, gradients averaged by dist.GradBuckets -------------------------------------------
 def _train_heads(dev):
     sys.path.insert(0, os.path.join(REPO, "tests"))

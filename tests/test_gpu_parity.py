@@ -328,6 +328,27 @@ def test_kernel_head_fp16_grade_and_handoff(gpu, weights):
         assert torch.equal(t, u)
 
 
+@pytest.mark.parametrize("mode", ["mixed16", "mixed"])
+def test_parity_grade_kernel_head_hands_hi_planes_to_the_mixed_modes(gpu, weights, mode):
+    """KernelHead at the parity grade (hi + lo bf16 planes) -> KernelUpdateIterHead in a mode that reads ONE bf16 plane: the hi
+    plane and the mask bits are adopted (no ingest / binarize pass) and decode to exactly what the fp32 tensors of the same
+    call decode to through the ingest kernel"""
+    B, H, W = 2, 8, 16
+    feats = [f.to(gpu) for f in Hh.neck_inputs(41, B, 256, H, W)]
+    kh = _kernel_head(weights, "fp32")
+    metas = [Hh.img_meta(H * 8, W * 8)] * B
+    (pf, xf, mp, cs, seg, df, dp, dpr, _) = kh.simple_test_rpn(feats, metas)
+    ih = _iter_head(weights, 3, precision=mode)
+    ih.set_precision(mode, torch.float16)
+    a = [t.clone() for t in ih.simple_test_mask_preds(xf, pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)]
+    plan = next(iter(ih._plans.values()))
+    assert plan.handoff_runs == 1
+    b = ih.simple_test_mask_preds(xf.clone(), pf, mp, cs, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)   # no hand-off
+    assert plan.handoff_runs == 1
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+
+
 def test_bf16_feature_inputs_skip_ingest(gpu, weights):
     """bf16 NCHW feature tensors are the plane format: same result as fp32 inputs rounded by the ingest kernel"""
     B, N, H, W, S = 1, 111, 8, 16, 2

@@ -149,3 +149,26 @@ def test_accept_loop_matches_reference_segments(case):
         assert a["id"] == b["id"] and a["category_id"] == b["category_id"] and a["isthing"] == b["isthing"]
     pan = torch.from_numpy(newid)[ids].numpy().astype(np.int32)
     assert np.array_equal(pan, z[f"{case}_pan"])
+
+
+def test_fp16_config_key_switches_both_heads():
+    """the reference's only mixed-precision hook is the config's `fp16` key (tools/test.py:202-204: wrap_fp16_model): heads
+    built from a detector config that carries it run at their fp16 grades, without it at the parity grade"""
+    import torch
+    from helpers import stage_cfg
+    from polyphonicformer_amd.registry import build_heads_from_config
+    import polyphonicformer_amd.kernel_head, polyphonicformer_amd.kernel_update  # noqa: F401,E401
+    model = dict(
+        type="PolyphonicFormer",
+        rpn_head=dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11,
+                      cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False, use_binary=True, proposal_feats_with_obj=True,
+                      localization_fpn=None, loss_seg=dict(type="FocalLoss", use_sigmoid=True)),
+        roi_head=dict(type="KernelUpdateIterHead", num_stages=3, assign_stages=3, stage_loss_weights=[1, 1, 1], num_proposals=100,
+                      num_thing_classes=8, num_stuff_classes=11, do_panoptic=True, mask_head=stage_cfg(256, 2048, 8, 19, 8, 11)),
+        train_cfg=None, test_cfg=dict(rpn=None, rcnn=dict(max_per_img=100, mask_thr=0.5)))
+    rpn, roi = build_heads_from_config(dict(model=model))
+    assert rpn.precision == "fp32" and roi.precision == "fp32" and roi.output_dtype == torch.float32
+    assert roi.test_cfg.max_per_img == 100
+    rpn, roi = build_heads_from_config(dict(model=model, fp16=dict(loss_scale=512.)))
+    assert rpn.precision == "fp16" and roi.precision == "fp16" and roi.output_dtype == torch.float16
+    assert all(h.precision == "fp16" for h in roi.mask_head)
