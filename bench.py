@@ -104,11 +104,11 @@ def kernel_breakdown(plan, iters=4):
     for s in range(p.S):
         last = s == p.S - 1
         o = p.stage_out[s]
-        seq.append(("pool", lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial)))
+        seq.append(("pool", lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial, counts=p.pcount)))
         for name, ph in (("query_pre", 1), ("query_post", 2)):
             seq.append((name, lambda ph=ph, k=k, q=q, s=s, last=last: E.query_stage(
                 p.partial, p.bits, k, q, p.packs[s], p.N, p.HW, cls_sigmoid=last, outs=p.stage_out[s], workspace=p.ws,
-                phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt)))
+                phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt, counts=p.pcount)))
         if not last:
             seq.append(("dynconv_bits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits)))
         else:

@@ -40,8 +40,12 @@ enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWOR
  *   PH_PREC_F16          IEEE fp16, one plane each (1 MFMA, ~2^-12 per operand; |values| < 65504)
  *   PH_PREC_BF16_KF16    ph_dynconv only: bf16 features in ONE plane, the dynamic kernels as ONE fp16 plane (PH_KERN_F16); the
  *                        feature fragments are converted to fp16 in registers (exact inside fp16's normal range) and the
- *                        product is one f16 MFMA: ~2^-12 on the kernels only -- 2.5e-4 per stage, single-plane speed. */
-enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5, PH_PREC_BF16_KF16 = 6 };
+ *                        product is one f16 MFMA: ~2^-12 on the kernels only -- 2.5e-4 per stage, single-plane speed.
+ *   PH_PREC_QHYBRID      ph_query_stage only: the updator half (pooled sums, gate products: unbounded operands) as
+ *                        PH_PREC_SPLIT, the attention / FFN / fc-tower half -- every product there has a LayerNorm- or softmax-
+ *                        bounded operand -- as ONE fp16 plane of weights and activations (1 MFMA, 2^-12 per operand, half the
+ *                        weight stream); weights packed accordingly (pack.py), dynamic kernels out as PH_KERN_F16. */
+enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5, PH_PREC_BF16_KF16 = 6, PH_PREC_QHYBRID = 7 };
 enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1, PH_OUT_F16 = 2 };
 enum { PH_KERN_BF16_PLANES = 0, PH_KERN_F16 = 1 };   /* ph_query_stage: format of the dynamic conv kernels it emits */
 enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3, PH_GN_TO_CPLANES = 4 };   /* ph_gn_apply modes */
@@ -79,6 +83,10 @@ int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bi
  * kernel_head.py:314-320 pools over the THING rows of the full mask tensor */
 int ph_pool_rows(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial,
                  int B, int N, int64_t HW, int nsplit, int prec, void* stream);
+/* ph_pool that also writes pcount[B][nsplit][ph_n_padded(N)] (int32): the set bits of every mask row in every pixel range -- the
+ * `count(M)` of the folded feat_transform bias (kernel_update_head.py:225,241), handed to ph_query_stage_counts */
+int ph_pool_counts(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int32_t* pcount,
+                   int B, int N, int64_t HW, int nsplit, int prec, void* stream);
 
 /* ---- packed per-stage weights -------------------------------------------------------------
  * One KernelUpdateHead stage (kernel_update_head.py:21-191 parameters) packed by the host into
@@ -149,6 +157,13 @@ int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits,
                    int B, int N, int64_t HW, int prec /* PH_PREC_BF16 | PH_PREC_SPLIT */,
                    int kern_format /* PH_KERN_BF16_PLANES: [P][2][B][Npad][256]; PH_KERN_F16: one fp16 plane */,
                    int phases, void* stream);
+/* the same, taking the hard masks' pixel counts from ph_pool_counts instead of counting the bit rows again; prec may also
+ * be PH_PREC_QHYBRID (with PH_KERN_F16) in both entry points */
+int ph_query_stage_counts(const float* partial, int nsplit, const uint32_t* bits, const int32_t* pcount, const float* k_in,
+                          const float* q_in, const uint16_t* wb, const float* wf, const ph_stage_layout* layout,
+                          float* obj, float* dobj, float* cls, int cls_sigmoid, uint16_t* kern, float* kbias,
+                          void* workspace, size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format,
+                          int phases, void* stream);
 
 /* ---- A13: dynamic 1x1 convolution -----------------------------------------------------------
  * kernel_update_head.py:317-329: logits[b][n][hw] = sum_c kern[b][n][c] * feat[b][c][hw] + kbias[b][n].

@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- MUST precede dlopen: libpolyhead has to bind to t
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
-PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16, PH_PREC_BF16_KF16 = 1, 2, 3, 5, 6
+PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16, PH_PREC_BF16_KF16, PH_PREC_QHYBRID = 1, 2, 3, 5, 6, 7
 PH_QUERY_WIDE = 0x100            # ph_query_stage phases flag: most rows per workgroup (launches that share the GPU)
 PH_OUT_F32, PH_OUT_BF16, PH_OUT_F16 = 0, 1, 2
 PH_KERN_BF16_PLANES, PH_KERN_F16 = 0, 1
@@ -38,9 +38,12 @@ SIGNATURES = {
     "ph_binarize": (C.c_int, [_P, _L, _P, _I, _I, _L, _P]),
     "ph_pool": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "ph_pool_rows": (C.c_int, [_P, _P, _P, _I, _P, _I, _I, _L, _I, _I, _P]),
+    "ph_pool_counts": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "ph_query_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ph_query_stage": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
                                  _P, _Z, _I, _I, _L, _I, _I, _I, _P]),
+    "ph_query_stage_counts": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(StageLayout), _P, _P, _P, _I, _P, _P,
+                                        _P, _Z, _I, _I, _L, _I, _I, _I, _P]),
     "ph_query_workspace_updator_offset": (C.c_size_t, [_I, _I, _I]),
     "ph_dynconv": (C.c_int, [_P, _P, _L, _L, _P, _L, _P, _P, _I, _L, _I, _I, _L, _I, _P]),
     "ph_khead_workspace_bytes": (C.c_size_t, [_I, _L, _I]),

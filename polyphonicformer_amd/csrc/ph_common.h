@@ -115,6 +115,12 @@ __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
 __device__ __forceinline__ uint32_t bf2h_pk(uint32_t w) { return f2h_pk(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)); }
 __device__ __forceinline__ uint4 bf2h_x8(uint4 v) { return make_uint4(bf2h_pk(v.x), bf2h_pk(v.y), bf2h_pk(v.z), bf2h_pk(v.w)); }
 
+template <int E> __device__ __forceinline__ f32x4_t mfma16e(uint4 a, uint4 b, f32x4_t c) {
+    if constexpr (E == PH_E_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return mfma16(a, b, c);
+}
 template <int E> __device__ __forceinline__ f32x16_t mfma32e(uint4 a, uint4 b, f32x16_t c) {
     if constexpr (E == PH_E_F16 || E == PH_E_F16_FROM_BF16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);

@@ -64,7 +64,7 @@ __device__ __forceinline__ int pool_swz(int row) { return (row >> 1) & 7; }
 template <int PA /*feature planes: 1 or 2*/, int NRT /*Npad/32*/, int E /*element format of the planes*/>
 __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xplanes, const uint16_t* __restrict__ dplanes,
                                               const uint32_t* __restrict__ bits, float* __restrict__ partial,
-                                              int B, int64_t HWp, int nsplit, int bits_rows) {
+                                              int B, int64_t HWp, int nsplit, int bits_rows, int32_t* __restrict__ pcount) {
     constexpr int Npad = NRT * 32;
     constexpr int NBI = (Npad * 2 + 63) / 64;                         // DMA instructions for the mask words of a chunk
     constexpr int NBW = (NBI + 3) / 4;                                // ... issued per wave
@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+    // pixel counts of the hard masks over this pixel range (the bias term of the folded feat_transform needs them,
+    // kernel_update_head.py:225,241): the mask words pass through this kernel anyway -- wave 0 of the first channel group
+    // counts them, so the query kernel does not read the bit rows again
+    const bool counting = pcount != nullptr && cg == 0 && wave == 0;
+    int pc[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) pc[rt] = 0;
 
     // LDS-DMA of chunk c: features = 16 wave-instructions of 1 KiB (8 channel rows x 128 B) per plane, mask
     // words = NBI instructions of 64 x 4 B (row = l>>1, word = l&1).  Nothing in the loop is a VGPR load, so the
@@ -165,6 +172,10 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         for (int rt = 0; rt < NRT; ++rt) w[rt] = lds_read32_asm(wb + 4 * ((rt * 32 + (lane & 31)) * 2 + g));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if (counting) {
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) pc[rt] += __popc(w[rt]);
+        }
         // A fragments from the lookup table, one row tile ahead of the MFMAs (LDS returns in order: lgkmcnt(4))
         u32x4_t a[2][4];
 #pragma unroll
@@ -194,6 +205,14 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         cur = cur + 1 == POOL_NBUF ? 0 : cur + 1;
     }
 
+    if (counting) {
+        // lane (row l & 31, half g) holds the count of its 32-pixel halves: add the two halves, lanes 0..31 write
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int tot = pc[rt] + __shfl_xor(pc[rt], 32);
+            if (lane < 32) pcount[((int64_t)b * nsplit + split) * Npad + rt * 32 + lane] = tot;
+        }
+    }
     // epilogue: partial[b][split][row][map*256 + ch]
     float* out = partial + (((int64_t)b * nsplit + split) * Npad) * 512 + map * 256 + ch0 + wave * 32 + (lane & 31);
 #pragma unroll
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
 
 template <int PA, int NRT, int E>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
-                        int nsplit, int bits_rows, hipStream_t s) {
+                        int nsplit, int bits_rows, int32_t* pcount, hipStream_t s) {
     const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
     static const bool once = [&] {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -215,11 +234,11 @@ static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bi
     }();
     (void)once;
     hipLaunchKernelGGL((k_pool<PA, NRT, E>), dim3(nsplit, d ? 4 : 2, B), dim3(256), lds, s, x, d, bits, partial, B, HWp,
-                       nsplit, bits_rows);
+                       nsplit, bits_rows, pcount);
 }
 
-static int pool_run(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial, int B,
-                    int N, int64_t HW, int nsplit, int prec, void* stream, const char* fn) {
+static int pool_run(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial, int32_t* pcount,
+                    int B, int N, int64_t HW, int nsplit, int prec, void* stream, const char* fn) {
     if (!(xplanes && bits && partial && B > 0 && N > 0 && HW > 0)) { ph_set_error("%s: bad pointer or size", fn); return PH_EINVAL; }
     if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16)) {
         ph_set_error("%s: prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16", fn);
@@ -234,9 +253,9 @@ static int pool_run(const uint16_t* xplanes, const uint16_t* dplanes, const uint
     hipStream_t s = (hipStream_t)stream;
 #define PH_POOL_CASE(R)                                                                         \
     case R:                                                                                     \
-        if (prec == PH_PREC_BF16) launch_pool<1, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s); \
-        else if (prec == PH_PREC_F16) launch_pool<1, R, PH_E_F16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s); \
-        else launch_pool<2, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, s);             \
+        if (prec == PH_PREC_BF16) launch_pool<1, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, pcount, s); \
+        else if (prec == PH_PREC_F16) launch_pool<1, R, PH_E_F16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, pcount, s); \
+        else launch_pool<2, R, PH_E_BF16>(xplanes, dplanes, bits, partial, B, HWp, nsplit, bits_rows, pcount, s);             \
         break;
     switch (nrt) {
         PH_POOL_CASE(1) PH_POOL_CASE(2) PH_POOL_CASE(3) PH_POOL_CASE(4)
@@ -250,12 +269,20 @@ static int pool_run(const uint16_t* xplanes, const uint16_t* dplanes, const uint
 
 extern "C" int ph_pool(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int B,
                        int N, int64_t HW, int nsplit, int prec, void* stream) {
-    return pool_run(xplanes, dplanes, bits, 0, partial, B, N, HW, nsplit, prec, stream, __func__);
+    return pool_run(xplanes, dplanes, bits, 0, partial, nullptr, B, N, HW, nsplit, prec, stream, __func__);
 }
 
 // the same over the FIRST ph_n_padded(N) rows of a bits tensor with `bits_rows` rows per frame (KernelHead's object
 // pooling over the thing rows of the full mask-bit tensor, kernel_head.py:314-320: no copy of the thing rows)
 extern "C" int ph_pool_rows(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, int bits_rows, float* partial,
                             int B, int N, int64_t HW, int nsplit, int prec, void* stream) {
-    return pool_run(xplanes, dplanes, bits, bits_rows, partial, B, N, HW, nsplit, prec, stream, __func__);
+    return pool_run(xplanes, dplanes, bits, bits_rows, partial, nullptr, B, N, HW, nsplit, prec, stream, __func__);
+}
+
+// ph_pool that also writes pcount[B][nsplit][Npad] (int32): the number of set mask bits of every row in every pixel range --
+// what ph_query_stage_counts takes instead of re-reading the bit rows
+extern "C" int ph_pool_counts(const uint16_t* xplanes, const uint16_t* dplanes, const uint32_t* bits, float* partial, int32_t* pcount,
+                              int B, int N, int64_t HW, int nsplit, int prec, void* stream) {
+    if (!pcount) { ph_set_error("ph_pool_counts: null pcount"); return PH_EINVAL; }
+    return pool_run(xplanes, dplanes, bits, 0, partial, pcount, B, N, HW, nsplit, prec, stream, __func__);
 }

@@ -39,6 +39,7 @@ struct QArgs {
     ph_stage_layout lay;
     int nsplit, B, N, Npad, cls_sigmoid, kern_f16;
     int64_t HWp;
+    const int32_t* pcount;     // optional [B][nsplit][Npad]: set bits per row and pixel range from ph_pool_counts (else counted from `bits`)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -135,7 +136,7 @@ __device__ __forceinline__ void tile_add_bias(Tile<NRT>& t, const float* __restr
 }
 
 // bf16 plane(s) of a tile -> LDS activation buffer [rows][LDA]
-template <int PA, int NRT>
+template <int PA, int NRT, int E = PH_E_BF16>
 __device__ __forceinline__ void tile_to_lds(const Tile<NRT>& t, uint16_t* dst, int plane, int wave, int lane) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -145,7 +146,7 @@ __device__ __forceinline__ void tile_to_lds(const Tile<NRT>& t, uint16_t* dst, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = (rt * 16 + g * 4 + r) * LDA + wave * WCOLS + ct * 16 + i;
-                if (PA == 1) dst[off] = (uint16_t)f2bf(t.v[rt][ct][r]);
+                if (PA == 1) dst[off] = (uint16_t)f2e<E>(t.v[rt][ct][r]);
                 else {
                     uint32_t hi, lo;
                     f2bf_split(t.v[rt][ct][r], hi, lo);
@@ -241,7 +242,8 @@ __device__ __forceinline__ void ln_tiles(Tile<NRT> (&t)[NT], const float* const 
 //  k_query_pre
 // ================================================================================================
 // in-projection epilogue: + bias, q scaled by head_dim^-0.5, bf16 plane(s) to the workspace
-template <int PA, int NRT, int PART>
+// QF16: ONE fp16 plane instead (the hybrid grade: the post kernel runs its products in fp16)
+template <int PA, int NRT, int PART, bool QF16 = false>
 __device__ __forceinline__ void store_qkv(const Tile<NRT>& T, const QArgs& a, const float* bias, int64_t qk_base,
                                           int64_t qk_plane, int64_t vt_base, int wave, int lane) {
     const int i = lane & 15, g = lane >> 4;
@@ -256,7 +258,8 @@ __device__ __forceinline__ void store_qkv(const Tile<NRT>& T, const QArgs& a, co
             for (int r = 0; r < 4; ++r) {
                 float v = T.v[rt][ct][r] + bv;
                 if (PART == 0) v *= 0.17677669529663687f;   // q * head_dim^-0.5
-                if (PA == 2) f2bf_split(v, hi[r], lo[r]);
+                if (QF16) { hi[r] = f2h(v); lo[r] = 0; }
+                else if (PA == 2) f2bf_split(v, hi[r], lo[r]);
                 else hi[r] = f2bf(v);
             }
             if (PART < 2) {
@@ -264,12 +267,12 @@ __device__ __forceinline__ void store_qkv(const Tile<NRT>& T, const QArgs& a, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dst[r * 256] = (uint16_t)hi[r];
-                    if (PA == 2) dst[qk_plane + r * 256] = (uint16_t)lo[r];
+                    if (PA == 2 && !QF16) dst[qk_plane + r * 256] = (uint16_t)lo[r];
                 }
             } else {   // V transposed: [feature][query row], 4 consecutive rows per lane
                 uint16_t* dst = a.Vt + vt_base + (int64_t)col * a.Npad + rt * 16 + g * 4;
                 *(uint2*)dst = make_uint2(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]));
-                if (PA == 2) *(uint2*)(dst + qk_plane) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
+                if (PA == 2 && !QF16) *(uint2*)(dst + qk_plane) = make_uint2(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]));
             }
         }
     }
@@ -905,7 +908,7 @@ __device__ __forceinline__ void w_prime(WStream<PA, NCT>& ws, const WRef2& r, in
 struct NoNext { __device__ __forceinline__ void operator()() const {} };
 
 // acc[rt][ct] += A(LDS [NRT*16 rows][lda], k-steps 0..NKS-1) x W(r);  `next()` is run when f[0] has become free
-template <int PA, int NRT, int NCT, int NKS, typename Next>
+template <int PA, int NRT, int NCT, int NKS, int E = PH_E_BF16, typename Next>
 __device__ __forceinline__ void gemm_stream(f32x4_t (&acc)[NRT][NCT], const uint16_t* A, int lda, int a_plane, WStream<PA, NCT>& ws,
                                             const WRef2& r, int64_t w_plane, int lane, Next next) {
     constexpr int KCH = kch<PA>(), NCH = NKS / KCH;
@@ -929,7 +932,7 @@ __device__ __forceinline__ void gemm_stream(f32x4_t (&acc)[NRT][NCT], const uint
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
-                    acc[rt][ct] = mfma16(a[0][rt], ws.f[kc & 1][0][k][ct], acc[rt][ct]);
+                    acc[rt][ct] = mfma16e<E>(a[0][rt], ws.f[kc & 1][0][k][ct], acc[rt][ct]);
                     if (PA == 2) {
                         acc[rt][ct] = mfma16(a[0][rt], ws.f[kc & 1][PA - 1][k][ct], acc[rt][ct]);
                         acc[rt][ct] = mfma16(a[PA - 1][rt], ws.f[kc & 1][0][k][ct], acc[rt][ct]);
@@ -941,7 +944,7 @@ __device__ __forceinline__ void gemm_stream(f32x4_t (&acc)[NRT][NCT], const uint
 }
 
 // bf16 plane(s) of an [NRT*16 x 16*NCT]-per-wave tile -> LDS buffer with row stride `ld`, column offset `col0`
-template <int PA, int NRT, int NCT>
+template <int PA, int NRT, int NCT, int E = PH_E_BF16>
 __device__ __forceinline__ void frag_to_lds(const f32x4_t (&t)[NRT][NCT], uint16_t* dst, int ld, int plane, int col0, int lane) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -951,7 +954,7 @@ __device__ __forceinline__ void frag_to_lds(const f32x4_t (&t)[NRT][NCT], uint16
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = (rt * 16 + g * 4 + r) * ld + col0 + ct * 16 + i;
-                if (PA == 1) dst[off] = (uint16_t)f2bf(t[rt][ct][r]);
+                if (PA == 1) dst[off] = (uint16_t)f2e<E>(t[rt][ct][r]);
                 else {
                     uint32_t hi, lo;
                     f2bf_split(t[rt][ct][r], hi, lo);
@@ -973,7 +976,7 @@ struct QArgs2 {
             aa.tl[(k)] = __builtin_amdgcn_s_memrealtime();                                                   \
     } while (0)
 
-template <int PA, int NRT>
+template <int PA, int NRT, bool QF16 = false>
 __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     const QArgs& a = aa.q;
     constexpr int ROWS = NRT * 16;
@@ -1026,14 +1029,19 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
             for (int e = 0; e < 16; ++e) u[e] = 0.f;
             int c = 0;
             if (row < Npad) {
-                const uint4* bw = (const uint4*)(a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32));
-                const int nq = (int)(a.HWp / 128);
-                for (int w0 = tid & 15; w0 < nq; w0 += 128) {
-                    uint4 q[8];
+                if (a.pcount) {
+                    // the pooling kernel counted the set bits of its pixel range: nsplit integers per row instead of HWp / 32 words
+                    for (int s0 = tid & 15; s0 < a.nsplit; s0 += 16) c += a.pcount[((int64_t)b * a.nsplit + s0) * Npad + row];
+                } else {
+                    const uint4* bw = (const uint4*)(a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32));
+                    const int nq = (int)(a.HWp / 128);
+                    for (int w0 = tid & 15; w0 < nq; w0 += 128) {
+                        uint4 q[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) q[j] = w0 + 16 * j < nq ? bw[w0 + 16 * j] : make_uint4(0, 0, 0, 0);
+                        for (int j = 0; j < 8; ++j) q[j] = w0 + 16 * j < nq ? bw[w0 + 16 * j] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) c += __popc(q[j].x) + __popc(q[j].y) + __popc(q[j].z) + __popc(q[j].w);
+                        for (int j = 0; j < 8; ++j) c += __popc(q[j].x) + __popc(q[j].y) + __popc(q[j].z) + __popc(q[j].w);
+                    }
                 }
                 for (int s0 = 0; s0 < a.nsplit; s0 += 4) {
                     float4 v[4][4];
@@ -1242,13 +1250,13 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
         Tile<NRT> T;
         tile_zero(T.v);
         gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_q, wpl, lane, prime(c_k));
-        store_qkv<PA, NRT, 0>(T, a, qkv_bias, qk_base, qk_plane, vt_base, wave, lane);
+        store_qkv<PA, NRT, 0, QF16>(T, a, qkv_bias, qk_base, qk_plane, vt_base, wave, lane);
         tile_zero(T.v);
         gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_k, wpl, lane, prime(c_v));
-        store_qkv<PA, NRT, 1>(T, a, qkv_bias + 256, qk_base, qk_plane, vt_base, wave, lane);
+        store_qkv<PA, NRT, 1, QF16>(T, a, qkv_bias + 256, qk_base, qk_plane, vt_base, wave, lane);
         tile_zero(T.v);
         gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_v, wpl, lane, NoNext());
-        store_qkv<PA, NRT, 2>(T, a, qkv_bias + 512, qk_base, qk_plane, vt_base, wave, lane);
+        store_qkv<PA, NRT, 2, QF16>(T, a, qkv_bias + 512, qk_base, qk_plane, vt_base, wave, lane);
     }
     PH_TL(7);
 }
@@ -1260,7 +1268,10 @@ template <int PA, int NRT> constexpr int post2_nhb() {
     return ((size_t)PA * NRT * 16 * LDA * 2 + 2 * (size_t)PA * NRT * 16 * (post2_hc<PA>() + 8) * 2 + 2 * 2 * NW * NRT * 16 * 4 + NW * PA * 16 * LDPT * 2 <= 150 * 1024) ? 2 : 1;
 }
 
-template <int PA, int NRT>
+// E: element format of the single-plane form (PA = 1): bf16 (the fast mode) or fp16 (the hybrid grade: q / k / v, weights,
+// LDS activations and attention probabilities as ONE fp16 plane -- every product of this kernel has a LayerNorm- or
+// softmax-bounded operand, 2^-12 per operand instead of hi + lo bf16 at three MFMAs)
+template <int PA, int NRT, int E = PH_E_BF16>
 __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
     const QArgs& a = aa.q;
     constexpr int ROWS = NRT * 16;
@@ -1327,7 +1338,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
         };
         auto score = [&](const uint4 (&kf)[PA], int rt) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-            s = mfma16(qf[0][rt], kf[0], s);
+            s = mfma16e<E>(qf[0][rt], kf[0], s);
             if (PA == 2) { s = mfma16(qf[0][rt], kf[PA - 1], s); s = mfma16(qf[PA - 1][rt], kf[0], s); }
             return s;
         };
@@ -1374,7 +1385,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                             f2bf_split(pv, hi, lo);
                             Pt[off] = (uint16_t)hi;
                             Pt[16 * LDPT + off] = (uint16_t)lo;
-                        } else Pt[off] = (uint16_t)f2bf(pv);
+                        } else Pt[off] = (uint16_t)f2e<E>(pv);
                     }
                 }
                 // the tile is private to this wave and LDS operations of one wave complete in order: no barrier
@@ -1383,7 +1394,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                 for (int p = 0; p < PA; ++p) pf[p] = *(const uint4*)(Pt + p * 16 * LDPT + i * LDPT + g * 8);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    At.v[rt][ct] = mfma16(pf[0], vf[ct][0], At.v[rt][ct]);
+                    At.v[rt][ct] = mfma16e<E>(pf[0], vf[ct][0], At.v[rt][ct]);
                     if (PA == 2) {
                         At.v[rt][ct] = mfma16(pf[0], vf[ct][PA - 1], At.v[rt][ct]);
                         At.v[rt][ct] = mfma16(pf[PA - 1], vf[ct][0], At.v[rt][ct]);
@@ -1400,14 +1411,14 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                 for (int ct = 0; ct < 2; ++ct) At.v[rt][ct][r] *= inv;
             }
     }
-    tile_to_lds<PA, NRT>(At, act, PLANE, wave, lane);
+    tile_to_lds<PA, NRT, E>(At, act, PLANE, wave, lane);
     __syncthreads();
 
     PH_TL(9);
     // ---- out_proj + identity + attention_norm (kernel_update_head.py:259-260) ----------------------------------------------
     Tile<NRT> O2[1];
     tile_zero(O2[0].v);
-    gemm_stream<PA, NRT, CT, 8>(O2[0].v, act, LDA, PLANE, ws, c_out, wpl, lane, [&]() { ffn1_prime(0); });
+    gemm_stream<PA, NRT, CT, 8, E>(O2[0].v, act, LDA, PLANE, ws, c_out, wpl, lane, [&]() { ffn1_prime(0); });
     tile_add_bias(O2[0], wf + VO[PH_V_OUT_B], wave, lane);
     {
         const float* o1 = a.o1 + (((int64_t)b * 2 + br) * Npad + row0) * 256;
@@ -1421,7 +1432,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
         const float* const bt[1] = {wf + VO[PH_V_LN_ATT_B]};
         ln_tiles<NRT, 1>(O2, gm, bt, red, wave, lane);          // barriers: readers of the attention output are done
     }
-    tile_to_lds<PA, NRT>(O2[0], act, PLANE, wave, lane);
+    tile_to_lds<PA, NRT, E>(O2[0], act, PLANE, wave, lane);
     // the FFN's residual waits in the scratch (each lane reads back what it wrote): 40 registers less across the FFN loop
     float* park = aa.pi + ((((int64_t)b * 2 + br) * Npad + row0) * 2) * 256;
 #pragma unroll
@@ -1447,8 +1458,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < CTH; ++ct) Hc[rt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if constexpr (CTH == CT) gemm_stream<PA, NRT, CT, 8>(Hc, act, LDA, PLANE, ws, ffn1_ref(c), wpl, lane, prime(w2));
-            else gemm_stream<PA, NRT, 1, 8>(Hc, act, LDA, PLANE, ws1, ffn1_ref(c), wpl, lane, prime(w2));
+            if constexpr (CTH == CT) gemm_stream<PA, NRT, CT, 8, E>(Hc, act, LDA, PLANE, ws, ffn1_ref(c), wpl, lane, prime(w2));
+            else gemm_stream<PA, NRT, 1, 8, E>(Hc, act, LDA, PLANE, ws1, ffn1_ref(c), wpl, lane, prime(w2));
 #pragma unroll
             for (int ct = 0; ct < CTH; ++ct) {
                 const float bv = (wf + VO[PH_V_FFN1_B])[c * HC + (wave * CTH + ct) * 16 + i];
@@ -1458,10 +1469,10 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                     for (int r = 0; r < 4; ++r) Hc[rt][ct][r] = fmaxf(Hc[rt][ct][r] + bv, 0.f);
             }
             if (NHB == 1 && c > 0) __syncthreads();             // every wave is done reading the previous chunk
-            frag_to_lds<PA, NRT, CTH>(Hc, hc, LDH, HPLANE, wave * CTH * 16, lane);
+            frag_to_lds<PA, NRT, CTH, E>(Hc, hc, LDH, HPLANE, wave * CTH * 16, lane);
             __syncthreads();
             // while the last weight chunk of this call is consumed: the next hidden chunk's first layer, or the first head
-            gemm_stream<PA, NRT, CT, HC / 32>(O3[0].v, hc, LDH, HPLANE, ws, w2, wpl, lane, [&]() {
+            gemm_stream<PA, NRT, CT, HC / 32, E>(O3[0].v, hc, LDH, HPLANE, ws, w2, wpl, lane, [&]() {
                 if (c + 1 < nchunk) ffn1_prime(c + 1);
                 else w_prime<PA, CT>(ws, br == 0 ? c_h0b : c_h0a, wpl, lane);
             });
@@ -1492,7 +1503,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                     if (row0 + rr < N) out[rr * 256 + wave * WCOLS + ct * 16 + i] = O3[0].v[rt][ct][r];
                 }
     }
-    tile_to_lds<PA, NRT>(O3[0], act, PLANE, wave, lane);
+    tile_to_lds<PA, NRT, E>(O3[0], act, PLANE, wave, lane);
     __syncthreads();
 
     PH_TL(12);
@@ -1501,7 +1512,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
     if (br == 0) {
         // mask_fcs first (its activation waits in registers), then cls_fcs; each Linear -> LN -> ReLU (:161-180)
         tile_zero(Hm[0].v);
-        gemm_stream<PA, NRT, CT, 8>(Hm[0].v, act, LDA, PLANE, ws, c_h0b, wpl, lane, prime(c_h0a));
+        gemm_stream<PA, NRT, CT, 8, E>(Hm[0].v, act, LDA, PLANE, ws, c_h0b, wpl, lane, prime(c_h0a));
         {
             const float* const gm[1] = {wf + VO[PH_V_LN_H0B_G]};
             const float* const bt[1] = {wf + VO[PH_V_LN_H0B_B]};
@@ -1511,7 +1522,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
         tile_zero(Hd[0].v);
         const int L = a.lay.num_classes, nct = (L + 15) / 16;
         auto cls_ref = [&](int ct) { return WRef2{wb + WO[PH_W_CLS], ct, 8, 0}; };
-        gemm_stream<PA, NRT, CT, 8>(Hd[0].v, act, LDA, PLANE, ws, c_h0a, wpl, lane, [&]() {
+        gemm_stream<PA, NRT, CT, 8, E>(Hd[0].v, act, LDA, PLANE, ws, c_h0a, wpl, lane, [&]() {
             w_prime<PA, CT>(ws, c_kern, wpl, lane);                                   // waits through fc_cls
             if (wave < nct) w_prime<PA, 1>(ws1, cls_ref(wave), wpl, lane);
         });
@@ -1529,7 +1540,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                     Hd[0].v[rt][ct][r] = fmaxf(Hd[0].v[rt][ct][r], 0.f);
                     Hm[0].v[rt][ct][r] = fmaxf(Hm[0].v[rt][ct][r], 0.f);
                 }
-        tile_to_lds<PA, NRT>(Hd[0], act, PLANE, wave, lane);
+        tile_to_lds<PA, NRT, E>(Hd[0], act, PLANE, wave, lane);
         __syncthreads();
         // fc_cls (:285)
         const float* bc = wf + VO[PH_V_CLS_B];
@@ -1537,7 +1548,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
             f32x4_t acc[NRT][1];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) acc[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            gemm_stream<PA, NRT, 1, 8>(acc, act, LDA, PLANE, ws1, cls_ref(ct), wpl, lane, [&]() {
+            gemm_stream<PA, NRT, 1, 8, E>(acc, act, LDA, PLANE, ws1, cls_ref(ct), wpl, lane, [&]() {
                 if (ct + NW < nct) w_prime<PA, 1>(ws1, cls_ref(ct + NW), wpl, lane);
             });
             const int col = ct * 16 + i;
@@ -1558,17 +1569,17 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
         __syncthreads();                                          // fc_cls readers are done
     } else {
         tile_zero(Hm[0].v);
-        gemm_stream<PA, NRT, CT, 8>(Hm[0].v, act, LDA, PLANE, ws, c_h0a, wpl, lane, prime(c_kern));
+        gemm_stream<PA, NRT, CT, 8, E>(Hm[0].v, act, LDA, PLANE, ws, c_h0a, wpl, lane, prime(c_kern));
         const float* const gm[1] = {wf + VO[PH_V_LN_H0A_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_H0A_B]};
         ln_tiles<NRT, 1>(Hm, gm, bt, red, wave, lane);          // depth_regs: Linear + LN, NO activation (:182-187)
     }
-    tile_to_lds<PA, NRT>(Hm[0], act, PLANE, wave, lane);
+    tile_to_lds<PA, NRT, E>(Hm[0], act, PLANE, wave, lane);
     __syncthreads();
     {   // fc_mask / fc_depth folded with feat_transform / feat_depth_transform -> conv kernel + bias
         Tile<NRT> Kt;
         tile_zero(Kt.v);
-        gemm_stream<PA, NRT, CT, 8>(Kt.v, act, LDA, PLANE, ws, c_kern, wpl, lane, [&]() {
+        gemm_stream<PA, NRT, CT, 8, E>(Kt.v, act, LDA, PLANE, ws, c_kern, wpl, lane, [&]() {
             if (wave == 0) w_prime<PA, 1>(ws1, c_kb, wpl, lane);                      // column 256: kernel . transform bias
         });
         const float* bk = wf + VO[PH_V_KERN_B];
@@ -1597,7 +1608,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
             f32x4_t acc[NRT][1];
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) acc[rt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            gemm_stream<PA, NRT, 1, 8>(acc, act, LDA, PLANE, ws1, c_kb, wpl, lane, NoNext());
+            gemm_stream<PA, NRT, 1, 8, E>(acc, act, LDA, PLANE, ws1, c_kb, wpl, lane, NoNext());
             if (i == 0) {
                 const float bv = bk[256];
 #pragma unroll
@@ -1618,11 +1629,11 @@ static size_t q_ws_bytes(int B, int Npad, int PA) {
 }
 
 extern "C" size_t ph_query_workspace_updator_offset(int B, int N, int prec) {
-    return (size_t)(prec == PH_PREC_SPLIT ? 2 : 1) * 3 * B * 2 * ph_n_padded(N) * 256 * sizeof(uint16_t);
+    return (size_t)((prec == PH_PREC_SPLIT || prec == PH_PREC_QHYBRID) ? 2 : 1) * 3 * B * 2 * ph_n_padded(N) * 256 * sizeof(uint16_t);
 }
 
 extern "C" size_t ph_query_workspace_bytes(int B, int N, int prec) {
-    return q_ws_bytes(B, ph_n_padded(N), prec == PH_PREC_SPLIT ? 2 : 1);
+    return q_ws_bytes(B, ph_n_padded(N), (prec == PH_PREC_SPLIT || prec == PH_PREC_QHYBRID) ? 2 : 1);
 }
 
 template <int PA, int NRT>
@@ -1644,9 +1655,26 @@ static void launch_query(const QArgs& a, int phases, hipStream_t s) {
     if (phases & 2) hipLaunchKernelGGL((k_query_post<PA, NRT>), grid, dim3(NTHREADS), lds_post, s, a);
 }
 
-template <int PA, int NRT>
+// HY: the hybrid grade -- pre kernel in split precision with fp16 q / k / v out, post kernel with ONE fp16 plane
+template <int PA, int NRT, bool HY = false>
 static void launch_query2(const QArgs2& a, int phases, hipStream_t s) {
     constexpr int ROWS = NRT * 16;
+    if constexpr (HY) {
+        static_assert(PA == 2, "hybrid = split pre kernel");
+        const size_t red = 2 * 2 * NW * ROWS * sizeof(float);
+        const size_t lds_pre = (size_t)2 * ROWS * LDA * 2 + red + ROWS * sizeof(float);
+        const size_t lds_post = (size_t)ROWS * LDA * 2 + (size_t)post2_nhb<1, NRT>() * ROWS * (post2_hc<1>() + 8) * 2 + red + (size_t)NW * 16 * LDPT * 2;
+        static const bool once = [] {
+            (void)hipFuncSetAttribute((const void*)k_query_pre2<2, NRT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_query_post2<1, NRT, PH_E_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+        }();
+        (void)once;
+        const dim3 grid(a.q.Npad / ROWS, 2, a.q.B);
+        if (phases & 1) hipLaunchKernelGGL((k_query_pre2<2, NRT, true>), grid, dim3(NTHREADS), lds_pre, s, a);
+        if (phases & 2) hipLaunchKernelGGL((k_query_post2<1, NRT, PH_E_F16>), grid, dim3(NTHREADS), lds_post, s, a);
+        return;
+    }
     const size_t red = 2 * 2 * NW * ROWS * sizeof(float);
     const size_t lds_pre = (size_t)PA * ROWS * LDA * 2 + red + ROWS * sizeof(float);
     const size_t lds_post = (size_t)PA * ROWS * LDA * 2 + (size_t)post2_nhb<PA, NRT>() * PA * ROWS * (post2_hc<PA>() + 8) * 2 + red +
@@ -1662,21 +1690,24 @@ static void launch_query2(const QArgs2& a, int phases, hipStream_t s) {
     if (phases & 2) hipLaunchKernelGGL((k_query_post2<PA, NRT>), grid, dim3(NTHREADS), lds_post, s, a);
 }
 
-extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits, const float* k_in, const float* q_in,
-                              const uint16_t* wb, const float* wf, const ph_stage_layout* layout, float* obj, float* dobj,
-                              float* cls, int cls_sigmoid, uint16_t* kern, float* kbias, void* workspace,
-                              size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format, int phases,
-                              void* stream) {
+// (error messages of both entry points name this function)
+static int query_run(const float* partial, int nsplit, const uint32_t* bits, const int32_t* pcount, const float* k_in, const float* q_in,
+                     const uint16_t* wb, const float* wf, const ph_stage_layout* layout, float* obj, float* dobj,
+                     float* cls, int cls_sigmoid, uint16_t* kern, float* kbias, void* workspace,
+                     size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format, int phases,
+                     void* stream) {
     PH_CHECK_ARG((phases & ~(PH_QUERY_BOTH | PH_QUERY_WIDE)) == 0 && (phases & PH_QUERY_BOTH) != 0,
                  "phases must be PH_QUERY_PRE | PH_QUERY_POST [| PH_QUERY_WIDE]");
     PH_CHECK_ARG(partial && bits && k_in && q_in && wb && wf && layout && obj && dobj && cls && kern && kbias && workspace,
                  "null pointer");
     PH_CHECK_ARG(B > 0 && N > 0 && N <= 256 && HW > 0 && nsplit >= 1, "bad size");
-    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_QHYBRID, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_QHYBRID");
     PH_CHECK_ARG(kern_format == PH_KERN_BF16_PLANES || kern_format == PH_KERN_F16, "bad kern_format");
+    PH_CHECK_ARG(prec != PH_PREC_QHYBRID || kern_format == PH_KERN_F16, "PH_PREC_QHYBRID emits the dynamic kernels as one fp16 plane (PH_KERN_F16)");
     PH_CHECK_ARG(layout->ffn_dim > 0 && layout->ffn_dim % 256 == 0, "ffn_dim must be a multiple of 256");
     PH_CHECK_ARG(layout->num_classes > 0 && layout->num_classes <= 1024, "bad num_classes");
-    const int PA = prec == PH_PREC_SPLIT ? 2 : 1, Npad = ph_n_padded(N);
+    const bool hybrid = prec == PH_PREC_QHYBRID;
+    const int PA = (prec == PH_PREC_SPLIT || hybrid) ? 2 : 1, Npad = ph_n_padded(N);
     const bool wide = (phases & PH_QUERY_WIDE) != 0;
     phases &= PH_QUERY_BOTH;
     if (workspace_bytes < q_ws_bytes(B, Npad, PA)) {
@@ -1684,14 +1715,14 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
         return PH_EWORKSPACE;
     }
     QArgs a;
-    a.partial = partial; a.bits = bits; a.k_in = k_in; a.q_in = q_in; a.wb = wb; a.wf = wf;
+    a.partial = partial; a.bits = bits; a.pcount = pcount; a.k_in = k_in; a.q_in = q_in; a.wb = wb; a.wf = wf;
     a.obj = obj; a.dobj = dobj; a.cls = cls; a.kern = kern; a.kbias = kbias;
     const size_t pl = (size_t)PA * B * 2 * Npad * 256;
     a.Qp = (uint16_t*)workspace; a.Kp = a.Qp + pl; a.Vt = a.Kp + pl; a.o1 = (float*)(a.Vt + pl);
     a.lay = *layout; a.cls_sigmoid = cls_sigmoid; a.kern_f16 = kern_format == PH_KERN_F16; a.nsplit = nsplit; a.B = B; a.N = N; a.Npad = Npad; a.HWp = ph_hw_padded(HW);
     hipStream_t s = (hipStream_t)stream;
     static const bool v1 = [] { const char* e = getenv("PH_QUERY_V1"); return e && atoi(e) != 0; }();
-    if (v1) {                  // first-generation kernels (32 / 16 rows per workgroup), kept for A/B measurements
+    if (v1 && !hybrid) {                  // first-generation kernels (32 / 16 rows per workgroup), kept for A/B measurements
         if (PA == 1) launch_query<1, 2>(a, phases, s);
         else launch_query<2, 1>(a, phases, s);
     } else {
@@ -1727,9 +1758,12 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
         static const int cap = [] { const char* e = getenv("PH_QUERY_NRT"); return e ? atoi(e) : 0; }();   // tuning knob
         if (cap > 0) { nrt = cap; while (t % nrt) --nrt; }
 #define PH_Q2(P, R) launch_query2<P, R>(a2, phases, s)
-        if (PA == 1) { switch (nrt) { case 5: PH_Q2(1, 5); break; case 4: PH_Q2(1, 4); break; case 3: PH_Q2(1, 3); break; case 2: PH_Q2(1, 2); break; default: PH_Q2(1, 1); } }
+#define PH_QH(R) launch_query2<2, R, true>(a2, phases, s)
+        if (hybrid) { switch (nrt) { case 5: PH_QH(5); break; case 4: PH_QH(4); break; case 3: PH_QH(3); break; case 2: PH_QH(2); break; default: PH_QH(1); } }
+        else if (PA == 1) { switch (nrt) { case 5: PH_Q2(1, 5); break; case 4: PH_Q2(1, 4); break; case 3: PH_Q2(1, 3); break; case 2: PH_Q2(1, 2); break; default: PH_Q2(1, 1); } }
         else { switch (nrt) { case 5: PH_Q2(2, 5); break; case 4: PH_Q2(2, 4); break; case 3: PH_Q2(2, 3); break; case 2: PH_Q2(2, 2); break; default: PH_Q2(2, 1); } }
 #undef PH_Q2
+#undef PH_QH
         if (tl) {
             unsigned long long h[16];
             (void)hipStreamSynchronize(s);
@@ -1741,4 +1775,25 @@ extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* 
     }
     PH_CHECK_LAUNCH();
     return PH_OK;
+}
+
+extern "C" int ph_query_stage(const float* partial, int nsplit, const uint32_t* bits, const float* k_in, const float* q_in,
+                              const uint16_t* wb, const float* wf, const ph_stage_layout* layout, float* obj, float* dobj,
+                              float* cls, int cls_sigmoid, uint16_t* kern, float* kbias, void* workspace,
+                              size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format, int phases,
+                              void* stream) {
+    return query_run(partial, nsplit, bits, nullptr, k_in, q_in, wb, wf, layout, obj, dobj, cls, cls_sigmoid, kern, kbias, workspace,
+                     workspace_bytes, B, N, HW, prec, kern_format, phases, stream);
+}
+
+// the same with the hard masks' pixel counts handed over by ph_pool_counts (pcount [B][nsplit][Npad] int32) instead of counted
+// from the bit rows (second-generation kernels; PH_QUERY_V1 ignores it)
+extern "C" int ph_query_stage_counts(const float* partial, int nsplit, const uint32_t* bits, const int32_t* pcount, const float* k_in,
+                                     const float* q_in, const uint16_t* wb, const float* wf, const ph_stage_layout* layout,
+                                     float* obj, float* dobj, float* cls, int cls_sigmoid, uint16_t* kern, float* kbias,
+                                     void* workspace, size_t workspace_bytes, int B, int N, int64_t HW, int prec, int kern_format,
+                                     int phases, void* stream) {
+    if (!pcount) { ph_set_error("ph_query_stage_counts: null pcount"); return PH_EINVAL; }
+    return query_run(partial, nsplit, bits, pcount, k_in, q_in, wb, wf, layout, obj, dobj, cls, cls_sigmoid, kern, kbias, workspace,
+                     workspace_bytes, B, N, HW, prec, kern_format, phases, stream);
 }

@@ -22,6 +22,10 @@ import collections
 #   feat  : element format / planes of the feature maps (ingest, pool)        query : the query-side GEMMs
 #   conv  : the dynamic 1x1 conv (feature planes x kernel planes)             kern_fmt : what the query kernel emits for it
 Mode = collections.namedtuple("Mode", "name feat query conv kern_fmt FP KP feat_dtype")
+import os as _os
+# query side of the modes that emit fp16 dynamic kernels: hybrid grade (updator half hi/lo bf16, attention / FFN / tower half one
+# fp16 plane, include/polyhead.h PH_PREC_QHYBRID) unless PH_QUERY_FULL_SPLIT=1 asks for hi/lo bf16 throughout
+_QH = _lib.PH_PREC_SPLIT if _os.environ.get("PH_QUERY_FULL_SPLIT") else _lib.PH_PREC_QHYBRID
 MODES = {
     # fast: bf16 everywhere, one plane (6e-3 per stage against fp32)
     "bf16": Mode("bf16", _lib.PH_PREC_BF16, _lib.PH_PREC_BF16, _lib.PH_PREC_BF16, _lib.PH_KERN_BF16_PLANES, 1, 1, torch.bfloat16),
@@ -30,9 +34,9 @@ MODES = {
     "mixed": Mode("mixed", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KSPLIT, _lib.PH_KERN_BF16_PLANES, 1, 2, torch.bfloat16),
     # as `mixed`, but the dynamic kernels as ONE fp16 plane: the conv converts its bf16 feature fragments to fp16 in registers
     # (exact) and runs one f16 MFMA -- the single-plane conv speed at 2.5e-4 per stage (kernel rounding 2^-12)
-    "mixed16": Mode("mixed16", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KF16, _lib.PH_KERN_F16, 1, 1, torch.bfloat16),
+    "mixed16": Mode("mixed16", _lib.PH_PREC_BF16, _QH, _lib.PH_PREC_BF16_KF16, _lib.PH_KERN_F16, 1, 1, torch.bfloat16),
     # fp16 feature planes / kernels / outputs (cfg5), fp32-grade query side
-    "fp16": Mode("fp16", _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_F16, _lib.PH_KERN_F16, 1, 1, torch.float16),
+    "fp16": Mode("fp16", _lib.PH_PREC_F16, _QH, _lib.PH_PREC_F16, _lib.PH_KERN_F16, 1, 1, torch.float16),
     # parity grade: every operand hi + lo (1.6e-5 per stage)
     "fp32": Mode("fp32", _lib.PH_PREC_SPLIT, _lib.PH_PREC_SPLIT, _lib.PH_PREC_SPLIT, _lib.PH_KERN_BF16_PLANES, 2, 2, None),
 }
@@ -119,20 +123,25 @@ def binarize(m, out=None):
     return out
 
 
-def pool(xp, dp, bits, N, HW, prec, nsplit=None, out=None):
+def pool(xp, dp, bits, N, HW, prec, nsplit=None, out=None, counts=None):
+    """`counts`: optional int32 [B, nsplit, Npad] that receives the masks' pixel counts per pixel range (ph_pool_counts)"""
     B = xp.shape[1]
     if nsplit is None:
         nsplit = default_nsplit(B, HW)
     if out is None:
         out = torch.empty((B, nsplit, n_padded(N), 512), dtype=torch.float32, device=xp.device)
     lib = _lib.load()
-    _lib.check(lib.ph_pool(_lib.ptr(xp), _lib.ptr(dp), _lib.ptr(bits), _lib.ptr(out), B, N, HW, nsplit, prec,
-                           _lib.stream_ptr()), "ph_pool")
+    if counts is not None:
+        _lib.check(lib.ph_pool_counts(_lib.ptr(xp), _lib.ptr(dp), _lib.ptr(bits), _lib.ptr(out), _lib.ptr(counts), B, N, HW, nsplit, prec,
+                                      _lib.stream_ptr()), "ph_pool_counts")
+    else:
+        _lib.check(lib.ph_pool(_lib.ptr(xp), _lib.ptr(dp), _lib.ptr(bits), _lib.ptr(out), B, N, HW, nsplit, prec,
+                               _lib.stream_ptr()), "ph_pool")
     return out
 
 
 def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=None, workspace=None, phases=3,
-                kern_fmt=_lib.PH_KERN_BF16_PLANES):
+                kern_fmt=_lib.PH_KERN_BF16_PLANES, counts=None):
     B, nsplit = partial.shape[0], partial.shape[1]
     dev = partial.device
     prec = pack.prec
@@ -147,12 +156,13 @@ def query_stage(partial, bits, k_in, q_in, pack, N, HW, cls_sigmoid=False, outs=
                     kbias=torch.empty((2, B, Npad), dtype=torch.float32, device=dev))
     if workspace is None:
         workspace = torch.empty((lib.ph_query_workspace_bytes(B, N, prec),), dtype=torch.uint8, device=dev)
-    _lib.check(lib.ph_query_stage(_lib.ptr(partial), nsplit, _lib.ptr(bits), _lib.ptr(k_in), _lib.ptr(q_in),
-                                  _lib.ptr(pack.wb), _lib.ptr(pack.wf), C.byref(pack.lay),
-                                  _lib.ptr(outs["obj"]), _lib.ptr(outs["dobj"]), _lib.ptr(outs["cls"]),
-                                  1 if cls_sigmoid else 0, _lib.ptr(outs["kern"]), _lib.ptr(outs["kbias"]),
-                                  _lib.ptr(workspace), workspace.numel(), B, N, HW, prec, kern_fmt, phases, _lib.stream_ptr()),
-               "ph_query_stage")
+    tail = (_lib.ptr(k_in), _lib.ptr(q_in), _lib.ptr(pack.wb), _lib.ptr(pack.wf), C.byref(pack.lay),
+            _lib.ptr(outs["obj"]), _lib.ptr(outs["dobj"]), _lib.ptr(outs["cls"]), 1 if cls_sigmoid else 0, _lib.ptr(outs["kern"]),
+            _lib.ptr(outs["kbias"]), _lib.ptr(workspace), workspace.numel(), B, N, HW, prec, kern_fmt, phases, _lib.stream_ptr())
+    if counts is not None:
+        _lib.check(lib.ph_query_stage_counts(_lib.ptr(partial), nsplit, _lib.ptr(bits), _lib.ptr(counts), *tail), "ph_query_stage_counts")
+    else:
+        _lib.check(lib.ph_query_stage(_lib.ptr(partial), nsplit, _lib.ptr(bits), *tail), "ph_query_stage")
     return outs
 
 
@@ -223,6 +233,7 @@ class DecodePlan:
         self.dp = e((P, B, 256, HWp), torch.int16)
         self.bits = e((B, Npad, HWp // 32), torch.int32)
         self.partial = e((B, self.nsplit, Npad, 512), torch.float32)
+        self.pcount = e((B, self.nsplit, Npad), torch.int32)      # the masks' pixel counts per pixel range, pool -> query kernel
         self.ws = e((_lib.load().ph_query_workspace_bytes(B, N, self.mode.query),), torch.uint8)
         self.stage_out = [dict(obj=e((B, N, 256), torch.float32), dobj=e((B, N, 256), torch.float32),
                                cls=e((B, N, L), torch.float32), kern=e((KP, 2, B, Npad, 256), torch.int16),
@@ -284,9 +295,9 @@ class DecodePlan:
         k, q = self.k0, self.q0
         for s in range(self.S):
             last = s == self.S - 1
-            pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial)
+            pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial, counts=self.pcount)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
-                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt,
+                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt, counts=self.pcount,
                             phases=3 | (_lib.PH_QUERY_WIDE if getattr(self, "shares_gpu", False) else 0))
             cv = self.mode.conv
             if not last:

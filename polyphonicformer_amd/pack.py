@@ -60,17 +60,22 @@ def _pad_rows(w, mult=16):
 def pack_stage(sd, prefix, num_classes, prec):
     """sd: dict of CPU tensors with the reference's key names under `prefix`
     (e.g. 'mask_head.0.').  Returns (wb int16 [P][plane], wf float32, StageLayout)."""
-    planes = 2 if prec == _lib.PH_PREC_SPLIT else 1
+    hybrid = prec == _lib.PH_PREC_QHYBRID
+    planes = 2 if (prec == _lib.PH_PREC_SPLIT or hybrid) else 1
     g = lambda k: sd[prefix + k].detach().to("cpu", torch.float64)
     lay = _lib.StageLayout()
-    wparts, vparts = [], []
+    wparts, vparts, wnames = [], [], []
     woff = voff = 0
+    # hybrid grade: the matrices the POST kernel multiplies with (every one of them has a LayerNorm- or softmax-bounded
+    # operand on the other side) are ONE fp16 plane, the PRE kernel's (pooled sums, gate products: unbounded) hi + lo bf16
+    POST = {"OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN"}
 
     def add_w(br, name, mat):
         nonlocal woff
         mat = _pad_rows(mat)
         lay.w[br][_lib.W_IDX[name]] = woff
         wparts.append(mat)
+        wnames.append(name)
         woff += mat.numel()
 
     def add_v(br, name, vec):
@@ -139,8 +144,23 @@ def pack_stage(sd, prefix, num_classes, prec):
         add_w(br, "KERN", _pad_rows(Wfold))                             # -> [272][256]
         add_v(br, "KERN_B", torch.cat([bfold, bfold.new_zeros(272 - 257)]))
 
-    frag = torch.cat([pack_b_fragments(_pad_rows(m)) for m in wparts])
-    wb = torch.stack(_bf16_planes(frag, planes), 0).contiguous()
+    if hybrid:
+        hi, lo = [], []
+        for nm, m in zip(wnames, wparts):
+            fr = pack_b_fragments(_pad_rows(m))
+            if nm in POST:
+                h16 = fr.to(torch.float32).to(torch.float16).view(torch.int16)
+                hi.append(h16)
+                lo.append(torch.zeros_like(h16))
+            else:
+                ph, pl = _bf16_planes(fr, 2)
+                hi.append(ph)
+                lo.append(pl)
+        frag = torch.cat([pack_b_fragments(_pad_rows(m)) for m in wparts])
+        wb = torch.stack([torch.cat(hi), torch.cat(lo)], 0).contiguous()
+    else:
+        frag = torch.cat([pack_b_fragments(_pad_rows(m)) for m in wparts])
+        wb = torch.stack(_bf16_planes(frag, planes), 0).contiguous()
     wf = torch.cat(vparts).to(torch.float32).contiguous()
     lay.wb_plane_elems = frag.numel()
     lay.ffn_dim = F
