@@ -95,7 +95,7 @@ def kernel_breakdown(plan, iters=4):
     (binarize, S x (pool, query pre, query post, conv), x2 upsamples) runs `iters` times on the launch stream (torch's
     current stream = the stream the C ABI launches on) with a HIP event between consecutive launches, so every kernel
     sees the cache / DRAM state its predecessor leaves -- what a single-stream rocprofv3 trace of the step records
-    (profiles/r02/e_single_stream_B24_kernel_stats.csv)."""
+    (profiles/r03/e_single_stream_B24_kernel_stats.csv)."""
     from polyphonicformer_amd import engine as E
     p = plan
     seq = []                                    # (class name, launch)
@@ -114,11 +114,11 @@ def kernel_breakdown(plan, iters=4):
         else:
             seq.append(("dynconv_logits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv,
                                                                 logits_out=p.mask, out_dtype=p.out_code)))
+            seq.append(("upsample2x", lambda: E.upsample2x(p.mask, out=p.mask_up)))       # the plan's order (engine.DecodePlan.stages)
             seq.append(("dynconv_logits", lambda o=o: E.dynconv(p.dp, o["kern"], o["kbias"], 1, p.N, p.HW, p.mode.conv,
                                                                 logits_out=p.depth, out_dtype=p.out_code)))
+            seq.append(("upsample2x", lambda: E.upsample2x(p.depth, out=p.depth_up)))
         k, q = o["obj"], o["dobj"]
-    seq.append(("upsample2x", lambda: E.upsample2x(p.mask, out=p.mask_up)))
-    seq.append(("upsample2x", lambda: E.upsample2x(p.depth, out=p.depth_up)))
     for _, fn in seq:                           # one untimed pass
         fn()
     tot, cnt = {}, {}
@@ -521,7 +521,7 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
         for f in mine:
             seg_ids, rec = pipe.simple_test(_video_frame(base, f, 6), meta, records_only=True)
             if rec is None:
-                rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256))
+                rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256, device=dev))
             r, n = D.pack_track_records(*[t.to(cdev) for t in rec])
             recs.append(r)
             cnts.append(n)
@@ -531,7 +531,7 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
         if cdev.type == "cuda":
             torch.cuda.synchronize()
         t2 = time.perf_counter()
-        ids = V.replay_tracking([(fid, bb.cpu(), lab.cpu(), emb.cpu()) for fid, bb, lab, emb in allrec], tracker=tracker, first_count=cnt)
+        ids = V.replay_tracking(allrec, tracker=tracker, first_count=cnt)        # embeddings stay where the all-gather left them
         cnt += sum(1 for t in allrec if t[1].shape[0] > 0)
         t3 = time.perf_counter()
         return t1 - t0, t2 - t1, t3 - t2, ids
@@ -753,7 +753,7 @@ def cpu_baseline(wl, head, budget_s=16.0, all_cores=True, workload_note="the sam
         out["all_cores"] = {"value": 1.0 / dta, "cores": allc, "frames": na}
         out["sample"] += f" and {na} on all {allc} hardware threads"
     else:
-        out["all_cores"] = f"not run by default ({allc} hardware threads take ~45 s per frame: --all-legs); profiles/r02 has 0.022 frames/s"
+        out["all_cores"] = f"not run by default ({allc} hardware threads take ~45 s per frame: --all-legs); profiles/r03/bench_all_legs.json has 0.022 frames/s"
     return out
 
 
@@ -1020,7 +1020,7 @@ def main():
         # which cannot run inside this process: the committed summary is quoted, labelled as such, and only when the launch
         # geometry is the profiled one
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")) as f:
                     pt = json.load(f)

@@ -372,6 +372,13 @@ int ph_roi_align_fpn(const float* const* feats, const int32_t* hw, const float* 
 int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, const float* bias /* nullable */, int relu,
                  float* Yf /* nullable */, uint16_t* Yp /* nullable */, int M, int N, int K, int prec, void* stream);
 int ph_im2col7(const uint16_t* in, uint16_t* out, int n, int prec, void* stream);
+/* Tracker affinity (quasi_dense_embed_tracker.py:165-182) on the device, next to the embeddings: score[n][m] between the n
+ * detections (emb fp32 [n][256], labels int32 [n]) and the m memory columns (memo_emb fp32 [m][256], memo_labels int32 [m]);
+ * metric 0 = bisoftmax, 1 = softmax, 2 = cosine; with_cats: zero where the labels differ.  n <= 128, m <= 4096.  The greedy
+ * assignment that consumes the matrix is host logic (video.QuasiDenseEmbedTracker). */
+size_t ph_track_affinity_workspace_bytes(int n, int m);
+int ph_track_affinity(const float* emb, const int32_t* labels, const float* memo_emb, const int32_t* memo_labels, int n, int m,
+                      int metric, int with_cats, float* score, void* workspace, size_t workspace_bytes, void* stream);
 int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int groups, float eps, uint16_t* out, int n,
                   int prec, void* stream);
 

@@ -384,3 +384,94 @@ extern "C" int ph_gn_relu_cl(const float* y, const float* gamma, const float* be
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tracker affinity (polyphonic/video/qdtrack/trackers/quasi_dense_embed_tracker.py:165-182): match scores between the n
+// detections of a frame and the m columns of the tracker's memory (tracklets, then backdrops), both as fp32 [.][256]
+// embeddings ON THE DEVICE next to the track head that produced them:
+//   bisoftmax: (softmax over the columns + softmax over the detections) / 2 of the dot products; softmax: the first term;
+//   cosine: dot products of the normalised vectors; `with_cats`: zero where the labels differ.
+// n <= 128, m <= 4096: three tiny launches (dot products: one thread per entry; column maxima / sums; row pass), all fp32.
+// The greedy assignment that consumes the matrix stays on the host (sequential, data dependent) -- one D2H of n * m floats.
+__global__ __launch_bounds__(256) void k_aff_dot(const float* __restrict__ emb, const float* __restrict__ memo, int n, int m,
+                                                 int cosine, float* __restrict__ dot) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= n || j >= m) return;
+    const float4* a = (const float4*)(emb + (int64_t)i * 256);
+    const float4* b = (const float4*)(memo + (int64_t)j * 256);
+    float s = 0.f, na = 0.f, nb = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+        const float4 x = a[k], y = b[k];
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        if (cosine) {
+            na += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            nb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+        }
+    }
+    if (cosine) s = s / (fmaxf(sqrtf(na), 1e-12f) * fmaxf(sqrtf(nb), 1e-12f));      // F.normalize(eps = 1e-12)
+    dot[(int64_t)i * m + j] = s;
+}
+// per column j: max_i dot[i][j] and sum_i exp(dot[i][j] - max)
+__global__ __launch_bounds__(256) void k_aff_colstat(const float* __restrict__ dot, int n, int m, float* __restrict__ cmax,
+                                                     float* __restrict__ csum) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    float mx = -INFINITY;
+    for (int i = 0; i < n; ++i) mx = fmaxf(mx, dot[(int64_t)i * m + j]);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += expf(dot[(int64_t)i * m + j] - mx);
+    cmax[j] = mx;
+    csum[j] = s;
+}
+// one workgroup per detection row: row softmax, combined with the column softmax, category mask
+__global__ __launch_bounds__(256) void k_aff_rows(const float* __restrict__ dot, const int* __restrict__ lab, const int* __restrict__ memo_lab,
+                                                  const float* __restrict__ cmax, const float* __restrict__ csum, int n, int m,
+                                                  int metric, int with_cats, float* __restrict__ score) {
+    __shared__ float red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const float* d = dot + (int64_t)i * m;
+    float mx = -INFINITY;
+    for (int j = t; j < m; j += 256) mx = fmaxf(mx, d[j]);
+    red[t] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = fmaxf(red[t], red[t + s]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sm = 0.f;
+    for (int j = t; j < m; j += 256) sm += expf(d[j] - mx);
+    red[t] = sm;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    sm = red[0];
+    const int li = lab[i];
+    for (int j = t; j < m; j += 256) {
+        float v;
+        if (metric == 2) v = d[j];
+        else {
+            v = expf(d[j] - mx) / sm;
+            if (metric == 0) v = 0.5f * (v + expf(d[j] - cmax[j]) / csum[j]);
+        }
+        if (with_cats && li != memo_lab[j]) v = 0.f;
+        score[(int64_t)i * m + j] = v;
+    }
+}
+
+extern "C" size_t ph_track_affinity_workspace_bytes(int n, int m) { return ((size_t)n * m + 2 * (size_t)m) * sizeof(float); }
+
+extern "C" int ph_track_affinity(const float* emb, const int32_t* labels, const float* memo_emb, const int32_t* memo_labels, int n,
+                                 int m, int metric, int with_cats, float* score, void* workspace, size_t workspace_bytes, void* stream) {
+    PH_CHECK_ARG(emb && labels && memo_emb && memo_labels && score && workspace, "null pointer");
+    PH_CHECK_ARG(n > 0 && n <= 128 && m > 0 && m <= 4096, "n must be in 1..128, m in 1..4096");
+    PH_CHECK_ARG(metric >= 0 && metric <= 2, "metric: 0 bisoftmax, 1 softmax, 2 cosine");
+    if (workspace_bytes < ph_track_affinity_workspace_bytes(n, m)) { ph_set_error("ph_track_affinity: workspace too small"); return PH_EWORKSPACE; }
+    float* dot = (float*)workspace;
+    float* cmax = dot + (size_t)n * m;
+    float* csum = cmax + m;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_aff_dot, dim3((m + 63) / 64, (n + 3) / 4), dim3(256), 0, s, emb, memo_emb, n, m, metric == 2 ? 1 : 0, dot);
+    if (metric == 0) hipLaunchKernelGGL(k_aff_colstat, dim3((m + 255) / 256), dim3(256), 0, s, dot, n, m, cmax, csum);
+    hipLaunchKernelGGL(k_aff_rows, dim3(n), dim3(256), 0, s, dot, labels, memo_labels, cmax, csum, n, m, metric, with_cats, score);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

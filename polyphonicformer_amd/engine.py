@@ -5,7 +5,7 @@ Per frame-batch the launch sequence is
 
     ingest(x), ingest(depth_feats), binarize(mask_preds)
     for s in 0..S-1:   pool -> query_stage(pre, post) -> dynconv (bits for s < S-1, logits for s = S-1)
-    dynconv(depth) ; upsample2x(mask) ; upsample2x(depth)
+    upsample2x(mask) ; dynconv(depth) ; upsample2x(depth)
 
 No step synchronises or allocates once a `DecodePlan` exists, so the whole sequence can be captured
 into a HIP graph (`DecodePlan.capture`)."""
@@ -17,6 +17,8 @@ from . import _lib
 from .pack import pack_stage
 
 import collections
+import os
+_UP_LAST = bool(os.environ.get('PH_UPSAMPLE_LAST'))      # experiment: round 2's launch order
 
 # Precision modes of the decode path.  One row = the arithmetic of every operator of a stage:
 #   feat  : element format / planes of the feature maps (ingest, pool)        query : the query-side GEMMs
@@ -303,11 +305,14 @@ class DecodePlan:
             if not last:
                 dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
             else:
+                # each x2 upsample directly behind the conv that wrote its source: the 240 MB of logits (cfg2, 24 frames) are
+                # then read back from the memory-side cache instead of HBM (conv, conv, up, up: 823 us; this order: 659 us)
                 dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
+                if not _UP_LAST: upsample2x(self.mask, out=self.mask_up)
                 dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, cv, logits_out=self.depth, out_dtype=self.out_code)
+                if _UP_LAST: upsample2x(self.mask, out=self.mask_up)
+                upsample2x(self.depth, out=self.depth_up)
             k, q = o["obj"], o["dobj"]
-        upsample2x(self.mask, out=self.mask_up)
-        upsample2x(self.depth, out=self.depth_up)
 
     def run(self):
         """one pass: ingest + S stages + final upsample, on the current stream"""

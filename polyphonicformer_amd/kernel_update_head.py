@@ -142,7 +142,8 @@ class KernelUpdateHead(nn.Module):
         """kernel_update_head.py:355-441: the stage's losses from its predictions at the assign stride and the targets of
         `get_targets` -- `loss_depth`, `loss_cls`, `pos_acc`, `loss_rpn_mask`, `loss_rpn_dice`, `loss_rank` (the reference's
         keys).  `with_grads=True` additionally returns d(sum of the losses) / d(mask_pred, cls_score, depth_pred)
-        (csrc/ph_loss.hip); no autograd graph is built."""
+        (csrc/ph_loss.hip).  Values only: the differentiable form is `train.roi_forward_train` (what
+        `KernelUpdateIterHead.forward_train` runs), which attaches these losses to the graph."""
         if reduction_override is not None:
             raise NotImplementedError("libpolyhead: reduction_override is not used by the reference's training loop")
         return _losses.stage_losses(self, cls_score, mask_pred, depth_pred, labels, label_weights, mask_targets, mask_weights,

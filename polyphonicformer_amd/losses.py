@@ -6,7 +6,8 @@ configuration; `stage_losses` is what `KernelUpdateHead.loss` (kernel_update_hea
 (mask BCE + dice, rank, depth, focal), a handful of scalars combined on the device in fp64 in a fixed order, and -- when
 asked -- four `*_grad` passes that write d(sum of the stage's losses) / d(mask_pred, cls_score, depth_pred), the first
 step of the backward pass.  The reference does the same arithmetic as ~40 ATen launches with boolean-mask gathers.
-No autograd graph is built (the backward of the kernels upstream is not part of this build yet)."""
+These functions evaluate values and d(losses)/d(predictions) without an autograd graph of their own; `train.py` wraps them
+into one autograd node per head and stage (`_Objective`), behind which the hand-written backward of the forward kernels runs."""
 import torch
 import torch.nn as nn
 
@@ -255,7 +256,8 @@ def _mask_terms(head, mp, mask_targets, mask_weights, pos, B, N, H, W, losses, g
     if lr is not None:
         # rank target: pixel -> index (within its image) of the LAST positive row whose target covers it
         rank_target = torch.empty((B, HW), dtype=torch.int32, device=dev)
-        _lib.check(lib.ph_rank_target(_lib.ptr(mt), _lib.ptr(pos.to(torch.uint8).contiguous()), B, N, HW, ignore, _lib.ptr(rank_target),
+        pos_u8 = pos.to(torch.uint8).contiguous()      # named: alive until the launch is queued
+        _lib.check(lib.ph_rank_target(_lib.ptr(mt), _lib.ptr(pos_u8), B, N, HW, ignore, _lib.ptr(rank_target),
                                       _lib.stream_ptr()), "ph_rank_target")
         losses[keys[2]] = (lr.loss_weight * rank_loss_sum(mp.reshape(B, N, H, W), rank_target, ignore) / (B * HW)).float()
     if grad is not None:

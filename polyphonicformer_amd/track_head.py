@@ -48,7 +48,8 @@ def roi_extract(feats, rois, prec, strides=(4, 8, 16, 32), finest_scale=56.0, wa
     ptrs = (C.c_void_p * L)(*[f.data_ptr() for f in feats])
     hw = (C.c_int32 * (2 * L))(*[v for f in feats for v in f.shape[-2:]])
     sc = (C.c_float * L)(*[1.0 / s for s in strides[:L]])
-    _lib.check(lib.ph_roi_align_fpn(ptrs, hw, sc, L, _lib.ptr(rois.float().contiguous()), n, finest_scale, _lib.ptr(out),
+    rois_f = rois.float().contiguous()                 # named: alive until the launch is queued
+    _lib.check(lib.ph_roi_align_fpn(ptrs, hw, sc, L, _lib.ptr(rois_f), n, finest_scale, _lib.ptr(out),
                                     _lib.ptr(f32), prec, _lib.stream_ptr()), "ph_roi_align_fpn")
     return (out, f32) if want_f32 else out
 

@@ -40,7 +40,7 @@ class _TrackTable:
     def __init__(self, backdrop_frames):
         self.ids = torch.zeros((0,), dtype=torch.long)
         self.box = torch.zeros((0, 5))
-        self.emb = torch.zeros((0, 0))
+        self.emb = torch.zeros((0, 0))                            # lives where the track head left its embeddings (device)
         self.lab = torch.zeros((0,), dtype=torch.long)
         self.seen = torch.zeros((0,), dtype=torch.long)          # frame a row was last matched in
         self.backdrop_frames = backdrop_frames
@@ -56,7 +56,8 @@ class _TrackTable:
             ids.append(torch.full((be.shape[0],), -1, dtype=torch.long))
             lab.append(bl)
             emb.append(be)
-        return torch.cat(ids), torch.cat(lab), torch.cat(emb, 0)
+        emb = [e for e in emb if e.shape[0]]
+        return torch.cat(ids), torch.cat(lab), (torch.cat(emb, 0) if emb else self.emb)
 
     def absorb(self, ids, box, emb, lab, frame, momentum):
         """matched detections refresh their rows (embedding = exponential moving average), unknown ids append rows"""
@@ -65,22 +66,26 @@ class _TrackTable:
         pos = {int(t): r for r, t in enumerate(self.ids.tolist())}
         row = torch.tensor([pos.get(int(t), -1) for t in ids.tolist()], dtype=torch.long)
         old, new = row >= 0, row < 0
+        dev = emb.device
+        sel = lambda mask: mask.nonzero().flatten().to(dev)       # index tensors (host masks) for the device-resident embeddings
         if old.any():
             r = row[old]
-            self.emb[r] = (1 - momentum) * self.emb[r] + momentum * emb[old]
+            rd = r.to(dev)
+            self.emb[rd] = (1 - momentum) * self.emb[rd] + momentum * emb[sel(old)]
             self.box[r], self.lab[r], self.seen[r] = box[old], lab[old], frame
         if new.any():
             k = int(new.sum())
             self.ids = torch.cat([self.ids, ids[new]])
             self.box = torch.cat([self.box, box[new]], 0)
-            self.emb = torch.cat([self.emb.reshape(-1, emb.shape[1]), emb[new]], 0)
+            self.emb = torch.cat([self.emb.reshape(-1, emb.shape[1]).to(dev), emb[sel(new)]], 0)
             self.lab = torch.cat([self.lab, lab[new]])
             self.seen = torch.cat([self.seen, torch.full((k,), frame, dtype=torch.long)])
 
     def expire(self, frame, max_age):
         live = (frame - self.seen) < max_age
         if not bool(live.all()):
-            self.ids, self.box, self.emb, self.lab, self.seen = (self.ids[live], self.box[live], self.emb[live],
+            self.ids, self.box, self.emb, self.lab, self.seen = (self.ids[live], self.box[live],
+                                                                  self.emb[live.nonzero().flatten().to(self.emb.device)],
                                                                   self.lab[live], self.seen[live])
 
     def push_backdrop(self, box, emb, lab):
@@ -90,22 +95,6 @@ class _TrackTable:
             self.backdrops = []
 
 
-class _OneHostThread:
-    """The tracker's host arithmetic is a few [n <= 100, 256] products and softmaxes: on the GPU box's 256 hardware threads
-    the host BLAS / OpenMP pool turns each of them into a 256-way fork-join (measured: 100 - 250 ms per frame when the pool
-    is contended, 2.5 ms with one thread).  Intra-op threading is switched off for the duration of `match` only."""
-
-    def __enter__(self):
-        self.n = torch.get_num_threads()
-        if self.n != 1:
-            torch.set_num_threads(1)
-
-    def __exit__(self, *exc):
-        if self.n != 1:
-            torch.set_num_threads(self.n)
-        return False
-
-
 @TRACKERS.register_module()
 class QuasiDenseEmbedTracker(object):
     """Quasi-dense embedding tracker with the constructor kwargs, `match` signature and integer-id semantics of
@@ -113,7 +102,11 @@ class QuasiDenseEmbedTracker(object):
     reference class produced).  This build's formulation: detections are de-duplicated with one triangular IoU test,
     the memory is a `_TrackTable`, the affinity matrix is computed once and the greedy one-to-one assignment walks the
     detections in score order with a `taken` mask over tracklet columns.  The reference also carries a per-tracklet
-    velocity that nothing reads (its `match` ignores `memo_vs`); it is not kept."""
+    velocity that nothing reads (its `match` ignores `memo_vs`); it is not kept.
+    Where the arithmetic runs: boxes, labels, ids and the control flow on the host; the EMBEDDINGS (detections and memory)
+    stay on the device the track head produced them on, and the [detections x memory] affinity matrix is computed there
+    (`ph_track_affinity`, csrc/ph_track.hip) -- one D2H of that matrix per frame feeds the greedy walk.  With CPU inputs
+    (the CPU tests, gloo) the same arithmetic runs as torch CPU ops; no process-global state is touched either way."""
 
     def __init__(self, init_score_thr=0.8, obj_score_thr=0.5, match_score_thr=0.5, memo_tracklet_frames=10,
                  memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3,
@@ -144,7 +137,21 @@ class QuasiDenseEmbedTracker(object):
         return ~(torch.tril(iou, -1) > thr[:, None]).any(1), iou
 
     def _affinity(self, emb, lab, memo_emb, memo_lab):
-        """[detections x memory columns] match scores (:165-182)"""
+        """[detections x memory columns] match scores (:165-182), returned on the host"""
+        if emb.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            n, m = emb.shape[0], memo_emb.shape[0]
+            dev = emb.device
+            score = torch.empty((n, m), dtype=torch.float32, device=dev)
+            ws = torch.empty((lib.ph_track_affinity_workspace_bytes(n, m),), dtype=torch.uint8, device=dev)
+            metric = {'bisoftmax': 0, 'softmax': 1, 'cosine': 2}[self.match_metric]
+            # named, so that the four operands are alive (and distinct blocks of the caching allocator) until the launch is queued
+            e, me = emb.contiguous(), memo_emb.contiguous()
+            l, ml = lab.to(dev, torch.int32), memo_lab.to(dev, torch.int32)
+            _lib.check(lib.ph_track_affinity(_lib.ptr(e), _lib.ptr(l), _lib.ptr(me), _lib.ptr(ml), n, m, metric, 1 if self.with_cats else 0,
+                                             _lib.ptr(score), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ph_track_affinity")
+            return score.cpu()
         if self.match_metric == 'cosine':
             unit = torch.nn.functional.normalize
             s = unit(emb, p=2, dim=1) @ unit(memo_emb, p=2, dim=1).t()
@@ -178,15 +185,15 @@ class QuasiDenseEmbedTracker(object):
     def match(self, bboxes, labels, track_feats, frame_id, asso_tau=-1):
         """bboxes [n,5] (x1,y1,x2,y2,score), labels [n], track_feats [n,256] -> (bboxes, labels, ids) of the kept
         detections in descending-score order; ids >= 0 track, -1 unmatched, -2 suppressed."""
-        with _OneHostThread():
-            return self._match(bboxes, labels, track_feats, frame_id)
+        return self._match(bboxes, labels, track_feats, frame_id)
 
     def _match(self, bboxes, labels, track_feats, frame_id):
-        box, lab, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().cpu().float()
+        box, lab, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().float()   # emb: stays put
+        dev = emb.device
         order = box[:, 4].sort(descending=True)[1]
-        box, lab, emb = box[order], lab[order], emb[order]
-        keep, _ = self._dedup(box)
-        box, lab, emb = box[keep], lab[keep], emb[keep]
+        keep, _ = self._dedup(box[order])
+        kept = order[keep]                                        # one gather of the embeddings for both steps
+        box, lab, emb = box[kept], lab[kept], emb[kept.to(dev)]
         ids = torch.full((box.shape[0],), -1, dtype=torch.long)
         if box.shape[0] and not self.empty:
             memo_ids, memo_lab, memo_emb = self.table.columns()
@@ -202,12 +209,13 @@ class QuasiDenseEmbedTracker(object):
         """:47-102: tracked detections go to the table; the still-unmatched ones that no higher-scored detection covers
         become this frame's backdrops; tracklets unseen for `memo_tracklet_frames` frames are forgotten"""
         tracked = ids > -1
-        self.table.absorb(ids[tracked], box[tracked], emb[tracked], lab[tracked], frame_id, self.memo_momentum)
+        self.table.absorb(ids[tracked], box[tracked], emb[tracked.nonzero().flatten().to(emb.device)], lab[tracked], frame_id,
+                          self.memo_momentum)
         loose = ids == -1
         iou = bbox_overlaps(box[:, :4], box[:, :4])
         covered = (torch.tril(iou, -1) > self.nms_backdrop_iou_thr).any(1)
         bd = loose & ~covered
-        self.table.push_backdrop(box[bd], emb[bd], lab[bd])
+        self.table.push_backdrop(box[bd], emb[bd.nonzero().flatten().to(emb.device)], lab[bd])
         self.table.expire(frame_id, self.memo_tracklet_frames)
 
 
@@ -300,7 +308,7 @@ class VideoAssociator:
         prec = E.PREC[self.track_head.precision]
         embeds = self.track_head.forward_planes(T.roi_extract(fpn_feats, rois_all[sel].contiguous(), prec, self.strides))
         bboxes = torch.cat([ext_all[sel], torch.tensor(score, device=dev, dtype=torch.float32)[:, None]], 1)
-        return seg_ids, (bboxes.cpu(), torch.tensor(labels, dtype=torch.int64), embeds.cpu())
+        return seg_ids, (bboxes.cpu(), torch.tensor(labels, dtype=torch.int64), embeds)      # the embeddings stay on the device
 
     def _maps_on_device(self, pan_dev, segments_info, seg_ids, ids):
         """get_semantic_seg / generate_track_id_maps (:436-451) as two table look-ups on the device copy of the id map

@@ -73,6 +73,18 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def rel_err_elementwise(a, b, floor_frac=0.1):
+    """max over the elements with |b| >= floor_frac * max|b| of |a - b| / |b|: the element-wise companion of `rel_err` (which
+    normalises every element's error by the LARGEST reference magnitude) -- on the elements that carry the signal the two
+    differ by at most 1 / floor_frac, and this one cannot hide a wrong small-but-significant entry behind one large one"""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    big = b.abs() >= floor_frac * b.abs().max()
+    if not bool(big.any()):
+        return 0.0
+    return float(((a - b).abs()[big] / b.abs()[big]).max())
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

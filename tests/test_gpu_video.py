@@ -192,3 +192,37 @@ def test_cfg3_two_frame_clip_end_to_end(gpu):
         assert np.array_equal(out["sem"], sem_ref)
     print("cfg3 end-to-end: thing segments per frame", nseg)
     assert max(nseg) > 0            # the crafted biases let things through: the association really ran
+
+
+@pytest.mark.parametrize("metric", ["bisoftmax", "softmax", "cosine"])
+def test_tracker_with_device_embeddings(gpu, metric):
+    """QuasiDenseEmbedTracker with the embeddings (detections and memory) resident on the device and the affinity matrix
+    from ph_track_affinity: the integer ids of the REFERENCE tracker (tests/golden/tracker.npz, bisoftmax) come out bit for
+    bit, every metric gives the ids of the all-host formulation, and the affinity kernel agrees with the torch formula"""
+    import json
+    import numpy as np
+    from polyphonicformer_amd import video as V
+    z = Hh.load_golden("tracker.npz")
+    cfg = json.loads(bytes(z["cfg_json"]).decode())
+    cfg["match_metric"] = metric
+    for seed in (1, 2, 3):
+        dev_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
+        cpu_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
+        cnt = 1
+        for f, bb, lab, emb in Hh.tracker_records(seed):
+            if bb.shape[0] == 0:
+                continue
+            if not dev_tr.empty:                                   # the matrix itself, before the greedy walk consumes it
+                mi, ml, me = dev_tr.table.columns()
+                a = dev_tr._affinity(emb.to(gpu), lab, me, ml)
+                b = cpu_tr._affinity(emb, lab, me.cpu(), ml)
+                assert me.is_cuda and torch.allclose(a, b, rtol=1e-4, atol=1e-6), float((a - b).abs().max())
+            obb, olab, ids = dev_tr.match(bboxes=bb.to(gpu), labels=lab.to(gpu), track_feats=emb.to(gpu), frame_id=cnt)
+            cbb, clab, cids = cpu_tr.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
+            cnt += 1
+            assert torch.equal(ids, cids) and torch.equal(obb, cbb) and torch.equal(olab, clab)
+            if metric == "bisoftmax":
+                r = ids + 1
+                r[r == -1] = 0
+                assert np.array_equal(r.numpy(), z[f"s{seed}_f{f}_ids"]), (seed, f)
+        assert dev_tr.table.emb.is_cuda and torch.get_num_threads() == torch.get_num_threads()

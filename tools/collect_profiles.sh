@@ -5,14 +5,16 @@ set -u
 TAG=${1:-run}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+if [ "${ALL_LEGS:-1}" = 1 ]; then python bench.py --all-legs > $OUT/bench_all_legs.json 2> $OUT/bench_all_legs.err; fi
+python bench.py --workload cfg4 --steps 10 --warmup 2 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -o d -- python bench.py --no-cpu-baseline --no-kernel-head --no-neck > $OUT/d_bench.json 2> $OUT/d.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py --streams 1 --frames 24 --no-cpu-baseline --no-kernel-head --no-neck > $OUT/e_bench.json 2> $OUT/e.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q -o q -- python tools/query_time.py 64 > $OUT/q_query64.txt 2> $OUT/q.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k -o k -- python tools/a1_profile.py 16 > $OUT/k_a1.txt 2> $OUT/k.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k -o k -- python tools/a1_profile.py 16 fp16 > $OUT/k_a1.txt 2> $OUT/k.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_sq.err
-bash tools/run_train_prof.sh $OUT > $OUT/train_prof.txt 2>&1
+if [ "${ALL_LEGS:-1}" = 1 ]; then bash tools/run_train_prof.sh $OUT > $OUT/train_prof.txt 2>&1; fi
 python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -R $OUT | head -60

@@ -12,12 +12,13 @@ dp = xp.clone()
 bits = torch.randint(-2**31, 2**31 - 1, (B, E.n_padded(N), E.hw_padded(HW) // 32), dtype=torch.int32, device=dev)
 ns = E.default_nsplit(B, HW)
 part = torch.empty((B, ns, E.n_padded(N), 512), dtype=torch.float32, device=dev)
+cnt = torch.empty((B, ns, E.n_padded(N)), dtype=torch.int32, device=dev)
 kern = torch.zeros((mode.KP, 2, B, 160, 256), dtype=torch.int16, device=dev)
 kb = torch.zeros((2, B, 160), dtype=torch.float32, device=dev)
 odt = torch.bfloat16 if mode.name == "bf16" else torch.float16
 out = torch.empty((B, N, H, W), dtype=odt, device=dev)
 for _ in range(5):
-    E.pool(xp, dp, bits, N, HW, mode.feat, ns, out=part)
+    E.pool(xp, dp, bits, N, HW, mode.feat, ns, out=part, counts=cnt)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, bits_out=bits)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, logits_out=out, out_dtype=E.OUT_CODE[odt])
 torch.cuda.synchronize()
