@@ -117,7 +117,7 @@ template <int E> __device__ __forceinline__ void st_from_f32(uint16_t* p, float 
 // stores per row).  It needs the 4 x 6 source neighbourhood: the 4 rows are loaded once (vector loads), the
 // two edge columns come from the neighbouring lanes by cross-lane shuffles (a real load only at wave / row
 // boundaries), so HBM sees the source once and the destination once (5 * planes*H*W elements).
-template <typename T, bool VEC, int E, bool REV = false>
+template <typename T, bool VEC, int E>
 __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T* __restrict__ dst, int64_t planes,
                                                     int H, int W) {
     const int W2 = 2 * W;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_upsample2x(const T* __restrict__ src, T
     const unsigned nthreads = gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
     const bool uniform_row = (segs % 64) == 0;                       // fp32 store exchange below
-    for (unsigned base = (REV ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * blockDim.x; base < total; base += nthreads) {
+    for (unsigned base = blockIdx.x * blockDim.x; base < total; base += nthreads) {
         const unsigned idx = base + threadIdx.x;
         const bool live = idx < total;
         const unsigned t = (live ? idx : total - 1) / segs;          // = p*hp + pair
@@ -238,9 +238,7 @@ extern "C" int ph_upsample2x(const void* src, void* dst, int dtype, int64_t plan
         if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_BF16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
         else hipLaunchKernelGGL((k_upsample2x<uint16_t, false, PH_E_BF16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
     } else {
-        static const bool rev = getenv("PH_UPSAMPLE_REV") != nullptr;      // experiment
-        if (vec && rev) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_F16, true>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
-        else if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_F16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
+        if (vec) hipLaunchKernelGGL((k_upsample2x<uint16_t, true, PH_E_F16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
         else hipLaunchKernelGGL((k_upsample2x<uint16_t, false, PH_E_F16>), dim3((int)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, planes, H, W);
     }
     PH_CHECK_LAUNCH();

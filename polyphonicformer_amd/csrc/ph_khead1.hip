@@ -25,10 +25,25 @@
 // the bound is the safety net).  All polled words are zeroed by a memset node in front of every launch.
 #include "ph_common.h"
 
-constexpr int K1_PX = 128;                 // pixels per workgroup and phase: four 32-px MFMA column tiles
-constexpr int K1_LD = K1_PX + 32;          // LDS row stride 80 dwords: rows r, r+1, r+2, r+3 of a transposing read start
-                                           // at banks 0 / 16 / 32 / 48 -> conflict free
-constexpr int K1_THREADS = 512;
+// Two geometries of the same kernel.  A wave always owns FOUR 32 x 32 accumulator tiles of the conv output (64 registers):
+//   K1Geo<1, 4> ("wide"):  8 waves, wave w = channels 32w..32w+31 of a 128-pixel slice; 159 KB of LDS -> ONE workgroup per CU;
+//   K1Geo<2, 2> ("pair"):  4 waves, wave w = channels 64w..64w+63 of a  64-pixel slice;  78 KB of LDS -> TWO workgroups per CU
+//                          (same registers per wave, same waves per CU).  Built on the SQ counters of the wide form (60 % of
+//                          the wave cycles waiting, MFMA busy 15 %, profiles/r03) in the hope that one workgroup computes
+//                          while the other waits; measured slower (see the launcher), compiled only with -DK1_WITH_PAIR.
+template <int RT_, int CT_> struct K1Geo {
+    static constexpr int RT = RT_, CT = CT_;                  // row tiles (32 channels) x column tiles (32 px) per wave
+    static constexpr int WAVES = 8 / RT, THREADS = 64 * WAVES, PX = 32 * CT;
+    // LDS row stride of the slice.  CT = 4: 160 elements = 80 dwords: rows r .. r+3 of a transposing read start at banks
+    // 0 / 16 / 32 / 48 -> conflict free.  CT = 2: 72 elements = 36 dwords (a conflict-free 96 would not leave room for two
+    // workgroups per CU): the second 16-pixel half of a 32-lane pass collides 2-way with one row of the first.
+    static constexpr int LD = CT == 4 ? 160 : 72;
+    static constexpr int WGS_PER_CU = CT == 4 ? 1 : 2;
+    static constexpr int SSB = CT == 4 ? 4096 : 2048;         // bytes of the ss / bitsl union: [256] float2, [256 rows][CT] words
+    static constexpr size_t LDS_BYTES = (size_t)256 * LD * 2 + (size_t)WAVES * 8192 + SSB + 3 * 512 * 4 + 288 * 4 + 64 * 4 + 64 * 4;
+};
+typedef K1Geo<1, 4> K1Wide;
+typedef K1Geo<2, 2> K1Pair;
 constexpr unsigned K1_SPIN_LIMIT = 1u << 22;
 
 #define K1_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -73,9 +88,10 @@ __device__ __forceinline__ void k1_wave_sync() {
 }
 
 // ---- staging registers of one [256 ch][128 px] input slice ----------------------------------------------------------
-template <int INFMT, int E> struct K1Stage;
-// fp32 NCHW, HW % 4 == 0: 32 threads x 16 B per channel row, 16 rows per pass, 16 passes
-template <int E> struct K1Stage<1, E> {
+template <int INFMT, int E, typename G> struct K1Stage;
+// fp32 NCHW, HW % 4 == 0: PX / 4 threads x 16 B per channel row, 16 rows per pass, 16 passes
+template <int E, typename G> struct K1Stage<1, E, G> {
+    static constexpr int TPR = G::PX / 4;                     // threads per channel row; THREADS / TPR = 16 rows per pass
     uint4 v[16];
     // part < 0: the whole slice; otherwise request `part` alone (the requests of the next slice are paced through the first
     // GEMM: a wave blocks in the issue of a vector-memory instruction while the CU's memory pipe is full, and 8 waves issuing
@@ -83,9 +99,9 @@ template <int E> struct K1Stage<1, E> {
     static constexpr int NREQ = 16;
     template <int part = -1> __device__ __forceinline__ void load(const K1Args& a, int m, int b, int64_t px0, int tid) {
         const float* src = (const float*)a.f[m] + (int64_t)b * 256 * a.HW;
-        int64_t col = px0 + (tid & 31) * 4;
+        int64_t col = px0 + (tid % TPR) * 4;
         if (col > a.HW - 4) col = a.HW - 4;                                   // clamped; zeroed in store()
-        const uint32_t voff = (uint32_t)((((int64_t)(tid >> 5)) * a.HW + col) * 4);
+        const uint32_t voff = (uint32_t)((((int64_t)(tid / TPR)) * a.HW + col) * 4);
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if (part < 0 || q == part) v[q] = ld_nt16((const char*)(src + (int64_t)q * 16 * a.HW) + voff);
@@ -94,7 +110,7 @@ template <int E> struct K1Stage<1, E> {
     // GEMM and its epilogue have the registers
     uint2 pk[16];
     __device__ __forceinline__ void pack(int tid, int64_t HW, int64_t px0) {
-        const bool ok = px0 + (tid & 31) * 4 < HW;                          // a 4-pixel group is inside or outside as a whole
+        const bool ok = px0 + (tid % TPR) * 4 < HW;                         // a 4-pixel group is inside or outside as a whole
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float x0 = ok ? __uint_as_float(v[q].x) : 0.f, x1 = ok ? __uint_as_float(v[q].y) : 0.f;
@@ -104,16 +120,17 @@ template <int E> struct K1Stage<1, E> {
     }
     __device__ __forceinline__ void store(uint16_t* T, int tid) const {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) *(uint2*)(T + (q * 16 + (tid >> 5)) * K1_LD + (tid & 31) * 4) = pk[q];
+        for (int q = 0; q < 16; ++q) *(uint2*)(T + (q * 16 + tid / TPR) * G::LD + (tid % TPR) * 4) = pk[q];
     }
 };
-// 16-bit planes (zero padded to HWp by their producer): 16 threads x 16 B per channel row, 32 rows per pass, 8 passes
-template <int E> struct K1Stage<2, E> {
+// 16-bit planes (zero padded to HWp by their producer): PX / 8 threads x 16 B per channel row, 32 rows per pass, 8 passes
+template <int E, typename G> struct K1Stage<2, E, G> {
+    static constexpr int TPR = G::PX / 8;
     uint4 v[8];
     static constexpr int NREQ = 8;
     template <int part = -1> __device__ __forceinline__ void load(const K1Args& a, int m, int b, int64_t px0, int tid) {
         const uint16_t* src = (const uint16_t*)a.f[m] + (int64_t)b * 256 * a.HWp;
-        const uint32_t voff = (uint32_t)((((int64_t)(tid >> 4)) * a.HWp + px0 + (tid & 15) * 8) * 2);
+        const uint32_t voff = (uint32_t)((((int64_t)(tid / TPR)) * a.HWp + px0 + (tid % TPR) * 8) * 2);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (part < 0 || q == part) v[q] = ld_nt16((const char*)(src + (int64_t)q * 32 * a.HWp) + voff);
@@ -121,7 +138,7 @@ template <int E> struct K1Stage<2, E> {
     __device__ __forceinline__ void pack(int, int64_t, int64_t) {}
     __device__ __forceinline__ void store(uint16_t* T, int tid) const {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *(uint4*)(T + (q * 32 + (tid >> 4)) * K1_LD + (tid & 15) * 8) = v[q];
+        for (int q = 0; q < 8; ++q) *(uint4*)(T + (q * 32 + tid / TPR) * G::LD + (tid % TPR) * 8) = v[q];
     }
 };
 
@@ -139,7 +156,7 @@ __device__ __forceinline__ void k1_load_a(uint4 (&af)[16], const uint16_t* __res
 // acc0 / acc1 [32 rows of A][32 px of column tiles ct, ct + 1] over K = 256 channel rows of the LDS tile.  Two independent
 // accumulator chains: consecutive MFMAs on ONE accumulator wait for each other's result (64 cycles), two chains issue at
 // the matrix pipe's rate.  `every2(j)` runs after k-steps 2j, 2j + 1 (the paced requests of the next slice).
-template <int E, typename F>
+template <int E, int K1_LD, typename F>
 __device__ __forceinline__ void k1_gemm2(const uint4 (&af)[16], const uint16_t* T, int ct, int lane, f32x16_t& acc0,
                                          f32x16_t& acc1, F&& every2) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
@@ -162,7 +179,7 @@ __device__ __forceinline__ void k1_gemm2(const uint4 (&af)[16], const uint16_t* 
     }
 }
 // the second GEMM's forms: D[px][kernel row] (operands swapped), accumulators start at the lane's bias
-template <int E>
+template <int E, int K1_LD>
 __device__ __forceinline__ f32x16_t k1_gemm_t(const uint4 (&w)[16], const uint16_t* T, int ct, int lane, float bz) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
     f32x16_t acc;
@@ -178,7 +195,7 @@ __device__ __forceinline__ f32x16_t k1_gemm_t(const uint4 (&w)[16], const uint16
     }
     return acc;
 }
-template <int E>
+template <int E, int K1_LD>
 __device__ __forceinline__ void k1_gemm2_t(const uint4 (&w)[16], const uint16_t* T, int ct, int lane, float bz, f32x16_t& acc0,
                                            f32x16_t& acc1) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
@@ -225,20 +242,22 @@ template <> __device__ __forceinline__ void k1_store_logit<uint16_t>(uint16_t* p
 // Rule of the loop body: between the request of the next slice and the top of the next phase a wave must not WAIT for any
 // vector-memory load (global or scratch) -- constants live in LDS, the second GEMM's weights are requested before the
 // slice, the next phase's conv weights after it.
-template <bool W0, int INFMT, int E, typename OutT, bool F32O>
+template <bool W0, int INFMT, int E, typename OutT, bool F32O, typename G>
 __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, int lane, int wave) {
-    uint16_t* T = lds;                                              // [256][K1_LD]: input slice, later the normalised slice
-    uint16_t* keepw = lds + 256 * K1_LD + wave * 4096;              // 8 KB per wave: loc in accumulator layout, later x rows
-    float2* ss = (float2*)(lds + 256 * K1_LD + 8 * 4096);           // [256] per-channel scale / shift of the normalisation ...
-    uint32_t* bitsl = (uint32_t*)ss;                                // ... and, later in the phase, [256 rows][4 words] mask bits
-    float* gnl = (float*)(bitsl + 256 * 4);                         // [3][2][256] gamma, beta of the three GroupNorms
+    constexpr int RT = G::RT, CT = G::CT, LD = G::LD;
+    uint16_t* T = lds;                                              // [256][LD]: input slice, later the normalised slice
+    uint16_t* keepw = lds + 256 * LD + wave * 4096;                 // 8 KB per wave: loc in accumulator layout, later x rows
+    float2* ss = (float2*)(lds + 256 * LD + G::WAVES * 4096);       // [256] per-channel scale / shift of the normalisation ...
+    uint32_t* bitsl = (uint32_t*)ss;                                // ... and, later in the phase, [256 rows][CT words] mask bits
+    float* gnl = (float*)((char*)ss + G::SSB);                      // [3][2][256] gamma, beta of the three GroupNorms
     float* b2l = gnl + 3 * 512;                                     // [256 + 32] bias of conv_seg, conv_direct_depth
     float* red = b2l + 288;                                         // [64] this slice's sums
     float* statl = red + 64;                                        // [64] (mean, rstd) x 32 groups
     const int g = lane >> 5;
-    uint16_t* rows = T + wave * 32 * K1_LD;                         // this wave's channel rows
+    const int ch0 = wave * RT * 32;                                 // this wave's first channel
+    uint16_t* rows = T + ch0 * LD;                                  // this wave's channel rows
     const int slot = blockIdx.x / a.P, pair = blockIdx.x - slot * a.P;
-    const int64_t px0 = (int64_t)pair * K1_PX;
+    const int64_t px0 = (int64_t)pair * G::PX;
     const int64_t wpr = a.HWp / 32;                                 // mask words per row
     const int nfr = slot < a.B ? (a.B - slot + a.F - 1) / a.F : 0;  // frames of this workgroup: slot, slot + F, ...
     const int nph = 3 * nfr;
@@ -246,11 +265,12 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
     gu64* g1 = (gu64*)a.gran1;
     gu64* g2 = (gu64*)a.gran2;
     gu32* gstatus = (gu32*)a.status;
+    (void)g;
 
-    K1Stage<INFMT, E> stg;
+    K1Stage<INFMT, E, G> stg;
     uint4 af[16];
     stg.load(a, 0, slot, px0, tid);
-    k1_load_a(af, a.wfrag[0], wave, lane);
+    k1_load_a(af, a.wfrag[0], wave * RT, lane);
     stg.pack(tid, a.HW, px0);
     for (int ph = 0; ph < nph; ++ph) {
         const int m = ph % 3, b = slot + (ph / 3) * a.F;
@@ -260,51 +280,69 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
         const int ph1 = ph + 1 < nph ? ph + 1 : ph;
         const int nm = ph1 % 3, nb = slot + (ph1 / 3) * a.F;
         K1_STAMP(0);
-        // second GEMM: every wave has ONE row tile of the static kernels and 1 / 2 / 4 column tiles of the slice
+        // second GEMM: wpr2 waves share a row tile of the static kernels (each takes CT / wpr2 column tiles of the slice);
+        // WAVES / wpr2 row tiles per pass, as many passes as the map's kernels need (one in the wide geometry)
         const int m2 = a.m2_tiles[m];
-        const int wpr2 = m2 >= 5 ? 1 : (m2 >= 3 ? 2 : 4);            // waves per row tile
-        const int rt2 = wave / wpr2, nct2 = 4 / wpr2, ct20 = (wave % wpr2) * nct2;
+        int wpr2 = CT;
+        while (wpr2 > 1 && G::WAVES / wpr2 < m2) wpr2 >>= 1;
+        const int rpass = G::WAVES / wpr2;
+        const int rt2 = wave / wpr2, nct2 = CT / wpr2, ct20 = (wave % wpr2) * nct2;
         const bool act2 = rt2 < m2;
         stg.store(T, k1_fresh(tid));
         __syncthreads();
         K1_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
-        // first GEMM; the next slice's 16 (8) requests are issued between its MFMAs, one per 4 (8) MFMAs -- except in wave
-        // 0, whose polls must not return behind them (vector memory returns in order): it requests its share after the polls
+        // first GEMM, tile q = t * CT + ct (row tile t of this wave, column tile ct).  The next slice's 16 (8) requests are
+        // issued between the MFMAs of the LAST row tile (behind the reload of the conv weights of that tile: vector memory
+        // returns in order), evenly paced -- except in wave 0, whose polls must not return behind them: it requests its share
+        // after the polls
         f32x16_t y[4];
         {
             const int l = k1_fresh(lane), t = k1_fresh(tid);
-            constexpr int NR = K1Stage<INFMT, E>::NREQ;
+            constexpr int NR = K1Stage<INFMT, E, G>::NREQ;
+            constexpr int QPS = 4 / CT;                     // request slots (of 16) per `every2` call of the last row tile
 #define K1_REQ(Q)                                                                       \
-    if (!W0 && (Q) % (16 / NR) == 0) stg.template load<(Q) / (16 / NR)>(a, nm, nb, px0, t)
+    if constexpr ((Q) < 16 && (Q) % (16 / NR) == 0) { if (!W0) stg.template load<(Q) / (16 / NR)>(a, nm, nb, px0, t); }
+#define K1_REQJ(BASE, J) { K1_REQ((BASE) + (J) * QPS); if constexpr (QPS == 2) { K1_REQ((BASE) + (J) * QPS + 1); } }
 #define K1_REQS(BASE)                                                                   \
     [&](int j) {                                                                        \
-        if (j == 0) { K1_REQ(BASE + 0); } else if (j == 1) { K1_REQ(BASE + 1); } else if (j == 2) { K1_REQ(BASE + 2); } \
-        else if (j == 3) { K1_REQ(BASE + 3); } else if (j == 4) { K1_REQ(BASE + 4); } else if (j == 5) { K1_REQ(BASE + 5); } \
-        else if (j == 6) { K1_REQ(BASE + 6); } else { K1_REQ(BASE + 7); }               \
+        if (j == 0) K1_REQJ(BASE, 0) else if (j == 1) K1_REQJ(BASE, 1) else if (j == 2) K1_REQJ(BASE, 2)      \
+        else if (j == 3) K1_REQJ(BASE, 3) else if (j == 4) K1_REQJ(BASE, 4) else if (j == 5) K1_REQJ(BASE, 5) \
+        else if (j == 6) K1_REQJ(BASE, 6) else K1_REQJ(BASE, 7)                                               \
     }
-            k1_gemm2<E>(af, T, 0, l, y[0], y[1], K1_REQS(0));
-            k1_gemm2<E>(af, T, 2, l, y[2], y[3], K1_REQS(8));
+            if constexpr (RT == 1) {
+                k1_gemm2<E, LD>(af, T, 0, l, y[0], y[1], K1_REQS(0));
+                k1_gemm2<E, LD>(af, T, 2, l, y[2], y[3], K1_REQS(8));
+            } else {
+                k1_gemm2<E, LD>(af, T, 0, l, y[0], y[1], [](int) {});
+                __builtin_amdgcn_sched_barrier(0);
+                k1_load_a(af, a.wfrag[m], wave * RT + 1, l);
+                __builtin_amdgcn_sched_barrier(0);
+                k1_gemm2<E, LD>(af, T, 0, l, y[2], y[3], K1_REQS(0));
+            }
 #undef K1_REQS
+#undef K1_REQJ
 #undef K1_REQ
         }
         __builtin_amdgcn_sched_barrier(0);
         K1_STAMP(2);
-        // ---- sums of this slice: wave w owns groups 4w .. 4w+3 (8 channels each: accumulator rows 8j .. 8j+7) --------
-        // (one group at a time, two running sums: the tree the compiler builds from a flat loop needs 30 more registers at
-        // the point where y, the second GEMM's weights and the next slice are all live)
+        // ---- sums of this slice: the wave owns groups 4 (RT wave + t) + j (8 channels each: accumulator rows 8j .. 8j+7 of
+        // row tile t).  (one group at a time, two running sums: the tree the compiler builds from a flat loop needs 30 more
+        // registers at the point where y, the second GEMM's weights and the next slice are all live)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float u = 0.f, w = 0.f;
+        for (int tt = 0; tt < RT; ++tt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int j = 0; j < 4; ++j) {
+                float u = 0.f, w = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const float v = y[ct][j * 4 + q]; u += v; w = fmaf(v, v, w); }
-            u = k1_wave_sum(u);
-            w = k1_wave_sum(w);
-            if (lane == 0) { red[(wave * 4 + j) * 2] = u; red[(wave * 4 + j) * 2 + 1] = w; }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float v = y[tt * CT + ct][j * 4 + q]; u += v; w = fmaf(v, v, w); }
+                u = k1_wave_sum(u);
+                w = k1_wave_sum(w);
+                if (lane == 0) { red[((wave * RT + tt) * 4 + j) * 2] = u; red[((wave * RT + tt) * 4 + j) * 2 + 1] = w; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         __syncthreads();                                             // red complete; every wave is past its GEMM
         K1_STAMP(3);
         if (W0) {
@@ -385,41 +423,42 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
         K1_STAMP(7);
         __builtin_amdgcn_sched_barrier(0);
         // ---- normalise in registers ------------------------------------------------------------------------------------
-        {
-            const int t = k1_fresh(tid);
-            if (t < 256) {
-                const float mean = statl[(t >> 3) * 2], rstd = statl[(t >> 3) * 2 + 1];
-                const float ga = gnl[m * 512 + t], be = gnl[m * 512 + 256 + t];
-                ss[t] = make_float2(rstd * ga, be - mean * rstd * ga);
-            }
+        for (int t = k1_fresh(tid); t < 256; t += G::THREADS) {
+            const float mean = statl[(t >> 3) * 2], rstd = statl[(t >> 3) * 2 + 1];
+            const float ga = gnl[m * 512 + t], be = gnl[m * 512 + 256 + t];
+            ss[t] = make_float2(rstd * ga, be - mean * rstd * ga);
         }
         __syncthreads();
         const int ln = k1_fresh(lane), gn = ln >> 5;                           // lane / half of this section
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float2 s = ss[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * gn];
+        for (int tt = 0; tt < RT; ++tt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const bool inside = px0 + ct * 32 + (ln & 31) < a.HW;
-                const float v = fmaxf(y[ct][r] * s.x + s.y, 0.f);
-                y[ct][r] = inside ? v : 0.f;                                   // planes are zero padded
+            for (int r = 0; r < 16; ++r) {
+                const float2 s = ss[ch0 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * gn];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bool inside = px0 + ct * 32 + (ln & 31) < a.HW;
+                    const float v = fmaxf(y[tt * CT + ct][r] * s.x + s.y, 0.f);
+                    y[tt * CT + ct][r] = inside ? v : 0.f;                     // planes are zero padded
+                }
             }
-        }
         K1_STAMP(8);
-        // one column tile at a time: the normalised values go to this wave's rows of T (the B operand of the second GEMM);
-        //   loc: a 16-bit copy in accumulator layout waits for the sem phase in this wave's 8 KB of `keep` (2 KB per column
+        // one tile at a time: the normalised values go to this wave's rows of T (the B operand of the second GEMM);
+        //   loc: a 16-bit copy in accumulator layout waits for the sem phase in this wave's 8 KB of `keep` (2 KB per
         //        tile: 2 x 16 bytes per lane, lane-linear);
         //   sem: x_feats = semantic_feats + loc_feats (kernel_head.py:303) overwrites that copy as [32 rows][32 px] rows;
         //   dfe: nothing else
         float* f32o = !F32O ? nullptr : (m == 1 ? a.x_f32 : (m == 2 ? a.dfe_f32 : nullptr));
-        // the weights of the second GEMM (one row tile per wave, 64 registers) are requested a quarter per column tile, as
-        // the accumulators of that tile die: by now the slice requested during the first GEMM has landed, so waiting for
+        // the weights of the second GEMM (one row tile per wave and pass, 64 registers) are requested a quarter per tile,
+        // as the accumulators of that tile die: by now the slice requested during the first GEMM has landed, so waiting for
         // them later (in order) costs nothing
         uint4 a2[16];
         const uint16_t* a2p = a.w2[m] + ((int64_t)(act2 ? rt2 : 0) * 16 * 64 + k1_fresh(lane)) * 8;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            uint4* kq = (uint4*)(keepw + ct * 1024);                          // this column tile's 2 KB
+        for (int q = 0; q < 4; ++q) {
+            const int tt = q / CT, ct = q % CT;
+            const int chq = ch0 + tt * 32;                                    // first channel of this tile
+            uint4* kq = (uint4*)(keepw + q * 1024);                           // this tile's 2 KB
             const bool f32w = F32O && f32o && px0 + ct * 32 + (ln & 31) < a.HW;
             if (m == 1) {
                 // x_feats = semantic_feats + loc_feats (kernel_head.py:303), 8 accumulator rows at a time; x overwrites loc in
@@ -432,9 +471,9 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = ii * 8 + e * 2;
-                        const float x0 = y[ct][r] + e2f<E>(w[e] & 0xFFFFu), x1 = y[ct][r + 1] + e2f<E>(w[e] >> 16);
+                        const float x0 = y[q][r] + e2f<E>(w[e] & 0xFFFFu), x1 = y[q][r + 1] + e2f<E>(w[e] >> 16);
                         if (f32w) {
-                            float* ub = f32o + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;
+                            float* ub = f32o + ((int64_t)b * 256 + chq + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;
                             ub[(uint32_t)(4 * gn * a.HW + (ln & 31))] = x0;
                             ub[(uint32_t)((4 * gn + 1) * a.HW + (ln & 31))] = x1;
                         }
@@ -448,47 +487,46 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
                     for (int ii = 0; ii < 2; ++ii) {
                         uint32_t w[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] = f2e_pk<E>(y[ct][ii * 8 + e * 2], y[ct][ii * 8 + e * 2 + 1]);
+                        for (int e = 0; e < 4; ++e) w[e] = f2e_pk<E>(y[q][ii * 8 + e * 2], y[q][ii * 8 + e * 2 + 1]);
                         kq[ii * 64 + ln] = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                 }
                 if (f32w) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float* ub = f32o + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;
-                        ub[(uint32_t)(4 * gn * a.HW + (ln & 31))] = y[ct][r];
+                        float* ub = f32o + ((int64_t)b * 256 + chq + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;
+                        ub[(uint32_t)(4 * gn * a.HW + (ln & 31))] = y[q][r];
                     }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                rows[((r & 3) + 8 * (r >> 2) + 4 * gn) * K1_LD + ct * 32 + (ln & 31)] = (uint16_t)f2e<E>(y[ct][r]);
+                rows[(tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * gn) * LD + ct * 32 + (ln & 31)] = (uint16_t)f2e<E>(y[q][r]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = ct * 4; ks < ct * 4 + 4; ++ks) a2[ks] = *(const uint4*)(a2p + ks * 512);
+            for (int ks = q * 4; ks < q * 4 + 4; ++ks) a2[ks] = *(const uint4*)(a2p + ks * 512);
             __builtin_amdgcn_sched_barrier(0);
         }
         K1_STAMP(9);
         if (m >= 1) {
-            // planes out, whole 256-byte row segments per 16 lanes.  dfe: straight from this wave's rows of T.  x: its
-            // accumulator-layout copy in `keep` goes through the wave's rows of the PAD columns' neighbour -- no: through a
-            // second pass over this wave's rows of T is impossible (they hold sem for the second GEMM), so x is transposed
-            // in registers: lane (px, half g) holds 16 rows x 4 column tiles; ds_bpermute-free route = LDS `xrow` staging in
-            // the lane's own keep slots rewritten as rows, one column tile at a time
+            // planes out, whole row segments (PX pixels = PX / 8 lanes x 16 bytes) of this wave's 32 RT channel rows, 8 wave
+            // stores.  dfe: straight from this wave's rows of T.  x: its accumulator-layout copy in `keep` is first rewritten
+            // in place as [32 rows][32 px] rows per tile (the wave's rows of T hold sem for the second GEMM)
             k1_wave_sync();
-            char* dstp = (char*)((m == 1 ? a.x_planes : a.dfe_planes) + ((int64_t)b * 256 + wave * 32) * a.HWp + px0);   // uniform
-            const int lp = k1_fresh(lane), piece = lp & 15;
-            const uint32_t voff = (uint32_t)(((int64_t)(lp >> 4) * a.HWp + piece * 8) * 2);
+            constexpr int TPRO = G::PX / 8, RPI = 64 / TPRO;              // lanes per row segment, rows per wave store
+            char* dstp = (char*)((m == 1 ? a.x_planes : a.dfe_planes) + ((int64_t)b * 256 + ch0) * a.HWp + px0);   // uniform
+            const int lp = k1_fresh(lane), piece = lp % TPRO, rowl = lp / TPRO;
+            const uint32_t voff = (uint32_t)(((int64_t)rowl * a.HWp + piece * 8) * 2);
             if (m == 1) {
-                // keep (accumulator layout, pairs of rows r, r+1 packed) -> [32 rows][32 px] rows per column tile, in place:
+                // keep (accumulator layout, pairs of rows r, r+1 packed) -> [32 rows][32 px] rows per tile, in place:
                 // every lane first reads its 2 x 16 bytes of the tile, the wave syncs, then writes 16 two-byte elements
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    uint4* kq = (uint4*)(keepw + ct * 1024);
+                for (int q = 0; q < 4; ++q) {
+                    uint4* kq = (uint4*)(keepw + q * 1024);
                     const uint4 q0 = kq[lp], q1 = kq[64 + lp];
                     k1_wave_sync();
                     const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                    uint16_t* xr = keepw + ct * 1024;
+                    uint16_t* xr = keepw + q * 1024;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = e * 2;
@@ -498,12 +536,14 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
                 }
                 k1_wave_sync();
             }
-            const uint16_t* src = m == 1 ? keepw + (piece >> 2) * 1024 + (lp >> 4) * 32 + (piece & 3) * 8
-                                         : rows + (lp >> 4) * K1_LD + piece * 8;
-            const int sstep = m == 1 ? 4 * 32 : 4 * K1_LD;
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                if (K1_OUT_ON) st_nt16(dstp + (int64_t)it * 8 * a.HWp + voff, *(const uint4*)(src + it * sstep));
+            for (int it = 0; it < 8; ++it) {
+                // row it * RPI + rowl of the wave's 32 RT rows: row tile (it * RPI) / 32 (compile time: RPI divides 32)
+                const int tt = (it * RPI) / 32, rin = (it * RPI) % 32 + rowl;
+                const uint16_t* src = m == 1 ? keepw + (tt * CT + (piece >> 2)) * 1024 + rin * 32 + (piece & 3) * 8
+                                             : rows + (it * RPI + rowl) * LD + piece * 8;
+                if (K1_OUT_ON) st_nt16(dstp + (int64_t)it * RPI * a.HWp * 2 + voff, *(const uint4*)src);
+            }
         }
         K1_STAMP(10);
         __syncthreads();
@@ -521,102 +561,113 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
             OutT* out2 = (OutT*)a.out2[m];
             OutT* out2b = (m == 1 && a.n_stuff > 0) ? (OutT*)a.out2[0] : nullptr;
             const float* bias = m == 1 ? b2l : b2l + 256;
-            if (act2) {
-                const int rt = rt2;
-                auto epilogue = [&](const f32x16_t& v, int ct) {
-                    const int l2 = k1_fresh(lane), g2h = l2 >> 5;   // per call: nothing lane-derived is hoisted across tiles
-                    const int row = rt * 32 + (l2 & 31);
-                    const int64_t pxb = px0 + ct * 32;
-                    OutT* tb = out2 + ((int64_t)b * a.out2_rows[m] + rt * 32) * a.HW + pxb;   // uniform
-                    const bool rok = row < a.n2[m];
-                    const bool dual = out2b && row >= a.stuff_lo && row < a.stuff_lo + a.n_stuff;
-                    OutT* tb2 = out2b ? out2b + ((int64_t)b * a.out2_rows[0] + a.n_init - a.stuff_lo + rt * 32) * a.HW + pxb : nullptr;
-                    if (K1_OUT_ON) {
-                        if (a.HW % 4 == 0) {
-                            const uint32_t go = (uint32_t)(((int64_t)(l2 & 31) * a.HW + 4 * g2h) * sizeof(OutT));   // lane's byte offset in the tile
+            auto epilogue = [&](const f32x16_t& v, int rt, int ct) {
+                const int l2 = k1_fresh(lane), g2h = l2 >> 5;   // per call: nothing lane-derived is hoisted across tiles
+                const int row = rt * 32 + (l2 & 31);
+                const int64_t pxb = px0 + ct * 32;
+                OutT* tb = out2 + ((int64_t)b * a.out2_rows[m] + rt * 32) * a.HW + pxb;   // uniform
+                const bool rok = row < a.n2[m];
+                const bool dual = out2b && row >= a.stuff_lo && row < a.stuff_lo + a.n_stuff;
+                OutT* tb2 = out2b ? out2b + ((int64_t)b * a.out2_rows[0] + a.n_init - a.stuff_lo + rt * 32) * a.HW + pxb : nullptr;
+                if (K1_OUT_ON) {
+                    if (a.HW % 4 == 0) {
+                        const uint32_t go = (uint32_t)(((int64_t)(l2 & 31) * a.HW + 4 * g2h) * sizeof(OutT));   // lane's byte offset in the tile
 #pragma unroll
-                            for (int jq = 0; jq < 4; ++jq) {
-                                const bool pin = pxb + 8 * jq + 4 * g2h < a.HW;        // 4 pixels are inside or outside as a whole
-                                if (sizeof(OutT) == 4) {
-                                    const uint4 q4 = make_uint4(__float_as_uint(v[4 * jq]), __float_as_uint(v[4 * jq + 1]),
-                                                                __float_as_uint(v[4 * jq + 2]), __float_as_uint(v[4 * jq + 3]));
-                                    if (rok && pin) *(uint4*)((char*)tb + go + jq * 8 * sizeof(OutT)) = q4;
-                                    if (dual && pin) *(uint4*)((char*)tb2 + go + jq * 8 * sizeof(OutT)) = q4;
-                                } else {
-                                    const uint2 q2 = make_uint2(f2h_pk(v[4 * jq], v[4 * jq + 1]), f2h_pk(v[4 * jq + 2], v[4 * jq + 3]));
-                                    if (rok && pin) *(uint2*)((char*)tb + go + jq * 8 * sizeof(OutT)) = q2;
-                                    if (dual && pin) *(uint2*)((char*)tb2 + go + jq * 8 * sizeof(OutT)) = q2;
-                                }
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int px = (r & 3) + 8 * (r >> 2) + 4 * g2h;
-                                if (pxb + px < a.HW) {
-                                    if (rok) k1_store_logit<OutT>(tb + (int64_t)(l2 & 31) * a.HW + px, v[r]);
-                                    if (dual) k1_store_logit<OutT>(tb2 + (int64_t)(l2 & 31) * a.HW + px, v[r]);
-                                }
+                        for (int jq = 0; jq < 4; ++jq) {
+                            const bool pin = pxb + 8 * jq + 4 * g2h < a.HW;        // 4 pixels are inside or outside as a whole
+                            if (sizeof(OutT) == 4) {
+                                const uint4 q4 = make_uint4(__float_as_uint(v[4 * jq]), __float_as_uint(v[4 * jq + 1]),
+                                                            __float_as_uint(v[4 * jq + 2]), __float_as_uint(v[4 * jq + 3]));
+                                if (rok && pin) *(uint4*)((char*)tb + go + jq * 8 * sizeof(OutT)) = q4;
+                                if (dual && pin) *(uint4*)((char*)tb2 + go + jq * 8 * sizeof(OutT)) = q4;
+                            } else {
+                                const uint2 q2 = make_uint2(f2h_pk(v[4 * jq], v[4 * jq + 1]), f2h_pk(v[4 * jq + 2], v[4 * jq + 3]));
+                                if (rok && pin) *(uint2*)((char*)tb + go + jq * 8 * sizeof(OutT)) = q2;
+                                if (dual && pin) *(uint2*)((char*)tb2 + go + jq * 8 * sizeof(OutT)) = q2;
                             }
                         }
-                    }
-#ifndef K1_NO_BITS
-                    if (a.bits && m < 2) {
-                        // hard mask of these logits (kernel_head.py:314-317): bit (r & 3) + 8 (r >> 2) of this lane's half word,
-                        // the upper half-wave's bits sit 4 places higher; lanes l and l + 32 together hold the row's word
-                        uint32_t mk = 0;
+                    } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int px = (r & 3) + 8 * (r >> 2);
-                            const bool on = v[r] > PH_BIN_THR && pxb + px + 4 * g2h < a.HW;
-                            mk |= on ? (1u << px) : 0u;
+                            const int px = (r & 3) + 8 * (r >> 2) + 4 * g2h;
+                            if (pxb + px < a.HW) {
+                                if (rok) k1_store_logit<OutT>(tb + (int64_t)(l2 & 31) * a.HW + px, v[r]);
+                                if (dual) k1_store_logit<OutT>(tb2 + (int64_t)(l2 & 31) * a.HW + px, v[r]);
+                            }
                         }
-                        mk <<= 4 * g2h;
-                        mk |= (uint32_t)__shfl_xor((int)mk, 32);
-                        if (l2 < 32) bitsl[(rt * 32 + l2) * 4 + ct] = mk;
                     }
+                }
+#ifndef K1_NO_BITS
+                if (a.bits && m < 2) {
+                    // hard mask of these logits (kernel_head.py:314-317): bit (r & 3) + 8 (r >> 2) of this lane's half word,
+                    // the upper half-wave's bits sit 4 places higher; lanes l and l + 32 together hold the row's word
+                    uint32_t mk = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = (r & 3) + 8 * (r >> 2);
+                        const bool on = v[r] > PH_BIN_THR && pxb + px + 4 * g2h < a.HW;
+                        mk |= on ? (1u << px) : 0u;
+                    }
+                    mk <<= 4 * g2h;
+                    mk |= (uint32_t)__shfl_xor((int)mk, 32);
+                    if (l2 < 32) bitsl[(rt * 32 + l2) * CT + ct] = mk;
+                }
 #endif
-                };
+            };
+            auto row_tile = [&](int rt) {
                 // the bias of a lane's kernel row initialises its accumulators
                 const float bz = m == 0 ? 0.f : bias[rt * 32 + (k1_fresh(lane) & 31)];
-#ifdef K1_TIMELINE
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) asm volatile("" ::"v"(__builtin_bit_cast(ph_u32x4, a2[ks])));
-                K1_STAMP(15);
-#endif
                 if (nct2 == 1) {
-                    const f32x16_t acc = k1_gemm_t<E>(a2, T, ct20, k1_fresh(lane), bz);
-                    K1_STAMP(16);
-                    epilogue(acc, ct20);
+                    const f32x16_t acc = k1_gemm_t<E, LD>(a2, T, ct20, k1_fresh(lane), bz);
+                    epilogue(acc, rt, ct20);
                 } else {
                     for (int cc = 0; cc < nct2; cc += 2) {
                         f32x16_t acc0, acc1;
-                        k1_gemm2_t<E>(a2, T, ct20 + cc, k1_fresh(lane), bz, acc0, acc1);
-                        if (cc == 0) K1_STAMP(16);
-                        epilogue(acc0, ct20 + cc);
-                        if (cc == 0) K1_STAMP(17);
+                        k1_gemm2_t<E, LD>(a2, T, ct20 + cc, k1_fresh(lane), bz, acc0, acc1);
+                        epilogue(acc0, rt, ct20 + cc);
                         __builtin_amdgcn_sched_barrier(0);
-                        epilogue(acc1, ct20 + cc + 1);
+                        epilogue(acc1, rt, ct20 + cc + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+            };
+#ifdef K1_TIMELINE
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) asm volatile("" ::"v"(__builtin_bit_cast(ph_u32x4, a2[ks])));
+            K1_STAMP(15);
+#endif
+            if (act2) row_tile(rt2);
+            K1_STAMP(16);
+            if constexpr (RT > 1) {
+                // further passes (more row tiles of static kernels than WAVES / wpr2): their weights are requested whole
+                for (int rt = rt2 + rpass; rt < m2; rt += rpass) {
+                    const uint16_t* ap = a.w2[m] + ((int64_t)rt * 16 * 64 + k1_fresh(lane)) * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) a2[ks] = *(const uint4*)(ap + ks * 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                    row_tile(rt);
+                }
             }
+            K1_STAMP(17);
+            (void)rpass;
         }
         // the conv weights of the next phase: requested behind the slice, needed only when it has landed
-        k1_load_a(af, a.wfrag[nm], wave, k1_fresh(lane));
+        k1_load_a(af, a.wfrag[nm], wave * RT, k1_fresh(lane));
         K1_STAMP(12);
         __syncthreads();                                              // T is free for the next slice; bitsl complete
         K1_STAMP(13);
         if (a.bits && m < 2) {
             const int N = a.n_init + a.n_stuff, t = k1_fresh(tid);
+            auto put_row = [&](int dst_row, const uint32_t* w /* null: zeros */) {
+                uint32_t* d = a.bits + ((int64_t)b * a.bits_rows + dst_row) * wpr + pair * CT;
+                if constexpr (CT == 4) *(uint4*)d = w ? *(const uint4*)w : make_uint4(0, 0, 0, 0);
+                else *(uint2*)d = w ? *(const uint2*)w : make_uint2(0, 0);
+            };
             if (m == 0) {
-                if (t < a.n_init)
-                    *(uint4*)(a.bits + ((int64_t)b * a.bits_rows + t) * wpr + pair * 4) = *(const uint4*)(bitsl + t * 4);
+                for (int r = t; r < a.n_init; r += G::THREADS) put_row(r, bitsl + r * CT);
             } else {
-                for (int r = a.n_init + t; r < a.bits_rows; r += K1_THREADS) {
-                    uint4 w = make_uint4(0, 0, 0, 0);
-                    if (r < N) w = *(const uint4*)(bitsl + (a.stuff_lo + r - a.n_init) * 4);
-                    *(uint4*)(a.bits + ((int64_t)b * a.bits_rows + r) * wpr + pair * 4) = w;
-                }
+                for (int r = a.n_init + t; r < a.bits_rows; r += G::THREADS)
+                    put_row(r, r < N ? bitsl + (a.stuff_lo + r - a.n_init) * CT : nullptr);
             }
             // bitsl is rewritten only after the next phase's barriers
         }
@@ -624,18 +675,18 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
     }
 }
 
-template <int INFMT, int E, typename OutT, bool F32O>
-__global__ __launch_bounds__(K1_THREADS) void k_khead_onepass(const K1Args a) {
+template <int INFMT, int E, typename OutT, bool F32O, typename G>
+__global__ __launch_bounds__(G::THREADS, 2) void k_khead_onepass(const K1Args a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // constants of all three phases go to LDS once (see k1_run's rule)
-    float* gnl = (float*)(lds + 256 * K1_LD + 8 * 4096) + 256 * 4;
+    float* gnl = (float*)((char*)(lds + 256 * G::LD + G::WAVES * 4096) + G::SSB);
     float* b2l = gnl + 3 * 512;
-    for (int i = tid; i < 3 * 512; i += K1_THREADS) gnl[i] = a.gn[i];
-    if (tid < 288) b2l[tid] = tid < 256 ? ((a.bias2[1] && tid < a.m2_tiles[1] * 32) ? a.bias2[1][tid] : 0.f)
-                                        : (a.bias2[2] ? a.bias2[2][tid - 256] : 0.f);
-    if (wave == 0) k1_run<true, INFMT, E, OutT, F32O>(a, lds, tid, lane, wave);
-    else k1_run<false, INFMT, E, OutT, F32O>(a, lds, tid, lane, wave);
+    for (int i = tid; i < 3 * 512; i += G::THREADS) gnl[i] = a.gn[i];
+    for (int i = tid; i < 288; i += G::THREADS)
+        b2l[i] = i < 256 ? ((a.bias2[1] && i < a.m2_tiles[1] * 32) ? a.bias2[1][i] : 0.f) : (a.bias2[2] ? a.bias2[2][i - 256] : 0.f);
+    if (wave == 0) k1_run<true, INFMT, E, OutT, F32O, G>(a, lds, tid, lane, wave);
+    else k1_run<false, INFMT, E, OutT, F32O, G>(a, lds, tid, lane, wave);
 }
 
 // ====================================================================================================================
@@ -657,7 +708,7 @@ extern "C" int ph_khead_onepass_supported(int B, int64_t HW, int groups, int pre
     if (B <= 0 || B > 4096 || HW <= 0) return 0;
     const int cu = k1_cus();
     const int64_t HWp = ph_hw_padded(HW);
-    if (cu <= 0 || HWp / K1_PX > cu) return 0;
+    if (cu <= 0 || HWp / K1Wide::PX > cu) return 0;
     if (groups != 32) return 0;
     if (!(prec == PH_PREC_BF16 || prec == PH_PREC_F16)) return 0;
     if (input_format == PH_IN_F32_NCHW && (HW % 4) != 0) return 0;
@@ -667,7 +718,7 @@ extern "C" int ph_khead_onepass_supported(int B, int64_t HW, int groups, int pre
 // bytes of the hand-off state; the first ph_khead_onepass_zeroed_bytes(B) of it are cleared by the call itself
 // hand-off state: [status (256 B)] [gran2: 3B x 128 x 8 B] [gran1: 3B x 64 x P x 8 B], all of it cleared by every call
 extern "C" size_t ph_khead_onepass_workspace_bytes(int B, int64_t HW) {
-    const int64_t P = ph_hw_padded(HW) / K1_PX;
+    const int64_t P = ph_hw_padded(HW) / K1Pair::PX;                 // the geometry with more slices
     return 256 + (size_t)3 * B * 128 * 8 + (size_t)3 * B * 64 * P * 8;
 }
 
@@ -714,27 +765,57 @@ extern "C" int ph_khead_onepass(const void* f0, const void* f1, const void* f2, 
     a.gran1 = a.gran2 + (size_t)3 * B * 128;
     a.B = B; a.HW = HW; a.HWp = HWp; a.eps = eps;
     a.timeline = g_k1_timeline;
-    a.P = (int)(HWp / K1_PX);
-    a.F = k1_cus() / a.P;
-    if (a.F > B) a.F = B;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)256 * K1_LD * 2 + 8 * K1_THREADS * 16 + 256 * 4 * 4 + 3 * 512 * 4 + 288 * 4 + 64 * 4 + 64 * 4;
-    const dim3 grid(a.F * a.P), block(K1_THREADS);
     const bool planes = input_format == PH_IN_PLANES, h = prec == PH_PREC_F16, o16 = out_dtype == PH_OUT_F16;
     const bool f32o = x_f32 || dfe_f32;          // the variant that also writes fp32 x_feats / depth_feats (the reference API's tensors)
     if (hipMemsetAsync(workspace, 0, ph_khead_onepass_workspace_bytes(B, HW), s) != hipSuccess) {
         ph_set_error("ph_khead_onepass: hipMemsetAsync failed");
         return PH_ELAUNCH;
     }
-#define K1_GO(I, E, O, F)                                                                                          \
+    // geometry: one 128-pixel workgroup per CU.  The pair geometry (two 64-pixel workgroups per CU) is compiled only with
+    // -DK1_WITH_PAIR (PH_EXTRA_HIPCC_FLAGS) and chosen with PH_KHEAD1_PAIR=1: it passes the same tests and is SLOWER -- cfg2,
+    // 16 frames: 1.02 against 0.96 ms; cfg5, 32 frames: 0.61 against 0.53 ms on one box.  A frame's pair-slices are spread
+    // over the whole chip, so the two workgroups of a CU sit in the same phase of the same frame and wait for the same
+    // statistics together, and the exchange itself grows from 10-11k to 16-20k cycles per phase with twice the workgroups.
+    const int cus = k1_cus();
+#ifdef K1_WITH_PAIR
+    static const bool want_pair = getenv("PH_KHEAD1_PAIR") != nullptr;
+#define K1_GO(I_, E_, O_, F_)                                                                                      \
+    do {                                                                                                           \
+        static const int pair_ok_ = [] {                                                                           \
+            (void)hipFuncSetAttribute((const void*)k_khead_onepass<I_, E_, O_, F_, K1Wide>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_khead_onepass<I_, E_, O_, F_, K1Pair>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            int nb = 0;                                                                                            \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_khead_onepass<I_, E_, O_, F_, K1Pair>, K1Pair::THREADS, \
+                                                             K1Pair::LDS_BYTES) != hipSuccess) nb = 0;              \
+            return nb >= 2 ? 1 : 0;                                                                                \
+        }();                                                                                                       \
+        if (pair_ok_ && want_pair) {                                                                               \
+            a.P = (int)(HWp / K1Pair::PX);                                                                         \
+            a.F = 2 * cus / a.P;                                                                                   \
+            if (a.F > B) a.F = B;                                                                                  \
+            hipLaunchKernelGGL((k_khead_onepass<I_, E_, O_, F_, K1Pair>), dim3(a.F * a.P), dim3(K1Pair::THREADS), K1Pair::LDS_BYTES, s, a); \
+        } else {                                                                                                   \
+            a.P = (int)(HWp / K1Wide::PX);                                                                         \
+            a.F = cus / a.P;                                                                                       \
+            if (a.F > B) a.F = B;                                                                                  \
+            hipLaunchKernelGGL((k_khead_onepass<I_, E_, O_, F_, K1Wide>), dim3(a.F * a.P), dim3(K1Wide::THREADS), K1Wide::LDS_BYTES, s, a); \
+        }                                                                                                          \
+    } while (0)
+#else
+    a.P = (int)(HWp / K1Wide::PX);
+    a.F = cus / a.P;
+    if (a.F > B) a.F = B;
+#define K1_GO(I_, E_, O_, F_)                                                                                      \
     do {                                                                                                           \
         static const bool once_ = [] {                                                                             \
-            (void)hipFuncSetAttribute((const void*)k_khead_onepass<I, E, O, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_khead_onepass<I_, E_, O_, F_, K1Wide>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             return true;                                                                                           \
         }();                                                                                                       \
         (void)once_;                                                                                               \
-        hipLaunchKernelGGL((k_khead_onepass<I, E, O, F>), grid, block, lds, s, a);                                 \
+        hipLaunchKernelGGL((k_khead_onepass<I_, E_, O_, F_, K1Wide>), dim3(a.F * a.P), dim3(K1Wide::THREADS), K1Wide::LDS_BYTES, s, a); \
     } while (0)
+#endif
 #define K1_GO_F(I, E, O)              \
     do {                              \
         if (f32o) K1_GO(I, E, O, true); \

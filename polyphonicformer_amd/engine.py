@@ -17,8 +17,6 @@ from . import _lib
 from .pack import pack_stage
 
 import collections
-import os
-_UP_LAST = bool(os.environ.get('PH_UPSAMPLE_LAST'))      # experiment: round 2's launch order
 
 # Precision modes of the decode path.  One row = the arithmetic of every operator of a stage:
 #   feat  : element format / planes of the feature maps (ingest, pool)        query : the query-side GEMMs
@@ -305,12 +303,12 @@ class DecodePlan:
             if not last:
                 dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
             else:
-                # each x2 upsample directly behind the conv that wrote its source: the 240 MB of logits (cfg2, 24 frames) are
-                # then read back from the memory-side cache instead of HBM (conv, conv, up, up: 823 us; this order: 659 us)
+                # each x2 upsample directly behind the conv that wrote its source (240 MB of logits at cfg2, 24 frames): on
+                # its own a part's four launches take 659 us in this order against 823 us as conv, conv, up, up; inside the
+                # four-stream step the other parts' streams evict the logits either way (same-box A/B: no difference)
                 dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
-                if not _UP_LAST: upsample2x(self.mask, out=self.mask_up)
+                upsample2x(self.mask, out=self.mask_up)
                 dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, cv, logits_out=self.depth, out_dtype=self.out_code)
-                if _UP_LAST: upsample2x(self.mask, out=self.mask_up)
                 upsample2x(self.depth, out=self.depth_up)
             k, q = o["obj"], o["dobj"]
 

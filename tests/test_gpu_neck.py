@@ -55,6 +55,30 @@ def test_conv_nhwc(gpu, prec, k, s, H, W):
     assert Hh.rel_err(stats.cpu()[..., 1], 1.0 / torch.sqrt(gm.var(2, unbiased=False) + 1e-5)) < 1e-4
 
 
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT])
+@pytest.mark.parametrize("H,W,with_add", [(128, 256, False), (16, 32, True), (6, 70, False), (3, 28, True), (5, 7, False)])
+def test_nhwc_ingest_exact(gpu, prec, H, W, with_add):
+    """fp32 NCHW (+ the positional encoding of level 3) -> 16-bit NHWC planes: every element is the correctly rounded
+    input, in the 16-byte form (H*W % 4 == 0) and the scalar form, ragged last tile included"""
+    g = torch.Generator().manual_seed(H * W)
+    B = 2
+    x = torch.randn(B, 256, H, W, generator=g) * 3
+    add = torch.randn(256, H, W, generator=g) if with_add else None
+    P = 2 if prec == _lib.PH_PREC_SPLIT else 1
+    out = torch.full((P, B, H * W, 256), 0x7FFF, dtype=torch.int16, device=gpu)
+    E.nhwc_ingest(x.to(gpu), None if add is None else add.to(gpu), prec, out)
+    v = (x + add[None]) if with_add else x
+    v = v.permute(0, 2, 3, 1).reshape(B, H * W, 256)
+    got = out.cpu()
+    if prec == _lib.PH_PREC_F16:
+        assert torch.equal(got[0].view(torch.float16), v.half())
+    else:
+        hi = v.bfloat16()
+        assert torch.equal(got[0].view(torch.bfloat16), hi)
+        if P == 2:
+            assert torch.equal(got[1].view(torch.bfloat16), (v - hi.float()).bfloat16())
+
+
 @pytest.mark.parametrize("H,W", [(5, 7), (8, 16)])
 def test_gn_apply_modes(gpu, H, W):
     g = torch.Generator().manual_seed(9)

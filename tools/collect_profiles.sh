@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k -o k -- python to
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq_query -o p -- python tools/query_time.py 24 > /dev/null 2> $OUT/pmc_sq_query.err
+python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_query > $OUT/pmc_sq_summary.txt 2>&1
 if [ "${ALL_LEGS:-1}" = 1 ]; then bash tools/run_train_prof.sh $OUT > $OUT/train_prof.txt 2>&1; fi
 python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete

@@ -24,7 +24,7 @@ for prec in ("bf16", "fp16"):
         for name, ph in (("pre", 1), ("post", 2), ("both", 3)):
             t[name] = bench.time_op(lambda ph=ph: E.query_stage(plan.partial, plan.bits, plan.k0, plan.q0, plan.packs[0], plan.N, plan.HW,
                                                                 outs=plan.stage_out[0], workspace=plan.ws, phases=ph,
-                                                                kern_fmt=plan.mode.kern_fmt), 20) * 1e3
+                                                                kern_fmt=plan.mode.kern_fmt, counts=plan.pcount), 20) * 1e3
         print(json.dumps({"prec": prec, "frames": B, "v1": os.environ.get("PH_QUERY_V1", "0"), "us": {k: round(v, 1) for k, v in t.items()},
                           "us_per_frame": round(t["both"] / B, 2)}), flush=True)
         del plan
