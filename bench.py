@@ -890,7 +890,7 @@ def main():
     ap.add_argument("--precision", default="mixed16", choices=["bf16", "mixed", "mixed16", "fp16", "fp32"],
                     help="engine.MODES: bf16 = one bf16 plane everywhere (fast, ~6e-3 per stage); mixed = bf16 feature planes as "
                          "given, fp32-grade arithmetic on them (1.2e-5 per stage on identical inputs), fp16 logits out; mixed16 = "
-                         "the same with ONE fp16 plane of dynamic kernels (2.4e-4 per stage: the cheapest mode inside the 1e-3 "
+                         "the same with ONE fp16 plane of dynamic kernels and of the attention / FFN / tower half of the query side (6e-4 per stage: the cheapest mode inside the 1e-3 "
                          "contract on bf16 inputs, the default); fp16 = fp16 planes / "
                          "kernels / logits (cfg5), fp32-grade query side; fp32 = every operand hi + lo (parity grade)")
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS) + ["cfg4"],
@@ -1038,8 +1038,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"bf16": "bf16", "mixed": "bf16 (feature planes as given; hi/lo bf16 query GEMMs and dynamic kernels, fp16 logits)",
-                      "mixed16": "bf16 (feature planes as given; hi/lo bf16 query GEMMs, one fp16 plane of dynamic kernels, fp16 logits)",
-                      "fp16": "fp16 (planes, dynamic kernels, logits; hi/lo bf16 query GEMMs)",
+                      "mixed16": "bf16 (feature planes as given; query side: updator half hi/lo bf16, attention / FFN / towers one fp16 plane; one fp16 plane of dynamic kernels, fp16 logits)",
+                      "fp16": "fp16 (planes, dynamic kernels, logits; query side: updator half hi/lo bf16, the rest one fp16 plane)",
                       "fp32": "bf16x3 (fp32-grade split)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: KernelUpdateIterHead.simple_test_mask_preds, "
@@ -1049,9 +1049,9 @@ def main():
                        "feature_input_dtype": in_dt, "mask_logit_input_dtype": "fp32", "output_dtype": str(out_dtype),
                        "parity_inputs": {"bf16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads); 6.6e-3 per stage: outside the 1e-3 contract",
                                          "mixed": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 1.2e-5 per stage",
-                                         "mixed16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 2.4e-4 per stage; "
+                                         "mixed16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 5.3e-4-6.6e-4 per stage; "
                                                     "against UNROUNDED fp32 features this mode is gated at 3e-3 -- the `fp16` mode (precision_modes) meets 1e-3 there",
-                                         "fp16": "unrounded fp32 features into the oracle, fp16-rounded into the device: 3.9e-4 per stage",
+                                         "fp16": "unrounded fp32 features into the oracle, fp16-rounded into the device: <= 6.6e-4 per stage",
                                          "fp32": "fp32 features on both sides: 1.3e-5 per stage"}[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -1090,8 +1090,8 @@ def main():
             # format and its own output dtype; per-stage error against the fp32 oracle from tests/test_gpu_configs.py
             err_note = {"bf16": "6.6e-3 per stage (identical bf16 inputs): the fast mode, outside the 1e-3 contract",
                         "mixed": "1.2e-5 per stage on identical bf16 inputs (1e-3 contract met)",
-                        "mixed16": "2.5e-4 per stage on identical bf16 inputs (1e-3 contract met)",
-                        "fp16": "2.4e-4 per stage on identical fp16 inputs, 3.9e-4 against unrounded fp32 inputs (1e-3 contract met)",
+                        "mixed16": "5.3e-4-6.6e-4 per stage on identical bf16 inputs (1e-3 contract met)",
+                        "fp16": "<= 6.6e-4 per stage against unrounded fp32 inputs (1e-3 contract met)",
                         "fp32": "1.3e-5 per stage against fp32 inputs (parity grade)"}
             res["precision_modes"] = {args.precision: {"value": round(fps, 2), "unit": "frames/s", "per_stage_rel_err": err_note[args.precision]}}
             for mode in (("bf16", "mixed", "mixed16", "fp16", "fp32") if full else ("fp16", "mixed16")):

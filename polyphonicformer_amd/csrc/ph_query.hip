@@ -889,17 +889,20 @@ constexpr int LDPT = 40;   // row stride of the per-wave [16][32] attention prob
 // a call's first fragments therefore overlaps whatever separates two calls.
 struct WRef2 { const uint16_t* W; int ct0, ks_total, wks0; };
 template <int PA> constexpr int kch() { return PA == 1 ? 4 : 2; }      // 32 registers per chunk buffer (NCT = 2) either way
-template <int PA, int NCT> struct WStream { uint4 f[2][PA][kch<PA>()][NCT]; };
+// (a chunk buffer is 4 x NCT fragments whatever PA is -- slot p * kch<PA>() + k -- so that ONE stream object can change its
+// plane count between two calls: the hybrid PRE kernel goes from hi / lo bf16 to one fp16 plane half way)
+template <int NCT> struct WStreamF { uint4 f[2][4][NCT]; };
+template <int PA, int NCT> using WStream = WStreamF<NCT>;
 
 template <int PA, int NCT>
-__device__ __forceinline__ void w_chunk_load(uint4 (&d)[PA][kch<PA>()][NCT], const WRef2& r, int kc, int64_t w_plane, int lane) {
+__device__ __forceinline__ void w_chunk_load(uint4 (&d)[4][NCT], const WRef2& r, int kc, int64_t w_plane, int lane) {
 #pragma unroll
     for (int p = 0; p < PA; ++p)
 #pragma unroll
         for (int k = 0; k < kch<PA>(); ++k)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                d[p][k][ct] = *(const uint4*)(r.W + p * w_plane + ((int64_t)(r.ct0 + ct) * r.ks_total + r.wks0 + kc * kch<PA>() + k) * 512 + lane * 8);
+                d[p * kch<PA>() + k][ct] = *(const uint4*)(r.W + p * w_plane + ((int64_t)(r.ct0 + ct) * r.ks_total + r.wks0 + kc * kch<PA>() + k) * 512 + lane * 8);
 }
 template <int PA, int NCT>
 __device__ __forceinline__ void w_prime(WStream<PA, NCT>& ws, const WRef2& r, int64_t w_plane, int lane) {
@@ -932,10 +935,10 @@ __device__ __forceinline__ void gemm_stream(f32x4_t (&acc)[NRT][NCT], const uint
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) {
-                    acc[rt][ct] = mfma16e<E>(a[0][rt], ws.f[kc & 1][0][k][ct], acc[rt][ct]);
+                    acc[rt][ct] = mfma16e<E>(a[0][rt], ws.f[kc & 1][k][ct], acc[rt][ct]);
                     if (PA == 2) {
-                        acc[rt][ct] = mfma16(a[0][rt], ws.f[kc & 1][PA - 1][k][ct], acc[rt][ct]);
-                        acc[rt][ct] = mfma16(a[PA - 1][rt], ws.f[kc & 1][0][k][ct], acc[rt][ct]);
+                        acc[rt][ct] = mfma16(a[0][rt], ws.f[kc & 1][(PA - 1) * KCH + k][ct], acc[rt][ct]);
+                        acc[rt][ct] = mfma16(a[PA - 1][rt], ws.f[kc & 1][k][ct], acc[rt][ct]);
                     }
                 }
         }
@@ -1005,6 +1008,13 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     const WRef2 c_ug{wb + WO[PH_W_UG], wave * CT, 8, 0}, c_ig{wb + WO[PH_W_IG], wave * CT, 8, 0}, c_fc{wb + WO[PH_W_FC], wave * CT, 8, 0};
     const WRef2 c_q{wb + WO[PH_W_QKV], wave * CT, 8, 0}, c_k{wb + WO[PH_W_QKV], 16 + wave * CT, 8, 0}, c_v{wb + WO[PH_W_QKV], 32 + wave * CT, 8, 0};
     auto prime = [&](const WRef2& r) { return [&, r]() { w_prime<PA, CT>(ws, r, wpl, lane); }; };
+    // the tail of the kernel -- the attention in-projection, whose input is a LayerNorm output and whose results leave as fp16
+    // anyway -- runs on ONE fp16 plane in the hybrid grade (QF16; pack.py packs QKV accordingly), like the POST kernel.
+    // (fc_layer on one fp16 plane as well: worst per-stage error 6.3e-4 -> 8.1e-4 at cfg2 for 4 us -- its output is the
+    // residual every later layer adds to; it stays hi / lo.)
+    constexpr int PT = QF16 ? 1 : PA;
+    constexpr int ET = QF16 ? PH_E_F16 : PH_E_BF16;
+    auto primeT = [&](const WRef2& r) { return [&, r]() { w_prime<PT, CT>(ws, r, wpl, lane); }; };
     w_prime<PA, CT>(ws, c_dyn_o, wpl, lane);        // in flight under the reduction of the pooling partials
     PH_TL(0);
 
@@ -1184,10 +1194,10 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     {
         // one gate at a time (two live tiles): f = sigmoid(LN(update_gate)) * norm_out + sigmoid(LN(input_gate)) * input_norm_out
         Tile<NRT> Fg;
-        auto gate = [&](const WRef2& cur, const WRef2& nxt, int b_idx, int g_idx, int be_idx, int which, bool first) {
+        auto gate = [&](const WRef2& cur, auto&& next, int b_idx, int g_idx, int be_idx, int which, bool first) {
             Tile<NRT> G[1];
             tile_zero(G[0].v);
-            gemm_stream<PA, NRT, CT, 8>(G[0].v, act, LDA, PLANE, ws, cur, wpl, lane, prime(nxt));
+            gemm_stream<PA, NRT, CT, 8>(G[0].v, act, LDA, PLANE, ws, cur, wpl, lane, next);
             tile_add_bias(G[0], wf + VO[b_idx], wave, lane);
             const float* const gm[1] = {wf + VO[g_idx]};
             const float* const bt[1] = {wf + VO[be_idx]};
@@ -1208,8 +1218,8 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
                     }
             }
         };
-        gate(c_ug, c_ig, PH_V_UG_B, PH_V_LN_UG_G, PH_V_LN_UG_B, 0, true);       // update_gate * norm_out(param_out)
-        gate(c_ig, c_fc, PH_V_IG_B, PH_V_LN_IG_G, PH_V_LN_IG_B, 1, false);      // + input_gate * input_norm_out(input_out)
+        gate(c_ug, prime(c_ig), PH_V_UG_B, PH_V_LN_UG_G, PH_V_LN_UG_B, 0, true);       // update_gate * norm_out(param_out)
+        gate(c_ig, prime(c_fc), PH_V_IG_B, PH_V_LN_IG_G, PH_V_LN_IG_B, 1, false);      // + input_gate * input_norm_out(input_out)
         // the second LayerNorm's barriers: every wave is done reading the gate input
         tile_to_lds<PA, NRT>(Fg, act, PLANE, wave, lane);
     }
@@ -1220,7 +1230,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     {
         Tile<NRT> O[1];
         tile_zero(O[0].v);
-        gemm_stream<PA, NRT, CT, 8>(O[0].v, act, LDA, PLANE, ws, c_fc, wpl, lane, prime(c_q));
+        gemm_stream<PA, NRT, CT, 8>(O[0].v, act, LDA, PLANE, ws, c_fc, wpl, lane, primeT(c_q));
         tile_add_bias(O[0], wf + VO[PH_V_FC_B], wave, lane);
         const float* const gm[1] = {wf + VO[PH_V_LN_FC_G]};
         const float* const bt[1] = {wf + VO[PH_V_LN_FC_B]};
@@ -1236,7 +1246,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
                     O[0].v[rt][ct][r] = v;
                     o1[(rt * 16 + g * 4 + r) * 256 + wave * WCOLS + ct * 16 + i] = v;   // residual for the post kernel
                 }
-        tile_to_lds<PA, NRT>(O[0], act, PLANE, wave, lane);
+        tile_to_lds<PT, NRT, ET>(O[0], act, PLANE, wave, lane);
     }
     __syncthreads();
 
@@ -1249,13 +1259,13 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     {
         Tile<NRT> T;
         tile_zero(T.v);
-        gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_q, wpl, lane, prime(c_k));
+        gemm_stream<PT, NRT, CT, 8, ET>(T.v, act, LDA, PLANE, ws, c_q, wpl, lane, primeT(c_k));
         store_qkv<PA, NRT, 0, QF16>(T, a, qkv_bias, qk_base, qk_plane, vt_base, wave, lane);
         tile_zero(T.v);
-        gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_k, wpl, lane, prime(c_v));
+        gemm_stream<PT, NRT, CT, 8, ET>(T.v, act, LDA, PLANE, ws, c_k, wpl, lane, primeT(c_v));
         store_qkv<PA, NRT, 1, QF16>(T, a, qkv_bias + 256, qk_base, qk_plane, vt_base, wave, lane);
         tile_zero(T.v);
-        gemm_stream<PA, NRT, CT, 8>(T.v, act, LDA, PLANE, ws, c_v, wpl, lane, NoNext());
+        gemm_stream<PT, NRT, CT, 8, ET>(T.v, act, LDA, PLANE, ws, c_v, wpl, lane, NoNext());
         store_qkv<PA, NRT, 2, QF16>(T, a, qkv_bias + 512, qk_base, qk_plane, vt_base, wave, lane);
     }
     PH_TL(7);

@@ -33,7 +33,7 @@ MODES = {
     # pooling, hi/lo split query GEMMs, hi/lo dynamic kernels x one feature plane (<= 1e-3 on identical inputs)
     "mixed": Mode("mixed", _lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16_KSPLIT, _lib.PH_KERN_BF16_PLANES, 1, 2, torch.bfloat16),
     # as `mixed`, but the dynamic kernels as ONE fp16 plane: the conv converts its bf16 feature fragments to fp16 in registers
-    # (exact) and runs one f16 MFMA -- the single-plane conv speed at 2.5e-4 per stage (kernel rounding 2^-12)
+    # (exact) and runs one f16 MFMA -- the single-plane conv speed (kernel rounding 2^-12: 2.5e-4 per stage on its own)
     "mixed16": Mode("mixed16", _lib.PH_PREC_BF16, _QH, _lib.PH_PREC_BF16_KF16, _lib.PH_KERN_F16, 1, 1, torch.bfloat16),
     # fp16 feature planes / kernels / outputs (cfg5), fp32-grade query side
     "fp16": Mode("fp16", _lib.PH_PREC_F16, _QH, _lib.PH_PREC_F16, _lib.PH_KERN_F16, 1, 1, torch.float16),

@@ -68,7 +68,8 @@ def pack_stage(sd, prefix, num_classes, prec):
     woff = voff = 0
     # hybrid grade: the matrices the POST kernel multiplies with (every one of them has a LayerNorm- or softmax-bounded
     # operand on the other side) are ONE fp16 plane, the PRE kernel's (pooled sums, gate products: unbounded) hi + lo bf16
-    POST = {"OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN"}
+    # -- except its last three calls, the attention in-projection (input: a LayerNorm output; results stored as fp16 anyway)
+    POST = {"OUT", "FFN1", "FFN2", "H0A", "H0B", "CLS", "KERN", "QKV"}
 
     def add_w(br, name, mat):
         nonlocal woff
