@@ -289,6 +289,19 @@ def check_rpn_topology(head):
         raise NotImplementedError("training forward: unsupported KernelHead topology: " + ", ".join(bad))
 
 
+def _valid_pixels(gt_masks_i, gt_sem_seg_i):
+    """1.0 where any instance or stuff mask of the image is set (kernel_head.py:415, kernel_update.py:238:
+    `torch.cat((gt_masks, gt_sem_seg)).sum(0).bool()`), without materialising the concatenation"""
+    v = None
+    for t in (gt_masks_i, gt_sem_seg_i):
+        if t.shape[0]:
+            a = t.ne(0).any(dim=0)
+            v = a if v is None else (v | a)
+    if v is None:
+        return torch.zeros(gt_masks_i.shape[1:], dtype=torch.float32, device=gt_masks_i.device)
+    return v.float()
+
+
 def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, want_grads=False):
     """KernelHead.forward_train, kernel_head.py:349-454, on the three post-neck maps (gradients flow into `feats` when they
     require them).  Returns (losses, r): `losses` = the reference's dict with the 'loss' entries attached to the graph
@@ -307,7 +320,7 @@ def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_s
     sdep = sdep0.detach().expand(-1, N, -1, -1)
     srs = []
     for i in range(len(img_metas)):                                                           # :411-426
-        valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()
+        valid = _valid_pixels(gt_masks[i], gt_sem_seg[i])
         ar = h.assigner.assign(smask[i].detach(), None, gt_masks[i], gt_labels[i], img_metas[i], depth_pred=sdep[i],
                                gt_depth=gt_depth[i], gt_valid=valid)
         sr = h.sampler.sample(ar, smask[i].detach(), gt_masks[i], depth=sdep[i])
@@ -365,6 +378,9 @@ def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_ma
     prev_cls = [None] * B                                                                      # :193-196
     if ih.hard_target:
         gt_masks = [m.bool().float() for m in gt_masks]
+    # the pixels some ground-truth mask covers (:238): the same for every stage -- evaluated once per image instead of once per
+    # image and stage (a 24 MB concatenation + reduction each at the assign stride of cfg2)
+    valids = [_valid_pixels(gt_masks[i], gt_sem_seg[i]) for i in range(B)]
     total, m, assign, values, grads = 0.0, mask_preds, [], {}, []
     cls = smask = None
     for s in range(ih.num_stages):
@@ -376,7 +392,7 @@ def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_ma
         if s < ih.assign_stages:
             assign = []
         for i in range(B):
-            valid = torch.cat((gt_masks[i], gt_sem_seg[i]), dim=0).sum(dim=0).bool().float()  # :238
+            valid = valids[i]
             if s < ih.assign_stages:
                 c = None if prev_cls[i] is None else prev_cls[i][:ih.num_proposals, :ih.num_thing_classes]
                 assign.append(ih.mask_assigner[s].assign(prev_mask[i][:ih.num_proposals], c, gt_masks[i], gt_labels[i], img_metas[i],
