@@ -44,6 +44,9 @@ template <int OFF> __device__ __forceinline__ void lds_write_asm(uint32_t byte_a
     const uint32_t h = f2h(v);
     asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(byte_addr), "v"(h), "n"(OFF) : "memory");
 }
+__device__ __forceinline__ void lds_write128_asm(uint32_t byte_addr, u32x4_t v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(PH_LDS const void*)p; }
 
 __device__ __forceinline__ void st_out(float* p, float v) { *p = v; }
@@ -72,7 +75,7 @@ __device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PF][
 }
 
 // PF feature planes x PK kernel planes: (1,1) a.b; (1,2) (a_hi + a_lo).b; (2,2) a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
-template <int PF, int PK, int E, int KB, int BI>
+template <int PF, int PK, int E, int KB, int BI, bool COOP = false>
 __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][16], u32x2_t (&bq)[2][PF][KB][2], f32x16_t& acc,
                                              const float (&bias)[16]) {
     constexpr int NBATCH = 16 / KB;
@@ -95,14 +98,14 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][
             for (int p = 0; p < PF; ++p)
             {
                 bf[p] = make_uint4(bq[BI & 1][p][k][0].x, bq[BI & 1][p][k][0].y, bq[BI & 1][p][k][1].x, bq[BI & 1][p][k][1].y);
-                if constexpr (E == PH_E_F16_FROM_BF16) bf[p] = bf2h_x8(bf[p]);      // 12 VALU ops under the previous MFMA
+                if constexpr (E == PH_E_F16_FROM_BF16 && !COOP) bf[p] = bf2h_x8(bf[p]);      // 12 VALU ops under the previous MFMA
             }
             acc = mfma32e<E>(af[0][BI * KB + k], bf[0], acc);
             if (PF == 2) acc = mfma32e<E>(af[0][BI * KB + k], bf[PF - 1], acc);
             if (PK == 2) acc = mfma32e<E>(af[PK - 1][BI * KB + k], bf[0], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        conv_batches<PF, PK, E, KB, BI + 1>(fa, af, bq, acc, bias);
+        conv_batches<PF, PK, E, KB, BI + 1, COOP>(fa, af, bq, acc, bias);
     }
 }
 
@@ -164,7 +167,10 @@ template <int PF, int PK, int NRT, bool BITS, typename OutT, bool F2 = false> st
     static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
 };
 
-template <int PF, int PK, int E, int NRT, bool BITS, typename OutT, bool F2 = false>
+// COOP (E = PH_E_F16_FROM_BF16 only): the landed bf16 tile is converted to fp16 ONCE, in place in LDS, every wave taking a
+// share of its 16-byte pieces, instead of by each of the NRT row-block waves on its own fragments (NRT x the VALU work);
+// costs one more barrier and one LDS round trip of the tile per tile.
+template <int PF, int PK, int E, int NRT, bool BITS, typename OutT, bool F2 = false, bool COOP = false>
 __global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT, F2>::NW * 64)) void k_dynconv(const uint16_t* __restrict__ planes,
                                                           const uint16_t* __restrict__ kern, int64_t kern_plane_stride,
                                                           int64_t kern_batch_stride, const float* __restrict__ kbias,
@@ -326,6 +332,26 @@ __global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT, F2>::NW * 64)) vo
             issue_next(nb);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (COOP) {
+            static_assert(PF == 1 && E == PH_E_F16_FROM_BF16, "cooperative conversion: one bf16 feature plane");
+            constexpr int PIECES = 256 * CONV_T * 2 / 16, LANES = C::NW * 64, ROUNDS = (PIECES + LANES - 1) / LANES;
+            const uint32_t tb = lds0 + cur * C::TILEB + 16u * (uint32_t)tid;
+            u32x4_t cv[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+                if ((r + 1) * LANES <= PIECES || wave * 64 < PIECES - r * LANES) cv[r] = lds_read128_asm(tb + r * LANES * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+                if ((r + 1) * LANES <= PIECES || wave * 64 < PIECES - r * LANES) {
+                    const uint4 h16 = bf2h_x8(__builtin_bit_cast(uint4, cv[r]));
+                    lds_write128_asm(tb + r * LANES * 16, __builtin_bit_cast(u32x4_t, h16));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
 #pragma unroll
         for (int h = 0; h < C::HPW; ++h) {
@@ -336,7 +362,7 @@ __global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT, F2>::NW * 64)) vo
         constexpr int KB = 2;                        // 4 * PF reads per batch (KB = 4 measured 7 % slower)
         u32x2_t bq[2][PF][KB][2];
         conv_read_batch<PF, KB, 0>(fa, bq[0]);
-        conv_batches<PF, PK, E, KB, 0>(fa, af, bq, acc, bias);
+        conv_batches<PF, PK, E, KB, 0, COOP>(fa, af, bq, acc, bias);
         // ---- epilogue of tile (b, t), 32-pixel half `half`
         const int px_base = t * CONV_T + half * 32;
         const int64_t px = (int64_t)px_base + (lane & 31);
@@ -426,18 +452,30 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     const dim3 grid(wgs);
     // tuning knob: PH_CONV_TWO_HALVES=1 forces the two-halves-per-wave form of the two-kernel-plane kernels (A/B measurements)
     static const bool two_halves = [] { const char* e = getenv("PH_CONV_TWO_HALVES"); return e && atoi(e) != 0; }();
-#define PH_CONV_LAUNCH_(BITS, T, F2)                                                                                 \
+    // the mixed16 conv converts its bf16 tile to fp16 once per tile in LDS (see k_dynconv); PH_CONV_COOP=0 restores the
+    // per-wave conversion in registers for A/B measurements (same box, 24 frames: bits 155 -> 130-136 us, logits 157-162 ->
+    // 148-151 us, the 96-frame step 13.16 k -> 13.53 k frames/s; results identical, the conversion is exact either way)
+    static const bool coop = [] { const char* e = getenv("PH_CONV_COOP"); return !(e && atoi(e) == 0); }();
+    (void)coop;
+#define PH_CONV_LAUNCH__(BITS, T, F2, CO)                                                                            \
     do {                                                                                                             \
         constexpr int lds = ConvCfg<PF, PK, NRT, BITS, T, F2>::LDSB;                                                 \
         const dim3 block(ConvCfg<PF, PK, NRT, BITS, T, F2>::NW * 64);                                                \
         static const bool once = [&] {                                                                               \
-            (void)hipFuncSetAttribute((const void*)k_dynconv<PF, PK, E, NRT, BITS, T, F2>,                           \
+            (void)hipFuncSetAttribute((const void*)k_dynconv<PF, PK, E, NRT, BITS, T, F2, CO>,                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
             return true;                                                                                             \
         }();                                                                                                         \
         (void)once;                                                                                                  \
-        hipLaunchKernelGGL((k_dynconv<PF, PK, E, NRT, BITS, T, F2>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs, \
+        hipLaunchKernelGGL((k_dynconv<PF, PK, E, NRT, BITS, T, F2, CO>), grid, block, lds, s, planes, kern, kps, kbs, kbias, bbs, \
                            bits_out, (T*)logits_out, obs, B, N, HW, HWp);                                            \
+    } while (0)
+#define PH_CONV_LAUNCH_(BITS, T, F2)                                                                                 \
+    do {                                                                                                             \
+        if constexpr (E == PH_E_F16_FROM_BF16 && PF == 1) {                                                          \
+            if (coop) PH_CONV_LAUNCH__(BITS, T, F2, true);                                                           \
+            else PH_CONV_LAUNCH__(BITS, T, F2, false);                                                               \
+        } else PH_CONV_LAUNCH__(BITS, T, F2, false);                                                                 \
     } while (0)
 #define PH_CONV_LAUNCH(BITS, T)                                                                                      \
     do {                                                                                                             \
@@ -452,6 +490,7 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     else PH_CONV_LAUNCH(false, uint16_t);
 #undef PH_CONV_LAUNCH
 #undef PH_CONV_LAUNCH_
+#undef PH_CONV_LAUNCH__
     return 0;
 }
 

@@ -67,8 +67,17 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
                                               int B, int64_t HWp, int nsplit, int bits_rows, int32_t* __restrict__ pcount) {
     constexpr int Npad = NRT * 32;
     constexpr int NBI = (Npad * 2 + 63) / 64;                         // DMA instructions for the mask words of a chunk
-    constexpr int NBW = (NBI + 3) / 4;                                // ... issued per wave
-    constexpr int PER_CHUNK = 4 * PA + NBW;                           // vector-memory instructions per wave per chunk
+#ifdef POOL_NO_BITS_DMA   // timing experiment only (results are wrong): what the mask-word requests cost (8 % at cfg2, round 3)
+    constexpr int NBW = 0;
+#else
+    constexpr int NBW = (NBI + 3) / 4;                                // ... issued per wave (at most)
+#endif
+    constexpr int PER_CHUNK = 4 * PA + NBW;                           // vector-memory instructions per wave per chunk ...
+#ifdef POOL_DUP_BITS
+    constexpr int NBREM = 0;
+#else
+    constexpr int NBREM = NBW ? NBI % 4 : 0;                          // ... one fewer in waves >= NBREM when NBI is no multiple of 4
+#endif
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     // [NBUF][PA][128][64] feature tiles | lut[256] (16 B each) | [NBUF][NBI*64] mask words
     uint4* lut = (uint4*)(lds + POOL_NBUF * PA * POOL_FT);
@@ -118,10 +127,16 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
             uint16_t* dst = lds + (buf * PA + p) * POOL_FT + jj * 512;          // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, PH_CPOL_STREAM);
         } else {
-            // every wave issues the same number of mask-word instructions (a wave past the end repeats the last one:
-            // the duplicate rewrites identical bytes), so ONE compile-time vmcnt covers a whole chunk for every wave
+            // NBI mask-word instructions per chunk, dealt round-robin: a wave past the end issues one fewer (round 3; it used
+            // to repeat the last one so that ONE vmcnt immediate served every wave -- 3 of 8 requests per chunk were duplicates at
+            // cfg2, and the mask-word requests cost 8 % of this kernel, POOL_NO_BITS_DMA); the counted waits below are per wave class
+#ifdef POOL_DUP_BITS   // round 2's form, for A/B timing
             int j = wave + 4 * (k - 4 * PA);
             if (j > NBI - 1) j = NBI - 1;
+#else
+            const int j = wave + 4 * (k - 4 * PA);
+            if (j > NBI - 1) return;
+#endif
             int row = j * 32 + (lane >> 1);
             if (row > Npad - 1) row = Npad - 1;                                    // tail lanes re-read the last row
             const uint32_t* src = brow + (int64_t)row * words_per_row + c * 2 + (lane & 1);
@@ -147,9 +162,15 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         // chunk c must have landed; the up to NBUF-2 younger chunks stay in flight ACROSS the barrier:
         // counted vmcnt + RAW s_barrier (__syncthreads would drain the DMA queue with vmcnt(0))
         const int younger = (c1 - 1 - c) < (POOL_NBUF - 2) ? (c1 - 1 - c) : (POOL_NBUF - 2);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_CHUNK) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBREM != 0 && wave >= NBREM) {       // this wave issues PER_CHUNK - 1 instructions per chunk (wave-uniform branch)
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PER_CHUNK - 1)) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_CHUNK) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // every wave is past compute(c-1): its buffer, (cur + NBUF-1) % NBUF, is free for chunk c + NBUF-1
