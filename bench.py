@@ -862,7 +862,7 @@ def cfg4_main(args, dev, world, rank, backend, json_fd):
            "value": run["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": run["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": {"fp16": "fp16 (planes, dynamic kernels, logits; hi/lo bf16 query GEMMs)", "bf16": "bf16", "fp32": "bf16x3 (fp32-grade split)"}[prec],
-           "data": "synthetic",
+           "data": "synthetic", "host_threads": torch.get_num_threads(),
            "config": {"workload": f"cfg4: poly_r50 video head, {wl['H'] * 8}x{wl['W'] * 8}, N={N}, S={wl['S']}, {args.clip_frames}-frame clip per "
                                   f"GPU and step, one frame per launch (samples_per_gpu = 1 as in the reference), module API, random-init weights",
                       "frames_per_step_per_gpu": args.clip_frames,
@@ -881,7 +881,23 @@ def cfg4_main(args, dev, world, rank, backend, json_fd):
     os.write(json_fd, (json.dumps(res) + "\n").encode())
 
 
+HOST_THREADS = 16
+
+
+def host_thread_policy():
+    """Host thread policy of THIS process (the bench, not the library): torch's intra-op pool defaults to one thread per
+    hardware thread -- 128 here on a 256-thread host -- whose workers keep spinning after every parallel region.  Inside a
+    container with a CPU quota that burns the quota and the kernel throttles the whole process for the rest of the 100 ms
+    period: 80-95 ms stalls in ANY host call (seen as spikes in `video_cfg3` / cfg4 frames: aten::tril of an 8 x 8 tensor
+    taking 90 ms; none with one thread, round 3).  16 threads is also the best setting of the CPU baseline sweep.  Returns the
+    setting for the JSON line."""
+    n = min(HOST_THREADS, torch.get_num_threads())
+    torch.set_num_threads(n)
+    return n
+
+
 def main():
+    host_threads = host_thread_policy()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -1041,7 +1057,7 @@ def main():
                       "mixed16": "bf16 (feature planes as given; query side: updator half hi/lo bf16, attention / FFN / towers one fp16 plane; one fp16 plane of dynamic kernels, fp16 logits)",
                       "fp16": "fp16 (planes, dynamic kernels, logits; query side: updator half hi/lo bf16, the rest one fp16 plane)",
                       "fp32": "bf16x3 (fp32-grade split)"}[args.precision],
-            "data": "synthetic",
+            "data": "synthetic", "host_threads": host_threads,
             "config": {"workload": f"{args.workload}: KernelUpdateIterHead.simple_test_mask_preds, "
                                    f"{wl['H'] * 8}x{wl['W'] * 8}, stride-8 {wl['H']}x{wl['W']}, N={N}, S={wl['S']}, "
                                    f"L={wl['n_thing'] + wl['n_stuff']}, random-init weights",
