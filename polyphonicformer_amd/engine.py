@@ -438,8 +438,12 @@ class KernelHeadPlan:
         if logit_dtype != torch.float32 and not self.onepass:
             raise _lib.PolyheadError("16-bit KernelHead logits need the one-pass form")
         self.logit_dtype = logit_dtype
+        self._st_host, self._st_ev = None, None
         if self.onepass:
             self.ws1 = e((lib.ph_khead_onepass_workspace_bytes(B, self.HW),), torch.uint8)
+            # the kernel's status word travels to this pinned word after every eager run (4 bytes, asynchronous) and is looked
+            # at when the next run starts: a hand-off that timed out is reported one call later without a synchronisation
+            self._st_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
         self.mask_preds = e((B, self.N, H, W), logit_dtype)
         self.seg_preds = e((B, pack.n_seg, H, W), logit_dtype)
         self.depth_pred = e((B, 1, H, W), logit_dtype)
@@ -487,6 +491,9 @@ class KernelHeadPlan:
         B, HW, prec = self.B, self.HW, pk.prec
         fmt = _lib.PH_IN_PLANES if self.in_planes else _lib.PH_IN_F32_NCHW
         if self.onepass:
+            eager = not torch.cuda.is_current_stream_capturing()
+            if eager:
+                self._deferred_status()
             # one read of the three maps: conv1x1+GN+ReLU x3, x = sem + loc, the static 1x1 convs AND the mask bits
             # (kernel_head.py:250-331, :314-317) in one persistent launch; the object pooling reads the thing rows of
             # the full bit tensor in place
@@ -498,6 +505,10 @@ class KernelHeadPlan:
                                             _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), OUT_CODE[self.logit_dtype],
                                             _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.ws1), self.ws1.numel(),
                                             B, HW, prec, fmt, s()), "ph_khead_onepass")
+            if eager:
+                self._st_host.copy_(self.ws1[:4].view(torch.int32), non_blocking=True)
+                self._st_ev = torch.cuda.Event()
+                self._st_ev.record()
             _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
                                         B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
         else:
@@ -521,13 +532,25 @@ class KernelHeadPlan:
                                           _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
 
+    _TIMEOUT = ("ph_khead_onepass: the statistics hand-off timed out (two persistent launches running concurrently on one "
+                "device?) -- results of that run are undefined")
+
+    def _deferred_status(self, wait=False):
+        """status word of the previous eager run, if its copy has arrived (or `wait`); raises on a time-out"""
+        if self._st_ev is not None and (wait or self._st_ev.query()):
+            if wait:
+                self._st_ev.synchronize()
+            self._st_ev = None
+            if int(self._st_host[0]) != 0:
+                raise _lib.PolyheadError(self._TIMEOUT)
+
     def check_status(self):
         """one-pass form: raise if a bounded spin of the last run timed out (synchronises the stream)"""
         if self.onepass:
+            self._deferred_status(wait=True)
             rc = _lib.load().ph_khead_onepass_status(_lib.ptr(self.ws1), self.B, _lib.stream_ptr())
             if rc != 0:
-                raise _lib.PolyheadError("ph_khead_onepass: the statistics hand-off timed out (two persistent launches "
-                                         "running concurrently on one device?) -- results of that run are undefined")
+                raise _lib.PolyheadError(self._TIMEOUT)
 
 
 # ---- SemanticFPNWrapper (N3) -------------------------------------------------------------------------------
