@@ -612,34 +612,73 @@ class NeckPlan:
         self.stats = e((B, 256, 2), torch.float32)
         self.outs = [e((B, 256, self.Ho, self.Wo), torch.float32) for _ in range(3)]
         self.pouts = None                                          # plane outputs, allocated on first use
+        # Round 3: the four level towers are independent until the level sum and the small ones leave most of the chip idle
+        # (a 3x3 conv at 16 x 32 x 16 frames is 32 workgroups): each tower gets its own buffers and its own HIP stream, the
+        # small launches run beside the stride-4 level's ingest + stride-2 conv.  PH_NECK_STREAMS=0: one stream, shared buffers.
+        self.multi = _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
+        self.lv = None
+        if self.multi:
+            self.lv = []
+            for lvl, (h, w) in enumerate(shapes):
+                # the towers of levels 2 and 3 upsample up to the output size between their convs; levels 0 and 1 are a single conv
+                n_small = self.Ho * self.Wo if lvl >= 2 else 1
+                self.lv.append(dict(xa=e((P, B, max(h * w, n_small), 256), torch.int16), xb=e((P, B, n_small, 256), torch.int16),   # ping / pong
+                                    y=e((B, n_small, 256), torch.float32), stats=e((B, 256, 2), torch.float32),
+                                    partial=e((lib.ph_conv_nhwc_partial_floats(B, self.Ho, self.Wo),), torch.float32)))
+        self._streams = None                                       # created on first use; not part of a copy of the plan
 
-    def _conv_gn(self, xp, pk, H, W, groups, y, stats):
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_streams"] = None               # HIP streams cannot be copied / pickled (copy.deepcopy of a module that holds a plan)
+        return d
+
+    def _conv_gn(self, xp, pk, H, W, groups, y, stats, partial=None):
         """conv + statistics; returns the conv output size"""
         B, prec = self.B, self.prec
+        partial = self.partial if partial is None else partial
         k, s = pk["k"], pk["s"]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
-        conv_nhwc(xp, pk, y, self.partial, B, H, W, prec)
+        conv_nhwc(xp, pk, y, partial, B, H, W, prec)
         nwg = _lib.load().ph_conv_nhwc_workgroups(k, s, Ho, Wo, prec)
-        gn_finalize(self.partial, stats, nwg, groups, Ho * Wo, B)
+        gn_finalize(partial, stats, nwg, groups, Ho * Wo, B)
         return Ho, Wo
+
+    def _tower(self, lvl, feat, pk, groups, posenc, bufs):
+        """one level: ingest -> (conv + GN + ReLU + x2 upsample)* -> last conv (its GroupNorm is applied by the level sum)"""
+        B, prec = self.B, self.prec
+        H, W = self.shapes[lvl]
+        xa, xb, y, stats, partial = bufs["xa"], bufs["xb"], bufs["y"], bufs["stats"], bufs["partial"]
+        nhwc_ingest(feat, posenc, prec, xa)
+        src = xa
+        convs = pk["levels"][lvl]
+        for j, c in enumerate(convs):
+            if j + 1 < len(convs):      # every non-final conv of levels 2 and 3 is followed by an x2 upsample
+                H, W = self._conv_gn(src, c, H, W, groups, y, stats, partial)
+                dst = xb if src is xa else xa
+                gn_apply(y, stats, c, groups, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=dst)
+                H, W, src = 2 * H, 2 * W, dst
+            else:
+                H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl], partial)
+                if (H, W) != (self.Ho, self.Wo):
+                    raise _lib.PolyheadError("level does not end at the stride-8 size")
 
     def run(self, feats, pk, groups, posenc, pos_level, to_planes=False):
         B, prec = self.B, self.prec
-        for lvl in range(4):
-            H, W = self.shapes[lvl]
-            nhwc_ingest(feats[lvl], posenc if lvl == pos_level else None, prec, self.xa)
-            src = self.xa
-            convs = pk["levels"][lvl]
-            for j, c in enumerate(convs):
-                if j + 1 < len(convs):      # every non-final conv of levels 2 and 3 is followed by an x2 upsample
-                    H, W = self._conv_gn(src, c, H, W, groups, self.y, self.stats)
-                    dst = self.xb if src is self.xa else self.xa
-                    gn_apply(self.y, self.stats, c, groups, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=dst)
-                    H, W, src = 2 * H, 2 * W, dst
-                else:
-                    H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl])
-                    if (H, W) != (self.Ho, self.Wo):
-                        raise _lib.PolyheadError("level does not end at the stride-8 size")
+        if self.multi:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=self.xa.device) for _ in range(4)]
+            cur = torch.cuda.current_stream()
+            for lvl in (0, 3, 2, 1):                # the longest chains first
+                st = self._streams[lvl]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    self._tower(lvl, feats[lvl], pk, groups, posenc if lvl == pos_level else None, self.lv[lvl])
+            for st in self._streams:
+                cur.wait_stream(st)
+        else:
+            shared = dict(xa=self.xa, xb=self.xb, y=self.y, stats=self.stats, partial=self.partial)
+            for lvl in range(4):
+                self._tower(lvl, feats[lvl], pk, groups, posenc if lvl == pos_level else None, shared)
         # sum over levels of ReLU(GN(.)) straight to conv input planes, then conv_pred / aux convs -> fp32 NCHW
         gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
         if to_planes and self.pouts is None:
