@@ -410,12 +410,19 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
     try:        # two module pipelines on two streams, the second one a phase behind: its neck (matrix-pipe bound) runs under
         #         the first one's KernelHead + decode (HBM bound) -- what a serving loop with two frame batches in flight does
         import copy
-        kh2, head2 = copy.deepcopy(kh), copy.deepcopy(head)
-        for m_ in (kh2, head2, getattr(kh2, "localization_fpn", None)):
-            if m_ is not None:
-                for attr in ("_plans", ):
-                    if hasattr(m_, attr):
-                        setattr(m_, attr, {})
+        # a second pair of modules with the same weights and its own plans: the originals' plans (GBs of device buffers, HIP
+        # streams and events) are taken out while the modules are copied
+        neck_ = getattr(kh, "localization_fpn", None)
+        if neck_ is not None:
+            neck_.tower_streams = False     # two pipelines x four tower streams in ONE captured graph: hipStreamEndCapture segfaults
+        held = [(m_, m_._plans) for m_ in (kh, head, neck_) if m_ is not None and hasattr(m_, "_plans")]
+        for m_, _ in held:
+            m_._plans = {}
+        try:
+            kh2, head2 = copy.deepcopy(kh), copy.deepcopy(head)
+        finally:
+            for m_, pl in held:
+                m_._plans = {} if m_ is neck_ else pl        # the neck re-plans without tower streams for this leg
         kh2._pack = None
         feats2 = tuple(f.clone() for f in feats)
         sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
@@ -449,6 +456,10 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
         del keep2, g2, kh2, head2
     except Exception as e:
         out["two_streams"] = {"error": repr(e)}
+    neck_ = getattr(kh, "localization_fpn", None)
+    if neck_ is not None and getattr(neck_, "tower_streams", True) is False:
+        neck_.tower_streams = True
+        neck_._plans = {}
     return out
 
 

@@ -532,6 +532,16 @@ class KernelHeadPlan:
                                           _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_st_ev"] = None                 # a HIP event cannot be copied / pickled (copy.deepcopy of a module that holds a plan)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        if self._st_host is not None:
+            self._st_host = torch.zeros((1,), dtype=torch.int32).pin_memory()     # the copy's own pinned word
+
     _TIMEOUT = ("ph_khead_onepass: the statistics hand-off timed out (two persistent launches running concurrently on one "
                 "device?) -- results of that run are undefined")
 
@@ -591,7 +601,7 @@ class NeckPlan:
     """buffers + launch sequence of SemanticFPNWrapper.forward for one (B, level shapes): channels-last bf16 planes
     between the convs, fp32 channels-last conv outputs (one per level for the fused level sum), three fp32 NCHW outputs"""
 
-    def __init__(self, B, shapes, prec, device):
+    def __init__(self, B, shapes, prec, device, tower_streams=True):
         self.B, self.shapes, self.prec = B, shapes, prec
         P = 2 if prec == _lib.PH_PREC_SPLIT else 1
         dev = torch.device(device)
@@ -614,8 +624,10 @@ class NeckPlan:
         self.pouts = None                                          # plane outputs, allocated on first use
         # Round 3: the four level towers are independent until the level sum and the small ones leave most of the chip idle
         # (a 3x3 conv at 16 x 32 x 16 frames is 32 workgroups): each tower gets its own buffers and its own HIP stream, the
-        # small launches run beside the stride-4 level's ingest + stride-2 conv.  PH_NECK_STREAMS=0: one stream, shared buffers.
-        self.multi = _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
+        # small launches run beside the stride-4 level's ingest + stride-2 conv.  PH_NECK_STREAMS=0 or the module attribute
+        # `tower_streams = False`: one stream, shared buffers (needed when TWO pipelines are captured into one HIP graph: the
+        # nested fork / join of 2 x 4 streams made hipStreamEndCapture segfault on ROCm 7.2).
+        self.multi = tower_streams and _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
         self.lv = None
         if self.multi:
             self.lv = []

@@ -136,7 +136,7 @@ class SemanticFPNWrapper(nn.Module):
         shapes = tuple(tuple(t.shape[-2:]) for t in inputs[:4])
         plan = self._plans.get((B, shapes, str(dev), self.precision))
         if plan is None:
-            plan = E.NeckPlan(B, shapes, prec, dev)
+            plan = E.NeckPlan(B, shapes, prec, dev, tower_streams=getattr(self, "tower_streams", True))
             self._plans[(B, shapes, str(dev), self.precision)] = plan
         add = self._posenc(*shapes[self.cat_coors_level], dev) if self.pos_cfg is not None else None
         outs = plan.run([t.float().contiguous() for t in inputs[:4]], pk, G, add, self.cat_coors_level, to_planes=_planes)
