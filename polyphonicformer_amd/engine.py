@@ -627,7 +627,9 @@ class NeckPlan:
         # small launches run beside the stride-4 level's ingest + stride-2 conv.  PH_NECK_STREAMS=0 or the module attribute
         # `tower_streams = False`: one stream, shared buffers (needed when TWO pipelines are captured into one HIP graph: the
         # nested fork / join of 2 x 4 streams made hipStreamEndCapture segfault on ROCm 7.2).
-        self.multi = tower_streams and _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
+        # (from 4 frames per call: one frame at a time -- the video loop -- is bound by the host's launch rate, where the stream
+        # switches cost more than the overlap returns: cfg4 7.95 -> 9.08 ms per two frames with tower streams)
+        self.multi = tower_streams and B >= 4 and _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
         self.lv = None
         if self.multi:
             self.lv = []

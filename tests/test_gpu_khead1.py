@@ -181,3 +181,24 @@ def test_onepass_full_size_cfg2(gpu):
     got = _unpack_bits(one.bits, one.bits.shape[1], H * W)
     want = (one.mask_preds.reshape(B, one.N, H * W) > 1.5 * 2.0 ** -24).cpu()
     assert torch.equal(got[:, :one.N], want) and not got[:, one.N:].any()
+
+
+def test_plan_survives_deepcopy(gpu):
+    """a module that holds a plan is deep-copied by serving code (bench's two-pipeline leg): the plan's HIP event / pinned
+    status word are not copied, the copy runs on its own buffers and gives the same result"""
+    import copy
+    H, W, B = 16, 32, 2
+    h, sd = _head("fp16")
+    one, _ = _plans(h, B, H, W, 8, 19, True, gpu)
+    feats = [f.to(gpu) for f in Hh.neck_inputs(4, B, 256, H, W)]
+    one.set_inputs(feats)
+    one.run()                       # leaves an event and a pending status copy behind
+    two = copy.deepcopy(one)
+    assert two._st_ev is None and two._st_host.is_pinned() and two.mask_preds.data_ptr() != one.mask_preds.data_ptr()
+    two.set_inputs(feats)
+    two.run()
+    torch.cuda.synchronize()
+    one.check_status()
+    two.check_status()
+    for name in ("mask_preds", "seg_preds", "depth_pred", "xp", "dp", "bits", "proposal"):
+        assert torch.equal(getattr(one, name), getattr(two, name)), name
