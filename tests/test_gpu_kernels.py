@@ -290,3 +290,17 @@ def test_upsample2x_fp16(gpu, H, W):
     assert out.dtype == torch.float16
     ref = F.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=False)
     assert (out.cpu().float() - ref).abs().max() <= 2.0 ** -10 * ref.abs().max()
+
+
+def test_dynconv_kf16_register_conversion_form(gpu):
+    """PH_CONV_COOP=0 (read once per process): the `mixed16` conv converting its bf16 fragments per wave in registers, the
+    form every test ran until the cooperative in-LDS conversion became the default -- the same exactness cases in a child"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PH_CONV_COOP") == "0":
+        pytest.skip("already the child process")
+    env = dict(os.environ, PH_CONV_COOP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_dynconv_ksplit_and_fp16"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "15 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
