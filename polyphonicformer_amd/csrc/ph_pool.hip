@@ -78,8 +78,20 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
 #else
     constexpr int NBREM = NBW ? NBI % 4 : 0;                          // ... one fewer in waves >= NBREM when NBI is no multiple of 4
 #endif
+    // POOL_PAIR_BITS (default): the mask words of TWO chunks travel together -- 4 words = 16 bytes per row and lane, 64 rows per
+    // instruction, NBI2 instructions per pair of chunks instead of 2 NBI (cfg2: 3 instead of 10), issued with the first chunk of
+    // the pair in front of that chunk's feature pieces; the words of a row land next to each other ([row][4 words], two pair
+    // buffers).  The 4-byte-per-lane requests of the per-chunk form touch 32 cache lines per instruction and cost 8 % of the
+    // kernel (POOL_NO_BITS_DMA).  -DPOOL_CHUNK_BITS restores the per-chunk form for A/B timing.
+#if defined(POOL_CHUNK_BITS) || defined(POOL_NO_BITS_DMA) || defined(POOL_DUP_BITS)
+    constexpr bool PAIRB = false;
+#else
+    constexpr bool PAIRB = true;
+#endif
+    constexpr int NBI2 = (Npad + 63) / 64;                            // pair form: DMA instructions per pair of chunks (<= 4: one per wave)
+    constexpr int NR64 = NBI2 * 64;                                   // rows of a pair buffer
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    // [NBUF][PA][128][64] feature tiles | lut[256] (16 B each) | [NBUF][NBI*64] mask words
+    // [NBUF][PA][128][64] feature tiles | lut[256] (16 B each) | mask words: [NBUF][NBI*64] (per chunk) or [2][NR64][4] (per pair)
     uint4* lut = (uint4*)(lds + POOL_NBUF * PA * POOL_FT);
     uint32_t* lbits = (uint32_t*)(lut + 256);
 
@@ -95,8 +107,19 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
     const int64_t words_per_row = HWp / 32;
     const uint32_t* brow = bits + (int64_t)b * bits_rows * words_per_row;      // bits_rows >= Npad rows per frame
 
-    const int nchunks = (int)(HWp / POOL_CHUNK);
-    const int c0 = (int)((int64_t)split * nchunks / nsplit), c1 = (int)((int64_t)(split + 1) * nchunks / nsplit);
+    const int nchunks = (int)(HWp / POOL_CHUNK);                      // even: HWp is a multiple of 128
+    int c0 = (int)((int64_t)split * nchunks / nsplit), c1 = (int)((int64_t)(split + 1) * nchunks / nsplit);
+    if (PAIRB) { c0 &= ~1; c1 = split + 1 == nsplit ? nchunks : (c1 & ~1); }      // pixel ranges of whole chunk pairs
+    const bool pair_wave = PAIRB && wave < NBI2;                      // this wave carries one mask-word instruction per pair
+    // pair form: mask words of the chunk pair starting at (even) chunk c -> pair buffer gb; 64 rows x 16 bytes per instruction
+    auto issue_pair_bits = [&](int c, int gb) {
+        if (!pair_wave) return;
+        int row = wave * 64 + lane;
+        if (row > Npad - 1) row = Npad - 1;                           // tail lanes re-read the last row (their LDS rows are never read)
+        const uint32_t* src = brow + (int64_t)row * words_per_row + c * 2;
+        uint32_t* dst = lbits + gb * (NR64 * 4) + wave * 256;         // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, 0);
+    };
 
     lut[tid] = expand8<E>((uint32_t)tid);                               // byte -> A fragment (8 x {0,1} bf16)
 
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
             const uint16_t* src = fbase + p * plane_stride + (int64_t)row * HWp + (int64_t)c * POOL_CHUNK + q * 8;
             uint16_t* dst = lds + (buf * PA + p) * POOL_FT + jj * 512;          // wave-uniform
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (PH_LDS void*)dst, 16, 0, PH_CPOL_STREAM);
-        } else {
+        } else if (!PAIRB) {
             // NBI mask-word instructions per chunk, dealt round-robin: a wave past the end issues one fewer (round 3; it used
             // to repeat the last one so that ONE vmcnt immediate served every wave -- 3 of 8 requests per chunk were duplicates at
             // cfg2, and the mask-word requests cost 8 % of this kernel, POOL_NO_BITS_DMA); the counted waits below are per wave class
@@ -150,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         for (int k = 0; k < PER_CHUNK; ++k) issue_piece(c, buf, k);
     };
 
+    if (PAIRB && c0 < c1) issue_pair_bits(c0, 0);
 #pragma unroll
     for (int d = 0; d < POOL_NBUF - 1; ++d)
         if (c0 + d < c1) issue_chunk(c0 + d, d);
@@ -162,7 +186,21 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         // chunk c must have landed; the up to NBUF-2 younger chunks stay in flight ACROSS the barrier:
         // counted vmcnt + RAW s_barrier (__syncthreads would drain the DMA queue with vmcnt(0))
         const int younger = (c1 - 1 - c) < (POOL_NBUF - 2) ? (c1 - 1 - c) : (POOL_NBUF - 2);
-        if (NBREM != 0 && wave >= NBREM) {       // this wave issues PER_CHUNK - 1 instructions per chunk (wave-uniform branch)
+        const int pos = (c - c0) & 1;                 // pair form: first / second chunk of its pair
+        if (PAIRB) {
+            // issue slot of chunk x: E(x) = [mask words of the pair after x's, if x is the first chunk of its pair][features of x + 3].
+            // In front of the FIRST chunk of a pair its own words sit in E(c-2), ahead of that slot's feature pieces: the youngest
+            // 4 PA x `younger` instructions (features of c+1, c+2) may stay in flight.  In front of the SECOND chunk the words
+            // arrived with E(c-3); E(c-1) holds the NEXT pair's words, which may stay in flight as well
+            const bool extra = pos == 1 && younger >= 1 && pair_wave;
+            if (younger >= 2) {
+                if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * PA + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * PA) : "memory");
+            } else if (younger == 1) {
+                if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PA + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PA) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (NBREM != 0 && wave >= NBREM) {       // this wave issues PER_CHUNK - 1 instructions per chunk (wave-uniform branch)
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PER_CHUNK - 1)) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK - 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
         if (nb >= POOL_NBUF) nb -= POOL_NBUF;
         const bool more = c + POOL_NBUF - 1 < c1;
         const uint32_t ft = lds_addr(lds + cur * PA * POOL_FT);
-        const uint32_t wb = lds_addr(lbits + cur * (NBI * 64));
+        const uint32_t wb = PAIRB ? lds_addr(lbits + (((c - c0) >> 1) & 1) * (NR64 * 4)) : lds_addr(lbits + cur * (NBI * 64));
         // B fragments (this lane's channel row, 4 k-steps of 8 pixels in its 32-pixel half) and the mask words
         u32x4_t xf[PA][4];
 #pragma unroll
@@ -190,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
                 xf[p][t] = lds_read128_asm(ft + 2 * (p * POOL_FT + frow * POOL_CHUNK + (((g * 4 + t) ^ pool_swz(frow)) * 8)));
         uint32_t w[NRT];
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) w[rt] = lds_read32_asm(wb + 4 * ((rt * 32 + (lane & 31)) * 2 + g));
+        for (int rt = 0; rt < NRT; ++rt)
+            w[rt] = PAIRB ? lds_read32_asm(wb + 4 * ((rt * 32 + (lane & 31)) * 4 + pos * 2 + g))
+                          : lds_read32_asm(wb + 4 * ((rt * 32 + (lane & 31)) * 2 + g));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (counting) {
@@ -217,6 +257,9 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
                 for (int p = 0; p < PA; ++p)
                     acc[rt] = mfma32e<E>(__builtin_bit_cast(uint4, a[rt & 1][t]), __builtin_bit_cast(uint4, xf[p][t]), acc[rt]);
             __builtin_amdgcn_sched_barrier(0);
+            // pair form: with the first chunk of a pair, the NEXT pair's mask words go out first (into the other pair buffer:
+            // its last reader was chunk c - 1, behind this chunk's barrier), then this slot's feature pieces
+            if (PAIRB && rt == 0 && pos == 0 && c + 2 < c1) issue_pair_bits(c + 2, (((c - c0) >> 1) + 1) & 1);
             if (more) {
 #pragma unroll
                 for (int k = rt; k < PER_CHUNK; k += NRT) issue_piece(c + POOL_NBUF - 1, nb, k);
@@ -248,7 +291,9 @@ __global__ __launch_bounds__(256, 2) void k_pool(const uint16_t* __restrict__ xp
 template <int PA, int NRT, int E>
 static void launch_pool(const uint16_t* x, const uint16_t* d, const uint32_t* bits, float* partial, int B, int64_t HWp,
                         int nsplit, int bits_rows, int32_t* pcount, hipStream_t s) {
-    const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4;
+    // mask words: per-chunk form 4 x NRT x 256 B, pair form 2 x ceil(Npad / 64) x 64 rows x 16 B -- the larger of the two
+    const size_t lbits_chunk = (size_t)POOL_NBUF * ((NRT * 64 + 63) / 64) * 64 * 4, lbits_pair = (size_t)2 * ((NRT * 32 + 63) / 64) * 64 * 16;
+    const size_t lds = (size_t)POOL_NBUF * PA * POOL_FT * sizeof(uint16_t) + 256 * 16 + (lbits_chunk > lbits_pair ? lbits_chunk : lbits_pair);
     static const bool once = [&] {
         (void)hipFuncSetAttribute((const void*)k_pool<PA, NRT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return true;
