@@ -9,8 +9,8 @@
 //     as fragments with ds_read_b128: lane (channel j, half g), step t <-> pixel 64*chunk + 32*g + 8*t + e (the
 //     k-slot <-> pixel map is a free permutation as long as A agrees).  Every feature byte is read from HBM
 //     exactly once.
-//   A operand (mask bits -> {0,1} bf16): the chunk's mask words also arrive by LDS-DMA (2 words per query
-//     row, default cache policy: a 128-byte line serves 16 chunks); an A fragment is ONE ds_read_b128 from a
+//   A operand (mask bits -> {0,1} bf16): the mask words also arrive by LDS-DMA (round 3: the 4 words of a query
+//     row for a PAIR of chunks in one 16-byte lane request, default cache policy); an A fragment is ONE ds_read_b128 from a
 //     256-entry byte -> 8 x bf16 lookup table in LDS, so no expanded mask tile exists at all.  LDS per
 //     workgroup at cfg2 (bf16): 4 x 16 KiB feature ring + 4 KiB table + 4 x 1.25 KiB mask words = 73 KiB
 //     -> 2 workgroups per CU, 96 KiB of feature loads in flight per CU.  {0,1} is exact in bf16, so split
