@@ -245,7 +245,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         run()
     t_all = time_op(graph.replay, steps)
     t_a1 = time_op(run_a1, steps)
-    kplan.check_status()
+    a1_timeouts = kplan.timeouts()
     # the same with fp16 mask / seg / depth logits out of KernelHead (the decode consumes the mask BITS; the logits are API
     # outputs of simple_test_rpn): 19 MB per frame less
     t_a1_h = None
@@ -291,7 +291,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
     except Exception as e:
         two = {"error": repr(e)}
     return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
-            "a1_only_ms_per_step": round(t_a1, 4), "a1_form": "one-pass (ph_khead_onepass)" if kplan.onepass else "two-pass (ph_khead_fused)",
+            "a1_only_ms_per_step": round(t_a1, 4), "a1_onepass_timeouts": a1_timeouts, "a1_form": "one-pass (ph_khead_onepass)" if kplan.onepass else "two-pass (ph_khead_fused)",
             "a1_only_ms_per_step_fp16_logits": round(t_a1_h, 4) if isinstance(t_a1_h, float) else t_a1_h, "two_streams": two,
             "a1_alg_bytes_per_frame": int(3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2),
             "a1_plus_a6_fraction_hbm": round(((3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2)
@@ -693,18 +693,34 @@ def panoptic_leg(wl, head, plan, dev):
     including the D2H of the int32 id map and the two fp32 depth maps that the reference API returns as numpy"""
     from polyphonicformer_amd import panoptic as Pn
     from polyphonicformer_amd.registry import ConfigDict
-    head.test_cfg = ConfigDict(max_per_img=wl["Nq"], merge_stuff_thing=dict(overlap_thr=0.6, instance_score_thr=0.3))
+    # An un-trained head accepts nothing (fc_cls.bias = -4.6 -> every score < instance_score_thr; its random masks overlap
+    # heavily, so the 0.6 overlap test fails too) and the leg would time a frame whose accept loop and depth paste are empty
+    # (VERDICT r03 weak 10).  The masks and depth maps are the step's real outputs; the class scores are synthetic -- 40 thing
+    # queries and every stuff class above the threshold -- and overlap_thr is 0 (a segment is accepted when it wins a pixel),
+    # as the video leg arranges it: tens of accepted segments, the workload of a trained model's frame.
+    head.test_cfg = ConfigDict(max_per_img=wl["Nq"], merge_stuff_thing=dict(overlap_thr=0.0, instance_score_thr=0.3))
     o = plan.outputs()
     H, W = wl["H"], wl["W"]
+    N, L, nt = wl["Nq"] + wl["n_stuff"], wl["n_thing"] + wl["n_stuff"], wl["n_thing"]
+    g = torch.Generator().manual_seed(17)
+    cls = torch.full((N, L), 0.02)
+    hot = torch.randperm(wl["Nq"], generator=g)[:40]
+    cls[hot, torch.randint(0, nt, (40,), generator=g)] = 0.35 + 0.6 * torch.rand(40, generator=g)
+    sidx = torch.arange(wl["n_stuff"])
+    cls[wl["Nq"] + sidx, nt + sidx] = 0.4 + 0.5 * torch.rand(wl["n_stuff"], generator=g)
+    cls = cls.to(dev)
     meta = dict(img_shape=(H * 8, W * 8, 3), ori_shape=(H * 8, W * 8, 3), batch_input_shape=(H * 8, W * 8))
     d0 = torch.randn(1, 2 * H, 2 * W, device=dev)
     ts = []
     for _ in range(4):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        r = Pn.get_panoptic(head, o["cls"][0], o["mask_up"][0], o["depth_up"][0], d0, meta)
+        r = Pn.get_panoptic(head, cls, o["mask_up"][0], o["depth_up"][0], d0, meta)
         ts.append((time.perf_counter() - t) * 1e3)
-    return {"ms_per_frame": round(min(ts[1:]), 3), "segments": len(r[2][1]), "output": f"int32 {H * 8}x{W * 8} id map + 2 fp32 depth maps on the host"}
+    return {"ms_per_frame": round(min(ts[1:]), 3), "segments": len(r[2][1]), "things": sum(1 for s_ in r[2][1] if s_["isthing"]),
+            "output": f"int32 {H * 8}x{W * 8} id map + 2 fp32 depth maps on the host",
+            "inputs": "the step's mask / depth logits of frame 0; synthetic class scores (40 thing queries + all stuff classes above "
+                      "instance_score_thr), overlap_thr 0 so that an un-trained network's overlapping masks are accepted"}
 
 
 def cpu_baseline(wl, head, budget_s=16.0, all_cores=True, workload_note="the same workload (1024x2048, N=153, S=3)"):
@@ -734,6 +750,14 @@ def cpu_baseline(wl, head, budget_s=16.0, all_cores=True, workload_note="the sam
     ncores = min(16, allc)
     n, dt = timed(ncores, budget_s * 0.5)
     n1, dt1 = timed(1, budget_s * 0.25)
+    # BASELINE.md section 4 asks for the all-cores figure in the default line.  All 256 hardware threads of the GPU box oversubscribe
+    # these small ops (~45 s per frame: --all-legs runs it once); the default line carries min(64, all) threads -- as many
+    # as there are physical cores on one socket's worth of the box -- on a 3-second sample
+    nmany = min(64, allc)
+    many = None
+    if nmany != ncores:
+        nm, dtm = timed(nmany, 3.0)
+        many = {"value": 1.0 / dtm, "cores": nmany, "frames": nm}
     if allc != ncores and all_cores:      # hundreds of threads on these small ops are pathologically slow (~45 s per frame on 256): ONE frame
         torch.set_num_threads(allc)
         with torch.no_grad():
@@ -760,11 +784,14 @@ def cpu_baseline(wl, head, budget_s=16.0, all_cores=True, workload_note="the sam
     out = dict(value=1.0 / dt, unit="frames/s", cores=ncores, kind="port", **extra,
                one_thread={"value": 1.0 / dt1, "cores": 1, "frames": n1},
                sample=f"{n} frame(s) of {workload_note}, fp32, B=1, after 1 warm-up; + {n1} frame(s) on 1 thread")
+    if many:
+        out["many_cores"] = many
+        out["sample"] += f"; + {many['frames']} frame(s) on {nmany} threads"
     if na:
         out["all_cores"] = {"value": 1.0 / dta, "cores": allc, "frames": na}
         out["sample"] += f" and {na} on all {allc} hardware threads"
     else:
-        out["all_cores"] = f"not run by default ({allc} hardware threads take ~45 s per frame: --all-legs); profiles/r03/bench_all_legs.json has 0.022 frames/s"
+        out["all_cores"] = f"not run by default ({allc} hardware threads take ~45 s per frame: --all-legs; profiles/r03/bench_all_legs.json has 0.022 frames/s) -- `many_cores` is the default line's wide figure"
     return out
 
 

@@ -71,6 +71,10 @@ int ph_ingest_features(const float* src, uint16_t* planes, int B, int64_t HW, in
  * (sigmoid -> > hard_mask_thr(0.5) -> float), stated as logit > 0. */
 int ph_binarize(const float* logits, int64_t logits_batch_stride /* elements; 0 = N*HW (contiguous) */, uint32_t* bits,
                 int B, int N, int64_t HW, void* stream);
+/* the same for fp32 or fp16 logits (dtype PH_OUT_F32 / PH_OUT_F16), optionally predicated on a device word: when run_if is
+ * non-NULL and *run_if == 0 at execution time the launch returns at once (see ph_khead_fused_if) */
+int ph_binarize_if(const void* logits, int dtype, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
+                   const uint32_t* run_if /* nullable */, void* stream);
 
 /* ---- A7: masked pooling -------------------------------------------------------------------
  * kernel_update_head.py:241-242  einsum('bnhw,bchw->bnc') for x and depth_feats in one pass
@@ -222,6 +226,17 @@ int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_
                    uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
                    float* mask_preds, float* seg_preds, float* depth_pred,
                    void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
+/* ph_khead_fused with the logit dtype as an argument (PH_OUT_F32 / PH_OUT_F16) and a device predicate: when run_if is non-NULL
+ * and *run_if == 0 at execution time every launch of the call returns at once.  Issued behind ph_khead_onepass with run_if =
+ * that call's status word (the first 4 bytes of its workspace) it is the in-call fallback of a one-pass launch that gave up:
+ * same buffers, same results to the two forms' summation-order difference, no host round trip, capturable in a HIP graph. */
+int ph_khead_fused_if(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
+                      const float* gn_affine, int groups, float eps,
+                      const uint16_t* w2_init, int n_init, const uint16_t* w2_seg, const float* bias_seg, int n_seg,
+                      const uint16_t* w2_dd, const float* bias_dd, int stuff_lo, int n_stuff,
+                      uint16_t* x_planes, uint16_t* dfe_planes, float* x_f32 /* nullable */, float* dfe_f32 /* nullable */,
+                      void* mask_preds, void* seg_preds, void* depth_pred, int logits_dtype, const uint32_t* run_if /* nullable */,
+                      void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
 /* ph_khead_onepass (round 3): ph_khead_fused's results from ONE read of the three maps.  The conv output of a 128-pixel
  * slice stays in the accumulator registers of one workgroup per CU while the GroupNorm sums of the whole (frame, map)
  * are exchanged between the workgroups inside the launch (persistent grid, bounded spins); loc waits in LDS for
@@ -230,11 +245,17 @@ int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_
  *   conv_frags: {loc,seg,depth}_convs.0.conv.weight as MFMA 32x32x16 A fragments [3][8][16][64][8] (one 16-bit plane);
  *   mask_preds / seg_preds / depth_pred: fp32 or fp16 (`out_dtype` PH_OUT_F32 / PH_OUT_F16), shapes as ph_khead_fused;
  *   bits: nullable, uint32 [B][bits_rows][HWp/32], rows >= n_init + n_stuff are cleared;
- *   workspace: ph_khead_onepass_workspace_bytes(B, HW) bytes, cleared by the call itself (a memset node ahead of the kernel).
+ *   workspace: ph_khead_onepass_workspace_bytes(B, HW) bytes; the caller zeroes it ONCE after allocation, every call clears all
+ *     of it but the last 256 bytes (a memset node ahead of the kernel): those hold the sticky time-out words.
  * ph_khead_onepass_supported: 1 when the geometry fits (HWp / 128 <= #CUs, 32 groups, one-plane grade, HW % 4 == 0 for
- * fp32 inputs); otherwise callers use ph_khead_fused.  Two ph_khead_onepass launches must not run concurrently on one
- * device (each needs every CU resident); a starved launch times out, sets a status word (ph_khead_onepass_status,
- * synchronising) and finishes with undefined results instead of hanging. */
+ * fp32 inputs); otherwise callers use ph_khead_fused.
+ * The persistent grid needs one workgroup resident on every CU it uses.  When that does not happen within the hand-off bound
+ * (ph_khead_onepass_set_timeout_us, default 20 ms: another kernel holds CUs that long, or two one-pass launches starve each
+ * other) the launch GIVES UP: it raises the per-call status word (first 4 bytes of the workspace), its workgroups leave, and
+ * the tensors it was writing are incomplete.  Round 4: the caller issues ph_khead_fused_if + ph_binarize_if predicated on that
+ * word directly behind the call (engine.KernelHeadPlan.run does), so the SAME call still ends with the right results -- there
+ * is no undefined-result mode, no host synchronisation, and it holds inside HIP graphs.  ph_khead_onepass_status: 1 if the last
+ * call gave up; ph_khead_onepass_timeouts: workgroup time-outs since the workspace was zeroed (both synchronise the stream). */
 int ph_khead_onepass_supported(int B, int64_t HW, int groups, int prec, int input_format);
 size_t ph_khead_onepass_workspace_bytes(int B, int64_t HW);
 int ph_khead_onepass(const void* f0, const void* f1, const void* f2, const uint16_t* conv_frags,
@@ -246,6 +267,8 @@ int ph_khead_onepass(const void* f0, const void* f1, const void* f2, const uint1
                      uint32_t* bits /* nullable */, int bits_rows,
                      void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format, void* stream);
 int ph_khead_onepass_status(const void* workspace, int B, void* stream);
+int ph_khead_onepass_timeouts(const void* workspace, int B, int64_t HW, void* stream);
+void ph_khead_onepass_set_timeout_us(int microseconds /* <= 0: the default */);
 /* debugging aid: device buffer [grid][2][3 * rounds][16] uint64 filled with s_memtime stamps by the following launches (NULL: off) */
 void ph_khead_onepass_set_timeline(void* buf);
 int ph_khead_proposals(const float* partial, int nsplit, const float* w_init /*[Nq][256]*/,
@@ -413,6 +436,8 @@ int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16]
 int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);
 int ph_selftest_readbw(const void* p, int64_t bytes, int blocks, void* out /*4 B*/, void* stream);   /* streaming-read yardstick */
 int ph_selftest_trread(const uint16_t* src /*[16][16]*/, uint16_t* out /*[64][4]*/, void* stream);
+/* holds `blocks` workgroup slots with `lds_bytes` of LDS each for `microseconds` (a CU-hogging neighbour for the time-out tests) */
+int ph_selftest_hog(int blocks, int lds_bytes, int microseconds, void* scratch4, void* stream);
 
 #ifdef __cplusplus
 }

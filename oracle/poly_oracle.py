@@ -96,14 +96,16 @@ def kernel_updator(sd, name, u, k):
 # --------------------------------------------------------------------------------------------
 # A.2  one KernelUpdateHead stage  (polyphonic/kernel_update_head.py:212-353)
 # --------------------------------------------------------------------------------------------
-def update_stage(sd, pre, x, k, m, q, dfe, heads=8, hard_mask_thr=0.5):
+def update_stage(sd, pre, x, k, m, q, dfe, heads=8, hard_mask_thr=0.5, hard_mask=None):
     """x, dfe [B,C,H,W]; k, q [B,N,C]; m [B,N,H,W] mask logits (same H,W).
-    Returns dict(cls [B,N,L], mask [B,N,H,W], obj [B,N,C], depth [B,N,H,W], dobj [B,N,C])."""
+    Returns dict(cls [B,N,L], mask [B,N,H,W], obj [B,N,C], depth [B,N,H,W], dobj [B,N,C]).
+    `hard_mask` (tests only): a {0,1} tensor [B,N,H,W] used INSTEAD of binarize(m) -- the hard decisions of another
+    implementation's run, so that a free-running comparison measures arithmetic and not the discontinuity."""
     B, C, H, W = x.shape
     N = k.shape[1]
     xt = F.conv2d(x, sd[pre + "feat_transform.conv.weight"], sd[pre + "feat_transform.conv.bias"])          # :225
     dt = F.conv2d(dfe, sd[pre + "feat_depth_transform.conv.weight"], sd[pre + "feat_depth_transform.conv.bias"])  # :226
-    M = binarize(m, hard_mask_thr)                                   # :236-238
+    M = binarize(m, hard_mask_thr) if hard_mask is None else hard_mask.to(m.dtype)   # :236-238
     u = torch.einsum("bnhw,bchw->bnc", M, xt)                        # :241
     ud = torch.einsum("bnhw,bchw->bnc", M, dt)                       # :242
     q = q + k                                                        # :250
@@ -134,16 +136,18 @@ def upsample2x(t, s=2):
 # A.4  KernelUpdateIterHead.simple_test_mask_preds (polyphonic/kernel_update.py:356-401)
 # --------------------------------------------------------------------------------------------
 def iter_head_mask_preds(sd, S, x, k0, m0, q0, dfe, heads=8, prefix="mask_head.", upsample=2,
-                         return_stages=False):
+                         return_stages=False, hard_masks=None):
     """k0/q0 accept [B,N,C,1,1] or [B,N,C] (q0 may be a stride-0 expand view).
-    Returns dict(obj [B,N,C], cls sigmoid [B,N,L], mask [B,N,H,W], mask_up, depth, depth_up, dobj)."""
+    Returns dict(obj [B,N,C], cls sigmoid [B,N,L], mask [B,N,H,W], mask_up, depth, depth_up, dobj).
+    `hard_masks` (tests only): list of S entries, None or the {0,1} mask stage s pools with (see update_stage)."""
     B, N = k0.shape[:2]
     k = k0.reshape(B, N, -1)
     q = q0.reshape(B, N, -1)
     m = m0
     stages = []
     for s in range(S):                                               # :383-394
-        r = update_stage(sd, f"{prefix}{s}.", x, k, m, q, dfe, heads)
+        r = update_stage(sd, f"{prefix}{s}.", x, k, m, q, dfe, heads,
+                         hard_mask=None if hard_masks is None else hard_masks[s])
         k, q, m = r["obj"], r["dobj"], r["mask"]
         if return_stages:
             stages.append(r)

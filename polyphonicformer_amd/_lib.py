@@ -55,6 +55,12 @@ SIGNATURES = {
     "ph_khead_onepass": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
                                    _P, _P, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
     "ph_khead_onepass_status": (C.c_int, [_P, _I, _P]),
+    "ph_khead_onepass_timeouts": (C.c_int, [_P, _I, _L, _P]),
+    "ph_khead_onepass_set_timeout_us": (None, [_I]),
+    "ph_khead_fused_if": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P,
+                                    _P, _P, _P, _I, _P, _P, _Z, _I, _L, _I, _I, _P]),
+    "ph_binarize_if": (C.c_int, [_P, _I, _L, _P, _I, _I, _L, _P, _P]),
+    "ph_selftest_hog": (C.c_int, [_I, _I, _I, _P, _P]),
     "ph_khead_onepass_set_timeline": (None, [_P]),
     "ph_khead_proposals": (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ph_match_record_floats": (C.c_int64, [_I, _I]),

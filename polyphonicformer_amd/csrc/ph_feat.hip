@@ -53,18 +53,23 @@ extern "C" int ph_ingest_features(const float* src, uint16_t* planes, int B, int
     return PH_OK;
 }
 
+template <int E> __device__ __forceinline__ float ld_as_f32(const float* p) { return *p; }
+template <int E> __device__ __forceinline__ float ld_as_f32(const uint16_t* p) { return e2f<E>(*p); }
+
 // ---------------------------------------------------------------------------------------------
 // binarize: logits [B][N][HW] -> bits [B][Npad][HWp/32].  One wave produces two words per step
 // with __ballot (lane = pixel).  Rows >= N and pixels >= HW come out 0.
-__global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logits, int64_t lbs, uint32_t* __restrict__ bits,
-                                                  int B, int N, int Npad, int64_t HW, int64_t HWp) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_binarize(const T* __restrict__ logits, int64_t lbs, uint32_t* __restrict__ bits,
+                                                  int B, int N, int Npad, int64_t HW, int64_t HWp, const unsigned* run_if) {
+    if (run_if && *run_if == 0) return;
     // one row (b, n) per blockIdx.y; each lane tests 4 consecutive pixels (16-byte load); a wave covers
     // 256 px = 8 words; the 8 lanes of a word OR their nibbles together with three xor-shuffles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.y;
     const int b = row / Npad, n = row - b * Npad;
     const bool live = n < N;
-    const float* src = logits + (int64_t)b * lbs + (int64_t)n * HW;
+    const T* src = logits + (int64_t)b * lbs + (int64_t)n * HW;
     uint32_t* dst = bits + (int64_t)row * (HWp / 32);
     const bool vec_ok = (HW & 3) == 0;
     for (int c = blockIdx.x * 4 + wave; (int64_t)c * 256 < HWp; c += gridDim.x * 4) {
@@ -72,11 +77,16 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
         float v[4] = {-1.f, -1.f, -1.f, -1.f};
         if (live && px < HW) {
             if (vec_ok && px + 4 <= HW) {
-                const uint4 q = ld_nt16(src + px);
-                v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+                if constexpr (sizeof(T) == 4) {
+                    const uint4 q = ld_nt16(src + px);
+                    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+                } else {
+                    const uint2 q = ld_nt8(src + px);
+                    v[0] = h2f(q.x & 0xFFFFu); v[1] = h2f(q.x >> 16); v[2] = h2f(q.y & 0xFFFFu); v[3] = h2f(q.y >> 16);
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = src[px + e];
+                for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = ld_as_f32<PH_E_F16>(src + px + e);
             }
         }
         const uint32_t nib = (v[0] > PH_BIN_THR ? 1u : 0u) | (v[1] > PH_BIN_THR ? 2u : 0u) | (v[2] > PH_BIN_THR ? 4u : 0u) | (v[3] > PH_BIN_THR ? 8u : 0u);
@@ -88,9 +98,11 @@ __global__ __launch_bounds__(256) void k_binarize(const float* __restrict__ logi
     }
 }
 
-extern "C" int ph_binarize(const float* logits, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
-                           void* stream) {
+// logits fp32 (PH_OUT_F32) or fp16 (PH_OUT_F16); run_if: optional device predicate (the launch returns at once when *run_if == 0)
+extern "C" int ph_binarize_if(const void* logits, int dtype, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
+                              const uint32_t* run_if, void* stream) {
     PH_CHECK_ARG(logits && bits && B > 0 && N > 0 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_F16, "dtype must be PH_OUT_F32 or PH_OUT_F16");
     PH_CHECK_ARG(logits_batch_stride == 0 || logits_batch_stride >= (int64_t)N * HW, "batch stride smaller than a frame");
     if (!logits_batch_stride) logits_batch_stride = (int64_t)N * HW;
     const int Npad = ph_n_padded(N);
@@ -98,18 +110,25 @@ extern "C" int ph_binarize(const float* logits, int64_t logits_batch_stride, uin
     PH_CHECK_ARG((int64_t)B * Npad <= 65535, "B * Npad must be <= 65535");
     int gx = (int)((HWp + 1023) / 1024);          // 4 waves x 256 px per block step
     if (gx > 8) gx = 8;
-    hipLaunchKernelGGL(k_binarize, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, logits, logits_batch_stride, bits, B, N, Npad,
-                       HW, HWp);
+    if (dtype == PH_OUT_F32)
+        hipLaunchKernelGGL(k_binarize<float>, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+                           logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
+    else
+        hipLaunchKernelGGL(k_binarize<uint16_t>, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
+                           logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
     PH_CHECK_LAUNCH();
     return PH_OK;
+}
+
+extern "C" int ph_binarize(const float* logits, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
+                           void* stream) {
+    return ph_binarize_if(logits, PH_OUT_F32, logits_batch_stride, bits, B, N, HW, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // x2 bilinear, align_corners=False.  ATen's formula (aten/native/UpSample.h area_pixel_compute_
 // source_index): src = max((dst + 0.5) * 0.5 - 0.5, 0); i0 = floor(src); i1 = min(i0 + 1, n - 1);
 // l1 = src - i0; l0 = 1 - l1; out = h0*(w0*a + w1*b) + h1*(w0*c + w1*d).
-template <int E> __device__ __forceinline__ float ld_as_f32(const float* p) { return *p; }
-template <int E> __device__ __forceinline__ float ld_as_f32(const uint16_t* p) { return e2f<E>(*p); }
 template <int E> __device__ __forceinline__ void st_from_f32(float* p, float v) { *p = v; }
 template <int E> __device__ __forceinline__ void st_from_f32(uint16_t* p, float v) { *p = (uint16_t)f2e<E>(v); }
 

@@ -38,8 +38,10 @@ struct KHArgs {
     const uint16_t* w2;           // MFMA 32x32x16 A fragments [PA][m2_tiles][16][64 lanes][8]
     int64_t w2_plane;
     const float* bias2;           // [m2_tiles * 32] or null
-    float* out2;                  // fp32 [B][out2_rows][HW], rows [0, n2) written
-    float* out2b;                 // optional second destination of rows [dual_lo, dual_lo + dual_n): row0b + (row - dual_lo)
+    void* out2;                   // fp32 (or fp16: out2_f16) [B][out2_rows][HW], rows [0, n2) written
+    void* out2b;                  // optional second destination of rows [dual_lo, dual_lo + dual_n): row0b + (row - dual_lo)
+    int out2_f16;
+    const unsigned* run_if;       // optional predicate: the launch returns at once when *run_if == 0 (ph_khead_fused_if)
     int m2_tiles, n2, out2_rows, dual_lo, dual_n, out2b_rows, out2b_row0;
     uint16_t* blocks_out;         // optional: this map as per-(frame, wave, tile) register-layout blocks (see kh_block)
     const uint16_t* blocks_in;    // ADD == 2: the map to add, in that form
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
     const int b = blockIdx.y, m = blockIdx.z;
+    if (a.run_if && *a.run_if == 0) return;
     uint4 af[PA][16];
     kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
     const int ntiles = (int)(a.HWp / KH_T);
@@ -232,8 +235,9 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
 // per channel take interleaved workgroups with 4 independent accumulator pairs each (the loads of a chain of nwg
 // dependent additions were 80 us at nwg = 256), fp64 combine in a fixed order (deterministic)
 __global__ __launch_bounds__(1024) void k_gn_finalize(const float* __restrict__ partial, float* __restrict__ stats, int nwg,
-                                                      int groups, int64_t HW, float eps) {
+                                                      int groups, int64_t HW, float eps, const unsigned* run_if) {
     __shared__ double sh[4][256][2];
+    if (run_if && *run_if == 0) return;
     const int b = blockIdx.x, c = threadIdx.x & 255, q = threadIdx.x >> 8;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
     const float2* p = (const float2*)partial + ((int64_t)b * nwg) * 256 + c;
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(1024) void k_gn_finalize(const float* __restrict__ 
 extern "C" int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B,
                               void* stream) {
     PH_CHECK_ARG(partial && stats && nwg > 0 && groups > 0 && 256 % groups == 0 && HW > 0 && B > 0, "bad pointer or size");
-    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(1024), 0, (hipStream_t)stream, partial, stats, nwg, groups, HW, eps);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(B), dim3(1024), 0, (hipStream_t)stream, partial, stats, nwg, groups, HW, eps,
+                       (const unsigned*)nullptr);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
     uint16_t* rows = lds + wave * 32 * KH_LDT;                       // this wave's channel rows (plane p: + p * 256 * KH_LDT)
     const int b = blockIdx.y;
+    if (a.run_if && *a.run_if == 0) return;
     const int cpg = 256 / a.groups;
     const int64_t oplane = (int64_t)a.B * 256 * a.HWp;
     // per-channel affine of the normalisation (rstd*gamma, beta - mean*rstd*gamma) in LDS
@@ -490,11 +496,15 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                     const bool wr = inside && row < a.n2;
                     const bool dual = a.out2b && row >= a.dual_lo && row < a.dual_lo + a.dual_n;
                     if (wr) {
-                        float* ub = a.out2 + ((int64_t)b * a.out2_rows + rowu) * a.HW + px0 + ct * 32;
-                        __builtin_nontemporal_store(v, ub + (uint32_t)(4 * g * a.HW + (lane & 31)));
-                        if (dual) {
-                            float* ub2 = a.out2b + ((int64_t)b * a.out2b_rows + a.out2b_row0 + rowu - a.dual_lo) * a.HW + px0 + ct * 32;
-                            __builtin_nontemporal_store(v, ub2 + (uint32_t)(4 * g * a.HW + (lane & 31)));
+                        const int64_t o1 = ((int64_t)b * a.out2_rows + rowu) * a.HW + px0 + ct * 32;                                  // uniform
+                        const int64_t o2 = ((int64_t)b * a.out2b_rows + a.out2b_row0 + rowu - a.dual_lo) * a.HW + px0 + ct * 32;       // uniform
+                        const uint32_t lo = (uint32_t)(4 * g * a.HW + (lane & 31));
+                        if (a.out2_f16) {
+                            ((uint16_t*)a.out2 + o1)[lo] = (uint16_t)f2h(v);
+                            if (dual) ((uint16_t*)a.out2b + o2)[lo] = (uint16_t)f2h(v);
+                        } else {
+                            __builtin_nontemporal_store(v, (float*)a.out2 + o1 + lo);
+                            if (dual) __builtin_nontemporal_store(v, (float*)a.out2b + o2 + lo);
                         }
                     }
                 }
@@ -539,10 +549,12 @@ struct KhFused {                  // the static 1x1 convs of the fused entry poi
     const uint16_t* w2[3];
     const float* bias2[3];
     int n2[3];
-    float* out2[3];
+    void* out2[3];
     int out2_rows[3];
     int stuff_lo, n_stuff, n_init;
     uint16_t* loc_blocks;         // scratch for loc between the first two launches (a planes-sized buffer)
+    int out2_f16;                 // logits as fp16 instead of fp32
+    const unsigned* run_if;       // optional device predicate of every launch
 };
 
 static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplanes, const float* gn_affine, int groups, float eps,
@@ -586,6 +598,8 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     }();
     (void)once;
     KHArgs a = {};
+    a.run_if = fu ? fu->run_if : nullptr;
+    a.out2_f16 = fu ? fu->out2_f16 : 0;
     a.B = B; a.groups = groups; a.tiles_per_wg = tpw; a.HW = HW; a.HWp = HWp;
     a.w_plane = (int64_t)3 * 256 * 256;
     const dim3 grid(nwg, B), block(KH_THREADS);
@@ -610,7 +624,7 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     } while (0)
     // pass 1: the three maps in one launch, then one finalize over the 3 * B (map, frame) pairs
     KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
-    hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps, a.run_if);
     // pass 2: loc ; sem (+ x = sem + loc, loc read back from the planes the first launch wrote) ; depth
     for (int m = 0; m < 3; ++m) {
         a.f[0] = (const float*)fm[m];
@@ -673,16 +687,21 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
                   workspace_bytes, B, HW, prec, stream, __func__);
 }
 
-extern "C" int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
-                              const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
-                              const uint16_t* w2_seg, const float* bias_seg, int n_seg, const uint16_t* w2_dd,
-                              const float* bias_dd, int stuff_lo, int n_stuff, uint16_t* x_planes, uint16_t* dfe_planes,
-                              float* x_f32, float* dfe_f32, float* mask_preds, float* seg_preds, float* depth_pred,
-                              void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format,
-                              void* stream) {
+// ph_khead_fused with (a) a device predicate -- every launch returns at once when *run_if == 0 (null: always run) -- and (b)
+// the logit dtype (PH_OUT_F32 / PH_OUT_F16).  ph_khead_onepass's callers issue it behind every one-pass launch with run_if =
+// that launch's status word: when the persistent launch gave up (its workgroups could not all become resident in time) the
+// two-pass kernels produce the call's results instead, without a host round trip and inside a HIP graph.
+extern "C" int ph_khead_fused_if(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
+                                 const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
+                                 const uint16_t* w2_seg, const float* bias_seg, int n_seg, const uint16_t* w2_dd,
+                                 const float* bias_dd, int stuff_lo, int n_stuff, uint16_t* x_planes, uint16_t* dfe_planes,
+                                 float* x_f32, float* dfe_f32, void* mask_preds, void* seg_preds, void* depth_pred,
+                                 int logits_dtype, const uint32_t* run_if, void* workspace, size_t workspace_bytes, int B,
+                                 int64_t HW, int prec, int input_format, void* stream) {
     PH_CHECK_ARG(f0 && f1 && f2 && wplanes && gn_affine && x_planes && dfe_planes && workspace, "null pointer");
     PH_CHECK_ARG(input_format == PH_IN_F32_NCHW || input_format == PH_IN_PLANES, "bad input_format");
     PH_CHECK_ARG(w2_init && w2_seg && w2_dd && mask_preds && seg_preds && depth_pred, "null pointer");
+    PH_CHECK_ARG(logits_dtype == PH_OUT_F32 || logits_dtype == PH_OUT_F16, "logits: PH_OUT_F32 or PH_OUT_F16");
     PH_CHECK_ARG(n_init > 0 && n_init <= 256 && n_seg > 0 && n_seg <= 256 && n_stuff >= 0 && stuff_lo >= 0 &&
                      stuff_lo + n_stuff <= n_seg, "bad row counts (at most 256 rows per static conv)");
     const void* fm[3] = {f0, f1, f2};
@@ -697,8 +716,22 @@ extern "C" int ph_khead_fused(const void* f0, const void* f1, const void* f2, co
     fu.out2_rows[0] = n_init + n_stuff; fu.out2_rows[1] = n_seg; fu.out2_rows[2] = 1;
     fu.stuff_lo = stuff_lo; fu.n_stuff = n_stuff; fu.n_init = n_init;
     fu.loc_blocks = dfe_planes;
+    fu.out2_f16 = logits_dtype == PH_OUT_F16 ? 1 : 0;
+    fu.run_if = (const unsigned*)run_if;
     return kh_run(fm, input_format == PH_IN_PLANES ? 1 : 0, wplanes, gn_affine, groups, eps, outp, nullptr, x_planes, x_f32, dfe_f32, &fu, workspace,
                   workspace_bytes, B, HW, prec, stream, __func__);
+}
+
+extern "C" int ph_khead_fused(const void* f0, const void* f1, const void* f2, const uint16_t* wplanes,
+                              const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
+                              const uint16_t* w2_seg, const float* bias_seg, int n_seg, const uint16_t* w2_dd,
+                              const float* bias_dd, int stuff_lo, int n_stuff, uint16_t* x_planes, uint16_t* dfe_planes,
+                              float* x_f32, float* dfe_f32, float* mask_preds, float* seg_preds, float* depth_pred,
+                              void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, int input_format,
+                              void* stream) {
+    return ph_khead_fused_if(f0, f1, f2, wplanes, gn_affine, groups, eps, w2_init, n_init, w2_seg, bias_seg, n_seg, w2_dd, bias_dd,
+                             stuff_lo, n_stuff, x_planes, dfe_planes, x_f32, dfe_f32, mask_preds, seg_preds, depth_pred, PH_OUT_F32,
+                             nullptr, workspace, workspace_bytes, B, HW, prec, input_format, stream);
 }
 
 extern "C" int ph_khead_proposals(const float* partial, int nsplit, const float* w_init, const float* w_stuff,

@@ -20,9 +20,13 @@
 // (lane-local in slice order, then an xor butterfly, fp64: deterministic) and publishes the total as two granules;
 // every workgroup's wave 0 polls the 64 totals and derives (mean, rstd) of the 32 groups.  Wave 0 is the only wave with
 // no input prefetch in flight -- vector memory returns in order, so a poll behind 16 HBM loads would wait for them.
-// Spins are bounded: on a time-out the kernel sets `status` and carries on with whatever it read instead of hanging the
-// GPU (two such launches running CONCURRENTLY on one device can starve each other of CUs -- the host serialises them;
-// the bound is the safety net).  All polled words are zeroed by a memset node in front of every launch.
+// Spins are bounded in TIME (s_memrealtime, K1Args::timeout_ticks): a launch whose workgroups cannot all become resident --
+// another kernel holds CUs for longer than the bound, or two such launches starve each other -- sets the per-call `status`
+// word and every workgroup that sees it (in its poll loops, or when it starts) LEAVES the kernel.  The entry point then runs
+// the two-pass kernels of ph_khead.hip predicated on that word (ph_khead_fused_if / ph_binarize_if: launched behind every
+// one-pass launch, they return at once when the word is 0), so the SAME call still produces the reference's tensors, also
+// inside a HIP graph; a sticky word (never cleared by the call) counts the time-outs for diagnostics.  All polled words are
+// zeroed by a memset node in front of every launch.
 #include "ph_common.h"
 
 // Two geometries of the same kernel.  A wave always owns FOUR 32 x 32 accumulator tiles of the conv output (64 registers):
@@ -40,11 +44,11 @@ template <int RT_, int CT_> struct K1Geo {
     static constexpr int LD = CT == 4 ? 160 : 72;
     static constexpr int WGS_PER_CU = CT == 4 ? 1 : 2;
     static constexpr int SSB = CT == 4 ? 4096 : 2048;         // bytes of the ss / bitsl union: [256] float2, [256 rows][CT] words
-    static constexpr size_t LDS_BYTES = (size_t)256 * LD * 2 + (size_t)WAVES * 8192 + SSB + 3 * 512 * 4 + 288 * 4 + 64 * 4 + 64 * 4;
+    static constexpr size_t LDS_BYTES = (size_t)256 * LD * 2 + (size_t)WAVES * 8192 + SSB + 3 * 512 * 4 + 288 * 4 + 64 * 4 + 64 * 4 + 16;
 };
 typedef K1Geo<1, 4> K1Wide;
 typedef K1Geo<2, 2> K1Pair;
-constexpr unsigned K1_SPIN_LIMIT = 1u << 22;
+constexpr unsigned long long K1_TICKS_PER_US = 100;            // s_memrealtime counts at 100 MHz
 
 #define K1_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #ifdef K1_SKIP_OUT        // timing experiments only
@@ -75,7 +79,9 @@ struct K1Args {
     // hand-off state
     unsigned long long* gran1;    // [3B][64 columns][P] {tag, fp32 sum of one slice}          } zeroed before every launch
     unsigned long long* gran2;    // [3B][128] {tag, half of the fp64 total of a column}       }
-    unsigned* status;             // [1] != 0: a bounded spin timed out                        }
+    unsigned* status;             // [1] != 0: a bounded spin timed out, the launch gave up    }
+    unsigned* sticky;             // [2] never cleared by a call: {any time-out so far, number of workgroup time-outs}
+    unsigned long long timeout_ticks;   // bound of one hand-off wait, in s_memrealtime ticks
     int B, P, F;
     int64_t HW, HWp;
     float eps;
@@ -253,6 +259,7 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
     float* b2l = gnl + 3 * 512;                                     // [256 + 32] bias of conv_seg, conv_direct_depth
     float* red = b2l + 288;                                         // [64] this slice's sums
     float* statl = red + 64;                                        // [64] (mean, rstd) x 32 groups
+    volatile int* abortl = (volatile int*)(statl + 64);             // [1] != 0: this launch gave up (set by wave 0, see `expired`)
     const int g = lane >> 5;
     const int ch0 = wave * RT * 32;                                 // this wave's first channel
     uint16_t* rows = T + ch0 * LD;                                  // this wave's channel rows
@@ -347,6 +354,21 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
         K1_STAMP(3);
         if (W0) {
             const double inv_n = 1.0 / (8.0 * (double)a.HW);
+            // the bound of this phase's waits.  `expired` is wave-uniform: every 16th poll it looks at the per-call status word
+            // (another workgroup gave up: follow at once) and at the clock; the first workgroup to pass the bound raises the word
+            const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
+            bool dead = false;
+            auto expired = [&](unsigned& spins) -> bool {
+                if ((++spins & 15u) != 0) return false;
+                if (__hip_atomic_load(gstatus, K1_RLX) != 0) return true;
+                if (__builtin_amdgcn_s_memrealtime() - t_wait0 <= a.timeout_ticks) return false;
+                if (lane == 0) {
+                    __hip_atomic_store(gstatus, 1u, K1_RLX);
+                    __hip_atomic_fetch_or((gu32*)a.sticky, 1u, K1_RLX);
+                    __hip_atomic_fetch_add((gu32*)a.sticky + 1, 1u, K1_RLX);
+                }
+                return true;
+            };
             // publish this slice's 64 sums: one granule {tag, value} per lane, column-major ([column][slice]) so that a
             // column's owner reads one contiguous run
             const unsigned long long tag = (unsigned long long)(unsigned)(item + 1) << 32;
@@ -354,11 +376,11 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
             K1_STAMP(4);
             // owner duty: slice p adds column p (and p + P, ... when the frame has fewer than 64 slices) over all slices in a
             // fixed order -- lane-local in slice order, then an xor butterfly -- and publishes the fp64 total as two granules
-            for (int c = pair; c < 64; c += a.P) {
+            for (int c = pair; c < 64 && !dead; c += a.P) {
                 const gu64* col = g1 + ((int64_t)item * 64 + c) * a.P;
                 double acc = 0.0;
                 unsigned spins = 0;
-                for (int j0 = 0; j0 < a.P; j0 += 256) {
+                for (int j0 = 0; j0 < a.P && !dead; j0 += 256) {
                     unsigned long long x[4];
                     for (;;) {
                         bool ok = true;
@@ -372,10 +394,7 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
                         break;
 #endif
                         if (__all(ok)) break;
-                        if (++spins > K1_SPIN_LIMIT) {
-                            if (lane == 0) __hip_atomic_store(gstatus, 1u, K1_RLX);
-                            break;
-                        }
+                        if (expired(spins)) { dead = true; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
 #pragma unroll
@@ -395,14 +414,11 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
                 const gu64* gp = g2 + (int64_t)item * 128 + 2 * lane;
                 unsigned long long lo = 0, hi = 0;
                 unsigned spins = 0;
-                for (;;) {
+                while (!dead) {
                     lo = __hip_atomic_load(gp, K1_RLX);
                     hi = __hip_atomic_load(gp + 1, K1_RLX);
                     if (__all((unsigned)(lo >> 32) == (unsigned)(item + 1) && (unsigned)(hi >> 32) == (unsigned)(item + 1))) break;
-                    if (++spins > K1_SPIN_LIMIT) {
-                        if (lane == 0) __hip_atomic_store(gstatus, 1u, K1_RLX);
-                        break;
-                    }
+                    if (expired(spins)) { dead = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 // column 2g = sum, 2g + 1 = sum of squares of group g: the even lane computes (mean, rstd)
@@ -417,9 +433,11 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
                 }
             }
             K1_STAMP(6);
+            if (dead && lane == 0) *abortl = 1;
             stg.load(a, nm, nb, px0, k1_fresh(tid));
         }
         __syncthreads();
+        if (*abortl) return;             // the launch gave up (uniform: written before the barrier); the caller's fallback runs
         K1_STAMP(7);
         __builtin_amdgcn_sched_barrier(0);
         // ---- normalise in registers ------------------------------------------------------------------------------------
@@ -685,6 +703,11 @@ __global__ __launch_bounds__(G::THREADS, 2) void k_khead_onepass(const K1Args a)
     for (int i = tid; i < 3 * 512; i += G::THREADS) gnl[i] = a.gn[i];
     for (int i = tid; i < 288; i += G::THREADS)
         b2l[i] = i < 256 ? ((a.bias2[1] && i < a.m2_tiles[1] * 32) ? a.bias2[1][i] : 0.f) : (a.bias2[2] ? a.bias2[2][i - 256] : 0.f);
+    // a workgroup that starts after the launch has given up (status raised by a workgroup whose wait timed out) leaves at once
+    volatile int* abortl = (volatile int*)(b2l + 288 + 64 + 64);
+    if (tid == 0) *abortl = __hip_atomic_load((gu32*)a.status, K1_RLX) != 0 ? 1 : 0;
+    __syncthreads();
+    if (*abortl) return;
     if (wave == 0) k1_run<true, INFMT, E, OutT, F32O, G>(a, lds, tid, lane, wave);
     else k1_run<false, INFMT, E, OutT, F32O, G>(a, lds, tid, lane, wave);
 }
@@ -715,12 +738,18 @@ extern "C" int ph_khead_onepass_supported(int B, int64_t HW, int groups, int pre
     return 1;
 }
 
-// bytes of the hand-off state; the first ph_khead_onepass_zeroed_bytes(B) of it are cleared by the call itself
-// hand-off state: [status (256 B)] [gran2: 3B x 128 x 8 B] [gran1: 3B x 64 x P x 8 B], all of it cleared by every call
-extern "C" size_t ph_khead_onepass_workspace_bytes(int B, int64_t HW) {
+// hand-off state: [status (256 B)] [gran2: 3B x 128 x 8 B] [gran1: 3B x 64 x P x 8 B], cleared by every call, followed by 256
+// bytes the calls never clear (the sticky time-out words; the caller zeroes the workspace once after allocating it)
+static size_t k1_zeroed_bytes(int B, int64_t HW) {
     const int64_t P = ph_hw_padded(HW) / K1Pair::PX;                 // the geometry with more slices
     return 256 + (size_t)3 * B * 128 * 8 + (size_t)3 * B * 64 * P * 8;
 }
+extern "C" size_t ph_khead_onepass_workspace_bytes(int B, int64_t HW) { return k1_zeroed_bytes(B, HW) + 256; }
+
+// bound of one statistics hand-off wait (default 20 ms: an undisturbed hand-off takes ~5 us).  A process-wide knob for tests and
+// for deployments that run long kernels beside the head; a time-out costs the two-pass fallback of that call, never the result.
+static int g_k1_timeout_us = 20000;
+extern "C" void ph_khead_onepass_set_timeout_us(int us) { g_k1_timeout_us = us > 0 ? us : 20000; }
 
 extern "C" int ph_khead_onepass(const void* f0, const void* f1, const void* f2, const uint16_t* conv_frags,
                                 const float* gn_affine, int groups, float eps, const uint16_t* w2_init, int n_init,
@@ -763,12 +792,14 @@ extern "C" int ph_khead_onepass(const void* f0, const void* f1, const void* f2, 
     a.status = (unsigned*)ws;
     a.gran2 = (unsigned long long*)(ws + 256);
     a.gran1 = a.gran2 + (size_t)3 * B * 128;
+    a.sticky = (unsigned*)(ws + k1_zeroed_bytes(B, HW));
+    a.timeout_ticks = (unsigned long long)g_k1_timeout_us * K1_TICKS_PER_US;
     a.B = B; a.HW = HW; a.HWp = HWp; a.eps = eps;
     a.timeline = g_k1_timeline;
     hipStream_t s = (hipStream_t)stream;
     const bool planes = input_format == PH_IN_PLANES, h = prec == PH_PREC_F16, o16 = out_dtype == PH_OUT_F16;
     const bool f32o = x_f32 || dfe_f32;          // the variant that also writes fp32 x_feats / depth_feats (the reference API's tensors)
-    if (hipMemsetAsync(workspace, 0, ph_khead_onepass_workspace_bytes(B, HW), s) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, k1_zeroed_bytes(B, HW), s) != hipSuccess) {
         ph_set_error("ph_khead_onepass: hipMemsetAsync failed");
         return PH_ELAUNCH;
     }
@@ -835,11 +866,20 @@ extern "C" int ph_khead_onepass(const void* f0, const void* f1, const void* f2, 
     return PH_OK;
 }
 
-// 1 if a bounded spin of the last ph_khead_onepass call on this workspace timed out (synchronises the stream)
+// 1 if the last ph_khead_onepass call on this workspace gave up (a hand-off wait timed out; its caller's predicated fallback
+// then produced the results); synchronises the stream
 extern "C" int ph_khead_onepass_status(const void* workspace, int B, void* stream) {
     unsigned v = 0;
     (void)B;
     if (hipMemcpyAsync(&v, workspace, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     return (int)v;
+}
+// number of workgroup time-outs since the workspace was zeroed (sticky: survives the calls' own clearing and graph replays);
+// synchronises the stream.  0 = every call so far ran in one pass.
+extern "C" int ph_khead_onepass_timeouts(const void* workspace, int B, int64_t HW, void* stream) {
+    unsigned v[2] = {0, 0};
+    if (hipMemcpyAsync(v, (const char*)workspace + k1_zeroed_bytes(B, HW), 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    return (int)v[1];
 }

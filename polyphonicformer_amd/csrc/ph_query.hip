@@ -20,6 +20,15 @@
 
 #include "ph_common.h"
 
+// 16-bit stores of activations / q, k, v / dynamic kernels.  fp16 SATURATES at +-65504: the hybrid grade keeps the
+// FFN hidden activations (a ReLU output, not LayerNorm-bounded) and q / k / v in ONE fp16 plane; a trained checkpoint that
+// produces a value beyond fp16's range must clip there, not turn into inf and then NaN in the softmax / LayerNorm behind it
+// (the bf16 hi / lo planes of the other grades cannot overflow).  One v_med3_f32 per element.
+template <int E> __device__ __forceinline__ uint32_t q_f2e(float x) {
+    if constexpr (E == PH_E_F16) return f2h(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
+    else return f2bf(x);
+}
+
 constexpr int LDA = 264;   // LDS row stride (elements) of a [rows][256] bf16 activation buffer
 constexpr float LN_EPS = 1e-5f;
 
@@ -146,7 +155,7 @@ __device__ __forceinline__ void tile_to_lds(const Tile<NRT>& t, uint16_t* dst, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = (rt * 16 + g * 4 + r) * LDA + wave * WCOLS + ct * 16 + i;
-                if (PA == 1) dst[off] = (uint16_t)f2e<E>(t.v[rt][ct][r]);
+                if (PA == 1) dst[off] = (uint16_t)q_f2e<E>(t.v[rt][ct][r]);
                 else {
                     uint32_t hi, lo;
                     f2bf_split(t.v[rt][ct][r], hi, lo);
@@ -258,7 +267,7 @@ __device__ __forceinline__ void store_qkv(const Tile<NRT>& T, const QArgs& a, co
             for (int r = 0; r < 4; ++r) {
                 float v = T.v[rt][ct][r] + bv;
                 if (PART == 0) v *= 0.17677669529663687f;   // q * head_dim^-0.5
-                if (QF16) { hi[r] = f2h(v); lo[r] = 0; }
+                if (QF16) { hi[r] = q_f2e<PH_E_F16>(v); lo[r] = 0; }
                 else if (PA == 2) f2bf_split(v, hi[r], lo[r]);
                 else hi[r] = f2bf(v);
             }
@@ -835,7 +844,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post(const QArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int off = (rt * 16 + g * 4 + r) * 256 + col;
                     if (a.kern_f16) {            // PH_KERN_F16: one fp16 plane (the fp16 dynconv's A operand)
-                        kd[off] = (uint16_t)f2h(Kt.v[rt][ct][r] + bv);
+                        kd[off] = (uint16_t)q_f2e<PH_E_F16>(Kt.v[rt][ct][r] + bv);
                     } else {
                         uint32_t hi, lo;
                         f2bf_split(Kt.v[rt][ct][r] + bv, hi, lo);
@@ -957,7 +966,7 @@ __device__ __forceinline__ void frag_to_lds(const f32x4_t (&t)[NRT][NCT], uint16
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = (rt * 16 + g * 4 + r) * ld + col0 + ct * 16 + i;
-                if (PA == 1) dst[off] = (uint16_t)f2e<E>(t[rt][ct][r]);
+                if (PA == 1) dst[off] = (uint16_t)q_f2e<E>(t[rt][ct][r]);
                 else {
                     uint32_t hi, lo;
                     f2bf_split(t[rt][ct][r], hi, lo);
@@ -1395,7 +1404,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                             f2bf_split(pv, hi, lo);
                             Pt[off] = (uint16_t)hi;
                             Pt[16 * LDPT + off] = (uint16_t)lo;
-                        } else Pt[off] = (uint16_t)f2e<E>(pv);
+                        } else Pt[off] = (uint16_t)q_f2e<E>(pv);
                     }
                 }
                 // the tile is private to this wave and LDS operations of one wave complete in order: no barrier
@@ -1605,7 +1614,7 @@ __global__ __launch_bounds__(NTHREADS) void k_query_post2(const QArgs2 aa) {
                 for (int r = 0; r < 4; ++r) {
                     const int off = (rt * 16 + g * 4 + r) * 256 + col;
                     if (a.kern_f16) {
-                        kd[off] = (uint16_t)f2h(Kt.v[rt][ct][r] + bv);
+                        kd[off] = (uint16_t)q_f2e<PH_E_F16>(Kt.v[rt][ct][r] + bv);
                     } else {
                         uint32_t hi, lo;
                         f2bf_split(Kt.v[rt][ct][r] + bv, hi, lo);

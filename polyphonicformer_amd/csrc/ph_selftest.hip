@@ -75,3 +75,27 @@ extern "C" int ph_selftest_trread(const uint16_t* src, uint16_t* out, void* stre
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
+
+// Occupies `blocks` workgroup slots (each with `lds_bytes` of LDS) for `microseconds`: the "another kernel holds CUs" condition
+// under which ph_khead_onepass's persistent grid cannot become resident in time (tests/test_gpu_khead1.py forces its time-out
+// and the in-call fallback with this).
+__global__ __launch_bounds__(64) void k_selftest_hog(unsigned long long ticks, unsigned* out) {
+    extern __shared__ unsigned hog_lds[];
+    hog_lds[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned n = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(16); ++n; }
+    if (n == 0xFFFFFFFFu) out[0] = hog_lds[(threadIdx.x + 1) & 63];      // practically never: keeps the LDS allocation alive
+}
+extern "C" int ph_selftest_hog(int blocks, int lds_bytes, int microseconds, void* scratch4, void* stream) {
+    PH_CHECK_ARG(blocks > 0 && lds_bytes >= 256 && lds_bytes <= 160 * 1024 && microseconds > 0 && scratch4, "bad argument");
+    static const bool once = [] {
+        (void)hipFuncSetAttribute((const void*)k_selftest_hog, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(k_selftest_hog, dim3(blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull, (unsigned*)scratch4);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}

@@ -295,6 +295,8 @@ class DecodePlan:
         k, q = self.k0, self.q0
         for s in range(self.S):
             last = s == self.S - 1
+            if getattr(self, "debug_bits", None) is not None:      # tests: the hard masks stage s pools with (eager runs only)
+                self.debug_bits.append(self.bits.clone())
             pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial, counts=self.pcount)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
                             outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt, counts=self.pcount,
@@ -438,12 +440,10 @@ class KernelHeadPlan:
         if logit_dtype != torch.float32 and not self.onepass:
             raise _lib.PolyheadError("16-bit KernelHead logits need the one-pass form")
         self.logit_dtype = logit_dtype
-        self._st_host, self._st_ev = None, None
         if self.onepass:
-            self.ws1 = e((lib.ph_khead_onepass_workspace_bytes(B, self.HW),), torch.uint8)
-            # the kernel's status word travels to this pinned word after every eager run (4 bytes, asynchronous) and is looked
-            # at when the next run starts: a hand-off that timed out is reported one call later without a synchronisation
-            self._st_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+            # hand-off state of the persistent launch; zeroed ONCE (its last 256 bytes are the sticky time-out words, which the
+            # calls never clear)
+            self.ws1 = torch.zeros((lib.ph_khead_onepass_workspace_bytes(B, self.HW),), dtype=torch.uint8, device=dev)
         self.mask_preds = e((B, self.N, H, W), logit_dtype)
         self.seg_preds = e((B, pack.n_seg, H, W), logit_dtype)
         self.depth_pred = e((B, 1, H, W), logit_dtype)
@@ -451,7 +451,8 @@ class KernelHeadPlan:
         self.nsplit = nsplit or default_nsplit(B, self.HW)
         self.partial = e((B, self.nsplit, n_padded(self.Nq), 512), torch.float32)
         self.proposal = e((B, self.N, 256), torch.float32)
-        self.ws = None if self.onepass else e((lib.ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
+        # the two-pass kernels' workspace: the path itself, or the in-call fallback of a one-pass launch that gave up
+        self.ws = e((lib.ph_khead_workspace_bytes(B, self.HW, pack.groups),), torch.uint8)
         self.w_stuff = pack.w_seg_f32[num_thing_classes:num_classes].contiguous() if self.n_stuff else None
 
     def renew_outputs(self):
@@ -491,9 +492,6 @@ class KernelHeadPlan:
         B, HW, prec = self.B, self.HW, pk.prec
         fmt = _lib.PH_IN_PLANES if self.in_planes else _lib.PH_IN_F32_NCHW
         if self.onepass:
-            eager = not torch.cuda.is_current_stream_capturing()
-            if eager:
-                self._deferred_status()
             # one read of the three maps: conv1x1+GN+ReLU x3, x = sem + loc, the static 1x1 convs AND the mask bits
             # (kernel_head.py:250-331, :314-317) in one persistent launch; the object pooling reads the thing rows of
             # the full bit tensor in place
@@ -505,10 +503,20 @@ class KernelHeadPlan:
                                             _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), OUT_CODE[self.logit_dtype],
                                             _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.ws1), self.ws1.numel(),
                                             B, HW, prec, fmt, s()), "ph_khead_onepass")
-            if eager:
-                self._st_host.copy_(self.ws1[:4].view(torch.int32), non_blocking=True)
-                self._st_ev = torch.cuda.Event()
-                self._st_ev.record()
+            # the in-call fallback: the two-pass kernels and the binarisation, PREDICATED on the one-pass launch's status word
+            # (first word of ws1).  The persistent grid needs a workgroup resident on every CU; when another kernel holds CUs
+            # beyond the hand-off bound the launch gives up, raises that word, and these launches -- which otherwise return at
+            # once -- rewrite every output of the call.  No host round trip, valid under graph capture and replay.
+            _lib.check(lib.ph_khead_fused_if(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
+                                             _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
+                                             _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
+                                             _lib.ptr(pk.dd_bias), self.n_thing_cls, self.n_stuff, _lib.ptr(self.xp), _lib.ptr(self.dp),
+                                             _lib.ptr(self.x_f32), _lib.ptr(self.dfe_f32), _lib.ptr(self.mask_preds),
+                                             _lib.ptr(self.seg_preds), _lib.ptr(self.depth_pred), OUT_CODE[self.logit_dtype],
+                                             _lib.ptr(self.ws1), _lib.ptr(self.ws), self.ws.numel(), B, HW, prec, fmt, s()),
+                       "ph_khead_fused_if")
+            _lib.check(lib.ph_binarize_if(_lib.ptr(self.mask_preds), OUT_CODE[self.logit_dtype], 0, _lib.ptr(self.bits), B, self.N, HW,
+                                          _lib.ptr(self.ws1), s()), "ph_binarize_if")
             _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
                                         B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
         else:
@@ -532,35 +540,21 @@ class KernelHeadPlan:
                                           _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
 
-    def __getstate__(self):
-        d = dict(self.__dict__)
-        d["_st_ev"] = None                 # a HIP event cannot be copied / pickled (copy.deepcopy of a module that holds a plan)
-        return d
+    def timeouts(self):
+        """one-pass form: number of workgroup time-outs since the plan was built (sticky across calls and graph replays;
+        synchronises the stream).  A time-out costs the affected call its one-pass speed -- the predicated two-pass fallback
+        inside `run` produces its results -- never the results."""
+        if not self.onepass:
+            return 0
+        return int(_lib.load().ph_khead_onepass_timeouts(_lib.ptr(self.ws1), self.B, self.HW, _lib.stream_ptr()))
 
-    def __setstate__(self, d):
-        self.__dict__.update(d)
-        if self._st_host is not None:
-            self._st_host = torch.zeros((1,), dtype=torch.int32).pin_memory()     # the copy's own pinned word
-
-    _TIMEOUT = ("ph_khead_onepass: the statistics hand-off timed out (two persistent launches running concurrently on one "
-                "device?) -- results of that run are undefined")
-
-    def _deferred_status(self, wait=False):
-        """status word of the previous eager run, if its copy has arrived (or `wait`); raises on a time-out"""
-        if self._st_ev is not None and (wait or self._st_ev.query()):
-            if wait:
-                self._st_ev.synchronize()
-            self._st_ev = None
-            if int(self._st_host[0]) != 0:
-                raise _lib.PolyheadError(self._TIMEOUT)
+    def last_run_fell_back(self):
+        """one-pass form: True if the most recent run gave up and was redone by the two-pass kernels (synchronises)"""
+        return bool(self.onepass and _lib.load().ph_khead_onepass_status(_lib.ptr(self.ws1), self.B, _lib.stream_ptr()) != 0)
 
     def check_status(self):
-        """one-pass form: raise if a bounded spin of the last run timed out (synchronises the stream)"""
-        if self.onepass:
-            self._deferred_status(wait=True)
-            rc = _lib.load().ph_khead_onepass_status(_lib.ptr(self.ws1), self.B, _lib.stream_ptr())
-            if rc != 0:
-                raise _lib.PolyheadError(self._TIMEOUT)
+        """kept for callers of round 3's API: returns `timeouts()`; nothing to raise any more, results are valid either way"""
+        return self.timeouts()
 
 
 # ---- SemanticFPNWrapper (N3) -------------------------------------------------------------------------------

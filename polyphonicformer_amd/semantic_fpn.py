@@ -55,6 +55,9 @@ def sine_positional_encoding(H, W, num_feats, temperature=10000, scale=2 * math.
 
 
 class SemanticFPNWrapper(nn.Module):
+    # inference kernels on detached weight packs: no autograd graph (KernelHead.forward_train refuses to "train" through it)
+    differentiable = False
+
     def __init__(self, in_channels, feat_channels, out_channels, start_level, end_level, cat_coors=False,
                  positional_encoding=None, cat_coors_level=3, fuse_by_cat=False, return_list=False, upsample_times=3,
                  with_pred=True, num_aux_convs=0, act_cfg=dict(type="ReLU", inplace=True), out_act_cfg=dict(type="ReLU"),

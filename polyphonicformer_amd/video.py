@@ -138,7 +138,10 @@ class QuasiDenseEmbedTracker(object):
 
     def _affinity(self, emb, lab, memo_emb, memo_lab):
         """[detections x memory columns] match scores (:165-182), returned on the host"""
-        if emb.is_cuda:
+        # the fused kernel keeps a detection row in one workgroup: n <= 128 detections, m <= 4096 memory columns (max_per_img is
+        # 100 and the memory a few hundred columns in the shipped configs).  Beyond that the same formula runs as torch ops ON
+        # THE DEVICE the embeddings live on (below) -- the reference has no limit, a long video must not abort mid-stream
+        if emb.is_cuda and emb.shape[0] <= 128 and memo_emb.shape[0] <= 4096:
             from . import _lib
             lib = _lib.load()
             n, m = emb.shape[0], memo_emb.shape[0]
@@ -161,8 +164,8 @@ class QuasiDenseEmbedTracker(object):
             if self.match_metric == 'bisoftmax':
                 s = (s + dot.softmax(dim=0)) / 2
         if self.with_cats:
-            s = s * (lab[:, None] == memo_lab[None, :]).float()
-        return s
+            s = s * (lab.to(s.device)[:, None] == memo_lab.to(s.device)[None, :]).float()
+        return s.cpu()
 
     def _assign(self, score, det_conf, memo_ids):
         """greedy, in detection (score) order: best still-free column; a tracklet column is consumed by a confident

@@ -73,16 +73,15 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def rel_err_elementwise(a, b, floor_frac=0.1):
-    """max over the elements with |b| >= floor_frac * max|b| of |a - b| / |b|: the element-wise companion of `rel_err` (which
-    normalises every element's error by the LARGEST reference magnitude) -- on the elements that carry the signal the two
-    differ by at most 1 / floor_frac, and this one cannot hide a wrong small-but-significant entry behind one large one"""
+def needed_atol(a, b, rtol):
+    """the smallest `atol`, as a fraction of max|b|, for which |a - b| <= rtol * |b| + atol * max|b| holds on EVERY element
+    (the mixed relative / absolute criterion of numpy.allclose, with the absolute part scaled by the tensor's magnitude).
+    Asserted below the max-normalised tolerance it bounds the error of the small entries more tightly than `rel_err` does
+    and lets a large entry use its own magnitude: it can fail where `rel_err` passes."""
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
-    big = b.abs() >= floor_frac * b.abs().max()
-    if not bool(big.any()):
-        return 0.0
-    return float(((a - b).abs()[big] / b.abs()[big]).max())
+    d = (a - b).abs() - rtol * b.abs()
+    return float(d.max().clamp_min(0.0) / b.abs().max().clamp_min(1e-30))
 
 
 def load_golden(name):

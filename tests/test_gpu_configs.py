@@ -22,6 +22,10 @@ torch.set_grad_enabled(False)
 TOL = {"fp32": 1e-3, "bf16": 3e-2, "mixed": 3e-3, "mixed16": 3e-3, "fp16": 1e-3}
 # identical (16-bit-rounded) feature inputs on both sides: north_star's 1e-3 for the modes that claim it
 TOL_IDENT = {"fp32": 1e-3, "mixed": 1e-3, "mixed16": 1e-3, "fp16": 1e-3, "bf16": 3e-2}
+# second, element-wise criterion of every teacher-forced output: |a - b| <= tol * |b| + ATOL_FRAC * tol * max|b| on EVERY element.
+# An entry far below the tensor's maximum must then be within ATOL_FRAC * tol of the maximum (tighter than `rel_err < tol` allows),
+# a large entry may use its own magnitude -- so this assertion can fail where the max-normalised one passes and vice versa.
+ATOL_FRAC = 0.75
 PLANE_DT = {"bf16": torch.bfloat16, "mixed": torch.bfloat16, "mixed16": torch.bfloat16, "fp16": torch.float16, "fp32": None}
 
 CFG2 = dict(H=128, W=256, Nq=100, n_thing=80, n_stuff=53, S=3, F=2048)
@@ -44,7 +48,7 @@ def _teacher_forced(head, sd, wl, inp, gpu, tol, feats_dtype=None):
     if feats_dtype is not None:
         x, dfe = x.to(feats_dtype), dfe.to(feats_dtype)
     k, q, m = inp["k0"].reshape(B, N, 256), inp["q0"].reshape(B, N, 256), inp["m0"]
-    errs, worst_ew = {}, 0.0
+    errs, worst_at = {}, 0.0
     for s in range(wl["S"]):
         r = ref["stages"][s]
         cls, nm, obj, nd, dobj = head.mask_head[s](x, k.to(gpu).reshape(B, N, 256, 1, 1), m.to(gpu),
@@ -52,15 +56,13 @@ def _teacher_forced(head, sd, wl, inp, gpu, tol, feats_dtype=None):
         got = dict(cls=cls, mask=nm, obj=obj.reshape(B, N, 256), depth=nd, dobj=dobj.reshape(B, N, 256))
         for name, t in got.items():
             errs[(s, name)] = Hh.rel_err(t.float().cpu(), r[name])
-            # element-wise relative error of every entry that is at least a tenth of the largest one: at most 10 x the
-            # max-normalised figure by construction, asserted so that no significant entry hides behind a large one
-            ew = Hh.rel_err_elementwise(t.float().cpu(), r[name], 0.1)
-            worst_ew = max(worst_ew, ew)
-            assert ew < 10 * tol, (s, name, ew)
+            at = Hh.needed_atol(t.float().cpu(), r[name], tol)
+            worst_at = max(worst_at, at)
+            assert at < ATOL_FRAC * tol, (s, name, at)
         k, q, m = r["obj"], r["dobj"], r["mask"]                 # teacher forcing: the oracle's outputs feed the next stage
     worst = max(errs.values())
     print("teacher-forced rel err:", {f"s{s}.{n}": f"{v:.1e}" for (s, n), v in errs.items()},
-          f"| element-wise (entries >= 0.1 max): {worst_ew:.1e}")
+          f"| needed atol / max|b| at rtol = {tol:g}: {worst_at:.1e}")
     assert worst < tol, (worst, errs)
     return errs
 
@@ -111,13 +113,44 @@ def test_cfg2_headline_function_identical_inputs(gpu, precision, out_dtype):
     e = {n: Hh.rel_err(t.float().cpu(), r) for n, t, r in (("obj", obj.reshape(1, N, 256), ref["obj"]), ("cls", cls, ref["cls"]),
                                                             ("mask", mask, ref["mask"]), ("mask_up", mask_up, ref["mask_up"]),
                                                             ("depth_up", plan.depth_up, ref["depth_up"]))}
-    print(f"cfg2 simple_test_mask_preds {precision}/{out_dtype}: flip rate {flips:.2e}, rel err", {k: f"{v:.1e}" for k, v in e.items()})
+    print(f"cfg2 simple_test_mask_preds {precision}/{out_dtype}: flip rate {flips:.2e}, rel err vs the free-running oracle", {k: f"{v:.1e}" for k, v in e.items()})
     assert flips < (1e-3 if precision == "mixed" else 5e-3)
-    assert max(e.values()) < (1e-3 if flips == 0 else 5e-2)
+    # no blanket 5e-2 once a pixel flipped.  The same call again, recording the hard masks every stage of the
+    # DEVICE run pooled with (DecodePlan.debug_bits); the oracle then follows those decisions (hard_masks=) instead of its own
+    # thresholds, so what is compared is the arithmetic of the timed function through all three stages -- at 1e-3 on every
+    # output, whatever flipped -- and the per-stage flip rates are the separately bounded quantity.
+    plan.debug_bits = []
+    obj, cls, mask, mask_up = head.simple_test_mask_preds(g["x"].to(rd), g["k0"].reshape(1, N, 256, 1, 1), g["m0"], None,
+                                                          [Hh.img_meta(1024, 2048)], depth_feats=g["dfe"].to(rd),
+                                                          depth_proposal=g["q0"].reshape(1, N, 256, 1, 1))
+    torch.cuda.synchronize()
+    dev_bits, plan.debug_bits = plan.debug_bits, None
+    assert len(dev_bits) == wl["S"]
+    HW = wl["H"] * wl["W"]
+    import numpy as np
+    hard = []
+    for b in dev_bits:
+        u = np.unpackbits(b.cpu().numpy().view("uint32").view("uint8"), axis=-1, bitorder="little")[:, :N, :HW]
+        hard.append(torch.from_numpy(u.astype("float32")).reshape(1, N, wl["H"], wl["W"]))
+    refs = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"], return_stages=True)
+    stage_flips = [float((hard[0] != O.binarize(inp["m0"])).float().mean())] + \
+                  [float((hard[s + 1] != O.binarize(refs["stages"][s]["mask"])).float().mean()) for s in range(wl["S"] - 1)]
+    assert stage_flips[0] == 0.0                                   # binarising the given logits is exact
+    refc = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"], hard_masks=hard)
+    plan = next(iter(head._plans.values()))
+    ec = {n: Hh.rel_err(t.float().cpu(), r) for n, t, r in (("obj", obj.reshape(1, N, 256), refc["obj"]), ("cls", cls, refc["cls"]),
+                                                             ("mask", mask, refc["mask"]), ("mask_up", mask_up, refc["mask_up"]),
+                                                             ("depth_up", plan.depth_up, refc["depth_up"]))}
+    print(f"   hard masks of the device run: flip rate per stage input {[f'{f:.1e}' for f in stage_flips]}; "
+          f"rel err vs the oracle on the same hard masks", {k: f"{v:.1e}" for k, v in ec.items()})
+    assert max(stage_flips) < (1e-3 if precision == "mixed" else 5e-3)
+    assert max(ec.values()) < 1e-3, ec
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "mixed16"])
 def test_cfg3_video_head_size_two_frames(gpu, precision):
+    """cfg3's head (N = 100 + 11) at full map size, two frames, teacher forced -- also in the grades the video legs run
+    (`fp16`; `mixed16` against fp32 inputs is gated at its input-rounding tolerance, as at cfg2)"""
     head, sd = _head_and_sd(CFG3, precision, gpu, seed=2)
     inp = bench.synth_inputs(CFG3, 2, seed=13)
     _teacher_forced(head, sd, CFG3, inp, gpu, TOL[precision])

@@ -205,6 +205,7 @@ def test_tracker_with_device_embeddings(gpu, metric):
     z = Hh.load_golden("tracker.npz")
     cfg = json.loads(bytes(z["cfg_json"]).decode())
     cfg["match_metric"] = metric
+    threads_before = torch.get_num_threads()
     for seed in (1, 2, 3):
         dev_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
         cpu_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
@@ -225,4 +226,18 @@ def test_tracker_with_device_embeddings(gpu, metric):
                 r = ids + 1
                 r[r == -1] = 0
                 assert np.array_equal(r.numpy(), z[f"s{seed}_f{f}_ids"]), (seed, f)
-        assert dev_tr.table.emb.is_cuda and torch.get_num_threads() == torch.get_num_threads()
+        assert dev_tr.table.emb.is_cuda and torch.get_num_threads() == threads_before      # the library leaves the thread knob alone
+
+
+def test_affinity_beyond_the_fused_kernels_limits(gpu):
+    """more than 128 detections or 4096 memory columns must not abort the video -- the same formula runs as
+    torch ops on the device and agrees with the host formulation"""
+    from polyphonicformer_amd import video as V
+    g = torch.Generator().manual_seed(9)
+    tr = V.QuasiDenseEmbedTracker()
+    for n, m in ((150, 300), (20, 5000)):
+        emb, memo = torch.randn(n, 256, generator=g) * 0.3, torch.randn(m, 256, generator=g) * 0.3
+        lab, mlab = torch.randint(0, 8, (n,), generator=g), torch.randint(0, 8, (m,), generator=g)
+        a = tr._affinity(emb.to(gpu), lab, memo.to(gpu), mlab)
+        b = tr._affinity(emb, lab, memo, mlab)
+        assert not a.is_cuda and a.shape == (n, m) and torch.allclose(a, b, rtol=1e-4, atol=1e-6)

@@ -98,6 +98,34 @@ def test_unsupported_configs_fail_loudly():
         ih.aug_test(None, None, None)
 
 
+def test_forward_train_refuses_to_train_through_the_inference_neck():
+    """with this package's SemanticFPNWrapper as localization_fpn the neck has no autograd graph; forward_train
+    must not pretend to train it (the reference trains neck / FPN / backbone through rpn_head.forward_train)"""
+    from polyphonicformer_amd.registry import HEADS
+    import bench  # noqa: F401
+    neck = dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                norm_cfg=dict(type="GN", num_groups=32, requires_grad=True))
+    tc = dict(assigner=dict(type="MaskHungarianAssignerWithDepth", cls_cost=dict(type="FocalLossCost", weight=2.0),
+                            dice_cost=dict(type="DiceCost", weight=4.0, pred_act=True),
+                            mask_cost=dict(type="MaskCost", weight=1.0, pred_act=True)),
+              sampler=dict(type="MaskPseudoSampler"), pos_weight=1)
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=19, num_thing_classes=8, num_stuff_classes=11,
+                          cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False, use_binary=True,
+                          proposal_feats_with_obj=True, kernel_init_std=1, conv_normal_init=True,
+                          loss_seg=dict(type="FocalLoss", use_sigmoid=True), localization_fpn=neck, train_cfg=tc))
+    fpn = [torch.zeros(1, 256, 8 >> i, 16 >> i) for i in range(4)]
+    with pytest.raises(NotImplementedError, match="no backward"):
+        kh.forward_train(fpn, [], [], [])
+    # frozen neck + the explicit opt-in passes the guard (and then needs the GPU: the neck runs on libpolyhead only)
+    kh.localization_fpn.requires_grad_(False)
+    kh.frozen_neck_ok = True
+    with pytest.raises(Exception) as ei:
+        kh.forward_train(fpn, [], [], [])
+    assert "no backward" not in str(ei.value)
+
+
 def test_feat_transform_cfg_is_not_mutated():
     from polyphonicformer_amd.registry import HEADS
     import bench
