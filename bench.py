@@ -111,6 +111,11 @@ def kernel_breakdown(plan, iters=4):
                 phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt, counts=p.pcount)))
         if not last:
             seq.append(("dynconv_bits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits)))
+        elif getattr(p, "fused_up", False):      # final conv + x2 upsample in one kernel (the plan's own launches)
+            seq.append(("dynconv_up2_mask", lambda o=o: E.dynconv_up2(p.xp, o["kern"], o["kbias"], 0, p.N, p.H, p.W, p.mode.conv, p.mask_up,
+                                                                      logits_out=p.mask, out_dtype=p.out_code)))
+            seq.append(("dynconv_up2_depth", lambda o=o: E.dynconv_up2(p.dp, o["kern"], o["kbias"], 1, p.N, p.H, p.W, p.mode.conv, p.depth_up,
+                                                                       logits_out=p.depth if p.want_depth_lowres else None, out_dtype=p.out_code)))
         else:
             seq.append(("dynconv_logits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv,
                                                                 logits_out=p.mask, out_dtype=p.out_code)))
@@ -136,7 +141,8 @@ def kernel_breakdown(plan, iters=4):
     t = {name: tot[name] / cnt[name] for name in tot}
     t["ingest"] = time_op(lambda: E.ingest(p.x, p.prec, out=p.xp), 4) if getattr(p, "x", None) is not None else 0.0
     counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
-                  dynconv_logits=2, upsample2x=2)
+                  dynconv_logits=2, upsample2x=2, dynconv_up2_mask=1, dynconv_up2_depth=1)
+    counts = {k: v for k, v in counts.items() if k in t}
     return t, counts
 
 
@@ -162,6 +168,10 @@ def algorithmic_bytes(plan, kernel):
         return feat + p.B * p.N * p.HW * eo
     if kernel == "upsample2x":
         return p.B * p.N * p.HW * eo * 5
+    if kernel == "dynconv_up2_mask":        # plane in, low-resolution logits + the x2 upsampled logits out
+        return feat + p.B * p.N * p.HW * eo * 5
+    if kernel == "dynconv_up2_depth":       # plane in, the x2 upsampled logits out
+        return feat + p.B * p.N * p.HW * eo * (5 if p.want_depth_lowres else 4)
     if kernel == "ingest":
         return p.B * 256 * p.HW * 4 + feat
     if kernel == "binarize":
@@ -1066,7 +1076,7 @@ def main():
         kplan = runner.halves[0] if args.streams > 1 else plan
         nplans = args.streams if args.streams > 1 else 1
         times, counts = kernel_breakdown(kplan)
-        per_step = {k: times[k] * counts[k] * nplans for k in times}
+        per_step = {k: times[k] * counts.get(k, 0) * nplans for k in times}
         dom = max((k for k in per_step if algorithmic_bytes(kplan, k)), key=lambda k: per_step[k])
         ab = algorithmic_bytes(kplan, dom)
         achieved = ab / (times[dom] * 1e-3) / 1e9
@@ -1119,7 +1129,9 @@ def main():
             # per-stage weight stream amortised over the frames of a launch)
             "algorithmic": algorithmic_rates(wl, N, kplan.B, fps / world, args.precision),
             "per_stage_ms": {"frames": kplan.B, "non_final": round(times["pool"] + times["query_pre"] + times["query_post"] + times["dynconv_bits"], 4),
-                             "final_incl_upsample": round(times["pool"] + times["query_pre"] + times["query_post"] + 2 * times["dynconv_logits"] + 2 * times["upsample2x"], 4)},
+                             "final_incl_upsample": round(times["pool"] + times["query_pre"] + times["query_post"] +
+                                                          (times["dynconv_up2_mask"] + times["dynconv_up2_depth"] if "dynconv_up2_mask" in times
+                                                           else 2 * times["dynconv_logits"] + 2 * times["upsample2x"]), 4)},
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "kernels_ms_per_step_note": f"sum of the isolated launch durations x launches per step; the step itself runs its {nplans} part(s) on "

@@ -187,6 +187,19 @@ int ph_dynconv(const uint16_t* planes, const uint16_t* kern, int64_t kern_plane_
 /* ---- A14: x2 bilinear upsample, align_corners=False (kernel_update.py:131-143); dtype PH_OUT_* ------------- */
 int ph_upsample2x(const void* src, void* dst, int dtype, int64_t planes /* B*N */, int H, int W, void* stream);
 
+/* ---- A13 of the final stage + A14 fused (round 4): up_out[b][n] = bilinear x2 (align_corners=False) of the 16-bit logits
+ * kern[b][n] . feat[b] + kbias[b][n], from ONE read of the feature plane; logits_out (nullable) additionally receives the
+ * low-resolution logits [B][N][H][W] themselves (kernel_update.py:131-143 returns both for the mask branch; the depth
+ * branch's low-resolution logits are never returned: kernel_update.py:338-345,401).  Same values as ph_dynconv followed by
+ * ph_upsample2x up to fp32 rounding inside the interpolation.  `kern`: ONE 16-bit plane [B][Npad][256] (frame stride given),
+ * prec PH_PREC_BF16 (out_dtype PH_OUT_BF16), PH_PREC_F16 or PH_PREC_BF16_KF16 (out_dtype PH_OUT_F16).
+ * ph_dynconv_up2_supported: W == 256 (tiles of 64 pixels must not straddle image rows; 2048 / 8), H * W % 128 == 0,
+ * 65 <= N <= 224; otherwise callers use the two-kernel form. */
+int ph_dynconv_up2_supported(int N, int H, int W, int prec, int out_dtype);
+int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
+                   int64_t kbias_batch_stride, void* logits_out /* nullable */, void* up_out, int out_dtype, int B, int N, int H,
+                   int W, int prec, void* stream);
+
 /* ---- A1-A5: KernelHead after localization_fpn (kernel_head.py:245-347) ------------------------
  * ph_khead_conv_gn: loc/sem/dfe = ReLU(GN(conv1x1(f0/f1/f2))) and x = sem + loc, from the three fp32
  *   post-neck maps [B][256][HW] to bf16 planes (+ optional fp32 NCHW x_feats / depth_feats).

@@ -267,7 +267,7 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
     const int64_t px0 = (int64_t)pair * G::PX;
     const int64_t wpr = a.HWp / 32;                                 // mask words per row
     const int nfr = slot < a.B ? (a.B - slot + a.F - 1) / a.F : 0;  // frames of this workgroup: slot, slot + F, ...
-    const int nph = 3 * nfr;
+    int nph = 3 * nfr;
     if (nph == 0) return;
     gu64* g1 = (gu64*)a.gran1;
     gu64* g2 = (gu64*)a.gran2;
@@ -437,7 +437,11 @@ __device__ __forceinline__ void k1_run(const K1Args& a, uint16_t* lds, int tid, 
             stg.load(a, nm, nb, px0, k1_fresh(tid));
         }
         __syncthreads();
-        if (*abortl) return;             // the launch gave up (uniform: written before the barrier); the caller's fallback runs
+        // the launch gave up (uniform: written before the barrier): this becomes the workgroup's LAST phase.  Not an early exit --
+        // `return` / `break` here adds an exit edge in the middle of the phase body and costs 36-40 spilled registers (a scratch
+        // reload waits behind the slice prefetch: a1 0.95 -> 1.22 ms per 16 frames, measured); the rest of the body has no wait on
+        // other workgroups, its stores are garbage that the caller's predicated fallback overwrites
+        if (*abortl) nph = 0;
         K1_STAMP(7);
         __builtin_amdgcn_sched_barrier(0);
         // ---- normalise in registers ------------------------------------------------------------------------------------

@@ -177,6 +177,18 @@ def dynconv(planes, kern, kbias, branch, N, HW, prec, bits_out=None, logits_out=
     return bits_out if bits_out is not None else logits_out
 
 
+def dynconv_up2(planes, kern, kbias, branch, N, H, W, prec, up_out, logits_out=None, out_dtype=_lib.PH_OUT_F16):
+    """final-stage dynamic conv + x2 bilinear upsample in one kernel (ph_dynconv_up2): kern [1,2,B,Npad,256] (one 16-bit
+    plane), kbias [2,B,Npad]; writes up_out [B,N,2H,2W] and, when given, the low-resolution logits [B,N,H,W]"""
+    B, Npad = kern.shape[2], kern.shape[3]
+    lib = _lib.load()
+    kptr = C.c_void_p(kern.data_ptr() + branch * B * Npad * 256 * 2)
+    bptr = C.c_void_p(kbias.data_ptr() + branch * B * Npad * 4)
+    _lib.check(lib.ph_dynconv_up2(_lib.ptr(planes), kptr, Npad * 256, bptr, Npad, _lib.ptr(logits_out), _lib.ptr(up_out), out_dtype,
+                                  B, N, H, W, prec, _lib.stream_ptr()), "ph_dynconv_up2")
+    return up_out
+
+
 def static_conv(planes, wplanes, bias, N, HW, prec, logits_out, out_rows):
     """the same 1x1 conv weights for every frame: wplanes [P,Npad,256] bf16 planes, bias fp32 [Npad];
     writes fp32 logits into rows [0, N) of each frame of `logits_out` ([B, out_rows, H, W] view)."""
@@ -245,6 +257,13 @@ class DecodePlan:
         self.depth_up = e((B, N, 2 * H, 2 * W), out_dtype)
         self.graph = None
         self.handoff_runs = 0          # runs that started from another kernel's planes (tests observe the path taken)
+        # Final stage: conv + x2 upsample in ONE kernel where it exists (W = 256, one-plane conv grades, 16-bit outputs): the
+        # low-resolution logits are not written and re-read, the depth branch's are not written at all (no caller of
+        # simple_test / simple_test_mask_preds ever receives them: kernel_update.py:338-345,401).  PH_CONV_UP2=0 restores the
+        # two-kernel form (A/B measurements); `want_depth_lowres` makes the fused depth launch write them too.
+        self.fused_up = (KP == 1 and _os.environ.get("PH_CONV_UP2", "1") != "0"
+                         and bool(_lib.load().ph_dynconv_up2_supported(N, H, W, self.mode.conv, OUT_CODE[out_dtype])))
+        self.want_depth_lowres = False
 
     @property
     def out_code(self):
@@ -308,10 +327,16 @@ class DecodePlan:
                 # each x2 upsample directly behind the conv that wrote its source (240 MB of logits at cfg2, 24 frames): on
                 # its own a part's four launches take 659 us in this order against 823 us as conv, conv, up, up; inside the
                 # four-stream step the other parts' streams evict the logits either way (same-box A/B: no difference)
-                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
-                upsample2x(self.mask, out=self.mask_up)
-                dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, cv, logits_out=self.depth, out_dtype=self.out_code)
-                upsample2x(self.depth, out=self.depth_up)
+                if self.fused_up:
+                    dynconv_up2(xp, o["kern"], o["kbias"], 0, self.N, self.H, self.W, cv, self.mask_up, logits_out=self.mask,
+                                out_dtype=self.out_code)
+                    dynconv_up2(dp, o["kern"], o["kbias"], 1, self.N, self.H, self.W, cv, self.depth_up,
+                                logits_out=self.depth if self.want_depth_lowres else None, out_dtype=self.out_code)
+                else:
+                    dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
+                    upsample2x(self.mask, out=self.mask_up)
+                    dynconv(dp, o["kern"], o["kbias"], 1, self.N, self.HW, cv, logits_out=self.depth, out_dtype=self.out_code)
+                    upsample2x(self.depth, out=self.depth_up)
             k, q = o["obj"], o["dobj"]
 
     def run(self):
@@ -347,7 +372,8 @@ class DecodePlan:
 
     def outputs(self):
         last = self.stage_out[-1]
-        return dict(obj=last["obj"], dobj=last["dobj"], cls=last["cls"], mask=self.mask, depth=self.depth,
+        depth = self.depth if (not self.fused_up or self.want_depth_lowres) else None      # fused final stage: never written
+        return dict(obj=last["obj"], dobj=last["dobj"], cls=last["cls"], mask=self.mask, depth=depth,
                     mask_up=self.mask_up, depth_up=self.depth_up)
 
 
@@ -507,6 +533,8 @@ class KernelHeadPlan:
             # (first word of ws1).  The persistent grid needs a workgroup resident on every CU; when another kernel holds CUs
             # beyond the hand-off bound the launch gives up, raises that word, and these launches -- which otherwise return at
             # once -- rewrite every output of the call.  No host round trip, valid under graph capture and replay.
+            if _os.environ.get("PH_KHEAD_NO_FALLBACK"):       # timing experiments only: what the predicated launches cost
+                return self._finish_run(lib, pk, s, B, HW, prec)
             _lib.check(lib.ph_khead_fused_if(_lib.ptr(self.f[0]), _lib.ptr(self.f[1]), _lib.ptr(self.f[2]), _lib.ptr(pk.wplanes),
                                              _lib.ptr(pk.gn), pk.groups, 1e-5, _lib.ptr(pk.init_frag), self.Nq,
                                              _lib.ptr(pk.seg_frag), _lib.ptr(pk.seg_bias), pk.n_seg, _lib.ptr(pk.dd_frag),
@@ -517,8 +545,6 @@ class KernelHeadPlan:
                        "ph_khead_fused_if")
             _lib.check(lib.ph_binarize_if(_lib.ptr(self.mask_preds), OUT_CODE[self.logit_dtype], 0, _lib.ptr(self.bits), B, self.N, HW,
                                           _lib.ptr(self.ws1), s()), "ph_binarize_if")
-            _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
-                                        B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
         else:
             # conv1x1+GN+ReLU x3, x = sem + loc, and the static 1x1 convs on the normalised tiles (kernel_head.py:250-331):
             # init_kernels(loc) -> thing rows of mask_preds (:256), conv_seg(sem) -> seg_preds (:295) and its stuff rows ->
@@ -533,9 +559,12 @@ class KernelHeadPlan:
             # object features: binarise the logits once (all rows: the decode stages start from these bits), pool x over the
             # THING rows (:314-320)
             _lib.check(lib.ph_binarize(_lib.ptr(self.mask_preds), 0, _lib.ptr(self.bits), B, self.N, HW, s()), "ph_binarize")
-            _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
-                                        B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
-        # add the pooled features to the kernels (:324-326)
+        self._finish_run(lib, pk, s, B, HW, prec)
+
+    def _finish_run(self, lib, pk, s, B, HW, prec):
+        # object features: pool x over the THING rows of the bit tensor (:314-320), add them to the kernels (:324-326)
+        _lib.check(lib.ph_pool_rows(_lib.ptr(self.xp), None, _lib.ptr(self.bits), self.bits.shape[1], _lib.ptr(self.partial),
+                                    B, self.Nq, HW, self.nsplit, prec, s()), "ph_pool_rows")
         _lib.check(lib.ph_khead_proposals(_lib.ptr(self.partial), self.nsplit, _lib.ptr(pk.w_init_f32),
                                           _lib.ptr(self.w_stuff),
                                           _lib.ptr(self.proposal), B, self.Nq, self.n_stuff, s()), "ph_khead_proposals")
@@ -759,4 +788,4 @@ class DualDecodePlan:
 
     def outputs(self):
         o = [h.outputs() for h in self.halves]
-        return {k: torch.cat([oi[k] for oi in o], 0) for k in o[0]}
+        return {k: (None if o[0][k] is None else torch.cat([oi[k] for oi in o], 0)) for k in o[0]}

@@ -304,3 +304,70 @@ def test_dynconv_kf16_register_conversion_form(gpu):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_dynconv_ksplit_and_fp16"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "15 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("prec,dt", [(_lib.PH_PREC_BF16_KF16, torch.float16), (_lib.PH_PREC_F16, torch.float16), (_lib.PH_PREC_BF16, torch.bfloat16)])
+@pytest.mark.parametrize("N,H,B,wgs", [(153, 6, 3, 0), (111, 16, 2, 5), (200, 3, 4, 3), (153, 128, 2, 0)])
+def test_dynconv_up2_fused_final_stage(gpu, monkeypatch, prec, dt, N, H, B, wgs):
+    """ph_dynconv_up2 = ph_dynconv (16-bit logits) + ph_upsample2x in one kernel (kernel_update_head.py:317-329 +
+    kernel_update.py:131-143).  W = 256; workgroup ranges of one row (rows < CUs), of many rows spanning frames (PH_UP2_WGS),
+    and cfg2's full map.  Low-resolution logits: bit-identical to the two-kernel form (same MFMA sequence).  Upsampled
+    logits: within one 16-bit ulp of F.interpolate on those low-resolution values (fp32 blend, one final rounding), and almost
+    everywhere bit-identical to ph_upsample2x (the blend is vertical-then-horizontal here, horizontal-then-vertical there)."""
+    if wgs:
+        monkeypatch.setenv("PH_UP2_WGS", str(wgs))
+    W = 256
+    lib = _lib.load()
+    oc = E.OUT_CODE[dt]
+    assert lib.ph_dynconv_up2_supported(N, H, W, prec, oc) == 1
+    g = torch.Generator().manual_seed(43 + N + H)
+    HW, Npad = H * W, E.n_padded(N)
+    x = torch.randn(B, 256, H, W, generator=g)
+    kern_f = torch.randn(2, B, Npad, 256, generator=g) * 0.1
+    kbias = (torch.randn(2, B, Npad, generator=g) * 0.1).to(gpu)
+    kdt = torch.bfloat16 if prec == _lib.PH_PREC_BF16 else torch.float16
+    kern = _planes16(kern_f, kdt)[None].contiguous().to(gpu)
+    xp = E.ingest(x.to(gpu), _lib.PH_PREC_F16 if prec == _lib.PH_PREC_F16 else _lib.PH_PREC_BF16)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    for br in (0, 1):
+        low2 = torch.empty(B, N, H, W, device=gpu, dtype=dt)
+        E.dynconv(xp, kern, kbias, br, N, HW, prec, logits_out=low2, out_dtype=oc)
+        up2 = E.upsample2x(low2)
+        low = torch.full((B, N, H, W), float("nan"), device=gpu, dtype=dt)
+        up = torch.full((B, N, 2 * H, 2 * W), float("nan"), device=gpu, dtype=dt)
+        E.dynconv_up2(xp, kern, kbias, br, N, H, W, prec, up, logits_out=low, out_dtype=oc)
+        assert torch.equal(low, low2), br
+        ref = F.interpolate(low2.float().cpu(), scale_factor=2, mode="bilinear", align_corners=False)
+        d = (up.float().cpu() - ref).abs()
+        assert not torch.isnan(up.float()).any()
+        assert bool((d <= ulp * ref.abs() + 1e-7).all()), float((d / ref.abs().clamp_min(1e-6)).max())
+        assert float((up != up2).float().mean()) < 2e-3
+        # without the low-resolution output (the depth branch's form): the same upsampled tensor
+        upn = torch.full_like(up, float("nan"))
+        E.dynconv_up2(xp, kern, kbias, br, N, H, W, prec, upn, logits_out=None, out_dtype=oc)
+        assert torch.equal(upn, up)
+
+
+def test_dynconv_up2_inside_the_decode_plan(gpu, monkeypatch):
+    """the S-stage plan with and without the fused final stage (PH_CONV_UP2=0): every output the API returns agrees -- the
+    low-resolution mask logits and the query outputs bit for bit, the upsampled logits except for rounding-boundary cases"""
+    import bench
+    wl = dict(H=8, W=256, Nq=100, n_thing=8, n_stuff=11, S=2, F=2048)
+    N = wl["Nq"] + wl["n_stuff"]
+    inp = bench.synth_inputs(wl, 3, seed=8)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PH_CONV_UP2", fused)
+        head = bench.build_head(wl, "mixed16", torch.float16, gpu, seed=4)
+        plan = head._plan(3, N, wl["H"], wl["W"], gpu)
+        assert plan.fused_up == (fused == "1")
+        plan.set_inputs(*[inp[k].to(gpu) for k in ("x", "dfe", "k0", "q0", "m0")])
+        plan.run()
+        torch.cuda.synchronize()
+        outs[fused] = {k: (None if v is None else v.clone()) for k, v in plan.outputs().items()}
+    assert outs["1"]["depth"] is None and outs["0"]["depth"] is not None
+    for k in ("obj", "dobj", "cls", "mask"):
+        assert torch.equal(outs["1"][k], outs["0"][k]), k
+    for k in ("mask_up", "depth_up"):
+        assert float((outs["1"][k] != outs["0"][k]).float().mean()) < 2e-3, k
+        assert Hh.rel_err(outs["1"][k].float().cpu(), outs["0"][k].float().cpu()) < 2e-3, k

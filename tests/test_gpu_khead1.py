@@ -198,9 +198,9 @@ def test_onepass_full_size_cfg2(gpu):
 @pytest.mark.parametrize("H,W,B,logit_dtype", [(48, 156, 5, torch.float32), (128, 256, 2, torch.float16)])
 def test_onepass_timeout_falls_back_inside_the_same_call(gpu, H, W, B, logit_dtype):
     """VERDICT r03 next #1b / ADVICE r03: the persistent launch assumes a workgroup resident on every CU it uses.  A kernel on
-    another stream that holds CUs (here: ph_selftest_hog, 8 KB of LDS per block -- the one-pass workgroup needs 159 of a CU's
-    160 KB) keeps part of the grid out; with the hand-off bound set to 0.5 ms the launch gives up, and the predicated two-pass
-    kernels issued behind it must leave the SAME call with oracle-correct tensors -- eagerly and from a replayed HIP graph."""
+    another stream that holds CUs (here: ph_selftest_hog with 100 KB of LDS per block -- the one-pass workgroup needs 159 of a
+    CU's 160 KB) keeps part of the grid out; with the hand-off bound set to 0.5 ms the launch gives up, and the predicated
+    two-pass kernels issued behind it must leave the SAME call with oracle-correct tensors -- eagerly and from a replayed HIP graph."""
     lib = _lib.load()
     n_thing, n_stuff = (80, 53) if H == 128 else (8, 11)
     h, sd = _head("fp16", n_thing=n_thing, n_stuff=n_stuff)
@@ -228,8 +228,14 @@ def test_onepass_timeout_falls_back_inside_the_same_call(gpu, H, W, B, logit_dty
         plan.bits.fill_(-1); plan.xp.fill_(0x7E00); plan.dp.fill_(0x7E00)
 
     def hog(ms):
+        # 200 blocks of 100 KB LDS: at most one per CU, so 200 of the 256 CUs cannot take a one-pass workgroup (159 KB) and 56
+        # can -- fewer than one frame's slices (59 / 256).  PARTIAL residency is the failing case: the resident workgroups spin
+        # on partners that cannot start before the hog ends.  (A hog on every CU merely delays the whole launch, and a
+        # launch whose resident part can finish its frames frees its CUs for the rest -- neither times out, both are fine.)
+        import time
         with torch.cuda.stream(side):
-            _lib.check(lib.ph_selftest_hog(2048, 8192, ms * 1000, _lib.ptr(scratch), _lib.stream_ptr()), "ph_selftest_hog")
+            _lib.check(lib.ph_selftest_hog(200, 100 * 1024, ms * 1000, _lib.ptr(scratch), _lib.stream_ptr()), "ph_selftest_hog")
+        time.sleep(0.003)          # let the hog's workgroups take their CUs before the one-pass launch is queued
 
     try:
         # undisturbed: one pass, no time-out
