@@ -31,9 +31,14 @@
 
 #include "ph_conv_inl.h"
 
-template <int OFF> __device__ __forceinline__ float lds_read32_asm(uint32_t byte_addr) {
-    float v;
+template <int OFF> __device__ __forceinline__ uint32_t lds_read32u_asm(uint32_t byte_addr) {
+    uint32_t v;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2_t lds_read64_asm(uint32_t byte_addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
 }
 template <int OFF> __device__ __forceinline__ u32x4_t lds_read128o_asm(uint32_t byte_addr) {
@@ -41,20 +46,47 @@ template <int OFF> __device__ __forceinline__ u32x4_t lds_read128o_asm(uint32_t 
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
 }
-template <int OFF> __device__ __forceinline__ void lds_write128o_asm(uint32_t byte_addr, u32x4_t v) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF) : "memory");
+// the low / the high 16 bits of a register to LDS
+template <int OFF> __device__ __forceinline__ void lds_write16lo_asm(uint32_t byte_addr, uint32_t v) {
+    asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_write16hi_asm(uint32_t byte_addr, uint32_t v) {
+    asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void lds_wait_all() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The upsampled rows and the low-resolution rows leave as whole, aligned 128-byte lines (8 lanes x 16 bytes per query row), so
+// they can bypass the caches like the stand-alone upsample kernel's output (-DUP2_CACHED_STORES: default policy, for A/B runs).
+// The first version of this kernel emitted windows shifted by 16 bytes (no data of the NEXT half needed, but every line
+// completed by two stores): 609 us per 24 frames with cached stores, 1 ms with non-temporal ones, 268 us with the stores
+// compiled out -- the memory system, not the arithmetic, and the reason for the one-half-late emission below.
+__device__ __forceinline__ void up_store(void* p, uint4 v) {
+#ifdef UP2_CACHED_STORES
+    *(uint4*)p = v;
+#else
+    st_nt16(p, v);
+#endif
+}
+
+// timing experiments only (-DUP2_TIMING + PH_UP2_DBG=bits at run time): 1 = no stores, 2 = no window passes, 4 = every row silent
+#ifdef UP2_TIMING
+#define UP2_DBG(bit) (dbg & (bit))
+#else
+#define UP2_DBG(bit) false
+#endif
+
 template <int NRT> struct UpCfg {
     static constexpr int NW = NRT + 1;                           // consumer waves + the producer wave
     static constexpr int TILEB = 256 * CONV_T * 2;               // bytes per ring stage (one 16-bit plane)
-    static constexpr int PLD = 40;                               // patch row: 8 history + 32 current source columns (floats)
-    static constexpr int PATCH1 = 32 * PLD * 4;
-    static constexpr int PATCHB = NRT * 2 * PATCH1;              // two patches per consumer wave (odd / even output row)
+    // per consumer wave: two 16-bit patches (P = previous image row, C = current one) of [32 q][3 slots x 32 source columns]:
+    // half hh of an image row lives in slot hh % 3, so that when half hh has been written the window of half hh - 1 -- which
+    // needs the last column of hh - 2 and the first of hh -- can be emitted
+    static constexpr int ROWB = 3 * 64 + 16;                     // bytes per patch row (16 bytes of padding)
+    static constexpr int PATCH1 = 32 * ROWB;
+    static constexpr int PATCHB = NRT * 2 * PATCH1;
     static constexpr int KBB = NRT * 32 * 4;
     static constexpr int NBUF = 3 * TILEB + PATCHB + KBB <= 160 * 1024 ? 3 : 2;
     static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
@@ -64,17 +96,29 @@ template <typename OutT> struct UpElem;
 template <> struct UpElem<ph_h16> { static constexpr int E = PH_E_F16; };
 template <> struct UpElem<uint16_t> { static constexpr int E = PH_E_BF16; };
 
+// patch writes of a lane's 16 D-layout values (packed pairs: register j = rows rr(2j) | rr(2j+1) << 16), immediate row offsets
+template <int ROWB, int BASE, int J = 0>
+__device__ __forceinline__ void up_patch_put(uint32_t wa, const uint32_t (&v)[8]) {
+    if constexpr (J < 8) {
+        constexpr int r0 = 2 * J, r1 = 2 * J + 1;
+        constexpr int rr0 = (r0 & 3) + 8 * (r0 >> 2), rr1 = (r1 & 3) + 8 * (r1 >> 2);
+        lds_write16lo_asm<BASE + rr0 * ROWB>(wa, v[J]);
+        lds_write16hi_asm<BASE + rr1 * ROWB>(wa, v[J]);
+        up_patch_put<ROWB, BASE, J + 1>(wa, v);
+    }
+}
+
 // E: MFMA element format (PH_E_BF16 / PH_E_F16 / PH_E_F16_FROM_BF16 = bf16 plane converted to fp16 once per tile in LDS);
 // OutT: ph_h16 (fp16) or uint16_t (bf16) outputs; LOWRES: also write the low-resolution logits [B][N][H][W]
 template <int E, int NRT, int NTR, bool LOWRES, typename OutT>
 __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t* __restrict__ planes, const uint16_t* __restrict__ kern,
                                                                  int64_t kern_batch_stride, const float* __restrict__ kbias,
                                                                  int64_t kbias_batch_stride, OutT* __restrict__ logits_out,
-                                                                 OutT* __restrict__ up_out, int B, int N, int H) {
+                                                                 OutT* __restrict__ up_out, int B, int N, int H, int dbg) {
     using C = UpCfg<NRT>;
-    constexpr int NBUF = C::NBUF, W = NTR * 64, PLD = C::PLD, EO = UpElem<OutT>::E;
+    constexpr int NBUF = C::NBUF, W = NTR * 64, ROWB = C::ROWB, EO = UpElem<OutT>::E, NH = 2 * NTR;
     constexpr bool COOP = E == PH_E_F16_FROM_BF16;
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][256][64] | patches [NRT][2][32][PLD] f32 | biases [NRT][32]
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];   // [NBUF][256][64] | patches [NRT][P, C][32][ROWB] | biases [NRT][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave == NRT;
@@ -118,24 +162,20 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
 #pragma unroll
     for (int h = 0; h < 2; ++h) frag_off[h] = 2u * (uint32_t)(row0 * CONV_T + (((h * 4 + gi * 2) ^ conv_swz(row0)) * 8) + (i16 & 3) * 4);
     const uint32_t lds0 = lds_addr(lds);
-    const uint32_t patchA = lds0 + NBUF * C::TILEB + rt * 2 * C::PATCH1, patchB = patchA + C::PATCH1;
+    const uint32_t patchP = lds0 + NBUF * C::TILEB + rt * 2 * C::PATCH1;            // the C patch follows at + PATCH1
     float* kb_lds = (float*)((unsigned char*)lds + NBUF * C::TILEB + C::PATCHB) + rt * 32;
     const uint32_t kb_addr = lds_addr(kb_lds) + 16 * g;
-    // patch addresses of this lane (bytes).  D layout: lane = source column `col`, rows rr + 4 g
-    const uint32_t pw_off = (uint32_t)(((4 * g) * PLD + 8 + col) * 4);                 // + rr * PLD * 4 immediates
-    const int hq = lane >> 1, hpart = lane & 1;                                        // history copy: row, 4-column part
-    const uint32_t hist_off = (uint32_t)((hq * PLD + 4 * hpart) * 4);                   // reads + 32 columns
-    const int sq = lane >> 3, ss = lane & 7;                                           // horizontal pass: row (+ 8 kk), 8-pixel segment
-    const uint32_t pr_off = (uint32_t)((sq * PLD + 4 * ss) * 4);                        // + kk * 8 * PLD * 4, element offsets 3 / 4 / 8
-    const int lq = lane >> 2, lseg = lane & 3;                                         // low-resolution pass: row (+ 16 j), 8-pixel segment
-    const uint32_t lr_off = (uint32_t)((lq * PLD + 8 + 8 * lseg) * 4);
+    // D layout (lane = source column `col`, rows rr + 4 g) -> patch write address; + rr * ROWB + slot * 64 as immediates
+    const uint32_t pw_addr = patchP + (uint32_t)((4 * g) * ROWB + 2 * col);
+    // window pass: lane = query row sq (+ 8 kk), 4 source columns 4 ss .. 4 ss + 3 of a half (8 output pixels)
+    const int sq = lane >> 3, ss = lane & 7;
+    const uint32_t pr_addr = patchP + (uint32_t)(sq * ROWB + 8 * ss);               // + slot * 64 + kk * 8 * ROWB (+ PATCH1 for C)
     // per-lane parts of the output addresses (bytes)
-    const int64_t up_plane = (int64_t)2 * H * 2 * W;                                   // elements per (frame, query) of the upsampled tensor
+    const int64_t up_plane = (int64_t)2 * H * 2 * W;                                 // elements per (frame, query) of the upsampled tensor
     const uint32_t up_lane_off = 2u * (uint32_t)(sq * up_plane + 8 * ss);
     const int64_t up_kk_bytes = 2 * 8 * up_plane;
-    const uint32_t upf_lane_off = 2u * (uint32_t)((lane & 31) * up_plane);               // row-end flush: one row per lane (lanes 0..31)
-    const uint32_t lr_lane_off = 2u * (uint32_t)(lq * HW + 8 * lseg);
-    const int64_t lr_j_bytes = 2 * 16 * HW;
+    const uint32_t lr_lane_off = 2u * (uint32_t)(sq * HW + 8 * ss);
+    const int64_t lr_kk_bytes = 2 * 8 * HW;
 
     uint4 af[1][16];
     uint32_t prev[NTR][2][8];                        // the previous image row at this wave's accumulator positions, packed 16-bit pairs
@@ -146,67 +186,22 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
 #pragma unroll
             for (int j = 0; j < 8; ++j) prev[a][h][j] = 0;
 
-    // one horizontal pass: the [32 q][40] fp32 patch (history in columns 0..7) -> 16-bit output row `R` of the upsampled tensor.
-    // HH = half index in the image row (compile time).
-    auto hpass = [&](uint32_t patch, char* ubase /* wave-uniform: (b, rt * 32, row R, column 64 HH - 8) */, auto hh_tag) {
-        constexpr int HH = decltype(hh_tag)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const uint32_t a = patch + pr_off + kk * 8 * PLD * 4;
-            const float f3 = lds_read32_asm<12>(a);
-            const u32x4_t m = lds_read128o_asm<16>(a);
-            const float f8 = lds_read32_asm<32>(a);
-            lds_wait_all();
-            const float f4 = __uint_as_float(m.x), f5 = __uint_as_float(m.y), f6 = __uint_as_float(m.z), f7 = __uint_as_float(m.w);
-            float o0 = 0.25f * f3 + 0.75f * f4;
-            if (HH == 0 && ss == 1) o0 = f4;                         // output column 0: source index clamped at 0, weights (1, 0)
-            const float o1 = 0.75f * f4 + 0.25f * f5, o2 = 0.25f * f4 + 0.75f * f5, o3 = 0.75f * f5 + 0.25f * f6;
-            const float o4 = 0.25f * f5 + 0.75f * f6, o5 = 0.75f * f6 + 0.25f * f7, o6 = 0.25f * f6 + 0.75f * f7;
-            const float o7 = 0.75f * f7 + 0.25f * f8;
-            const uint4 pk = make_uint4(f2e_pk<EO>(o0, o1), f2e_pk<EO>(o2, o3), f2e_pk<EO>(o4, o5), f2e_pk<EO>(o6, o7));
-            const bool ok = rt * 32 + sq + 8 * kk < N && !(HH == 0 && ss == 0);
-            if (ok) st_nt16(ubase + kk * up_kk_bytes + up_lane_off, pk);
-        }
-        if (HH == 2 * NTR - 1) {
-            // the last 8 output columns of the image row: source columns W-5 .. W-1 = patch columns 35 .. 39, the column
-            // past the end clamped (ATen: i1 = min(i0 + 1, W - 1))
-            const uint32_t a = patch + (uint32_t)(((lane & 31) * PLD) * 4);
-            const float f3 = lds_read32_asm<35 * 4>(a);
-            const u32x4_t m = lds_read128o_asm<36 * 4>(a);
-            lds_wait_all();
-            const float f4 = __uint_as_float(m.x), f5 = __uint_as_float(m.y), f6 = __uint_as_float(m.z), f7 = __uint_as_float(m.w);
-            const float f8 = f7;
-            const float o0 = 0.25f * f3 + 0.75f * f4, o1 = 0.75f * f4 + 0.25f * f5, o2 = 0.25f * f4 + 0.75f * f5, o3 = 0.75f * f5 + 0.25f * f6;
-            const float o4 = 0.25f * f5 + 0.75f * f6, o5 = 0.75f * f6 + 0.25f * f7, o6 = 0.25f * f6 + 0.75f * f7, o7 = 0.75f * f7 + 0.25f * f8;
-            const uint4 pk = make_uint4(f2e_pk<EO>(o0, o1), f2e_pk<EO>(o2, o3), f2e_pk<EO>(o4, o5), f2e_pk<EO>(o6, o7));
-            if (lane < 32 && rt * 32 + lane < N) st_nt16(ubase + 2 * 64 + upf_lane_off, pk);     // window base + 64 = column 2 W - 8
-        }
-    };
-    // history: the previous half's last 8 source columns (patch columns 32..39) -> columns 0..7; must run before ANYTHING
-    // overwrites columns 32..39 of that patch for the new half
-    auto hist_move = [&](uint32_t patch) {
-        const u32x4_t t = lds_read128o_asm<32 * 4>(patch + hist_off);
-        lds_wait_all();
-        lds_write128o_asm<0>(patch + hist_off, t);
-    };
-    // the new [32 q][32 px] values into columns 8..39 of a patch
-    auto patch_fill = [&](uint32_t patch, const f32x16_t& v, auto hh_tag) {
-        constexpr int HH = decltype(hh_tag)::value;
-        conv_patch_put<float, PLD>(patch + pw_off, v);
-        if (HH == 0) {
-            // left image border: source column -1 := column 0 (patch column 7 := 8)
-            lds_wait_all();
-            const float t = lds_read32_asm<8 * 4>(patch + (uint32_t)((lane & 31) * PLD * 4));
-            lds_wait_all();
-            if (lane < 32) lds_write_asm<7 * 4>(patch + (uint32_t)((lane & 31) * PLD * 4), t, (float*)nullptr);
-        }
-        lds_wait_all();
+    // blend of one image-row pair over 6 source columns (index 0 = left neighbour, 1..4 = the lane's columns, 5 = right
+    // neighbour) -> 8 output pixels of one output row: ATen's x2 weights, even output column 2j = .25 in[j-1] + .75 in[j], odd
+    // 2j + 1 = .75 in[j] + .25 in[j+1]
+    auto hblend = [&](const float (&f)[6], bool exact0) -> uint4 {
+        float o0 = 0.25f * f[0] + 0.75f * f[1];
+        if (exact0) o0 = f[1];                                   // output column 0: source index clamped at 0, weights (1, 0)
+        const float o1 = 0.75f * f[1] + 0.25f * f[2], o2 = 0.25f * f[1] + 0.75f * f[2], o3 = 0.75f * f[2] + 0.25f * f[3];
+        const float o4 = 0.25f * f[2] + 0.75f * f[3], o5 = 0.75f * f[3] + 0.25f * f[4], o6 = 0.25f * f[3] + 0.75f * f[4];
+        const float o7 = 0.75f * f[4] + 0.25f * f[5];
+        return make_uint4(f2e_pk<EO>(o0, o1), f2e_pk<EO>(o2, o3), f2e_pk<EO>(o4, o5), f2e_pk<EO>(o6, o7));
     };
 
     int cur = 0, cur_b = -1;
     for (int gr = R0 - halo; gr < R1; ++gr) {
         const int b = gr / H, r = gr - b * H;
-        const bool silent = gr < R0, first = r == 0, last = r == H - 1;
+        const bool silent = gr < R0 || UP2_DBG(4), first = r == 0, last = r == H - 1;
         if (!producer && b != cur_b) {
             // the A operand and biases of the frame (ordinary loads; the wait also drains this wave's stores, once per frame)
             const uint16_t* kr = kern + (int64_t)b * kern_batch_stride + (rt * 32 + (lane & 31)) * PH_C + g * 8;
@@ -219,6 +214,74 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
         // wave-uniform output bases of this image row
         char* up_row = (char*)(up_out + ((int64_t)b * N + rt * 32) * up_plane + (int64_t)(2 * r) * (2 * W));    // output row 2r
         char* lr_row = LOWRES ? (char*)(logits_out + ((int64_t)b * N + rt * 32) * HW + (int64_t)r * W) : nullptr;
+
+        // the window of half EH of this image row: output columns 64 EH .. 64 EH + 63 of output rows 2r - 1 (unless r = 0), 2r and,
+        // on the last image row, 2H - 1; needs halves EH - 1 (last column) and EH + 1 (first column) in their slots
+        auto window = [&](auto eh_tag) {
+            constexpr int EH = decltype(eh_tag)::value;
+            constexpr int SB = (EH % 3) * 64;                                            // byte offset of the half's slot in a patch row
+            // neighbours: lane ss = 0 takes the last column of half EH - 1 (image border: its own first column, the value is unused),
+            // lane ss = 7 the first column of half EH + 1 (image border: its own last column = the clamped source index)
+            constexpr int LEFT_IN = SB - 4, LEFT_EDGE = EH > 0 ? ((EH - 1) % 3) * 64 + 60 : SB;          // the dword holding the neighbour
+            constexpr int RIGHT_IN = SB + 8, RIGHT_EDGE = EH < NH - 1 ? ((EH + 1) % 3) * 64 - 56 : SB + 4;  // (relative to the lane's 8 ss)
+            const uint32_t la = pr_addr + (uint32_t)(ss == 0 ? LEFT_EDGE : LEFT_IN);
+            const uint32_t ra = pr_addr + (uint32_t)(ss == 7 ? RIGHT_EDGE : RIGHT_IN);
+            const bool left_hi = !(EH == 0 && ss == 0);                                  // which half of the dword is the neighbour
+            const bool right_hi = EH == NH - 1 && ss == 7;
+            char* ub = up_row + 2 * 64 * EH;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                uint32_t pl[2], pr[2], cl[2], cr[2];
+                u32x2_t pb[2], cb[2];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const uint32_t ko = (uint32_t)((kp * 2 + k2) * 8 * ROWB);
+                    pl[k2] = lds_read32u_asm<0>(la + ko);
+                    pb[k2] = lds_read64_asm<SB>(pr_addr + ko);
+                    pr[k2] = lds_read32u_asm<0>(ra + ko);
+                    cl[k2] = lds_read32u_asm<C::PATCH1>(la + ko);
+                    cb[k2] = lds_read64_asm<SB + C::PATCH1>(pr_addr + ko);
+                    cr[k2] = lds_read32u_asm<C::PATCH1>(ra + ko);
+                }
+                lds_wait_all();
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kk = kp * 2 + k2;
+                    float pf[6], cf[6];
+                    pf[0] = e2f<EO>(left_hi ? pl[k2] >> 16 : pl[k2] & 0xFFFFu);
+                    pf[1] = e2f<EO>(pb[k2].x & 0xFFFFu); pf[2] = e2f<EO>(pb[k2].x >> 16);
+                    pf[3] = e2f<EO>(pb[k2].y & 0xFFFFu); pf[4] = e2f<EO>(pb[k2].y >> 16);
+                    pf[5] = e2f<EO>(right_hi ? pr[k2] >> 16 : pr[k2] & 0xFFFFu);
+                    cf[0] = e2f<EO>(left_hi ? cl[k2] >> 16 : cl[k2] & 0xFFFFu);
+                    cf[1] = e2f<EO>(cb[k2].x & 0xFFFFu); cf[2] = e2f<EO>(cb[k2].x >> 16);
+                    cf[3] = e2f<EO>(cb[k2].y & 0xFFFFu); cf[4] = e2f<EO>(cb[k2].y >> 16);
+                    cf[5] = e2f<EO>(right_hi ? cr[k2] >> 16 : cr[k2] & 0xFFFFu);
+                    const bool ok = rt * 32 + sq + 8 * kk < N && !UP2_DBG(1);
+                    const bool exact0 = EH == 0 && ss == 0;
+                    char* dst = ub + kk * up_kk_bytes + up_lane_off;
+                    float v[6];
+                    if (!first) {
+                        // output row 2r - 1: source rows (r - 1, r), weights (.75, .25)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) v[i] = 0.75f * pf[i] + 0.25f * cf[i];
+                        const uint4 pk = hblend(v, exact0);
+                        if (ok) up_store(dst - 2 * (2 * W), pk);
+                    }
+                    // output row 2r: source rows (r - 1, r), weights (.25, .75); r = 0: clamped, weights (0, 1)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) v[i] = first ? cf[i] : 0.25f * pf[i] + 0.75f * cf[i];
+                    const uint4 pk = hblend(v, exact0);
+                    if (ok) up_store(dst, pk);
+                    if (last) {
+                        // output row 2H - 1: source index clamped at H - 1 on both sides -> .75 C + .25 C
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) v[i] = 0.75f * cf[i] + 0.25f * cf[i];
+                        const uint4 pl2 = hblend(v, exact0);
+                        if (ok) up_store(dst + 2 * (2 * W), pl2);
+                    }
+                }
+            }
+        };
 
         auto tile = [&](auto tc_tag) {
             constexpr int TC = decltype(tc_tag)::value;
@@ -262,69 +325,47 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
                 conv_bias_get(kb_addr, bias);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    constexpr int HH0 = 2 * TC;
                     const uint32_t fa = lds0 + cur * C::TILEB + frag_off[h];
                     f32x16_t acc;
                     constexpr int KB = 2;
                     u32x2_t bq[2][1][KB][2];
                     conv_read_batch<1, KB, 0>(fa, bq[0]);
                     conv_batches<1, 1, E, KB, 0, true>(fa, af, bq, acc, bias);
-                    // the low-resolution logits as the 16-bit values the API returns; everything below blends THOSE
+                    // the low-resolution logits as the 16-bit values the API returns: everything below blends THOSE (exactly what
+                    // ph_upsample2x reads in the two-kernel form); fp32 arithmetic on them, one rounding at the end
                     uint32_t cu[8];
-                    f32x16_t Cf, Pf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        cu[j] = f2e_pk<EO>(acc[2 * j], acc[2 * j + 1]);
-                        Cf[2 * j] = e2f<EO>(cu[j] & 0xFFFFu);
-                        Cf[2 * j + 1] = e2f<EO>(cu[j] >> 16);
-                        Pf[2 * j] = e2f<EO>(prev[TC][h][j] & 0xFFFFu);
-                        Pf[2 * j + 1] = e2f<EO>(prev[TC][h][j] >> 16);
-                        prev[TC][h][j] = cu[j];
-                    }
+                    for (int j = 0; j < 8; ++j) cu[j] = f2e_pk<EO>(acc[2 * j], acc[2 * j + 1]);
                     if (!silent) {
                         auto body = [&](auto hh_tag) {
                             constexpr int HH = decltype(hh_tag)::value;
-                            char* ub = up_row + 2 * (64 * HH - 8);                      // window base of output row 2r
-                            if (HH > 0) {           // both patches' histories first: the passes below overwrite columns 32..39
-                                if (!first) hist_move(patchA);
-                                hist_move(patchB);
+                            constexpr int SB = (HH % 3) * 64;
+                            up_patch_put<ROWB, SB>(pw_addr, prev[TC][h]);                       // P: the previous image row
+                            up_patch_put<ROWB, SB + C::PATCH1>(pw_addr, cu);                    // C: this one
+                            lds_wait_all();
+                            if (!UP2_DBG(2)) {
+                                if constexpr (HH > 0) window(std::integral_constant<int, HH - 1>{});
+                                if constexpr (HH == NH - 1) window(std::integral_constant<int, HH>{});
                             }
-                            if (LOWRES) {
-                                conv_patch_put<float, PLD>(patchA + pw_off, Cf);        // columns 8..39; the history (0..7) is untouched
+                            if constexpr (LOWRES && (HH & 1) == 1) {
+                                // the tile's low-resolution logits: 64 pixels = one 128-byte line per query row, halves HH - 1 | HH
+                                constexpr int S0 = ((HH - 1) % 3) * 64, S1 = SB;
+                                const uint32_t a = pr_addr + C::PATCH1 + (uint32_t)(ss < 4 ? S0 + 8 * ss : S1 + 8 * ss - 64);     // 16 ss bytes in all
+                                u32x4_t x[4];
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) x[kk] = lds_read128o_asm<0>(a + kk * 8 * ROWB);
                                 lds_wait_all();
 #pragma unroll
-                                for (int j = 0; j < 2; ++j) {
-                                    const u32x4_t x0 = lds_read128o_asm<0>(patchA + lr_off + j * 16 * PLD * 4);
-                                    const u32x4_t x1 = lds_read128o_asm<16>(patchA + lr_off + j * 16 * PLD * 4);
-                                    lds_wait_all();
-                                    const uint4 pk = make_uint4(f2e_pk<EO>(__uint_as_float(x0.x), __uint_as_float(x0.y)),
-                                                                f2e_pk<EO>(__uint_as_float(x0.z), __uint_as_float(x0.w)),
-                                                                f2e_pk<EO>(__uint_as_float(x1.x), __uint_as_float(x1.y)),
-                                                                f2e_pk<EO>(__uint_as_float(x1.z), __uint_as_float(x1.w)));
-                                    // default (cached) stores: a caller reads these next
-                                    if (rt * 32 + lq + 16 * j < N) *(uint4*)(lr_row + 2 * 32 * HH + j * lr_j_bytes + lr_lane_off) = pk;
-                                }
-                            }
-                            if (!first) {
-                                // output row 2r - 1: source rows (r-1, r), weights (.75, .25)
-                                f32x16_t v;
-#pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = 0.75f * Pf[q] + 0.25f * Cf[q];
-                                patch_fill(patchA, v, hh_tag);
-                                hpass(patchA, ub - 2 * (2 * W), hh_tag);
-                            }
-                            {
-                                // output row 2r: source rows (r-1, r), weights (.25, .75); r = 0: clamped, weights (0, 1)
-                                f32x16_t v;
-#pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = first ? Cf[q] : 0.25f * Pf[q] + 0.75f * Cf[q];
-                                patch_fill(patchB, v, hh_tag);
-                                hpass(patchB, ub, hh_tag);
+                                for (int kk = 0; kk < 4; ++kk)     // default (cached) stores: a caller reads these next
+                                    if (rt * 32 + sq + 8 * kk < N)
+                                        *(uint4*)(lr_row + 2 * 64 * TC + kk * lr_kk_bytes + lr_lane_off) = __builtin_bit_cast(uint4, x[kk]);
                             }
                         };
-                        if (h == 0) body(std::integral_constant<int, HH0>{});
-                        else body(std::integral_constant<int, HH0 + 1>{});
+                        if (h == 0) body(std::integral_constant<int, 2 * TC>{});
+                        else body(std::integral_constant<int, 2 * TC + 1>{});
                     }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) prev[TC][h][j] = cu[j];
                 }
             }
             cur = cur + 1 == NBUF ? 0 : cur + 1;
@@ -335,34 +376,6 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
         if constexpr (NTR > 2) tile(std::integral_constant<int, 2>{});
         if constexpr (NTR > 3) tile(std::integral_constant<int, 3>{});
         static_assert(NTR >= 1 && NTR <= 4, "image rows of 64, 128, 192 or 256 pixels");
-
-        if (!producer && last && !silent) {
-            // output row 2H - 1: source index clamped at H - 1 on both sides -> .75 C + .25 C of the row just finished (in `prev`)
-            char* ub_last = up_row + 2 * (2 * W);
-            auto fin = [&](auto tc_tag, auto h_tag) {
-                constexpr int TC = decltype(tc_tag)::value, HX = decltype(h_tag)::value;
-                f32x16_t v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float c0 = e2f<EO>(prev[TC][HX][j] & 0xFFFFu), c1 = e2f<EO>(prev[TC][HX][j] >> 16);
-                    v[2 * j] = 0.75f * c0 + 0.25f * c0;
-                    v[2 * j + 1] = 0.75f * c1 + 0.25f * c1;
-                }
-                if (2 * TC + HX > 0) hist_move(patchA);
-                patch_fill(patchA, v, std::integral_constant<int, 2 * TC + HX>{});
-                hpass(patchA, ub_last + 2 * (64 * (2 * TC + HX) - 8), std::integral_constant<int, 2 * TC + HX>{});
-            };
-#define UP_FIN(T)                                                                        \
-    do {                                                                                 \
-        fin(std::integral_constant<int, T>{}, std::integral_constant<int, 0>{});         \
-        fin(std::integral_constant<int, T>{}, std::integral_constant<int, 1>{});         \
-    } while (0)
-            UP_FIN(0);
-            if constexpr (NTR > 1) UP_FIN(1);
-            if constexpr (NTR > 2) UP_FIN(2);
-            if constexpr (NTR > 3) UP_FIN(3);
-#undef UP_FIN
-        }
     }
 }
 
@@ -398,6 +411,7 @@ static void launch_up(const uint16_t* planes, const uint16_t* kern, int64_t kbs,
     if (wgs > rows) wgs = (int)rows;
     const dim3 grid(wgs), block((NRT + 1) * 64);
     constexpr int lds = UpCfg<NRT>::LDSB;
+    const int dbg = getenv("PH_UP2_DBG") ? atoi(getenv("PH_UP2_DBG")) : 0;     // timing experiments only
 #define UP_GO(LR)                                                                                                             \
     do {                                                                                                                      \
         static const bool once = [] {                                                                                         \
@@ -406,7 +420,7 @@ static void launch_up(const uint16_t* planes, const uint16_t* kern, int64_t kbs,
         }();                                                                                                                  \
         (void)once;                                                                                                           \
         hipLaunchKernelGGL((k_dynconv_up2<E, NRT, NTR, LR, OutT>), grid, block, lds, s, planes, kern, kbs, kbias, bbs, (OutT*)logits_out, \
-                           (OutT*)up_out, B, N, H);                                                                           \
+                           (OutT*)up_out, B, N, H, dbg);                                                                           \
     } while (0)
     if (logits_out) UP_GO(true);
     else UP_GO(false);

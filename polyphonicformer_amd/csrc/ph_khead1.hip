@@ -716,6 +716,11 @@ __global__ __launch_bounds__(G::THREADS, 2) void k_khead_onepass(const K1Args a)
     else k1_run<false, INFMT, E, OutT, F32O, G>(a, lds, tid, lane, wave);
 }
 
+__global__ __launch_bounds__(256) void k_k1_clear(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ====================================================================================================================
 static unsigned long long* g_k1_timeline = nullptr;
 // debugging aid (tools): device buffer of [grid][2][3 * rounds][16] uint64 that the next launches fill with s_memtime stamps
@@ -803,9 +808,14 @@ extern "C" int ph_khead_onepass(const void* f0, const void* f1, const void* f2, 
     hipStream_t s = (hipStream_t)stream;
     const bool planes = input_format == PH_IN_PLANES, h = prec == PH_PREC_F16, o16 = out_dtype == PH_OUT_F16;
     const bool f32o = x_f32 || dfe_f32;          // the variant that also writes fp32 x_feats / depth_feats (the reference API's tensors)
-    if (hipMemsetAsync(workspace, 0, k1_zeroed_bytes(B, HW), s) != hipSuccess) {
-        ph_set_error("ph_khead_onepass: hipMemsetAsync failed");
-        return PH_ELAUNCH;
+    // The hand-off state is cleared by a kernel of this library, not by hipMemsetAsync: captured into a HIP graph (torch.cuda.graph,
+    // ROCm 7.2) the memset node left pointer-like garbage in the first 16 bytes of the region from the second replay on (round 4,
+    // scratch/k1_diag.py: status word 0 after eager calls and after replay 0, {0x80600000, 0x7366, ...} after every later replay) --
+    // harmless while nothing read the status word before the polls, fatal once late workgroups leave on a raised status.
+    {
+        const size_t n16 = k1_zeroed_bytes(B, HW) / 16;
+        const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_k1_clear, dim3(blocks), dim3(256), 0, s, (uint4*)workspace, n16);
     }
     // geometry: one 128-pixel workgroup per CU.  The pair geometry (two 64-pixel workgroups per CU) is compiled only with
     // -DK1_WITH_PAIR (PH_EXTRA_HIPCC_FLAGS) and chosen with PH_KHEAD1_PAIR=1: it passes the same tests and is SLOWER -- cfg2,
