@@ -532,6 +532,9 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
     tracker = V.QuasiDenseEmbedTracker(**tcfg)
     per_step = world * clip_frames
     ids_log, t_heads, t_coll, t_replay, cnt = {}, [], [], [], 1
+    # round 4: the rank's frames go through video.VideoStreamRunner (heads from ONE HIP graph, merge + record on the device);
+    # PH_VIDEO_EAGER=1 restores the module-API call per frame (same records, same ids)
+    runner = None if os.environ.get("PH_VIDEO_EAGER") else V.VideoStreamRunner(pipe, meta[0])
 
     def one_step(step):
         nonlocal cnt
@@ -540,7 +543,8 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for f in mine:
-            seg_ids, rec = pipe.simple_test(_video_frame(base, f, 6), meta, records_only=True)
+            xf = _video_frame(base, f, 6)
+            seg_ids, rec = runner.push_record(xf) if runner is not None else pipe.simple_test(xf, meta, records_only=True)
             if rec is None:
                 rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256, device=dev))
             r, n = D.pack_track_records(*[t.to(cdev) for t in rec])
@@ -577,7 +581,8 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
            "clip_frames_per_rank": clip_frames, "world_size": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
            "heads_merge_records_ms_per_step": round(D.barrier_and_max(med(t_heads), cdev) * 1e3, 3),
            "allgather_track_records_us_per_step": round(D.barrier_and_max(med(t_coll), cdev) * 1e6, 1),
-           "replay_tracking_ms_per_step": round(D.barrier_and_max(med(t_replay), cdev) * 1e3, 3), "precision": precision}
+           "replay_tracking_ms_per_step": round(D.barrier_and_max(med(t_replay), cdev) * 1e3, 3), "precision": precision,
+           "frame_loop": "module API, eager launches" if runner is None else "video.VideoStreamRunner: heads replayed from one HIP graph"}
     if collect_ids:
         out["track_ids"] = ids_log
     return out, pipe
@@ -613,10 +618,33 @@ def video_leg(dev, precision="bf16", frames=6):
             t_heads.append(t1 - t0), t_assoc.append(t2 - t1)
             nthing.append(sum(1 for s_ in res[2][1] if s_["isthing"]))
     med = lambda v: sorted(v)[len(v) // 2]
-    return {"ms_per_frame": round((med(t_heads) + med(t_assoc)) * 1e3, 3), "heads_and_merge_ms": round(med(t_heads) * 1e3, 3),
-            "association_ms": round(med(t_assoc) * 1e3, 3), "thing_segments_per_frame": nthing, "frames_timed": frames,
-            "precision": precision, "note": "one frame at a time (samples_per_gpu = 1 as in the reference), module API, host "
-            "wall time incl. the D2H of the id / depth maps and the host-side tracker"}
+    out = {"ms_per_frame": round((med(t_heads) + med(t_assoc)) * 1e3, 3), "heads_and_merge_ms": round(med(t_heads) * 1e3, 3),
+           "association_ms": round(med(t_assoc) * 1e3, 3), "thing_segments_per_frame": nthing, "frames_timed": frames,
+           "precision": precision, "note": "one frame at a time (samples_per_gpu = 1 as in the reference), module API, host "
+           "wall time incl. the D2H of the id / depth maps and the host-side tracker"}
+    # the same clip through video.VideoStreamRunner (round 4): heads from one HIP graph, the id map stays on the device, result
+    # maps downloaded on a side stream under the next frame; steady-state wall time per frame, results one frame late
+    try:
+        from polyphonicformer_amd import video as V
+        runner = V.VideoStreamRunner(pipe, meta[0])
+        for rep_ in range(2):                      # first pass: capture + warm-up; second: timed
+            pipe.assoc.init_tracker()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = 0
+            for f in range(frames, 3 * frames):
+                r = runner.push(_video_frame(base, f, frames))
+                got += r is not None
+            got += runner.flush() is not None
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert got == 2 * frames
+        out["stream_runner"] = {"ms_per_frame": round(dt / (2 * frames) * 1e3, 3), "frames_timed": 2 * frames,
+                                "note": "video.VideoStreamRunner: same kernels / tracker calls / results, heads replayed from one HIP "
+                                        "graph, sem / track / depth maps copied to pinned host memory under the next frame"}
+    except Exception as e:
+        out["stream_runner"] = {"error": repr(e)}
+    return out
 
 
 def train_leg(wl, dev, world, B=2, steps=4):

@@ -82,11 +82,13 @@ extern "C" int ph_selftest_trread(const uint16_t* src, uint16_t* out, void* stre
 __global__ __launch_bounds__(64) void k_selftest_hog(unsigned long long ticks, unsigned* out) {
     extern __shared__ unsigned hog_lds[];
     hog_lds[threadIdx.x] = threadIdx.x;
+    if (threadIdx.x == 0) atomicAdd(out + 1, 1u);            // out[1]: blocks that hold their slot by now (the host waits for them)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned n = 0;
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(16); ++n; }
     if (n == 0xFFFFFFFFu) out[0] = hog_lds[(threadIdx.x + 1) & 63];      // practically never: keeps the LDS allocation alive
 }
+// scratch4: 4 device words; word 1 counts the blocks that have started (zero it before the call)
 extern "C" int ph_selftest_hog(int blocks, int lds_bytes, int microseconds, void* scratch4, void* stream) {
     PH_CHECK_ARG(blocks > 0 && lds_bytes >= 256 && lds_bytes <= 160 * 1024 && microseconds > 0 && scratch4, "bad argument");
     static const bool once = [] {

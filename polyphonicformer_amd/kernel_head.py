@@ -111,7 +111,7 @@ class KernelHead(nn.Module):
     def _get_pack(self, device):
         prec = E.KHEAD_PREC[self.precision]
         own = {k: v for k, v in self.state_dict().items() if not k.startswith("localization_fpn.")}
-        ver = tuple(p._version for p in self.parameters())
+        ver = _lib.param_versions(self)
         if self._pack is None or self._pack[0] != (prec, str(device), ver):
             self._pack = ((prec, str(device), ver),
                           E.KernelHeadPack(own, prec, device, self.norm_cfg.get('num_groups', 32)))

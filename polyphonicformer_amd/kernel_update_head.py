@@ -101,7 +101,7 @@ class KernelUpdateHead(nn.Module):
 
     def stage_pack(self, device, precision=None):
         prec = E.MODES[precision or self.precision].query
-        ver = tuple(p._version for p in self.parameters())
+        ver = _lib.param_versions(self)
         key = (prec, str(device))
         hit = self._packs.get(key)
         if hit is None or hit[0] != ver:

@@ -44,7 +44,7 @@ class KernelUpdator(nn.Module):
         """a synthetic one-branch 'stage' (identity feat_transform, zero everything downstream) so the
         fused query kernel's PRE phase evaluates exactly this module."""
         prec = E.PREC[self.precision]
-        key = (prec, str(device), tuple(p._version for p in self.parameters()))
+        key = (prec, str(device), _lib.param_versions(self))
         if self._pack is not None and self._pack[0] == key:
             return self._pack[1]
         sd = {}

@@ -65,9 +65,11 @@ def _geom(src_hw, img_meta):
     return (C.c_int32 * 8)(src_hw[0], src_hw[1], Hb, Wb, h, w, Ho, Wo), (Ho, Wo)
 
 
-def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, num_thing_classes,
-                 instance_score_thr, overlap_thr, from_probs=False):
-    """argmax -> accept loop -> paste on already activated maps (device fp32)."""
+def merge_on_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, num_thing_classes,
+                    instance_score_thr, overlap_thr, from_probs=False):
+    """argmax -> accept loop -> paste on already activated maps (device fp32).  Returns DEVICE tensors
+    (panoptic ids int32 [Ho, Wo], depth_basic, depth_final fp32) and the host-side segments_info: the one
+    synchronisation in here is the 2K-int histogram copy the accept loop needs."""
     lib, dev = _lib.load(), act_mask.device
     K = act_mask.shape[0]
     Ho, Wo = out_hw
@@ -88,7 +90,15 @@ def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, 
     _lib.check(lib.ph_panoptic_paste(_lib.ptr(ids), _lib.ptr(nid), _lib.ptr(act_depth), _lib.ptr(act_depth0), geom,
                                      1 if from_probs else 0, _lib.ptr(pan), _lib.ptr(d_basic), _lib.ptr(d_final),
                                      _lib.stream_ptr()), "ph_panoptic_paste")
-    # results go to pinned host memory (torch's caching host allocator) with async copies and ONE final sync
+    return pan, info, d_basic, d_final
+
+
+def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, num_thing_classes,
+                 instance_score_thr, overlap_thr, from_probs=False):
+    """`merge_on_device` + the reference API's host results (numpy): the three maps go to pinned host memory (torch's
+    caching host allocator) with async copies and ONE final sync"""
+    pan, info, d_basic, d_final = merge_on_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw,
+                                                  num_thing_classes, instance_score_thr, overlap_thr, from_probs)
     outs = []
     for t in (pan, d_basic, d_final):
         h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
@@ -98,17 +108,16 @@ def merge_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, 
     return outs[0].numpy(), info, outs[1].numpy(), outs[2].numpy()
 
 
-def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
-    """kernel_update.py:421-469 for one image.  cls_scores [N, L] (post-sigmoid), mask_preds /
-    depth_preds [N, 2H, 2W] logits (fp32 or bf16), depth_init [1, 2H, 2W] fp32 logits; all on the GPU.
-    Returns (None, None, (panoptic_seg int32 ndarray, segments_info), depth_basic, depth_final)."""
+def _activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
+    """segment selection (host) + ph_panoptic_activate: everything `merge_*` needs"""
     if not head.merge_joint:
         raise NotImplementedError               # as the reference (:467-468)
     lib, dev = _lib.load(), mask_preds.device
     cfg = head.test_cfg
-    merge_cfg = cfg.merge_stuff_thing
-    q, labels, scores = select_segments(cls_scores.detach().float().cpu(), head.num_proposals,
-                                        head.num_thing_classes, cfg.max_per_img)
+    cls_h = torch.empty(cls_scores.shape, dtype=torch.float32, pin_memory=True)
+    cls_h.copy_(cls_scores.detach().float(), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    q, labels, scores = select_segments(cls_h, head.num_proposals, head.num_thing_classes, cfg.max_per_img)
     K = len(q)
     N, h2, w2 = mask_preds.shape
     mask_preds, depth_preds = mask_preds.contiguous(), depth_preds.contiguous()
@@ -117,7 +126,7 @@ def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta
         raise _lib.PolyheadError("mask/depth logits must both be fp32, both bf16 or both fp16")
     dt = codes[mask_preds.dtype]
     d0 = depth_init.reshape(h2, w2).float().contiguous()
-    qd = q.to(torch.int32).to(dev)
+    qd = q.to(torch.int32).pin_memory().to(dev, non_blocking=True)
     act_mask = torch.empty((K, h2, w2), dtype=torch.float32, device=dev)
     act_depth = torch.empty((K, h2, w2), dtype=torch.float32, device=dev)
     act_d0 = torch.empty((h2, w2), dtype=torch.float32, device=dev)
@@ -126,6 +135,20 @@ def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta
                                         mode, _lib.ptr(act_mask), _lib.ptr(act_depth), _lib.ptr(act_d0), _lib.stream_ptr()),
                "ph_panoptic_activate")
     geom, out_hw = _geom((h2, w2), img_meta)
-    pan, info, d_basic, d_final = merge_device(act_mask, act_depth, act_d0, scores, labels, geom, out_hw,
-                                               head.num_thing_classes, merge_cfg.instance_score_thr, merge_cfg.overlap_thr)
+    merge_cfg = cfg.merge_stuff_thing
+    return (act_mask, act_depth, act_d0, scores, labels, geom, out_hw, head.num_thing_classes, merge_cfg.instance_score_thr,
+            merge_cfg.overlap_thr)
+
+
+def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
+    """kernel_update.py:421-469 for one image.  cls_scores [N, L] (post-sigmoid), mask_preds /
+    depth_preds [N, 2H, 2W] logits (fp32 or bf16), depth_init [1, 2H, 2W] fp32 logits; all on the GPU.
+    Returns (None, None, (panoptic_seg int32 ndarray, segments_info), depth_basic, depth_final)."""
+    pan, info, d_basic, d_final = merge_device(*_activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta))
     return None, None, (pan, info), d_basic, d_final
+
+
+def get_panoptic_device(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
+    """the same with the three result maps left on the DEVICE (int32 ids, fp32 depth_basic, depth_final) for callers that
+    go on working there -- the video association step needs the id map on the GPU, not on the host"""
+    return merge_on_device(*_activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta))

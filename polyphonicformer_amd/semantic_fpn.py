@@ -98,7 +98,7 @@ class SemanticFPNWrapper(nn.Module):
     # ---- packed parameters ---------------------------------------------------------------------------------
     def _pack(self, dev):
         # keyed on the parameter versions too: load_state_dict / init_weights / fine-tuning after a first forward re-pack
-        key = (str(dev), self.precision, tuple(p._version for p in self.parameters()))
+        key = (str(dev), self.precision, _lib.param_versions(self))
         if key not in self._packs:
             self._packs.clear()
             prec = E.KHEAD_PREC[self.precision]             # 'fp16': one fp16 plane of weights and activations (f16 MFMA)

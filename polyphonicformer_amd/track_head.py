@@ -98,7 +98,7 @@ class QuasiDenseMaskEmbedHeadGTMask(nn.Module):
 
     def _get_pack(self, device):
         prec = E.PREC[self.precision]
-        ver = tuple(p._version for p in self.parameters())
+        ver = _lib.param_versions(self)
         key = (prec, str(device), ver)
         if self._pack is None or self._pack[0] != key:
             P = 2 if prec == _lib.PH_PREC_SPLIT else 1

@@ -233,10 +233,20 @@ def test_onepass_timeout_falls_back_inside_the_same_call(gpu, H, W, B, logit_dty
         # on partners that cannot start before the hog ends.  (A hog on every CU merely delays the whole launch, and a
         # launch whose resident part can finish its frames frees its CUs for the rest -- neither times out, both are fine.)
         import time
+        scratch.zero_()
+        torch.cuda.synchronize()
         with torch.cuda.stream(side):
             _lib.check(lib.ph_selftest_hog(200, 100 * 1024, ms * 1000, _lib.ptr(scratch), _lib.stream_ptr()), "ph_selftest_hog")
-        time.sleep(0.003)          # let the hog's workgroups take their CUs before the one-pass launch is queued
+        # the hog's workgroups must HOLD their CUs before the one-pass launch is queued (the first launch of a kernel loads its
+        # code object: milliseconds): word 1 counts the blocks that have started
+        t0 = time.perf_counter()
+        while int(scratch[1]) < 190 and time.perf_counter() - t0 < 0.02:
+            pass
+        assert int(scratch[1]) >= 190, "the hog did not start in time"
 
+    with torch.cuda.stream(side):     # first launch of the hog kernel (code-object load) outside the timed choreography
+        _lib.check(lib.ph_selftest_hog(1, 1024, 1, _lib.ptr(scratch), _lib.stream_ptr()), "ph_selftest_hog")
+    torch.cuda.synchronize()
     try:
         # undisturbed: one pass, no time-out
         plan.run()

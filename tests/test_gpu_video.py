@@ -241,3 +241,43 @@ def test_affinity_beyond_the_fused_kernels_limits(gpu):
         a = tr._affinity(emb.to(gpu), lab, memo.to(gpu), mlab)
         b = tr._affinity(emb, lab, memo, mlab)
         assert not a.is_cuda and a.shape == (n, m) and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_stream_runner_equals_the_module_api_loop(gpu, graph):
+    """video.VideoStreamRunner (round 4: heads from one HIP graph, id map kept on the device, result maps downloaded under the
+    next frame, results one frame late) against `VideoFramePipeline.simple_test` frame by frame on a 5-frame clip at cfg3's
+    full size: semantic, track-id and depth maps bit-identical (same kernels, same tracker calls); also `push_record` =
+    `simple_test(records_only=True)`"""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu)
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(33)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    frames = [tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base) for f in range(5)]
+    meta = [Hh.img_meta(H8, W8)]
+    pipe.init_tracker()
+    want = [pipe.simple_test(x, meta)[0] for x in frames]
+    pipe.init_tracker()
+    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph)
+    got = []
+    for x in frames:
+        r = runner.push(x)
+        if r is not None:
+            got.append(r[0])
+    got.append(runner.flush()[0])
+    assert runner.flush() is None and len(got) == len(want)
+    nthing = 0
+    for a, b in zip(got, want):
+        for k in ("sem", "track", "depth"):
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+        nthing += int((a["track"] > 0).any())
+    assert nthing > 0                                  # tracks were really assigned
+    # the sharded mode's records
+    pipe.init_tracker()
+    for x in frames[:2]:
+        ids_a, rec_a = runner.push_record(x)
+        ids_b, rec_b = pipe.simple_test(x, meta, records_only=True)
+        assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
+        if rec_a is not None:
+            assert torch.equal(rec_a[0], rec_b[0]) and torch.equal(rec_a[1], rec_b[1]) and torch.equal(rec_a[2], rec_b[2])
