@@ -542,9 +542,13 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
         recs, cnts = [], []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        outs = []
         for f in mine:
             xf = _video_frame(base, f, 6)
-            seg_ids, rec = runner.push_record(xf) if runner is not None else pipe.simple_test(xf, meta, records_only=True)
+            outs.append(runner.push_record(xf) if runner is not None else pipe.simple_test(xf, meta, records_only=True))
+        if runner is not None:                  # pipelined: call k returns frame k - 1's record, the flush the last one
+            outs = outs[1:] + [runner.flush_record()]
+        for seg_ids, rec in outs:
             if rec is None:
                 rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256, device=dev))
             r, n = D.pack_track_records(*[t.to(cdev) for t in rec])
@@ -635,13 +639,14 @@ def video_leg(dev, precision="bf16", frames=6):
             for f in range(frames, 3 * frames):
                 r = runner.push(_video_frame(base, f, frames))
                 got += r is not None
-            got += runner.flush() is not None
+            got += len(runner.flush())
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         assert got == 2 * frames
         out["stream_runner"] = {"ms_per_frame": round(dt / (2 * frames) * 1e3, 3), "frames_timed": 2 * frames,
                                 "note": "video.VideoStreamRunner: same kernels / tracker calls / results, heads replayed from one HIP "
-                                        "graph, sem / track / depth maps copied to pinned host memory under the next frame"}
+                                        "graph per slot, two slots (frame t's heads run under frame t - 1's merge / association), sem / track / "
+                                        "depth maps copied to pinned host memory on a side stream; results two frames late"}
     except Exception as e:
         out["stream_runner"] = {"error": repr(e)}
     return out

@@ -307,10 +307,10 @@ class VideoAssociator:
         if pan_dev is None:
             pan_dev = torch.from_numpy(panoptic_seg).to(dev)
         rois_all, ext_all = T.segment_boxes(pan_dev, int(max(s['id'] for s in segments_info)))
-        sel = torch.tensor([i - 1 for i in seg_ids], device=dev)
+        sel = _h2d([i - 1 for i in seg_ids], torch.int64, dev)
         prec = E.PREC[self.track_head.precision]
         embeds = self.track_head.forward_planes(T.roi_extract(fpn_feats, rois_all[sel].contiguous(), prec, self.strides))
-        bboxes = torch.cat([ext_all[sel], torch.tensor(score, device=dev, dtype=torch.float32)[:, None]], 1)
+        bboxes = torch.cat([ext_all[sel], _h2d(score, torch.float32, dev)[:, None]], 1)
         return seg_ids, (bboxes.cpu(), torch.tensor(labels, dtype=torch.int64), embeds)      # the embeddings stay on the device
 
     def _maps_on_device(self, pan_dev, segments_info, seg_ids, ids, to_host=True):
@@ -395,80 +395,126 @@ class VideoFramePipeline:
         return self.assoc.step(x, panoptic_seg, segments_info, depth_final, records_only=records_only)
 
 
+def _h2d(values, dtype, dev):
+    """a small host list -> device tensor through pinned memory, asynchronously (torch.tensor(..., device=dev) goes through
+    pageable memory and costs ~110 us per call on the GPU box: six of them per frame)"""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(dev, non_blocking=True)
+
+
 class VideoStreamRunner:
     """Throughput form of the reference's per-frame video loop (polyphonic/apis/video_inference.py:8-31 ->
     PolyphonicVideo.simple_test, polyphonic_former_video.py:327-405) for ONE stream of equally sized frames: the same kernels,
     the same tracker calls and therefore the same results as `VideoFramePipeline.simple_test`, issued so that the GPU box's
     host is not the bottleneck (round 4; the module-API loop spends ~80 % of a 5 ms frame on the host):
 
-      * neck -> KernelHead -> 3-stage decode -> x2 upsample of depth_pred are ONE HIP graph, captured on the first frame from
+      * neck -> KernelHead -> 3-stage decode -> x2 upsample of depth_pred are ONE HIP graph per slot, captured on first use from
         the unmodified module calls (`rpn_head.simple_test_rpn`, `roi_head._decode`) on static copies of the FPN levels and
         replayed for every later frame (~70 kernel launches -> one graph launch);
+      * TWO slots (the second one a deep copy of the two head modules with its own plans and buffers): the heads of frame t run
+        on their slot's stream while the host walks frame t - 1 through merge -> boxes -> RoIAlign -> track head -> tracker,
+        whose four small D2H reads (class scores, area histograms, boxes, affinity matrix) synchronise the MAIN stream only.
+        The tracker sees the frames in order; heads are frame-independent (SURVEY 8e);
       * the panoptic id map never visits the host: the merge's result stays on the device (`panoptic.get_panoptic_device`)
-        where the association step (boxes, RoIAlign, track head, the sem / track look-ups) consumes it;
+        where the association step consumes it;
       * what the reference returns as numpy -- the uint8 semantic map, the float64 track-id map, the fp32 depth map (26 MB per
-        1024x2048 frame) -- is copied to pinned host memory on a side stream while the NEXT frame is computed: `push(x)` returns
-        the result of the PREVIOUS frame (None for the first), `flush()` the last one.
+        1024x2048 frame) -- is copied to pinned host memory on a side stream under the following frames.
 
-    The synchronisation points that remain per frame are the four small D2H reads the host logic needs (class scores, the
-    merge's area histograms, the boxes, the affinity matrix).  Weights are packed at capture time: call `reset()` after
-    changing them."""
+    `push(x)` therefore returns the result of frame t - 2 (None for the first two frames); `flush()` returns the list of the
+    results still in flight, oldest first.  `pipelined=False`: one slot, results one frame late (round 4's first form).
+    Weights are packed at capture time: call `reset()` after changing them."""
 
-    def __init__(self, pipe, img_meta, graph=True):
-        self.pipe, self.metas, self.use_graph = pipe, [img_meta], graph
-        self._graph = self._static_x = self._outs = None
-        self._copy_stream = None
-        self._pending = None
+    def __init__(self, pipe, img_meta, graph=True, pipelined=True):
+        self.pipe, self.metas, self.use_graph, self.pipelined = pipe, [img_meta], graph, pipelined
+        self.reset()
 
     def reset(self):
-        self._graph = self._static_x = self._outs = None
-        self._pending = None
+        self._slots = []                 # per slot: dict(rpn, roi, x, graph, outs, stream, done)
+        self._copy_stream = None
+        self._inflight = None            # frame whose heads are running: (slot index)
+        self._downloads = []             # [(event, host tensors, device sources)] oldest first
+        self._n = 0
 
-    def _heads_device(self, x):
-        from . import engine as E
+    # -- slots ---------------------------------------------------------------------------------------------------
+    def _slot(self, i):
+        while len(self._slots) <= i:
+            if not self._slots:
+                rpn, roi = self.pipe.rpn_head, self.pipe.roi_head
+            else:
+                rpn, roi = self._clone_heads()
+            self._slots.append(dict(rpn=rpn, roi=roi, x=None, graph=None, outs=None, stream=torch.cuda.Stream(), done=None))
+        return self._slots[i]
+
+    def _clone_heads(self):
+        """a second pair of head modules with the same weights and its own plans / buffers (the originals' plans -- GBs of
+        device buffers, HIP streams -- are taken out while the modules are copied)"""
+        import copy
         rpn, roi = self.pipe.rpn_head, self.pipe.roi_head
+        held = [(m, m._plans) for m in (rpn, roi, getattr(rpn, "localization_fpn", None)) if m is not None and hasattr(m, "_plans")]
+        for m, _ in held:
+            m._plans = {}
+        try:
+            rpn2, roi2 = copy.deepcopy(rpn), copy.deepcopy(roi)
+        finally:
+            for m, pl in held:
+                m._plans = pl
+        return rpn2, roi2
+
+    def _heads_device(self, sl, x):
+        from . import engine as E
         (proposal_feats, x_feats, mask_preds, cls_scores, seg_preds, depth_feats, depth_proposal, depth_pred,
-         semantic_aspp_out) = rpn.simple_test_rpn(x, self.metas)
-        o = roi._decode(x_feats, proposal_feats, mask_preds, depth_feats, depth_proposal)
+         semantic_aspp_out) = sl["rpn"].simple_test_rpn(x, self.metas)
+        o = sl["roi"]._decode(x_feats, proposal_feats, mask_preds, depth_feats, depth_proposal)
         depth_init = E.upsample2x(depth_pred.float().contiguous())                         # kernel_update.py:302-307
         return o["cls"], o["mask_up"], o["depth_up"], depth_init
 
-    def _run_heads(self, x):
+    def _start_heads(self, i, x):
+        """copy the frame into slot i's static inputs and start its heads on the slot's stream"""
+        sl = self._slot(i)
+        main = torch.cuda.current_stream()
         if not self.use_graph:
-            return self._heads_device(x)
-        if self._graph is None:
-            self._static_x = tuple(torch.empty_like(t) for t in x)
-            for d, t in zip(self._static_x, x):
+            sl["x"] = x
+            sl["outs"] = self._heads_device(sl, x)
+            sl["done"] = torch.cuda.Event()
+            sl["done"].record(main)
+            return
+        if sl["graph"] is None:
+            sl["x"] = tuple(torch.empty_like(t) for t in x)
+            for d, t in zip(sl["x"], x):
                 d.copy_(t)
-            self._heads_device(self._static_x)               # warm-up outside the capture: plans, packs, kernel attributes
+            self._heads_device(sl, sl["x"])                 # warm-up outside the capture: plans, packs, kernel attributes
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._outs = self._heads_device(self._static_x)
-            self._graph = g
-        for d, t in zip(self._static_x, x):
-            d.copy_(t, non_blocking=True)
-        self._graph.replay()
-        return self._outs
+                sl["outs"] = self._heads_device(sl, sl["x"])
+            sl["graph"] = g
+        for d, t in zip(sl["x"], x):
+            d.copy_(t, non_blocking=True)                    # on the caller's stream: x may be reused once push returns
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(sl["stream"]):
+            sl["stream"].wait_event(ready)
+            sl["graph"].replay()
+            sl["done"] = torch.cuda.Event()
+            sl["done"].record(sl["stream"])
 
-    def push(self, x):
-        """x: the four FPN levels of ONE frame (device tensors).  Returns the previous frame's result list
-        [{"sem", "track", "depth"}] (numpy, owned by the caller) or None for the first frame."""
+    # -- the part of a frame that follows the heads -----------------------------------------------------------------
+    def _merge(self, i):
         from . import panoptic as Pn
-        if x[0].shape[0] != 1:
-            raise NotImplementedError("video inference is one frame at a time (samples_per_gpu = 1, as in the reference)")
+        sl = self._slots[i]
+        torch.cuda.current_stream().wait_event(sl["done"])
+        cls, mask_up, depth_up, depth_init = sl["outs"]
+        return Pn.get_panoptic_device(sl["roi"], cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0])
+
+    def _finish(self, i):
+        """merge -> association -> start the download of frame (slot i)'s result maps"""
+        pan_dev, info, _, d_final = self._merge(i)
+        sem, trk = self.pipe.assoc.step_device(self._slots[i]["x"], pan_dev, info)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
-        roi = self.pipe.roi_head
-        cls, mask_up, depth_up, depth_init = self._run_heads(x)
-        pan_dev, info, _, d_final = Pn.get_panoptic_device(roi, cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0])
-        fx = self._static_x if self._graph is not None else x
-        sem, trk = self.pipe.assoc.step_device(fx, pan_dev, info)
-        # download on the side stream into fresh pinned buffers (the caller owns them); the device sources stay referenced
-        # until the copy has finished
         main = torch.cuda.current_stream()
         done_main = torch.cuda.Event()
         done_main.record(main)
+        # fresh pinned buffers (the caller owns them); the device sources stay referenced until the copy has finished
         host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (sem, trk, d_final)]
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(done_main)
@@ -477,29 +523,68 @@ class VideoStreamRunner:
                 h.copy_(t, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
-        prev, self._pending = self._pending, (ev, host, (sem, trk, d_final))
-        return self._collect(prev)
-
-    def push_record(self, x):
-        """the sharded mode's per-frame work (`simple_test(..., records_only=True)`): heads from the HIP graph, merge and
-        record on the device; returns (segment ids, (bboxes, labels, embeds) or None) at once -- nothing map-sized is downloaded"""
-        from . import panoptic as Pn
-        if x[0].shape[0] != 1:
-            raise NotImplementedError("video inference is one frame at a time (samples_per_gpu = 1, as in the reference)")
-        roi = self.pipe.roi_head
-        cls, mask_up, depth_up, depth_init = self._run_heads(x)
-        pan_dev, info, _, _ = Pn.get_panoptic_device(roi, cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0])
-        fx = self._static_x if self._graph is not None else x
-        return self.pipe.assoc.record(fx, None, info, pan_dev)
+        self._downloads.append((ev, host, (sem, trk, d_final)))
 
     @staticmethod
     def _collect(p):
-        if p is None:
-            return None
         ev, host, _keep = p
         ev.synchronize()
         return [{"sem": host[0].numpy(), "track": host[1].numpy(), "depth": host[2].numpy()}]
 
+    def _check(self, x):
+        if x[0].shape[0] != 1:
+            raise NotImplementedError("video inference is one frame at a time (samples_per_gpu = 1, as in the reference)")
+
+    def push(self, x):
+        """x: the four FPN levels of ONE frame (device tensors).  Returns the result list [{"sem", "track", "depth"}] (numpy,
+        owned by the caller) of the frame pushed two calls ago (one call ago with pipelined=False), or None."""
+        self._check(x)
+        if not self.pipelined:
+            self._start_heads(0, x)
+            self._finish(0)
+            self._n += 1
+            return self._collect(self._downloads.pop(0)) if len(self._downloads) > 1 else None
+        i = self._n & 1
+        self._start_heads(i, x)                              # frame t: heads on slot i's stream ...
+        if self._inflight is not None:
+            self._finish(self._inflight)                     # ... while the host takes frame t - 1 through merge / association
+        self._inflight = i
+        self._n += 1
+        return self._collect(self._downloads.pop(0)) if len(self._downloads) > 1 else None
+
     def flush(self):
-        p, self._pending = self._pending, None
-        return self._collect(p)
+        """the results still in flight, oldest first (a list of result lists)"""
+        if self._inflight is not None:
+            self._finish(self._inflight)
+            self._inflight = None
+        out = [self._collect(p) for p in self._downloads]
+        self._downloads = []
+        return out
+
+    def push_record(self, x):
+        """the sharded mode's per-frame work (`simple_test(..., records_only=True)`) for the frame pushed ONE call ago (None for
+        the first call): its heads ran while the caller dealt with the frame before; `flush_record()` returns the last frame's.
+        Returns (segment ids, (bboxes, labels, embeds) or None); nothing map-sized is downloaded."""
+        self._check(x)
+        i = self._n & 1 if self.pipelined else 0
+        prev = None
+        if not self.pipelined:
+            self._start_heads(0, x)
+            self._n += 1
+            return self._record(0)
+        self._start_heads(i, x)
+        if self._inflight is not None:
+            prev = self._record(self._inflight)
+        self._inflight = i
+        self._n += 1
+        return prev
+
+    def flush_record(self):
+        if self._inflight is None:
+            return None
+        i, self._inflight = self._inflight, None
+        return self._record(i)
+
+    def _record(self, i):
+        pan_dev, info, _, _ = self._merge(i)
+        return self.pipe.assoc.record(self._slots[i]["x"], None, info, pan_dev)

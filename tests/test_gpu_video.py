@@ -243,12 +243,12 @@ def test_affinity_beyond_the_fused_kernels_limits(gpu):
         assert not a.is_cuda and a.shape == (n, m) and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_stream_runner_equals_the_module_api_loop(gpu, graph):
-    """video.VideoStreamRunner (round 4: heads from one HIP graph, id map kept on the device, result maps downloaded under the
-    next frame, results one frame late) against `VideoFramePipeline.simple_test` frame by frame on a 5-frame clip at cfg3's
-    full size: semantic, track-id and depth maps bit-identical (same kernels, same tracker calls); also `push_record` =
-    `simple_test(records_only=True)`"""
+@pytest.mark.parametrize("graph,pipelined", [(True, True), (True, False), (False, True)])
+def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
+    """video.VideoStreamRunner (round 4: heads from one HIP graph per slot, two slots so that frame t's heads run under frame
+    t - 1's merge / association, id map kept on the device, result maps downloaded on a side stream) against
+    `VideoFramePipeline.simple_test` frame by frame on a 5-frame clip at cfg3's full size: semantic, track-id and depth maps
+    bit-identical (same kernels, same tracker calls in the same order); also `push_record` = `simple_test(records_only=True)`"""
     from polyphonicformer_amd import video as V
     pipe, sd, cfg, wl = _cfg3_pipeline(gpu)
     H8, W8 = wl["H"] * 8, wl["W"] * 8
@@ -259,14 +259,14 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph):
     pipe.init_tracker()
     want = [pipe.simple_test(x, meta)[0] for x in frames]
     pipe.init_tracker()
-    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph)
+    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph, pipelined=pipelined)
     got = []
     for x in frames:
-        r = runner.push(x)
+        r = runner.push(tuple(t.clone() for t in x))
         if r is not None:
             got.append(r[0])
-    got.append(runner.flush()[0])
-    assert runner.flush() is None and len(got) == len(want)
+    got += [r[0] for r in runner.flush()]
+    assert runner.flush() == [] and len(got) == len(want)
     nthing = 0
     for a, b in zip(got, want):
         for k in ("sem", "track", "depth"):
@@ -274,9 +274,10 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph):
         nthing += int((a["track"] > 0).any())
     assert nthing > 0                                  # tracks were really assigned
     # the sharded mode's records
-    pipe.init_tracker()
-    for x in frames[:2]:
-        ids_a, rec_a = runner.push_record(x)
+    recs = [runner.push_record(x) for x in frames[:3]] + [runner.flush_record()]
+    recs = [r for r in recs if r is not None]
+    assert len(recs) == 3 and runner.flush_record() is None
+    for x, (ids_a, rec_a) in zip(frames[:3], recs):
         ids_b, rec_b = pipe.simple_test(x, meta, records_only=True)
         assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
         if rec_a is not None:
