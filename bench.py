@@ -542,12 +542,10 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
         recs, cnts = [], []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        outs = []
-        for f in mine:
-            xf = _video_frame(base, f, 6)
-            outs.append(runner.push_record(xf) if runner is not None else pipe.simple_test(xf, meta, records_only=True))
-        if runner is not None:                  # pipelined: call k returns frame k - 1's record, the flush the last one
-            outs = outs[1:] + [runner.flush_record()]
+        if runner is not None:                  # the clip's frames, two sets of heads in flight
+            outs = runner.records([_video_frame(base, f, 6) for f in mine])
+        else:
+            outs = [pipe.simple_test(_video_frame(base, f, 6), meta, records_only=True) for f in mine]
         for seg_ids, rec in outs:
             if rec is None:
                 rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256, device=dev))

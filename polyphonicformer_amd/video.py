@@ -561,6 +561,22 @@ class VideoStreamRunner:
         self._downloads = []
         return out
 
+    def records(self, frames):
+        """the sharded mode's per-step work for a rank's clip: `simple_test(..., records_only=True)` of every frame in order.
+        The heads of up to two frames are in flight at a time: frame k + 1's are started BEFORE frame k's merge / record, and the
+        clip's first two frames start back to back.  Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame."""
+        frames = list(frames)
+        out, started = [], 0
+        assert self._inflight is None, "records() and push() / push_record() must not be interleaved"
+        depth = 2 if self.pipelined else 1
+        for k in range(len(frames)):
+            while started < len(frames) and started < k + depth:
+                self._check(frames[started])
+                self._start_heads(started % depth, frames[started])
+                started += 1
+            out.append(self._record(k % depth))
+        return out
+
     def push_record(self, x):
         """the sharded mode's per-frame work (`simple_test(..., records_only=True)`) for the frame pushed ONE call ago (None for
         the first call): its heads ran while the caller dealt with the frame before; `flush_record()` returns the last frame's.

@@ -274,7 +274,10 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
         nthing += int((a["track"] > 0).any())
     assert nthing > 0                                  # tracks were really assigned
     # the sharded mode's records
+    recs0 = runner.records(frames[:3])
     recs = [runner.push_record(x) for x in frames[:3]] + [runner.flush_record()]
+    for (ia, ra), (ib, rb) in zip(recs0, [r for r in recs if r is not None]):
+        assert ia == ib and (ra is None) == (rb is None) and (ra is None or all(torch.equal(u, v) for u, v in zip(ra, rb)))
     recs = [r for r in recs if r is not None]
     assert len(recs) == 3 and runner.flush_record() is None
     for x, (ids_a, rec_a) in zip(frames[:3], recs):

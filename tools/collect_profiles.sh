@@ -15,7 +15,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq_query -o p -- python tools/query_time.py 24 > /dev/null 2> $OUT/pmc_sq_query.err
-python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_query > $OUT/pmc_sq_summary.txt 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq_a1 -o p -- python tools/a1_profile.py 16 fp16 > /dev/null 2> $OUT/pmc_sq_a1.err
+python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_query $OUT/pmc_sq_a1 > $OUT/pmc_sq_summary.txt 2>&1
+python tools/r04_kernels.py mixed16 > $OUT/r04_kernels.json 2> $OUT/r04_kernels.err; python tools/r04_kernels.py fp16 >> $OUT/r04_kernels.json 2>> $OUT/r04_kernels.err
+python tools/a1_time.py 16 fp16 > $OUT/a1_time.json 2> $OUT/a1_time.err; PH_KHEAD_NO_FALLBACK=1 python tools/a1_time.py 16 fp16 >> $OUT/a1_time.json 2>> $OUT/a1_time.err
 if [ "${ALL_LEGS:-1}" = 1 ]; then bash tools/run_train_prof.sh $OUT > $OUT/train_prof.txt 2>&1; fi
 python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete

@@ -1,4 +1,4 @@
-"""runs only the pooling + conv kernels at the cfg2 shape in the launch geometry of the headline step (24 frames per launch),
+"""runs only the pooling + conv (+ upsample, + fused conv-upsample) kernels at the cfg2 shape in the launch geometry of the headline step (24 frames per launch),
 for the rocprofv3 --pmc passes.  usage: python tools/pool_only.py [mode = mixed16 | mixed | bf16 | fp16]"""
 import sys, torch
 sys.path.insert(0, ".")
@@ -17,8 +17,14 @@ kern = torch.zeros((mode.KP, 2, B, 160, 256), dtype=torch.int16, device=dev)
 kb = torch.zeros((2, B, 160), dtype=torch.float32, device=dev)
 odt = torch.bfloat16 if mode.name == "bf16" else torch.float16
 out = torch.empty((B, N, H, W), dtype=odt, device=dev)
+up = torch.empty((B, N, 2 * H, 2 * W), dtype=odt, device=dev)
+fused = mode.KP == 1 and _lib.load().ph_dynconv_up2_supported(N, H, W, mode.conv, E.OUT_CODE[odt])
 for _ in range(5):
     E.pool(xp, dp, bits, N, HW, mode.feat, ns, out=part, counts=cnt)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, bits_out=bits)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, logits_out=out, out_dtype=E.OUT_CODE[odt])
+    E.upsample2x(out, out=up)
+    if fused:       # round 4: the final stage's conv + x2 upsample in one kernel (mask form with low-res logits, depth form without)
+        E.dynconv_up2(xp, kern, kb, 0, N, H, W, mode.conv, up, logits_out=out, out_dtype=E.OUT_CODE[odt])
+        E.dynconv_up2(dp, kern, kb, 1, N, H, W, mode.conv, up, logits_out=None, out_dtype=E.OUT_CODE[odt])
 torch.cuda.synchronize()
