@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_binarize(const T* __restrict__ logits, 
     // one row (b, n) per blockIdx.y; each lane tests 4 consecutive pixels (16-byte load); a wave covers
     // 256 px = 8 words; the 8 lanes of a word OR their nibbles together with three xor-shuffles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.y;
+    for (int row = blockIdx.y; row < B * Npad; row += gridDim.y) {
     const int b = row / Npad, n = row - b * Npad;
     const bool live = n < N;
     const T* src = logits + (int64_t)b * lbs + (int64_t)n * HW;
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_binarize(const T* __restrict__ logits, 
         word |= __shfl_xor(word, 4);
         if ((lane & 7) == 0 && (int64_t)c * 256 + (lane >> 3) * 32 < HWp) dst[c * 8 + (lane >> 3)] = word;
     }
+    }
 }
 
 // logits fp32 (PH_OUT_F32) or fp16 (PH_OUT_F16); run_if: optional device predicate (the launch returns at once when *run_if == 0)
@@ -110,11 +111,15 @@ extern "C" int ph_binarize_if(const void* logits, int dtype, int64_t logits_batc
     PH_CHECK_ARG((int64_t)B * Npad <= 65535, "B * Npad must be <= 65535");
     int gx = (int)((HWp + 1023) / 1024);          // 4 waves x 256 px per block step
     if (gx > 8) gx = 8;
+    // predicated use (the fallback of a one-pass KernelHead launch): a grid that walks the rows, so that the launch that returns
+    // at once is 8 x 256 workgroups and not 8 x B x Npad (20 480 at cfg2, 16 frames: 9 us of empty workgroups per call)
+    int gy = B * Npad;
+    if (run_if && gy > 256) gy = 256;
     if (dtype == PH_OUT_F32)
-        hipLaunchKernelGGL(k_binarize<float>, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+        hipLaunchKernelGGL(k_binarize<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
                            logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
     else
-        hipLaunchKernelGGL(k_binarize<uint16_t>, dim3(gx, B * Npad), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
+        hipLaunchKernelGGL(k_binarize<uint16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
                            logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
     PH_CHECK_LAUNCH();
     return PH_OK;

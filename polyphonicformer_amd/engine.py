@@ -317,6 +317,8 @@ class DecodePlan:
             if getattr(self, "debug_bits", None) is not None:      # tests: the hard masks stage s pools with (eager runs only)
                 self.debug_bits.append(self.bits.clone())
             pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial, counts=self.pcount)
+            if s == 0 and getattr(self, "on_first_pool", None) is not None:
+                self.on_first_pool()       # multi-part callers skew their parts by one phase (an event recorded here)
             o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
                             outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt, counts=self.pcount,
                             phases=3 | (_lib.PH_QUERY_WIDE if getattr(self, "shares_gpu", False) else 0))
