@@ -66,7 +66,7 @@ def _geom(src_hw, img_meta):
 
 
 def merge_on_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_hw, num_thing_classes,
-                    instance_score_thr, overlap_thr, from_probs=False, pan_out=None):
+                    instance_score_thr, overlap_thr, from_probs=False):
     """argmax -> accept loop -> paste on already activated maps (device fp32).  Returns DEVICE tensors
     (panoptic ids int32 [Ho, Wo], depth_basic, depth_final fp32) and the host-side segments_info: the one
     synchronisation in here is the 2K-int histogram copy the accept loop needs."""
@@ -84,7 +84,7 @@ def merge_on_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_h
     cnt = cnt_h.numpy()
     newid, info = accept_loop(scores, labels, cnt[0], cnt[1], num_thing_classes, instance_score_thr, overlap_thr)
     nid = torch.from_numpy(newid).pin_memory().to(dev, non_blocking=True)
-    pan = torch.empty((Ho, Wo), dtype=torch.int32, device=dev) if pan_out is None else pan_out      # `pan_out`: a caller's static buffer
+    pan = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
     d_basic = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
     d_final = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
     _lib.check(lib.ph_panoptic_paste(_lib.ptr(ids), _lib.ptr(nid), _lib.ptr(act_depth), _lib.ptr(act_depth0), geom,
@@ -148,7 +148,7 @@ def get_panoptic(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta
     return None, None, (pan, info), d_basic, d_final
 
 
-def get_panoptic_device(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta, pan_out=None):
+def get_panoptic_device(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
     """the same with the three result maps left on the DEVICE (int32 ids, fp32 depth_basic, depth_final) for callers that
     go on working there -- the video association step needs the id map on the GPU, not on the host"""
-    return merge_on_device(*_activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta), pan_out=pan_out)
+    return merge_on_device(*_activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta))

@@ -503,83 +503,12 @@ class VideoStreamRunner:
         sl = self._slots[i]
         torch.cuda.current_stream().wait_event(sl["done"])
         cls, mask_up, depth_up, depth_init = sl["outs"]
-        if self.use_graph and sl.get("pan") is None:
-            Ho, Wo = self.metas[0]['ori_shape'][:2]
-            sl["pan"] = torch.empty((Ho, Wo), dtype=torch.int32, device=cls.device)      # static: the record graphs read it
-        return Pn.get_panoptic_device(sl["roi"], cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0], pan_out=sl.get("pan"))
-
-    # -- things -> boxes -> FPN RoIAlign -> track head as a fixed-shape HIP graph ---------------------------------------
-    _BUCKETS = (8, 16, 32, 64, 128)
-
-    def _record_slot(self, i, pan_dev, info):
-        """`VideoAssociator.record` for slot i.  With graphs: the sixteen small launches of that path (segment boxes, RoIAlign,
-        4 x (im2col, GEMM, GroupNorm), fc, fc_embed, the gathers) are captured once per RoI-count bucket on fixed shapes -- every
-        segment id up to max_per_img + num_stuff gets a box, the selected RoIs are padded to the bucket with RoI 0 -- and replayed;
-        per RoI the arithmetic is that of the eager path (rows of the GEMMs, per-RoI GroupNorm), so the records are identical."""
-        assoc = self.pipe.assoc
-        sl = self._slots[i]
-        if not self.use_graph or sl.get("pan") is None:
-            return assoc.record(sl["x"], None, info, pan_dev)
-        from . import track_head as T, engine as E
-        seg_ids, idxs, labels, score = things_for_tracking(None, info)
-        if not seg_ids:
-            return seg_ids, None
-        n = len(seg_ids)
-        nb = next((b for b in self._BUCKETS if b >= n), None)
-        if nb is None:
-            return assoc.record(sl["x"], None, info, pan_dev)
-        dev = sl["pan"].device
-        roi = sl["roi"]
-        kmax = int(roi.test_cfg.max_per_img) + int(roi.num_stuff_classes)            # segment ids are 1 .. <= kmax
-        recs = sl.setdefault("rec", {})
-        rg = recs.get(nb)
-        sel_h = torch.zeros((nb,), dtype=torch.int64).pin_memory() if rg is None else rg["sel_h"]
-        sc_h = torch.zeros((nb,), dtype=torch.float32).pin_memory() if rg is None else rg["sc_h"]
-        sel_h.zero_()
-        sc_h.zero_()
-        sel_h[:n] = torch.tensor([s_ - 1 for s_ in seg_ids], dtype=torch.int64)
-        sc_h[:n] = torch.tensor(score, dtype=torch.float32)
-        if rg is None:
-            rg = dict(sel_h=sel_h, sc_h=sc_h, sel=torch.zeros((nb,), dtype=torch.int64, device=dev),
-                      sc=torch.zeros((nb,), dtype=torch.float32, device=dev))
-            rg["sel"].copy_(sel_h)
-            rg["sc"].copy_(sc_h)
-            prec = E.PREC[assoc.track_head.precision]
-
-            def body():
-                rois_all, ext_all = T.segment_boxes(sl["pan"], kmax)
-                emb = assoc.track_head.forward_planes(T.roi_extract(sl["x"], rois_all[rg["sel"]].contiguous(), prec, assoc.strides))
-                return emb, torch.cat([ext_all[rg["sel"]], rg["sc"][:, None]], 1)
-
-            body()                                               # warm-up outside the capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                rg["emb"], rg["bb"] = body()
-            rg["graph"] = g
-            recs[nb] = rg
-        rg["sel"].copy_(sel_h, non_blocking=True)
-        rg["sc"].copy_(sc_h, non_blocking=True)
-        rg["graph"].replay()
-        bb_h = torch.empty((n, 5), dtype=torch.float32, pin_memory=True)
-        bb_h.copy_(rg["bb"][:n], non_blocking=True)
-        emb = rg["emb"][:n].clone()                              # the tracker keeps embeddings: not a view of the graph's buffer
-        torch.cuda.current_stream().synchronize()
-        return seg_ids, (bb_h, torch.tensor(labels, dtype=torch.int64), emb)
+        return Pn.get_panoptic_device(sl["roi"], cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0])
 
     def _finish(self, i):
         """merge -> association -> start the download of frame (slot i)'s result maps"""
         pan_dev, info, _, d_final = self._merge(i)
-        assoc = self.pipe.assoc
-        seg_ids, rec = self._record_slot(i, pan_dev, info)
-        ids = []
-        if rec is not None:
-            _, _, ids = assoc.tracker.match(bboxes=rec[0], labels=rec[1], track_feats=rec[2], frame_id=assoc.cnt)
-            assoc.cnt += 1
-            ids = ids + 1
-            ids[ids == -1] = 0
-            ids = ids.tolist()
-        sem, trk = assoc._maps_on_device(pan_dev, info, seg_ids, ids, to_host=False)
+        sem, trk = self.pipe.assoc.step_device(self._slots[i]["x"], pan_dev, info)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -674,4 +603,4 @@ class VideoStreamRunner:
 
     def _record(self, i):
         pan_dev, info, _, _ = self._merge(i)
-        return self._record_slot(i, pan_dev, info)
+        return self.pipe.assoc.record(self._slots[i]["x"], None, info, pan_dev)
