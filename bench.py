@@ -1168,7 +1168,7 @@ def main():
         # which cannot run inside this process: the committed summary is quoted, labelled as such, and only when the launch
         # geometry is the profiled one
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")) as f:
                     pt = json.load(f)
@@ -1326,7 +1326,7 @@ def main():
                 res["train_step"] = {"error": repr(e)}
         if not full:
             res["legs_not_run"] = "secondary legs (all precision modes, cfg5, panoptic merge, neck, whole head from the FPN levels, video cfg3, " \
-                                  "assigner, training step) need --all-legs; profiles/r03/bench_all_legs.json holds this round's full line"
+                                  "assigner, training step) need --all-legs; profiles/r04/bench_all_legs.json holds this round's full line"
         if not args.no_cpu_baseline:                       # rank 0, at every N: the line of an N-GPU run carries it too
             res["cpu_baseline"] = cpu_baseline(wl, head, all_cores=full)
         os.write(json_fd, (json.dumps(res) + "\n").encode())
