@@ -16,6 +16,14 @@ from .registry import Registry
 TRACKERS = Registry("trackers")
 
 
+def _idx_to(dev, idx):
+    """a host index tensor to the device the embeddings live on: through pinned memory and asynchronously when that is a GPU
+    (six such transfers per frame in `match`; pageable ones cost 30-100 us each on the GPU box), a no-op on the CPU"""
+    if torch.device(dev).type != "cuda":
+        return idx
+    return idx.pin_memory().to(dev, non_blocking=True)
+
+
 def bbox_overlaps(b1, b2, eps=1e-6):
     """IoU matrix of xyxy boxes [n,4] x [m,4] (what mmdet.core.bbox_overlaps(mode='iou') returns)"""
     n, m = b1.shape[0], b2.shape[0]
@@ -67,10 +75,10 @@ class _TrackTable:
         row = torch.tensor([pos.get(int(t), -1) for t in ids.tolist()], dtype=torch.long)
         old, new = row >= 0, row < 0
         dev = emb.device
-        sel = lambda mask: mask.nonzero().flatten().to(dev)       # index tensors (host masks) for the device-resident embeddings
+        sel = lambda mask: _idx_to(dev, mask.nonzero().flatten())   # index tensors (host masks) for the device-resident embeddings
         if old.any():
             r = row[old]
-            rd = r.to(dev)
+            rd = _idx_to(dev, r)
             self.emb[rd] = (1 - momentum) * self.emb[rd] + momentum * emb[sel(old)]
             self.box[r], self.lab[r], self.seen[r] = box[old], lab[old], frame
         if new.any():
@@ -85,7 +93,7 @@ class _TrackTable:
         live = (frame - self.seen) < max_age
         if not bool(live.all()):
             self.ids, self.box, self.emb, self.lab, self.seen = (self.ids[live], self.box[live],
-                                                                  self.emb[live.nonzero().flatten().to(self.emb.device)],
+                                                                  self.emb[_idx_to(self.emb.device, live.nonzero().flatten())],
                                                                   self.lab[live], self.seen[live])
 
     def push_backdrop(self, box, emb, lab):
@@ -196,7 +204,7 @@ class QuasiDenseEmbedTracker(object):
         order = box[:, 4].sort(descending=True)[1]
         keep, _ = self._dedup(box[order])
         kept = order[keep]                                        # one gather of the embeddings for both steps
-        box, lab, emb = box[kept], lab[kept], emb[kept.to(dev)]
+        box, lab, emb = box[kept], lab[kept], emb[_idx_to(dev, kept)]
         ids = torch.full((box.shape[0],), -1, dtype=torch.long)
         if box.shape[0] and not self.empty:
             memo_ids, memo_lab, memo_emb = self.table.columns()
@@ -212,13 +220,13 @@ class QuasiDenseEmbedTracker(object):
         """:47-102: tracked detections go to the table; the still-unmatched ones that no higher-scored detection covers
         become this frame's backdrops; tracklets unseen for `memo_tracklet_frames` frames are forgotten"""
         tracked = ids > -1
-        self.table.absorb(ids[tracked], box[tracked], emb[tracked.nonzero().flatten().to(emb.device)], lab[tracked], frame_id,
+        self.table.absorb(ids[tracked], box[tracked], emb[_idx_to(emb.device, tracked.nonzero().flatten())], lab[tracked], frame_id,
                           self.memo_momentum)
         loose = ids == -1
         iou = bbox_overlaps(box[:, :4], box[:, :4])
         covered = (torch.tril(iou, -1) > self.nms_backdrop_iou_thr).any(1)
         bd = loose & ~covered
-        self.table.push_backdrop(box[bd], emb[bd.nonzero().flatten().to(emb.device)], lab[bd])
+        self.table.push_backdrop(box[bd], emb[_idx_to(emb.device, bd.nonzero().flatten())], lab[bd])
         self.table.expire(frame_id, self.memo_tracklet_frames)
 
 
@@ -487,6 +495,9 @@ class VideoStreamRunner:
             with torch.cuda.graph(g):
                 sl["outs"] = self._heads_device(sl, sl["x"])
             sl["graph"] = g
+        if len(x) != len(sl["x"]) or any(tuple(d.shape) != tuple(t.shape) or d.dtype != t.dtype for d, t in zip(sl["x"], x)):
+            raise ValueError("VideoStreamRunner: the FPN levels changed shape / dtype; one runner serves one stream of equally "
+                             "sized frames (call reset() to re-capture)")
         for d, t in zip(sl["x"], x):
             d.copy_(t, non_blocking=True)                    # on the caller's stream: x may be reused once push returns
         ready = torch.cuda.Event()

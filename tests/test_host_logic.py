@@ -200,3 +200,27 @@ def test_fp16_config_key_switches_both_heads():
     rpn, roi = build_heads_from_config(dict(model=model, fp16=dict(loss_scale=512.)))
     assert rpn.precision == "fp16" and roi.precision == "fp16" and roi.output_dtype == torch.float16
     assert all(h.precision == "fp16" for h in roi.mask_head)
+
+
+def test_param_versions_sees_in_place_updates_and_replaced_parameters():
+    """_lib.param_versions (the cache key of the packed device weights) walks a cached module list: an in-place update bumps it,
+    a replaced Parameter object is seen through the live `_parameters` dicts, and a deep copy gets its own list"""
+    import copy
+    from polyphonicformer_amd import _lib
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.LayerNorm(4))
+    v0 = _lib.param_versions(m)
+    assert len(v0) == 4 and _lib.param_versions(m) == v0
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    v1 = _lib.param_versions(m)
+    assert v1 != v0
+    m[1].bias = torch.nn.Parameter(torch.zeros(4))
+    with torch.no_grad():
+        m[1].bias.add_(1.0)
+        m[1].bias.add_(1.0)
+    assert _lib.param_versions(m) != v1
+    m2 = copy.deepcopy(m)
+    assert m2.__dict__["_ph_modules"][0] is m2 and m2.__dict__["_ph_modules"][1] is m2[0]
+    with torch.no_grad():
+        m2[0].weight.mul_(2.0)
+    assert _lib.param_versions(m2) != _lib.param_versions(m)
