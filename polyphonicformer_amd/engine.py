@@ -259,9 +259,13 @@ class DecodePlan:
         self.handoff_runs = 0          # runs that started from another kernel's planes (tests observe the path taken)
         # Final stage: conv + x2 upsample in ONE kernel where it exists (W = 256, one-plane conv grades, 16-bit outputs): the
         # low-resolution logits are not written and re-read, the depth branch's are not written at all (no caller of
-        # simple_test / simple_test_mask_preds ever receives them: kernel_update.py:338-345,401).  PH_CONV_UP2=0 restores the
-        # two-kernel form (A/B measurements); `want_depth_lowres` makes the fused depth launch write them too.
-        self.fused_up = (KP == 1 and _os.environ.get("PH_CONV_UP2", "1") != "0"
+        # simple_test / simple_test_mask_preds ever receives them: kernel_update.py:338-345,401).  `want_depth_lowres` makes the
+        # fused depth launch write them too.
+        # Chosen when the batch has at least two image rows per CU (B * H >= 512): below that a workgroup's range is one or two rows
+        # and the silent halo row above it doubles its work -- one frame per launch: 34 us against 26 us for the two kernels, equal
+        # at 2-4 frames, ahead from 8 (same box).  PH_CONV_UP2=1 forces the fused form at any size (tests), =0 the two-kernel form.
+        _up2 = _os.environ.get("PH_CONV_UP2", "auto")
+        self.fused_up = (KP == 1 and _up2 != "0" and (_up2 == "1" or B * H >= 512)
                          and bool(_lib.load().ph_dynconv_up2_supported(N, H, W, self.mode.conv, OUT_CODE[out_dtype])))
         self.want_depth_lowres = False
 
