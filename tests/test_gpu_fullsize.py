@@ -130,6 +130,7 @@ def test_cfg2_multi_stream_plan_equals_single_plan(head_cfg2, parts, monkeypatch
     split-K factor of the pooling depends on the batch size by default (it fixes the order of the fp32 partial sums),
     so it is pinned for the comparison."""
     monkeypatch.setenv("PH_POOL_NSPLIT", "4")
+    monkeypatch.setenv("PH_CONV_UP2", "1")      # the final-stage form depends on the part size by default (fused from B * H >= 512)
     wl, head = head_cfg2
     dev = torch.device("cuda:0")
     B, N = 7, wl["Nq"] + wl["n_stuff"]
