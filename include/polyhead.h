@@ -408,6 +408,14 @@ int ph_roi_align_fpn(const float* const* feats, const int32_t* hw, const float* 
 int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, const float* bias /* nullable */, int relu,
                  float* Yf /* nullable */, uint16_t* Yp /* nullable */, int M, int N, int K, int prec, void* stream);
 int ph_im2col7(const uint16_t* in, uint16_t* out, int n, int prec, void* stream);
+/* ph_gemm_rows for the association step's small M (a dozen RoIs): K split over several hundred workgroups, partial sums in
+ * `workspace`, added in a fixed order (deterministic; the split depends on M, N, K only).  im2col7 = 1: X is the channels-last
+ * [P][M / 49][49][256] maps and the 3x3 / pad-1 patches are gathered by the operand loads (K = 2304; what ph_im2col7 +
+ * ph_gemm_rows compute through a materialised matrix). */
+size_t ph_gemm_rows_workspace_bytes(int M, int N, int K);
+int ph_gemm_rows_splitk(const uint16_t* X, int im2col7, const uint16_t* Wp, int64_t w_plane_elems, const float* bias /* nullable */,
+                        int relu, float* Yf /* nullable */, uint16_t* Yp /* nullable */, int M, int N, int K, int prec,
+                        void* workspace, size_t workspace_bytes, void* stream);
 /* Tracker affinity (quasi_dense_embed_tracker.py:165-182) on the device, next to the embeddings: score[n][m] between the n
  * detections (emb fp32 [n][256], labels int32 [n]) and the m memory columns (memo_emb fp32 [m][256], memo_labels int32 [m]);
  * metric 0 = bisoftmax, 1 = softmax, 2 = cosine; with_cats: zero where the labels differ.  n <= 128, m <= 4096.  The greedy

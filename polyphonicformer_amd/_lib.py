@@ -100,6 +100,8 @@ SIGNATURES = {
     "ph_track_affinity_workspace_bytes": (C.c_size_t, [_I, _I]),
     "ph_track_affinity": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "ph_im2col7": (C.c_int, [_P, _P, _I, _I, _P]),
+    "ph_gemm_rows_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ph_gemm_rows_splitk": (C.c_int, [_P, _I, _P, _L, _P, _I, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "ph_gn_relu_cl": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _I, _I, _P]),
     "ph_nhwc_ingest": (C.c_int, [_P, _P, _P, _I, _L, _I, _P]),
     "ph_conv_nhwc_partial_floats": (C.c_size_t, [_I, _I, _I]),

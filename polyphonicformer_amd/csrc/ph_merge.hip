@@ -38,12 +38,25 @@ __device__ __forceinline__ Tap make_tap(int dst, int in_size, int out_size) {
     return t;
 }
 
+// ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11) with the roundings PINNED (the form the compiler
+// had chosen for this expression, and what the golden id maps were checked with): each of the three sums is one fma whose addend is a
+// rounded product.  Both forms of the argmax kernel and the paste kernel go through these two helpers, so that a pixel's probability
+// is the same bit pattern wherever it is evaluated.
+__device__ __forceinline__ float lerp_pinned(float l0, float a, float l1, float b) {
+#pragma clang fp contract(off)
+    const float t = l1 * b;
+    return __builtin_fmaf(l0, a, t);
+}
+__device__ __forceinline__ float bilerp_pinned(const Tap& ty, const Tap& tx, float v00, float v01, float v10, float v11) {
+    return lerp_pinned(ty.l0, lerp_pinned(tx.l0, v00, tx.l1, v01), ty.l1, lerp_pinned(tx.l0, v10, tx.l1, v11));
+}
+
 // value of the batch-resolution map at integer (y, x): bilinear of the source map
 __device__ __forceinline__ float sample_mid(const float* __restrict__ src, const PanGeom& G, int y, int x) {
     const Tap ty = make_tap(y, G.sh, G.Hb), tx = make_tap(x, G.sw, G.Wb);
     const float* r0 = src + (int64_t)ty.i0 * G.sw;
     const float* r1 = src + (int64_t)ty.i1 * G.sw;
-    return ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
+    return bilerp_pinned(ty, tx, r0[tx.i0], r0[tx.i1], r1[tx.i0], r1[tx.i1]);
 }
 
 struct OutTaps { Tap ty, tx; bool identity; };
@@ -126,6 +139,106 @@ __global__ __launch_bounds__(256) void k_pan_argmax(const float* __restrict__ ac
         if (hist[i]) atomicAdd(&counts[i], hist[i]);
 }
 
+// The shipped geometry -- stride-4 logits, no padding, ori_shape = img_shape: the second resize is the identity and the first an exact x4
+// -- as blocks of 4 x 2 output pixels per thread.  The generic kernel walks K maps with four scattered loads per pixel and map (the
+// texture path saturates: 0.36 ms per 1024x2048 frame and 111 maps); here a block's eight pixels share 2 source rows x 3 source columns,
+// i.e. 6 loads per map for 8 pixels, the horizontal blends are shared by the two output rows, and the >= 0.5 histogram is taken with
+// wave ballots (lane l of a wave keeps the count of map 64 j + l, one LDS atomic per lane and 64 maps) instead of one LDS atomic per
+// pixel and map.  Taps come from the same make_tap, values from the same pinned blend: ids and both histograms are bit-identical to the
+// generic kernel's (tests/test_gpu_panoptic.py runs both).
+// x = 4 j + d: d in {0, 1} blends source columns (cb, cb + 1), d in {2, 3} the pair that follows it (the same pair in the first block of
+// a row, where the source index is clamped at 0); y = 2 by + e: both e share one pair of source rows.
+__global__ __launch_bounds__(256) void k_pan_argmax_x4(const float* __restrict__ act_mask, const float* __restrict__ scores, int K,
+                                                       PanGeom G, int* __restrict__ ids, int* __restrict__ counts) {
+    extern __shared__ int hist[];   // [2][K]
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int nbx = (G.Wo + 3) >> 2, nby = (G.Ho + 1) >> 1, lane = threadIdx.x & 63;
+    const int64_t nblk = (int64_t)nbx * nby, src_hw = (int64_t)G.sh * G.sw;
+    for (int64_t t0 = blockIdx.x * (int64_t)blockDim.x; t0 < nblk; t0 += (int64_t)gridDim.x * blockDim.x) {      // wave-uniform trip count
+        const int64_t t = t0 + threadIdx.x;
+        const bool live_t = t < nblk;
+        const int64_t tc = live_t ? t : nblk - 1;
+        const int by = (int)(tc / nbx), bx = (int)(tc - (int64_t)by * nbx), x0 = 4 * bx, y0 = 2 * by;
+        Tap tx[4], ty[2];
+        bool lx[4], ly[2];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lx[d] = live_t && x0 + d < G.Wo;
+            tx[d] = make_tap(min(x0 + d, G.Wo - 1), G.sw, G.Wb);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ly[e] = live_t && y0 + e < G.Ho;
+            ty[e] = make_tap(min(y0 + e, G.Ho - 1), G.sh, G.Hb);
+            if (!ly[e]) ty[e].l0 = ty[e].l1 = 0.f;            // a pixel outside the map evaluates to 0: never counted, never stored
+        }
+        const int cb = tx[0].i0, c1 = min(cb + 1, G.sw - 1), c2 = min(cb + 2, G.sw - 1);
+        const bool a_first = tx[2].i0 == cb, b_second = tx[2].i1 == c1;       // which of the three columns the second pair is
+        const int o00 = ty[0].i0 * G.sw + cb, o01 = ty[0].i0 * G.sw + c1, o02 = ty[0].i0 * G.sw + c2;
+        const int o10 = ty[0].i1 * G.sw + cb, o11 = ty[0].i1 * G.sw + c1, o12 = ty[0].i1 * G.sw + c2;
+        float best[2][4];
+        int bi[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { best[e][d] = -INFINITY; bi[e][d] = 0; }
+        int cnt = 0;
+        const float* m = act_mask;
+        for (int k = 0; k < K; ++k, m += src_hw) {
+            const float v00 = m[o00], v01 = m[o01], v02 = m[o02], v10 = m[o10], v11 = m[o11], v12 = m[o12];
+            const float sk = scores[k];
+            float h[2][4];
+            h[0][0] = lerp_pinned(tx[0].l0, v00, tx[0].l1, v01);
+            h[0][1] = lerp_pinned(tx[1].l0, v00, tx[1].l1, v01);
+            h[1][0] = lerp_pinned(tx[0].l0, v10, tx[0].l1, v11);
+            h[1][1] = lerp_pinned(tx[1].l0, v10, tx[1].l1, v11);
+            const float a0 = a_first ? v00 : v01, b0 = b_second ? v01 : v02, a1 = a_first ? v10 : v11, b1 = b_second ? v11 : v12;
+            h[0][2] = lerp_pinned(tx[2].l0, a0, tx[2].l1, b0);
+            h[0][3] = lerp_pinned(tx[3].l0, a0, tx[3].l1, b0);
+            h[1][2] = lerp_pinned(tx[2].l0, a1, tx[2].l1, b1);
+            h[1][3] = lerp_pinned(tx[3].l0, a1, tx[3].l1, b1);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float p = lerp_pinned(ty[e].l0, h[0][d], ty[e].l1, h[1][d]);
+                    c += __popcll(__ballot(lx[d] && p >= 0.5f));               // original_area  (kernel_update.py:508)
+                    const float v = sk * p;                                     // cur_prob_masks (:492)
+                    if (v > best[e][d] || (v != v && best[e][d] == best[e][d])) { best[e][d] = v; bi[e][d] = k; }
+                }
+            cnt += lane == (k & 63) ? c : 0;
+            if ((k & 63) == 63 || k == K - 1) {
+                if (cnt) atomicAdd(&hist[K + (k & ~63) + lane], cnt);
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!ly[e]) continue;
+            int* row = ids + (int64_t)(y0 + e) * G.Wo + x0;
+            if (lx[3] && (G.Wo & 3) == 0) *(int4*)row = make_int4(bi[e][0], bi[e][1], bi[e][2], bi[e][3]);
+            else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (lx[d]) row[d] = bi[e][d];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (lx[d]) atomicAdd(&hist[bi[e][d]], 1);                       // mask_area      (:506-507)
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x)
+        if (hist[i]) atomicAdd(&counts[i], hist[i]);
+}
+
+__global__ void k_pan_clear(int* __restrict__ counts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = 0;
+}
+
 template <bool FROM_PROBS>
 __global__ __launch_bounds__(256) void k_pan_paste(const int* __restrict__ ids, const int* __restrict__ newid,
                                                    const float* __restrict__ act_depth, const float* __restrict__ act_depth0,
@@ -187,13 +300,16 @@ extern "C" int ph_panoptic_argmax(const float* act_mask, const float* scores, in
     PanGeom G;
     PH_CHECK_ARG(fill_geom(G, geom, from_probs) == 0, "bad geometry");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, (size_t)2 * K * sizeof(int32_t), s) != hipSuccess) {
-        ph_set_error("ph_panoptic_argmax: memset failed");
-        return PH_ELAUNCH;
-    }
+    // a kernel, not hipMemsetAsync: a captured memset node misbehaves on replay (see ph_khead1.hip)
+    hipLaunchKernelGGL(k_pan_clear, dim3((2 * K + 255) / 256), dim3(256), 0, s, counts, 2 * K);
     const int grid = grid_for((int64_t)G.Ho * G.Wo);
     const size_t lds = (size_t)2 * K * sizeof(int);
-    if (from_probs) hipLaunchKernelGGL(k_pan_argmax<true>, dim3(grid), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
+    const bool generic_only = getenv("PH_PAN_GENERIC") != nullptr;             // tests: the generic kernel on the x4 geometry
+    const bool x4 = !from_probs && !generic_only && G.h == G.Ho && G.w == G.Wo && G.Hb == 4 * G.sh && G.Wb == 4 * G.sw;
+    if (x4) {
+        const int64_t nblk = (int64_t)((G.Wo + 3) >> 2) * ((G.Ho + 1) >> 1);
+        hipLaunchKernelGGL(k_pan_argmax_x4, dim3(grid_for(nblk)), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
+    } else if (from_probs) hipLaunchKernelGGL(k_pan_argmax<true>, dim3(grid), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
     else hipLaunchKernelGGL(k_pan_argmax<false>, dim3(grid), dim3(256), lds, s, act_mask, scores, K, G, ids, counts);
     PH_CHECK_LAUNCH();
     return PH_OK;

@@ -9,34 +9,43 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // segment statistics.  st [nseg][3] = count, sum_row, sum_col ; emin [nseg][2] = min_r, min_c ; emax [nseg][2] = max_r, max_c
-// Per-block privatisation: a block accumulates its pixels in LDS (integer atomics; a wave whose 64 pixels all carry the
-// same id -- the common case inside a segment -- reduces across lanes first and issues one LDS atomic per quantity) and
-// adds its non-empty rows to the global record once.  With atomics straight to global memory every pixel of a segment hit
-// the same few addresses: 80-100 ms per 1024x2048 map; this form takes well under a millisecond.  All sums are integers
-// (exact, order free); the mean absolute deviations are accumulated in fp64.
+// Per-block privatisation: a block accumulates its pixels in LDS (integer atomics) and adds its non-empty rows to the global
+// record once.  With atomics straight to global memory every pixel of a segment hit the same few addresses: 80-100 ms per
+// 1024x2048 map.  All sums are integers (exact, order free); the mean absolute deviations are accumulated in fp64.
 constexpr int SEG_LDS_MAX = 1024;          // segments per id map this path handles (ids beyond: global-atomic fallback)
 
-__device__ __forceinline__ int wave_sum_i(int v) {
+// VEC consecutive pixels of one image row per thread (VEC = 8 when W % 8 == 0: two 16-byte loads); a run that lies inside one
+// segment -- nearly all of them -- is added as ONE record (count VEC, VEC * row, the arithmetic series of its columns, its end
+// points), so the atomics per pixel drop by VEC; runs that straddle a boundary fall back to per-pixel updates.
+struct SegAcc {
+    unsigned int* lst; int* lmin; int* lmax; int nl;
+    unsigned long long* st; int* emin; int* emax;
+    __device__ __forceinline__ void add(int s, int n, int sr, int sc, int r, int c_lo, int c_hi) const {
+        if (s < nl) {
+            atomicAdd(&lst[s * 3 + 0], (unsigned)n); atomicAdd(&lst[s * 3 + 1], (unsigned)sr); atomicAdd(&lst[s * 3 + 2], (unsigned)sc);
+            atomicMin(&lmin[s * 2 + 0], r); atomicMin(&lmin[s * 2 + 1], c_lo);
+            atomicMax(&lmax[s * 2 + 0], r); atomicMax(&lmax[s * 2 + 1], c_hi);
+        } else {
+            atomicAdd(&st[s * 3 + 0], (unsigned long long)n); atomicAdd(&st[s * 3 + 1], (unsigned long long)sr);
+            atomicAdd(&st[s * 3 + 2], (unsigned long long)sc);
+            atomicMin(&emin[s * 2 + 0], r); atomicMin(&emin[s * 2 + 1], c_lo);
+            atomicMax(&emax[s * 2 + 0], r); atomicMax(&emax[s * 2 + 1], c_hi);
+        }
+    }
+};
+
+template <int VEC>
+__device__ __forceinline__ void seg_load(const int* __restrict__ pan, int64_t p, int (&id)[VEC]) {
+    if constexpr (VEC == 8) {
+        const int4 a = *(const int4*)(pan + p), b = *(const int4*)(pan + p + 4);
+        id[0] = a.x; id[1] = a.y; id[2] = a.z; id[3] = a.w; id[4] = b.x; id[5] = b.y; id[6] = b.z; id[7] = b.w;
+    } else {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+        for (int j = 0; j < VEC; ++j) id[j] = pan[p + j];
+    }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void k_seg_stats(const int* __restrict__ pan, int H, int W, int nseg,
                                                    unsigned long long* __restrict__ st, int* __restrict__ emin, int* __restrict__ emax) {
     extern __shared__ unsigned int lst[];          // [nl][3] count, sum_row, sum_col | [nl][2] min | [nl][2] max
@@ -46,41 +55,24 @@ __global__ __launch_bounds__(256) void k_seg_stats(const int* __restrict__ pan, 
     for (int k = threadIdx.x; k < 3 * nl; k += blockDim.x) lst[k] = 0u;
     for (int k = threadIdx.x; k < 2 * nl; k += blockDim.x) { lmin[k] = 0x7f7f7f7f; lmax[k] = 0; }
     __syncthreads();
-    const int64_t npx = (int64_t)H * W;
+    const SegAcc acc{lst, lmin, lmax, nl, st, emin, emax};
+    const int64_t nrun = (int64_t)H * W / VEC;     // VEC divides W
     // a block's share is < 2^20 pixels with coordinates < 2^16 -> its coordinate sums fit 32 bits as long as
     // pixels-per-block * max-coordinate < 2^32 (checked by the launcher)
-    for (int64_t p0 = blockIdx.x * (int64_t)blockDim.x; p0 < npx; p0 += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = p0 + threadIdx.x;
-        const int id = p < npx ? pan[p] : 0;
-        const bool live = id >= 1 && id <= nseg;
-        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W), s = id - 1;
-        const int first = __builtin_amdgcn_readfirstlane(id);
-        if (__all(id == first)) {                  // whole wave in one segment (or all outside): one atomic per quantity
-            if (!live) continue;
-            const int n = 64, sr = wave_sum_i(r), sc = wave_sum_i(c);
-            const int mnr = wave_min_i(r), mnc = wave_min_i(c), mxr = wave_max_i(r), mxc = wave_max_i(c);
-            if ((threadIdx.x & 63) == 0) {
-                if (s < nl) {
-                    atomicAdd(&lst[s * 3 + 0], (unsigned)n); atomicAdd(&lst[s * 3 + 1], (unsigned)sr); atomicAdd(&lst[s * 3 + 2], (unsigned)sc);
-                    atomicMin(&lmin[s * 2 + 0], mnr); atomicMin(&lmin[s * 2 + 1], mnc);
-                    atomicMax(&lmax[s * 2 + 0], mxr); atomicMax(&lmax[s * 2 + 1], mxc);
-                } else {
-                    atomicAdd(&st[s * 3 + 0], (unsigned long long)n); atomicAdd(&st[s * 3 + 1], (unsigned long long)sr);
-                    atomicAdd(&st[s * 3 + 2], (unsigned long long)sc);
-                    atomicMin(&emin[s * 2 + 0], mnr); atomicMin(&emin[s * 2 + 1], mnc);
-                    atomicMax(&emax[s * 2 + 0], mxr); atomicMax(&emax[s * 2 + 1], mxc);
-                }
-            }
-        } else if (live) {
-            if (s < nl) {
-                atomicAdd(&lst[s * 3 + 0], 1u); atomicAdd(&lst[s * 3 + 1], (unsigned)r); atomicAdd(&lst[s * 3 + 2], (unsigned)c);
-                atomicMin(&lmin[s * 2 + 0], r); atomicMin(&lmin[s * 2 + 1], c);
-                atomicMax(&lmax[s * 2 + 0], r); atomicMax(&lmax[s * 2 + 1], c);
-            } else {
-                atomicAdd(&st[s * 3 + 0], 1ull); atomicAdd(&st[s * 3 + 1], (unsigned long long)r); atomicAdd(&st[s * 3 + 2], (unsigned long long)c);
-                atomicMin(&emin[s * 2 + 0], r); atomicMin(&emin[s * 2 + 1], c);
-                atomicMax(&emax[s * 2 + 0], r); atomicMax(&emax[s * 2 + 1], c);
-            }
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nrun; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = q * VEC;
+        const int r = (int)(p / W), c0 = (int)(p - (int64_t)r * W);
+        int id[VEC];
+        seg_load<VEC>(pan, p, id);
+        bool uni = true;
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) uni = uni && id[j] == id[0];
+        if (uni) {
+            if (id[0] >= 1 && id[0] <= nseg) acc.add(id[0] - 1, VEC, VEC * r, VEC * c0 + VEC * (VEC - 1) / 2, r, c0, c0 + VEC - 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (id[j] >= 1 && id[j] <= nseg) acc.add(id[j] - 1, 1, r, c0 + j, r, c0 + j, c0 + j);
         }
     }
     __syncthreads();
@@ -94,43 +86,63 @@ __global__ __launch_bounds__(256) void k_seg_stats(const int* __restrict__ pan, 
     }
 }
 // dev [nseg][2] (double): sum |row - mean_row|, sum |col - mean_col| with the fp32 means the reference uses
+template <int VEC>
 __global__ __launch_bounds__(256) void k_seg_absdev(const int* __restrict__ pan, int H, int W, int nseg,
                                                     const unsigned long long* __restrict__ st, double* __restrict__ dev) {
     extern __shared__ double ldev[];               // [nl][2]
     const int nl = nseg < SEG_LDS_MAX ? nseg : SEG_LDS_MAX;
     for (int k = threadIdx.x; k < 2 * nl; k += blockDim.x) ldev[k] = 0.0;
     __syncthreads();
-    const int64_t npx = (int64_t)H * W;
-    for (int64_t p0 = blockIdx.x * (int64_t)blockDim.x; p0 < npx; p0 += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = p0 + threadIdx.x;
-        const int id = p < npx ? pan[p] : 0;
-        const bool live = id >= 1 && id <= nseg;
-        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W), s = live ? id - 1 : 0;
-        double dr = 0.0, dc = 0.0;
-        if (live) {
-            const double n = (double)st[s * 3];
-            const float mr = (float)((double)st[s * 3 + 1] / n), mc = (float)((double)st[s * 3 + 2] / n);
-            dr = (double)fabsf((float)r - mr);
-            dc = (double)fabsf((float)c - mc);
-        }
-        const int first = __builtin_amdgcn_readfirstlane(id);
-        if (__all(id == first)) {
-            if (!live) continue;
-            const double sr = wave_sum_d(dr), sc = wave_sum_d(dc);
-            if ((threadIdx.x & 63) == 0) {
-                double* d = s < nl ? ldev : dev;
-                atomicAdd(&d[s * 2 + 0], sr);
-                atomicAdd(&d[s * 2 + 1], sc);
-            }
-        } else if (live) {
+    const int64_t nrun = (int64_t)H * W / VEC;
+    auto means = [&](int s, float& mr, float& mc) {
+        const double n = (double)st[s * 3];
+        mr = (float)((double)st[s * 3 + 1] / n);
+        mc = (float)((double)st[s * 3 + 2] / n);
+    };
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nrun; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = q * VEC;
+        const int r = (int)(p / W), c0 = (int)(p - (int64_t)r * W);
+        int id[VEC];
+        seg_load<VEC>(pan, p, id);
+        bool uni = true;
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) uni = uni && id[j] == id[0];
+        if (uni) {
+            if (id[0] < 1 || id[0] > nseg) continue;
+            const int s = id[0] - 1;
+            float mr, mc;
+            means(s, mr, mc);
+            const double dr = (double)VEC * (double)fabsf((float)r - mr);      // VEC equal terms (exact: a power of two)
+            double dc = 0.0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dc += (double)fabsf((float)(c0 + j) - mc);
             double* d = s < nl ? ldev : dev;
             atomicAdd(&d[s * 2 + 0], dr);
             atomicAdd(&d[s * 2 + 1], dc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (id[j] < 1 || id[j] > nseg) continue;
+                const int s = id[j] - 1;
+                float mr, mc;
+                means(s, mr, mc);
+                double* d = s < nl ? ldev : dev;
+                atomicAdd(&d[s * 2 + 0], (double)fabsf((float)r - mr));
+                atomicAdd(&d[s * 2 + 1], (double)fabsf((float)(c0 + j) - mc));
+            }
         }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * nl; k += blockDim.x)
         if (ldev[k] != 0.0) atomicAdd(&dev[k], ldev[k]);
+}
+__global__ void k_seg_init(unsigned long long* __restrict__ st, double* __restrict__ dev, int* __restrict__ emin, int* __restrict__ emax, int nseg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    st[s * 3] = st[s * 3 + 1] = st[s * 3 + 2] = 0ull;
+    dev[s * 2] = dev[s * 2 + 1] = 0.0;
+    emin[s * 2] = emin[s * 2 + 1] = 0x7f7f7f7f;      // > any coordinate
+    emax[s * 2] = emax[s * 2 + 1] = 0;
 }
 // rois [nseg][5] = (0, x1, y1, x2, y2) clamped at 0 ; ext_boxes [nseg][4] xyxy
 __global__ void k_seg_boxes(const unsigned long long* __restrict__ st, const int* __restrict__ emin, const int* __restrict__ emax,
@@ -170,16 +182,22 @@ extern "C" int ph_segment_boxes(const int32_t* pan, int H, int W, int nseg, floa
     double* dev = (double*)(st + 3 * nseg);
     int* emin = (int*)(dev + 2 * nseg);
     int* emax = emin + 2 * nseg;
-    (void)hipMemsetAsync(st, 0, (size_t)nseg * (3 * 8 + 2 * 8), s);
-    (void)hipMemsetAsync(emin, 0x7f, (size_t)nseg * 2 * sizeof(int), s);      // 0x7f7f7f7f > any coordinate
-    (void)hipMemsetAsync(emax, 0, (size_t)nseg * 2 * sizeof(int), s);
+    // one kernel instead of three memset nodes (a captured hipMemsetAsync node misbehaves on replay, see ph_khead1.hip)
+    hipLaunchKernelGGL(k_seg_init, dim3((nseg + 63) / 64), dim3(64), 0, s, st, dev, emin, emax, nseg);
     const int64_t npx = (int64_t)H * W;
-    int grid = (int)((npx + 255) / 256 < 2048 ? (npx + 255) / 256 : 2048);
+    const int vec = (W % 8 == 0 && ((uintptr_t)pan & 15) == 0) ? 8 : 1;
+    const int64_t nrun = npx / vec;
+    int grid = (int)((nrun + 255) / 256 < 2048 ? (nrun + 255) / 256 : 2048);
     // a block's coordinate sums are 32-bit in LDS: pixels per block x largest coordinate must stay below 2^32
-    PH_CHECK_ARG(((npx + grid - 1) / grid + 256) * (int64_t)(H > W ? H : W) < (1ll << 32), "id map too large");
+    PH_CHECK_ARG(((nrun + grid - 1) / grid + 256) * vec * (int64_t)(H > W ? H : W) < (1ll << 32), "id map too large");
     const int nl = nseg < SEG_LDS_MAX ? nseg : SEG_LDS_MAX;
-    hipLaunchKernelGGL(k_seg_stats, dim3(grid), dim3(256), (size_t)nl * 7 * sizeof(int), s, pan, H, W, nseg, st, emin, emax);
-    hipLaunchKernelGGL(k_seg_absdev, dim3(grid), dim3(256), (size_t)nl * 2 * sizeof(double), s, pan, H, W, nseg, st, dev);
+    if (vec == 8) {
+        hipLaunchKernelGGL(k_seg_stats<8>, dim3(grid), dim3(256), (size_t)nl * 7 * sizeof(int), s, pan, H, W, nseg, st, emin, emax);
+        hipLaunchKernelGGL(k_seg_absdev<8>, dim3(grid), dim3(256), (size_t)nl * 2 * sizeof(double), s, pan, H, W, nseg, st, dev);
+    } else {
+        hipLaunchKernelGGL(k_seg_stats<1>, dim3(grid), dim3(256), (size_t)nl * 7 * sizeof(int), s, pan, H, W, nseg, st, emin, emax);
+        hipLaunchKernelGGL(k_seg_absdev<1>, dim3(grid), dim3(256), (size_t)nl * 2 * sizeof(double), s, pan, H, W, nseg, st, dev);
+    }
     hipLaunchKernelGGL(k_seg_boxes, dim3((nseg + 63) / 64), dim3(64), 0, s, st, emin, emax, dev, nseg, rois, ext_boxes);
     PH_CHECK_LAUNCH();
     return PH_OK;
@@ -203,7 +221,9 @@ __device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H
 template <int PA>
 __global__ __launch_bounds__(256) void k_roi_align_fpn(FpnArgs a, const float* __restrict__ rois, int n, float finest,
                                                         uint16_t* __restrict__ out_cl, float* __restrict__ out_f32) {
-    const int roi = blockIdx.x, c = threadIdx.x;                 // one block per RoI, one thread per channel
+    // one block per (RoI, output bin), one thread per channel: 49 n blocks of 16 scattered loads per thread (the planes are NCHW, a
+    // wave's 64 channels are 64 cache lines per tap) instead of n blocks walking 784 of them -- same arithmetic per bin
+    const int roi = blockIdx.x, c = threadIdx.x, ph = blockIdx.y / 7, pw = blockIdx.y - 7 * (blockIdx.y / 7);
     const float* r = rois + roi * 5;
     const float sc = sqrtf((r[3] - r[1]) * (r[4] - r[2]));
     int lv = (int)floorf(log2f(sc / finest + 1e-6f));
@@ -214,23 +234,20 @@ __global__ __launch_bounds__(256) void k_roi_align_fpn(FpnArgs a, const float* _
     const float x1 = r[1] * s - 0.5f, y1 = r[2] * s - 0.5f, x2 = r[3] * s - 0.5f, y2 = r[4] * s - 0.5f;
     const float bw = (x2 - x1) / 7.f, bh = (y2 - y1) / 7.f;
     const int64_t plane = (int64_t)n * 49 * 256;
-    for (int ph = 0; ph < 7; ++ph)
-        for (int pw = 0; pw < 7; ++pw) {
-            float acc = 0.f;
+    float acc = 0.f;
 #pragma unroll
-            for (int iy = 0; iy < 2; ++iy) {
-                const float yy = y1 + ph * bh + (iy + 0.5f) * bh / 2.f;
+    for (int iy = 0; iy < 2; ++iy) {
+        const float yy = y1 + ph * bh + (iy + 0.5f) * bh / 2.f;
 #pragma unroll
-                for (int ix = 0; ix < 2; ++ix) acc += roi_bilinear(f, H, W, yy, x1 + pw * bw + (ix + 0.5f) * bw / 2.f);
-            }
-            const float v = acc / 4.f;
-            uint32_t hi, lo;
-            f2bf_split(v, hi, lo);
-            const int64_t o = ((int64_t)roi * 49 + ph * 7 + pw) * 256 + c;
-            out_cl[o] = (uint16_t)hi;
-            if (PA == 2) out_cl[o + plane] = (uint16_t)lo;
-            if (out_f32) out_f32[((int64_t)roi * 256 + c) * 49 + ph * 7 + pw] = v;
-        }
+        for (int ix = 0; ix < 2; ++ix) acc += roi_bilinear(f, H, W, yy, x1 + pw * bw + (ix + 0.5f) * bw / 2.f);
+    }
+    const float v = acc / 4.f;
+    uint32_t hi, lo;
+    f2bf_split(v, hi, lo);
+    const int64_t o = ((int64_t)roi * 49 + ph * 7 + pw) * 256 + c;
+    out_cl[o] = (uint16_t)hi;
+    if (PA == 2) out_cl[o + plane] = (uint16_t)lo;
+    if (out_f32) out_f32[((int64_t)roi * 256 + c) * 49 + ph * 7 + pw] = v;
 }
 
 extern "C" int ph_roi_align_fpn(const float* const* feats, const int32_t* hw /*[nlev][2]*/, const float* scales, int nlev,
@@ -241,8 +258,8 @@ extern "C" int ph_roi_align_fpn(const float* const* feats, const int32_t* hw /*[
     FpnArgs a;
     a.nlev = nlev;
     for (int l = 0; l < nlev; ++l) { a.feat[l] = feats[l]; a.H[l] = hw[2 * l]; a.W[l] = hw[2 * l + 1]; a.scale[l] = scales[l]; }
-    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_roi_align_fpn<1>, dim3(n), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
-    else hipLaunchKernelGGL(k_roi_align_fpn<2>, dim3(n), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_roi_align_fpn<1>, dim3(n, 49), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
+    else hipLaunchKernelGGL(k_roi_align_fpn<2>, dim3(n, 49), dim3(256), 0, (hipStream_t)stream, a, rois, n, finest_scale, out_cl, out_f32);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -307,6 +324,143 @@ extern "C" int ph_gemm_rows(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     hipStream_t s = (hipStream_t)stream;
     if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gemm_rows<1>, grid, dim3(256), 0, s, X, (int64_t)M * K, Wp, w_plane_elems, bias, relu, Yf, Yp, (int64_t)M * N, M, N, K);
     else hipLaunchKernelGGL(k_gemm_rows<2>, grid, dim3(256), 0, s, X, (int64_t)M * K, Wp, w_plane_elems, bias, relu, Yf, Yp, (int64_t)M * N, M, N, K);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// The same GEMM for the association step's shapes (a dozen RoIs: M = 49 n = 539 rows for the convs, M = n = 11 for the fc whose
+// weight matrix is 51 MB): K is split over blockIdx.z so that several hundred workgroups stream the operands instead of 16-68, four
+// k-steps of loads are issued before their MFMAs, and the 3x3 patches are gathered by the A-operand loads themselves (IM2COL: X is the
+// channels-last [P][n][49][256] maps, k = tap * 256 + channel) instead of through a materialised [M][2304] matrix.  Every split
+// accumulates its k-steps in order into part[z][M][N]; k_gemm_finish adds the splits in order: deterministic, and per element the same
+// products as k_gemm_rows in a different association.  The split depends on (M, N, K) only.
+template <int PA, bool IM2COL>
+__global__ __launch_bounds__(256) void k_gemm_rows_sk(const uint16_t* __restrict__ X, int64_t x_plane, const uint16_t* __restrict__ Wp,
+                                                      int64_t w_plane, float* __restrict__ part, int M, int N, int K, int steps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 32, ct = blockIdx.y * 4 + wave;
+    if (ct * 16 >= N) return;
+    const int KS = K / 32, ks0 = blockIdx.z * steps, ks1 = ks0 + steps < KS ? ks0 + steps : KS;
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const uint16_t* wb = Wp + ((int64_t)ct * KS) * 512 + lane * 8;
+    const uint16_t* xr[2];
+    bool rv[2];
+    int py[2], px[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = row0 + rt * 16 + i;
+        rv[rt] = row < M;
+        const int rc = rv[rt] ? row : 0;
+        if (IM2COL) {
+            const int smp = rc / 49, pos = rc - smp * 49;
+            py[rt] = pos / 7; px[rt] = pos - 7 * py[rt];
+            xr[rt] = X + (int64_t)smp * 49 * 256 + g * 8;
+        } else {
+            py[rt] = px[rt] = 0;
+            xr[rt] = X + (int64_t)rc * K + g * 8;
+        }
+    }
+    constexpr int U = 4;
+    for (int kb = ks0; kb < ks1; kb += U) {
+        uint4 a[U][PA][2], b[U][PA];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = kb + u;
+            if (ks >= ks1) continue;                    // uniform
+#pragma unroll
+            for (int p = 0; p < PA; ++p) b[u][p] = *(const uint4*)(wb + p * w_plane + (int64_t)ks * 512);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                bool ok = rv[rt];
+                int64_t off;
+                if (IM2COL) {
+                    const int tap = ks >> 3, y = py[rt] + tap / 3 - 1, x = px[rt] + tap % 3 - 1;
+                    ok = ok && y >= 0 && y < 7 && x >= 0 && x < 7;
+                    off = (int64_t)(y * 7 + x) * 256 + (ks & 7) * 32;
+                } else off = (int64_t)ks * 32;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) a[u][p][rt] = ok ? *(const uint4*)(xr[rt] + p * x_plane + off) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kb + u >= ks1) continue;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc[rt] = mfma16(a[u][0][rt], b[u][0], acc[rt]);
+                if (PA == 2) { acc[rt] = mfma16(a[u][0][rt], b[u][PA - 1], acc[rt]); acc[rt] = mfma16(a[u][PA - 1][rt], b[u][0], acc[rt]); }
+            }
+        }
+    }
+    float* out = part + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + rt * 16 + g * 4 + r;
+            if (row < M) out[(int64_t)row * N + ct * 16 + i] = acc[rt][r];
+        }
+}
+
+template <int PA>
+__global__ __launch_bounds__(256) void k_gemm_finish(const float* __restrict__ part, int S, const float* __restrict__ bias, int relu,
+                                                     float* __restrict__ Yf, uint16_t* __restrict__ Yp, int64_t y_plane, int M, int N) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        float v = part[idx];
+        for (int z = 1; z < S; ++z) v += part[(int64_t)z * total + idx];
+        if (bias) v += bias[idx % N];
+        if (relu) v = fmaxf(v, 0.f);
+        if (Yf) Yf[idx] = v;
+        if (Yp) {
+            uint32_t hi, lo;
+            f2bf_split(v, hi, lo);
+            Yp[idx] = (uint16_t)hi;
+            if (PA == 2) Yp[idx + y_plane] = (uint16_t)lo;
+        }
+    }
+}
+
+static void gemm_split(int M, int N, int K, int& S, int& steps) {
+    const int64_t tiles = (int64_t)((M + 31) / 32) * ((N / 16 + 3) / 4);
+    const int KS = K / 32;
+    steps = 8;
+    S = (KS + steps - 1) / steps;
+    while (S > 1 && tiles * S > 2048) { steps *= 2; S = (KS + steps - 1) / steps; }
+}
+
+extern "C" size_t ph_gemm_rows_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 32) return 0;
+    int S, steps;
+    gemm_split(M, N, K, S, steps);
+    return (size_t)S * M * N * sizeof(float);
+}
+
+extern "C" int ph_gemm_rows_splitk(const uint16_t* X, int im2col7, const uint16_t* Wp, int64_t w_plane_elems, const float* bias, int relu,
+                                   float* Yf, uint16_t* Yp, int M, int N, int K, int prec, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    PH_CHECK_ARG(X && Wp && (Yf || Yp) && workspace && M > 0 && N > 0 && K > 0, "bad pointer or size");
+    PH_CHECK_ARG(N % 16 == 0 && K % 32 == 0, "N % 16 == 0 and K % 32 == 0 required");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT, "prec must be PH_PREC_BF16 or PH_PREC_SPLIT");
+    PH_CHECK_ARG(!im2col7 || (K == 2304 && M % 49 == 0), "im2col7: X is [P][M / 49][49][256] and K = 9 * 256");
+    if (workspace_bytes < ph_gemm_rows_workspace_bytes(M, N, K)) { ph_set_error("ph_gemm_rows_splitk: workspace too small"); return PH_EWORKSPACE; }
+    int S, steps;
+    gemm_split(M, N, K, S, steps);
+    const dim3 grid((M + 31) / 32, (N / 16 + 3) / 4, S);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    const int64_t x_plane = im2col7 ? (int64_t)M * 256 : (int64_t)M * K;
+    if (prec == PH_PREC_BF16) {
+        if (im2col7) hipLaunchKernelGGL((k_gemm_rows_sk<1, true>), grid, dim3(256), 0, s, X, x_plane, Wp, w_plane_elems, part, M, N, K, steps);
+        else hipLaunchKernelGGL((k_gemm_rows_sk<1, false>), grid, dim3(256), 0, s, X, x_plane, Wp, w_plane_elems, part, M, N, K, steps);
+    } else {
+        if (im2col7) hipLaunchKernelGGL((k_gemm_rows_sk<2, true>), grid, dim3(256), 0, s, X, x_plane, Wp, w_plane_elems, part, M, N, K, steps);
+        else hipLaunchKernelGGL((k_gemm_rows_sk<2, false>), grid, dim3(256), 0, s, X, x_plane, Wp, w_plane_elems, part, M, N, K, steps);
+    }
+    const int64_t total = (int64_t)M * N;
+    const int fgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gemm_finish<1>, dim3(fgrid), dim3(256), 0, s, part, S, bias, relu, Yf, Yp, total, M, N);
+    else hipLaunchKernelGGL(k_gemm_finish<2>, dim3(fgrid), dim3(256), 0, s, part, S, bias, relu, Yf, Yp, total, M, N);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

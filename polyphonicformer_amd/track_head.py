@@ -126,25 +126,26 @@ class QuasiDenseMaskEmbedHeadGTMask(nn.Module):
         if P != pk["P"]:
             raise _lib.PolyheadError("RoI feature planes were produced in a different precision than the head's")
         prec, s = pk["prec"], _lib.stream_ptr
-        M = n * 49
-        col = torch.empty((P, M, 2304), dtype=torch.int16, device=dev)
+        M, F_ = n * 49, self.fc_out_channels
+        # split-K GEMMs (a dozen RoIs leave 16-68 workgroups otherwise); the convs gather their 3x3 patches in the operand loads
+        ws = torch.empty((max(lib.ph_gemm_rows_workspace_bytes(M, 256, 2304), lib.ph_gemm_rows_workspace_bytes(n, F_, 49 * 256),
+                              lib.ph_gemm_rows_workspace_bytes(n, self.embed_channels, F_)),), dtype=torch.uint8, device=dev)
         y = torch.empty((M, 256), dtype=torch.float32, device=dev)
         cur = x_cl.contiguous()
         for wp, (ga, be) in zip(pk["convs"], pk["gn"]):
-            _lib.check(lib.ph_im2col7(_lib.ptr(cur), _lib.ptr(col), n, prec, s()), "ph_im2col7")
-            _lib.check(lib.ph_gemm_rows(_lib.ptr(col), _lib.ptr(wp), wp.shape[1], None, 0, _lib.ptr(y), None, M, 256, 2304, prec, s()),
-                       "ph_gemm_rows(conv)")
+            _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(cur), 1, _lib.ptr(wp), wp.shape[1], None, 0, _lib.ptr(y), None, M, 256, 2304, prec,
+                                               _lib.ptr(ws), ws.numel(), s()), "ph_gemm_rows_splitk(conv)")
             nxt = torch.empty((P, n, 49, 256), dtype=torch.int16, device=dev)
             _lib.check(lib.ph_gn_relu_cl(_lib.ptr(y), _lib.ptr(ga), _lib.ptr(be), self.groups, 1e-5, _lib.ptr(nxt), n, prec, s()),
                        "ph_gn_relu_cl")
             cur = nxt
-        F_ = self.fc_out_channels
         h = torch.empty((P, n, F_), dtype=torch.int16, device=dev)
-        _lib.check(lib.ph_gemm_rows(_lib.ptr(cur), _lib.ptr(pk["fc"]), pk["fc"].shape[1], _lib.ptr(pk["fc_b"]), 1, None, _lib.ptr(h),
-                                    n, F_, 49 * 256, prec, s()), "ph_gemm_rows(fc)")
+        _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(cur), 0, _lib.ptr(pk["fc"]), pk["fc"].shape[1], _lib.ptr(pk["fc_b"]), 1, None, _lib.ptr(h),
+                                           n, F_, 49 * 256, prec, _lib.ptr(ws), ws.numel(), s()), "ph_gemm_rows_splitk(fc)")
         out = torch.empty((n, self.embed_channels), dtype=torch.float32, device=dev)
-        _lib.check(lib.ph_gemm_rows(_lib.ptr(h), _lib.ptr(pk["emb"]), pk["emb"].shape[1], _lib.ptr(pk["emb_b"]), 0, _lib.ptr(out), None,
-                                    n, self.embed_channels, F_, prec, s()), "ph_gemm_rows(fc_embed)")
+        _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(h), 0, _lib.ptr(pk["emb"]), pk["emb"].shape[1], _lib.ptr(pk["emb_b"]), 0, _lib.ptr(out),
+                                           None, n, self.embed_channels, F_, prec, _lib.ptr(ws), ws.numel(), s()),
+                   "ph_gemm_rows_splitk(fc_embed)")
         return out
 
     def forward(self, x):

@@ -88,6 +88,35 @@ def test_get_panoptic_fused_vs_reference_golden(gpu, case, dtype):
     assert np.abs(out[4] - dfin_ref).max() < 1e-3 * np.abs(dfin_ref).max()
 
 
+@pytest.mark.parametrize("shape", [(24, 40, 0, 0), (17, 23, 3, 2), (8, 16, 1, 3), (1, 1, 0, 0), (64, 128, 0, 0)])
+def test_argmax_x4_form_equals_the_generic_kernel(gpu, shape, monkeypatch):
+    """the shipped geometry (identity second resize, exact x4 first) takes a kernel of its own (4 x 2 pixel blocks, ballot
+    histograms): ids and both histograms must be the generic kernel's bit for bit, cropped maps and borders included"""
+    from polyphonicformer_amd import _lib
+    sh, sw, cut_h, cut_w = shape
+    K = 70
+    g = torch.Generator().manual_seed(sh * 131 + sw)
+    act = torch.rand(K, sh, sw, generator=g)
+    act[:, : sh // 2] = (act[:, : sh // 2] * 8).round() / 8              # exact ties and exact 0.5s
+    act[3, 0, 0] = float("nan")
+    sc = torch.rand(K, generator=g)
+    sc[5] = sc[4]
+    Ho, Wo = 4 * sh - cut_h, 4 * sw - cut_w
+    geom = (Pn.C.c_int32 * 8)(sh, sw, 4 * sh, 4 * sw, Ho, Wo, Ho, Wo)
+    lib = _lib.load()
+    a, s = act.to(gpu).contiguous(), sc.to(gpu)
+    outs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("PH_PAN_GENERIC", "1")
+        ids = torch.full((Ho, Wo), -7, dtype=torch.int32, device=gpu)
+        cnt = torch.empty((2, K), dtype=torch.int32, device=gpu)
+        _lib.check(lib.ph_panoptic_argmax(_lib.ptr(a), _lib.ptr(s), K, geom, 0, _lib.ptr(ids), _lib.ptr(cnt), _lib.stream_ptr()), "argmax")
+        outs.append((ids.cpu(), cnt.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert int(outs[0][1][0].sum()) == Ho * Wo and int(outs[0][0].min()) >= 0
+
+
 def test_simple_test_whole_path_golden(gpu):
     """KernelHead.simple_test_rpn -> KernelUpdateIterHead.simple_test exactly as Polyphonic.simple_test
     (polyphonic_former.py:145-161) against the reference's golden panoptic outputs."""

@@ -59,6 +59,47 @@ def test_track_embed_head_golden(gpu, precision):
     assert e < (1e-3 if precision == "fp32" else 3e-2)
 
 
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16])
+@pytest.mark.parametrize("n", [1, 11, 100])
+def test_splitk_row_gemm_equals_the_materialised_form(gpu, n, prec):
+    """ph_gemm_rows_splitk (K split over workgroups, 3x3 patches gathered by the operand loads) against ph_im2col7 + ph_gemm_rows
+    on the same planes: the same products, another association (fp32 rounding only), deterministic, bias / relu / plane outputs"""
+    from polyphonicformer_amd.pack import pack_b_fragments
+    lib, P = _lib.load(), 2 if prec == _lib.PH_PREC_SPLIT else 1
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(P, n, 49, 256, generator=g).to(torch.bfloat16).view(torch.int16).to(gpu)
+    w = T._planes(pack_b_fragments((torch.randn(256, 2304, generator=g, dtype=torch.float64) / 48)), P).to(gpu)
+    M = n * 49
+    col = torch.empty((P, M, 2304), dtype=torch.int16, device=gpu)
+    y0, y1, y2 = (torch.empty((M, 256), dtype=torch.float32, device=gpu) for _ in range(3))
+    s = _lib.stream_ptr
+    _lib.check(lib.ph_im2col7(_lib.ptr(x), _lib.ptr(col), n, prec, s()), "im2col")
+    _lib.check(lib.ph_gemm_rows(_lib.ptr(col), _lib.ptr(w), w.shape[1], None, 0, _lib.ptr(y0), None, M, 256, 2304, prec, s()), "gemm")
+    ws = torch.empty((lib.ph_gemm_rows_workspace_bytes(M, 256, 2304),), dtype=torch.uint8, device=gpu)
+    for y in (y1, y2):
+        _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(x), 1, _lib.ptr(w), w.shape[1], None, 0, _lib.ptr(y), None, M, 256, 2304, prec,
+                                           _lib.ptr(ws), ws.numel(), s()), "splitk")
+    assert torch.equal(y1, y2)
+    assert Hh.rel_err(y1.cpu(), y0.cpu()) < 1e-5
+    # fc shape: bias + relu + plane output, rows not a multiple of the tile
+    K, N = 49 * 256, 64
+    wf = T._planes(pack_b_fragments((torch.randn(N, K, generator=g, dtype=torch.float64) / 112)), P).to(gpu)
+    bias = torch.randn(N, generator=g).to(gpu)
+    h0, h1 = (torch.zeros((P, n, N), dtype=torch.int16, device=gpu) for _ in range(2))
+    f0, f1 = (torch.empty((n, N), dtype=torch.float32, device=gpu) for _ in range(2))
+    xf = x.reshape(P, n, K).contiguous()
+    _lib.check(lib.ph_gemm_rows(_lib.ptr(xf), _lib.ptr(wf), wf.shape[1], _lib.ptr(bias), 1, _lib.ptr(f0), _lib.ptr(h0), n, N, K, prec, s()), "gemm")
+    ws = torch.empty((lib.ph_gemm_rows_workspace_bytes(n, N, K),), dtype=torch.uint8, device=gpu)
+    _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(xf), 0, _lib.ptr(wf), wf.shape[1], _lib.ptr(bias), 1, _lib.ptr(f1), _lib.ptr(h1), n, N, K, prec,
+                                       _lib.ptr(ws), ws.numel(), s()), "splitk")
+    assert Hh.rel_err(f1.cpu(), f0.cpu()) < 1e-5 and float(f1.min()) >= 0
+    rec = lambda h: sum(h[p].view(torch.bfloat16).float() for p in range(P)).cpu()
+    assert Hh.rel_err(rec(h1), f1.cpu()) < (2e-5 if P == 2 else 5e-3)
+    with pytest.raises(_lib.PolyheadError):
+        _lib.check(lib.ph_gemm_rows_splitk(_lib.ptr(xf), 0, _lib.ptr(wf), wf.shape[1], None, 0, _lib.ptr(f1), None, n, N, K, prec,
+                                           _lib.ptr(ws), 16, s()), "splitk")
+
+
 def test_association_chain_vs_oracle(gpu):
     """pan map -> boxes -> FPN RoIAlign -> embed head -> tracker, as polyphonic_former_video.py:359-396 wires it"""
     from polyphonicformer_amd import video as V
