@@ -75,7 +75,8 @@ def merge_on_device(act_mask, act_depth, act_depth0, scores, labels, geom, out_h
     Ho, Wo = out_hw
     ids = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
     counts = torch.empty((2, K), dtype=torch.int32, device=dev)
-    sc = scores.to(dev, torch.float32).contiguous()
+    sc = scores.to(torch.float32).contiguous()
+    sc = sc if sc.is_cuda else sc.pin_memory().to(dev, non_blocking=True)    # (a pageable H2D copy synchronises)
     _lib.check(lib.ph_panoptic_argmax(_lib.ptr(act_mask), _lib.ptr(sc), K, geom, 1 if from_probs else 0, _lib.ptr(ids),
                                       _lib.ptr(counts), _lib.stream_ptr()), "ph_panoptic_argmax")
     cnt_h = torch.empty((2, K), dtype=torch.int32, pin_memory=True)

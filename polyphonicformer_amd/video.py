@@ -9,6 +9,7 @@ reference's, and the integer ids are pinned to the reference class's own output 
 With frames sharded over GPUs (`dist.shard_frames`) every rank all-gathers the per-frame records
 (`dist.allgather_track_records`) and replays `match` in frame order; integer track ids are then identical to the
 single-process run (`replay_tracking`, tests/test_tracker.py and tests/test_dist_gloo.py)."""
+import numpy as np
 import torch
 
 from .registry import Registry
@@ -39,61 +40,82 @@ def bbox_overlaps(b1, b2, eps=1e-6):
     return inter / (a1[:, None] + a2[None, :] - inter).clamp(min=eps)
 
 
+def _iou_np(b1, b2, eps=1e-6):
+    """`bbox_overlaps` on numpy float32 arrays: the same fp32 operations in the same order (bit-identical values), at numpy's
+    per-call cost -- the tracker's bookkeeping is ~60 tiny array operations per frame"""
+    n, m = b1.shape[0], b2.shape[0]
+    if n == 0 or m == 0:
+        return np.zeros((n, m), dtype=np.float32)
+    x1 = np.maximum(b1[:, None, 0], b2[None, :, 0])
+    y1 = np.maximum(b1[:, None, 1], b2[None, :, 1])
+    x2 = np.minimum(b1[:, None, 2], b2[None, :, 2])
+    y2 = np.minimum(b1[:, None, 3], b2[None, :, 3])
+    inter = np.maximum(x2 - x1, np.float32(0)) * np.maximum(y2 - y1, np.float32(0))
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    return inter / np.maximum(a1[:, None] + a2[None, :] - inter, np.float32(eps))
+
+
+def _rows_to(dev, rows):
+    """numpy row indices -> an index tensor where the embeddings live"""
+    return _idx_to(dev, torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)))
+
+
 class _TrackTable:
     """The tracker's memory as a struct of arrays: one row per live tracklet, in creation order (the order the
     affinity columns are laid out in, which decides ties), plus the most recent frames' unmatched detections
     ("backdrops", newest frame first).  Rows are updated / appended / expired with index operations; nothing here is
-    per-object Python state."""
+    per-object Python state.  ids / boxes / labels / last-seen frames are numpy arrays on the host, the embeddings a torch
+    tensor on the device the track head left them on."""
 
     def __init__(self, backdrop_frames):
-        self.ids = torch.zeros((0,), dtype=torch.long)
-        self.box = torch.zeros((0, 5))
+        self.ids = np.zeros((0,), dtype=np.int64)
+        self.box = np.zeros((0, 5), dtype=np.float32)
         self.emb = torch.zeros((0, 0))                            # lives where the track head left its embeddings (device)
-        self.lab = torch.zeros((0,), dtype=torch.long)
-        self.seen = torch.zeros((0,), dtype=torch.long)          # frame a row was last matched in
+        self.lab = np.zeros((0,), dtype=np.int64)
+        self.seen = np.zeros((0,), dtype=np.int64)                # frame a row was last matched in
         self.backdrop_frames = backdrop_frames
         self.backdrops = []                                       # [(box, emb, lab)], newest first
 
     def __len__(self):
-        return int(self.ids.numel())
+        return int(self.ids.shape[0])
 
     def columns(self):
         """(ids, labels, embeds) of everything a detection can be matched to: tracklets, then backdrops (id -1)"""
         ids, lab, emb = [self.ids], [self.lab], [self.emb]
         for (bb, be, bl) in self.backdrops:
-            ids.append(torch.full((be.shape[0],), -1, dtype=torch.long))
+            ids.append(np.full((be.shape[0],), -1, dtype=np.int64))
             lab.append(bl)
             emb.append(be)
         emb = [e for e in emb if e.shape[0]]
-        return torch.cat(ids), torch.cat(lab), (torch.cat(emb, 0) if emb else self.emb)
+        return np.concatenate(ids), np.concatenate(lab), (torch.cat(emb, 0) if len(emb) > 1 else (emb[0] if emb else self.emb))
 
     def absorb(self, ids, box, emb, lab, frame, momentum):
         """matched detections refresh their rows (embedding = exponential moving average), unknown ids append rows"""
-        if ids.numel() == 0:
+        if ids.shape[0] == 0:
             return
-        pos = {int(t): r for r, t in enumerate(self.ids.tolist())}
-        row = torch.tensor([pos.get(int(t), -1) for t in ids.tolist()], dtype=torch.long)
+        pos = {t: r for r, t in enumerate(self.ids.tolist())}
+        row = np.array([pos.get(t, -1) for t in ids.tolist()], dtype=np.int64)
         old, new = row >= 0, row < 0
         dev = emb.device
-        sel = lambda mask: _idx_to(dev, mask.nonzero().flatten())   # index tensors (host masks) for the device-resident embeddings
         if old.any():
             r = row[old]
-            rd = _idx_to(dev, r)
-            self.emb[rd] = (1 - momentum) * self.emb[rd] + momentum * emb[sel(old)]
+            rd = _rows_to(dev, r)
+            self.emb[rd] = (1 - momentum) * self.emb[rd] + momentum * emb[_rows_to(dev, np.flatnonzero(old))]
             self.box[r], self.lab[r], self.seen[r] = box[old], lab[old], frame
         if new.any():
             k = int(new.sum())
-            self.ids = torch.cat([self.ids, ids[new]])
-            self.box = torch.cat([self.box, box[new]], 0)
-            self.emb = torch.cat([self.emb.reshape(-1, emb.shape[1]).to(dev), emb[sel(new)]], 0)
-            self.lab = torch.cat([self.lab, lab[new]])
-            self.seen = torch.cat([self.seen, torch.full((k,), frame, dtype=torch.long)])
+            self.ids = np.concatenate([self.ids, ids[new]])
+            self.box = np.concatenate([self.box, box[new]], 0)
+            self.emb = torch.cat([self.emb.reshape(-1, emb.shape[1]).to(dev), emb[_rows_to(dev, np.flatnonzero(new))]], 0)
+            self.lab = np.concatenate([self.lab, lab[new]])
+            self.seen = np.concatenate([self.seen, np.full((k,), frame, dtype=np.int64)])
 
     def expire(self, frame, max_age):
         live = (frame - self.seen) < max_age
-        if not bool(live.all()):
+        if not live.all():
             self.ids, self.box, self.emb, self.lab, self.seen = (self.ids[live], self.box[live],
-                                                                  self.emb[_idx_to(self.emb.device, live.nonzero().flatten())],
+                                                                  self.emb[_rows_to(self.emb.device, np.flatnonzero(live))],
                                                                   self.lab[live], self.seen[live])
 
     def push_backdrop(self, box, emb, lab):
@@ -111,10 +133,12 @@ class QuasiDenseEmbedTracker(object):
     the memory is a `_TrackTable`, the affinity matrix is computed once and the greedy one-to-one assignment walks the
     detections in score order with a `taken` mask over tracklet columns.  The reference also carries a per-tracklet
     velocity that nothing reads (its `match` ignores `memo_vs`); it is not kept.
-    Where the arithmetic runs: boxes, labels, ids and the control flow on the host; the EMBEDDINGS (detections and memory)
-    stay on the device the track head produced them on, and the [detections x memory] affinity matrix is computed there
-    (`ph_track_affinity`, csrc/ph_track.hip) -- one D2H of that matrix per frame feeds the greedy walk.  With CPU inputs
-    (the CPU tests, gloo) the same arithmetic runs as torch CPU ops; no process-global state is touched either way."""
+    Where the arithmetic runs: boxes, labels, ids and the control flow on the host, as numpy float32 / int64 arrays (the same
+    IEEE operations as the torch CPU ops they replace -- same values, a third of the per-call cost; the frame's ~60 tiny array
+    operations were 0.6 ms of a 2 ms video frame); the EMBEDDINGS (detections and memory) stay on the device the track head
+    produced them on, and the [detections x memory] affinity matrix is computed there (`ph_track_affinity`, csrc/ph_track.hip)
+    -- one D2H of that matrix per frame feeds the greedy walk.  With CPU inputs (the CPU tests, gloo) the affinity runs as
+    torch CPU ops; no process-global state is touched either way."""
 
     def __init__(self, init_score_thr=0.8, obj_score_thr=0.5, match_score_thr=0.5, memo_tracklet_frames=10,
                  memo_backdrop_frames=1, memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3,
@@ -138,14 +162,15 @@ class QuasiDenseEmbedTracker(object):
     # -- pieces of `match` ---------------------------------------------------------------------------------
     def _dedup(self, box):
         """a detection is dropped when ANY higher-scored detection (kept or not) overlaps it by more than the IoU
-        threshold of its own score class (:147-155)"""
-        iou = bbox_overlaps(box[:, :4], box[:, :4])
-        thr = torch.where(box[:, 4] < self.obj_score_thr, torch.tensor(self.nms_backdrop_iou_thr),
-                          torch.tensor(self.nms_class_iou_thr))
-        return ~(torch.tril(iou, -1) > thr[:, None]).any(1), iou
+        threshold of its own score class (:147-155).  box: numpy float32 [n, 5], descending score"""
+        f32 = np.float32
+        iou = _iou_np(box[:, :4], box[:, :4])
+        thr = np.where(box[:, 4] < f32(self.obj_score_thr), f32(self.nms_backdrop_iou_thr), f32(self.nms_class_iou_thr))
+        return ~(np.tril(iou, -1) > thr[:, None]).any(1), iou
 
     def _affinity(self, emb, lab, memo_emb, memo_lab):
-        """[detections x memory columns] match scores (:165-182), returned on the host"""
+        """[detections x memory columns] match scores (:165-182), returned on the host (torch fp32).  Labels: numpy or torch"""
+        lab, memo_lab = torch.as_tensor(lab), torch.as_tensor(memo_lab)
         # the fused kernel keeps a detection row in one workgroup: n <= 128 detections, m <= 4096 memory columns (max_per_img is
         # 100 and the memory a few hundred columns in the shipped configs).  Beyond that the same formula runs as torch ops ON
         # THE DEVICE the embeddings live on (below) -- the reference has no limit, a long video must not abort mid-stream
@@ -159,10 +184,15 @@ class QuasiDenseEmbedTracker(object):
             metric = {'bisoftmax': 0, 'softmax': 1, 'cosine': 2}[self.match_metric]
             # named, so that the four operands are alive (and distinct blocks of the caching allocator) until the launch is queued
             e, me = emb.contiguous(), memo_emb.contiguous()
-            l, ml = lab.to(dev, torch.int32), memo_lab.to(dev, torch.int32)
+            both = torch.cat([lab.reshape(-1), memo_lab.reshape(-1)]).to(torch.int32)          # ONE pinned transfer for both label vectors
+            both = both.to(dev) if both.is_cuda else both.pin_memory().to(dev, non_blocking=True)
+            l, ml = both[:n], both[n:]
             _lib.check(lib.ph_track_affinity(_lib.ptr(e), _lib.ptr(l), _lib.ptr(me), _lib.ptr(ml), n, m, metric, 1 if self.with_cats else 0,
                                              _lib.ptr(score), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ph_track_affinity")
-            return score.cpu()
+            host = torch.empty((n, m), dtype=torch.float32, pin_memory=True)
+            host.copy_(score, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return host
         if self.match_metric == 'cosine':
             unit = torch.nn.functional.normalize
             s = unit(emb, p=2, dim=1) @ unit(memo_emb, p=2, dim=1).t()
@@ -178,18 +208,22 @@ class QuasiDenseEmbedTracker(object):
     def _assign(self, score, det_conf, memo_ids):
         """greedy, in detection (score) order: best still-free column; a tracklet column is consumed by a confident
         detection, a weak detection that resembles a tracklet is marked -2 (neither a new track nor a backdrop),
-        matches to backdrop columns assign nothing (:183-197)"""
+        matches to backdrop columns assign nothing (:183-197).  numpy: score fp32 [n, m], det_conf fp32 [n], memo_ids int64 [m]"""
+        f32 = np.float32
         n = score.shape[0]
-        out = torch.full((n,), -1, dtype=torch.long)
-        taken = torch.zeros(score.shape[1], dtype=torch.bool)
+        out = np.full((n,), -1, dtype=np.int64)
+        taken = np.zeros(score.shape[1], dtype=bool)
+        match_thr, obj_thr, conf_thr = f32(self.match_score_thr), f32(self.obj_score_thr), f32(self.nms_conf_thr)
         for i in range(n):
-            conf, j = score[i].masked_fill(taken, 0).max(0)
-            if not conf > self.match_score_thr or memo_ids[j] < 0:
+            row = np.where(taken, f32(0), score[i])
+            j = int(row.argmax())                                  # first maximal column, like torch.max(0)
+            conf = row[j]
+            if not conf > match_thr or memo_ids[j] < 0:
                 continue
-            if det_conf[i] > self.obj_score_thr:
+            if det_conf[i] > obj_thr:
                 out[i] = memo_ids[j]
                 taken[j] = True
-            elif conf > self.nms_conf_thr:
+            elif conf > conf_thr:
                 out[i] = -2
         return out
 
@@ -199,34 +233,35 @@ class QuasiDenseEmbedTracker(object):
         return self._match(bboxes, labels, track_feats, frame_id)
 
     def _match(self, bboxes, labels, track_feats, frame_id):
-        box, lab, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().float()   # emb: stays put
+        box_t, lab_t, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().float()   # emb: stays put
         dev = emb.device
-        order = box[:, 4].sort(descending=True)[1]
-        keep, _ = self._dedup(box[order])
+        order = box_t[:, 4].sort(descending=True)[1].numpy()      # torch's order among equal scores (what the goldens were pinned with)
+        box, lab = box_t.numpy()[order], lab_t.numpy()[order]
+        keep, iou = self._dedup(box)
         kept = order[keep]                                        # one gather of the embeddings for both steps
-        box, lab, emb = box[kept], lab[kept], emb[_idx_to(dev, kept)]
-        ids = torch.full((box.shape[0],), -1, dtype=torch.long)
+        box, lab, emb = box[keep], lab[keep], emb[_rows_to(dev, kept)]
+        ids = np.full((box.shape[0],), -1, dtype=np.int64)
         if box.shape[0] and not self.empty:
             memo_ids, memo_lab, memo_emb = self.table.columns()
-            ids = self._assign(self._affinity(emb, lab, memo_emb, memo_lab), box[:, 4], memo_ids)
-        born = (ids == -1) & (box[:, 4] > self.init_score_thr)
+            ids = self._assign(self._affinity(emb, lab, memo_emb, memo_lab).numpy(), box[:, 4], memo_ids)
+        born = (ids == -1) & (box[:, 4] > np.float32(self.init_score_thr))
         k = int(born.sum())
-        ids[born] = torch.arange(self.num_tracklets, self.num_tracklets + k, dtype=torch.long)
+        ids[born] = np.arange(self.num_tracklets, self.num_tracklets + k, dtype=np.int64)
         self.num_tracklets += k
-        self._remember(ids, box, emb, lab, frame_id)
-        return box, lab, ids
+        self._remember(ids, box, emb, lab, frame_id, iou[keep][:, keep])
+        return torch.from_numpy(box), torch.from_numpy(lab), torch.from_numpy(ids)
 
-    def _remember(self, ids, box, emb, lab, frame_id):
+    def _remember(self, ids, box, emb, lab, frame_id, iou):
         """:47-102: tracked detections go to the table; the still-unmatched ones that no higher-scored detection covers
-        become this frame's backdrops; tracklets unseen for `memo_tracklet_frames` frames are forgotten"""
+        become this frame's backdrops; tracklets unseen for `memo_tracklet_frames` frames are forgotten.  `iou`: the kept
+        detections' pairwise IoU (the de-duplication's matrix restricted to them -- the same values)"""
         tracked = ids > -1
-        self.table.absorb(ids[tracked], box[tracked], emb[_idx_to(emb.device, tracked.nonzero().flatten())], lab[tracked], frame_id,
+        self.table.absorb(ids[tracked], box[tracked], emb[_rows_to(emb.device, np.flatnonzero(tracked))], lab[tracked], frame_id,
                           self.memo_momentum)
         loose = ids == -1
-        iou = bbox_overlaps(box[:, :4], box[:, :4])
-        covered = (torch.tril(iou, -1) > self.nms_backdrop_iou_thr).any(1)
+        covered = (np.tril(iou, -1) > np.float32(self.nms_backdrop_iou_thr)).any(1)
         bd = loose & ~covered
-        self.table.push_backdrop(box[bd], emb[_idx_to(emb.device, bd.nonzero().flatten())], lab[bd])
+        self.table.push_backdrop(box[bd], emb[_rows_to(emb.device, np.flatnonzero(bd))], lab[bd])
         self.table.expire(frame_id, self.memo_tracklet_frames)
 
 
@@ -317,9 +352,16 @@ class VideoAssociator:
         rois_all, ext_all = T.segment_boxes(pan_dev, int(max(s['id'] for s in segments_info)))
         sel = _h2d([i - 1 for i in seg_ids], torch.int64, dev)
         prec = E.PREC[self.track_head.precision]
+        # the extent boxes start their way to the host BEFORE the RoIAlign / track-head launches are queued, so that the read
+        # below waits for the box kernels only, not for the embeddings (which stay on the device)
+        ext_h = torch.empty((len(seg_ids), 4), dtype=torch.float32, pin_memory=True)
+        ext_h.copy_(ext_all[sel], non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
         embeds = self.track_head.forward_planes(T.roi_extract(fpn_feats, rois_all[sel].contiguous(), prec, self.strides))
-        bboxes = torch.cat([ext_all[sel], _h2d(score, torch.float32, dev)[:, None]], 1)
-        return seg_ids, (bboxes.cpu(), torch.tensor(labels, dtype=torch.int64), embeds)      # the embeddings stay on the device
+        copied.synchronize()
+        bboxes = torch.cat([ext_h, torch.tensor(score, dtype=torch.float32)[:, None]], 1)
+        return seg_ids, (bboxes, torch.tensor(labels, dtype=torch.int64), embeds)            # the embeddings stay on the device
 
     def _maps_on_device(self, pan_dev, segments_info, seg_ids, ids, to_host=True):
         """get_semantic_seg / generate_track_id_maps (:436-451) as two table look-ups on the device copy of the id map
@@ -436,7 +478,7 @@ class VideoStreamRunner:
         self.reset()
 
     def reset(self):
-        self._slots = []                 # per slot: dict(rpn, roi, x, graph, outs, stream, done)
+        self._slots = []                 # per slot: dict(rpn, roi, g = {frames per launch: dict(x, graph, outs)}, cur, stream, done)
         self._copy_stream = None
         self._inflight = None            # frame whose heads are running: (slot index)
         self._downloads = []             # [(event, host tensors, device sources)] oldest first
@@ -449,7 +491,7 @@ class VideoStreamRunner:
                 rpn, roi = self.pipe.rpn_head, self.pipe.roi_head
             else:
                 rpn, roi = self._clone_heads()
-            self._slots.append(dict(rpn=rpn, roi=roi, x=None, graph=None, outs=None, stream=torch.cuda.Stream(), done=None))
+            self._slots.append(dict(rpn=rpn, roi=roi, g={}, cur=None, stream=torch.cuda.Stream(), done=None))
         return self._slots[i]
 
     def _clone_heads(self):
@@ -470,56 +512,69 @@ class VideoStreamRunner:
     def _heads_device(self, sl, x):
         from . import engine as E
         (proposal_feats, x_feats, mask_preds, cls_scores, seg_preds, depth_feats, depth_proposal, depth_pred,
-         semantic_aspp_out) = sl["rpn"].simple_test_rpn(x, self.metas)
+         semantic_aspp_out) = sl["rpn"].simple_test_rpn(x, self.metas * x[0].shape[0])
         o = sl["roi"]._decode(x_feats, proposal_feats, mask_preds, depth_feats, depth_proposal)
         depth_init = E.upsample2x(depth_pred.float().contiguous())                         # kernel_update.py:302-307
         return o["cls"], o["mask_up"], o["depth_up"], depth_init
 
-    def _start_heads(self, i, x):
-        """copy the frame into slot i's static inputs and start its heads on the slot's stream"""
+    def _start_heads(self, i, frames):
+        """copy the frames (a list of one-frame FPN level tuples: ONE for the per-frame calls, a clip's chunk for `records`) into
+        slot i's static inputs for that many frames per launch and start its heads on the slot's stream"""
         sl = self._slot(i)
         main = torch.cuda.current_stream()
+        B = len(frames)
+        sl["cur"] = B
         if not self.use_graph:
-            sl["x"] = x
-            sl["outs"] = self._heads_device(sl, x)
+            x = frames[0] if B == 1 else tuple(torch.cat([f[l] for f in frames], 0) for l in range(len(frames[0])))
+            sl["g"][B] = dict(x=x, graph=None, outs=self._heads_device(sl, x))
             sl["done"] = torch.cuda.Event()
             sl["done"].record(main)
             return
-        if sl["graph"] is None:
-            sl["x"] = tuple(torch.empty_like(t) for t in x)
-            for d, t in zip(sl["x"], x):
-                d.copy_(t)
-            self._heads_device(sl, sl["x"])                 # warm-up outside the capture: plans, packs, kernel attributes
+        st = sl["g"].get(B)
+        if st is None:
+            st = sl["g"][B] = dict(x=tuple(t.new_empty((B,) + tuple(t.shape[1:])) for t in frames[0]), graph=None, outs=None)
+            for b, f in enumerate(frames):
+                for d, t in zip(st["x"], f):
+                    d[b:b + 1].copy_(t)
+            self._heads_device(sl, st["x"])                 # warm-up outside the capture: plans, packs, kernel attributes
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                sl["outs"] = self._heads_device(sl, sl["x"])
-            sl["graph"] = g
-        if len(x) != len(sl["x"]) or any(tuple(d.shape) != tuple(t.shape) or d.dtype != t.dtype for d, t in zip(sl["x"], x)):
-            raise ValueError("VideoStreamRunner: the FPN levels changed shape / dtype; one runner serves one stream of equally "
-                             "sized frames (call reset() to re-capture)")
-        for d, t in zip(sl["x"], x):
-            d.copy_(t, non_blocking=True)                    # on the caller's stream: x may be reused once push returns
+                st["outs"] = self._heads_device(sl, st["x"])
+            st["graph"] = g
+        for f in frames:
+            if len(f) != len(st["x"]) or any(tuple(d.shape[1:]) != tuple(t.shape[1:]) or d.dtype != t.dtype for d, t in zip(st["x"], f)):
+                raise ValueError("VideoStreamRunner: the FPN levels changed shape / dtype; one runner serves one stream of equally "
+                                 "sized frames (call reset() to re-capture)")
+        for b, f in enumerate(frames):
+            for d, t in zip(st["x"], f):
+                d[b:b + 1].copy_(t, non_blocking=True)       # on the caller's stream: the frame may be reused once push returns
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(sl["stream"]):
             sl["stream"].wait_event(ready)
-            sl["graph"].replay()
+            st["graph"].replay()
             sl["done"] = torch.cuda.Event()
             sl["done"].record(sl["stream"])
 
+    def _frame_levels(self, i, b=0):
+        """the FPN levels of frame b of slot i's current launch (views of its static inputs)"""
+        sl = self._slots[i]
+        x = sl["g"][sl["cur"]]["x"]
+        return x if sl["cur"] == 1 else tuple(t[b:b + 1] for t in x)
+
     # -- the part of a frame that follows the heads -----------------------------------------------------------------
-    def _merge(self, i):
+    def _merge(self, i, b=0):
         from . import panoptic as Pn
         sl = self._slots[i]
         torch.cuda.current_stream().wait_event(sl["done"])
-        cls, mask_up, depth_up, depth_init = sl["outs"]
-        return Pn.get_panoptic_device(sl["roi"], cls[0], mask_up[0], depth_up[0], depth_init[0], self.metas[0])
+        cls, mask_up, depth_up, depth_init = sl["g"][sl["cur"]]["outs"]
+        return Pn.get_panoptic_device(sl["roi"], cls[b], mask_up[b], depth_up[b], depth_init[b], self.metas[0])
 
     def _finish(self, i):
         """merge -> association -> start the download of frame (slot i)'s result maps"""
         pan_dev, info, _, d_final = self._merge(i)
-        sem, trk = self.pipe.assoc.step_device(self._slots[i]["x"], pan_dev, info)
+        sem, trk = self.pipe.assoc.step_device(self._frame_levels(i), pan_dev, info)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -551,12 +606,12 @@ class VideoStreamRunner:
         owned by the caller) of the frame pushed two calls ago (one call ago with pipelined=False), or None."""
         self._check(x)
         if not self.pipelined:
-            self._start_heads(0, x)
+            self._start_heads(0, [x])
             self._finish(0)
             self._n += 1
             return self._collect(self._downloads.pop(0)) if len(self._downloads) > 1 else None
         i = self._n & 1
-        self._start_heads(i, x)                              # frame t: heads on slot i's stream ...
+        self._start_heads(i, [x])                            # frame t: heads on slot i's stream ...
         if self._inflight is not None:
             self._finish(self._inflight)                     # ... while the host takes frame t - 1 through merge / association
         self._inflight = i
@@ -572,20 +627,48 @@ class VideoStreamRunner:
         self._downloads = []
         return out
 
+    def clip_batch(self, frames):
+        """frames per launch for `records`: the heads are frame independent, so a clip's frames go through neck ->
+        KernelHead -> decode TOGETHER -- at one frame per launch those kernels are latency bound and two frames cost barely more
+        than one.  Every frame's tensors must stay those of the per-frame loop bit for bit, so the batch is limited to sizes whose
+        plans pick the kernel forms (and the pooling's pixel split) of the one-frame plan, and to the grades whose KernelHead runs
+        the one-pass kernel (fp16 / bf16: a frame's GroupNorm partial sums are grouped by its own pixel slices; the two-pass kernel
+        of the fp32 / mixed grades sizes its workgroups' tile runs by the batch, which regroups the fp32 partial sums -- 1e-6
+        differences, not bit identity).  `PH_VIDEO_CLIP_BATCH=1` restores one frame per launch."""
+        import os
+        from . import _lib, engine as E
+        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "4"))
+        grade = E.KHEAD_PREC.get(getattr(self.pipe.rpn_head, "precision", None))
+        if grade not in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) or os.environ.get("PH_KHEAD_TWOPASS"):
+            return 1
+        H, W = frames[0][1].shape[-2:]                        # the decode runs at stride 8
+        ok = lambda B: E.default_nsplit(B, H * W) == E.default_nsplit(1, H * W) and (B * H >= 512) == (H >= 512)
+        for B in range(max(1, min(cap, len(frames))), 1, -1):
+            if ok(B):
+                return B
+        return 1
+
     def records(self, frames):
         """the sharded mode's per-step work for a rank's clip: `simple_test(..., records_only=True)` of every frame in order.
-        The heads of up to two frames are in flight at a time: frame k + 1's are started BEFORE frame k's merge / record, and the
-        clip's first two frames start back to back.  Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame."""
+        The clip goes through the heads in chunks of `clip_batch` frames per launch; the heads of up to two chunks are in flight
+        at a time: chunk k + 1's are started BEFORE chunk k's merges / records, and the clip's first two chunks start back to back.
+        Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame."""
         frames = list(frames)
-        out, started = [], 0
         assert self._inflight is None, "records() and push() / push_record() must not be interleaved"
+        if not frames:
+            return []
+        for f in frames:
+            self._check(f)
+        Bc = self.clip_batch(frames)
+        chunks = [frames[k:k + Bc] for k in range(0, len(frames), Bc)]
+        out, started = [], 0
         depth = 2 if self.pipelined else 1
-        for k in range(len(frames)):
-            while started < len(frames) and started < k + depth:
-                self._check(frames[started])
-                self._start_heads(started % depth, frames[started])
+        for c in range(len(chunks)):
+            while started < len(chunks) and started < c + depth:
+                self._start_heads(started % depth, chunks[started])
                 started += 1
-            out.append(self._record(k % depth))
+            for b in range(len(chunks[c])):
+                out.append(self._record(c % depth, b))
         return out
 
     def push_record(self, x):
@@ -596,10 +679,10 @@ class VideoStreamRunner:
         i = self._n & 1 if self.pipelined else 0
         prev = None
         if not self.pipelined:
-            self._start_heads(0, x)
+            self._start_heads(0, [x])
             self._n += 1
             return self._record(0)
-        self._start_heads(i, x)
+        self._start_heads(i, [x])
         if self._inflight is not None:
             prev = self._record(self._inflight)
         self._inflight = i
@@ -612,6 +695,6 @@ class VideoStreamRunner:
         i, self._inflight = self._inflight, None
         return self._record(i)
 
-    def _record(self, i):
-        pan_dev, info, _, _ = self._merge(i)
-        return self.pipe.assoc.record(self._slots[i]["x"], None, info, pan_dev)
+    def _record(self, i, b=0):
+        pan_dev, info, _, _ = self._merge(i, b)
+        return self.pipe.assoc.record(self._frame_levels(i, b), None, info, pan_dev)

@@ -315,6 +315,7 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
         nthing += int((a["track"] > 0).any())
     assert nthing > 0                                  # tracks were really assigned
     # the sharded mode's records
+    assert runner.clip_batch(frames) == 1              # fp32 grade: the two-pass KernelHead kernel is not batch invariant
     recs0 = runner.records(frames[:3])
     recs = [runner.push_record(x) for x in frames[:3]] + [runner.flush_record()]
     for (ia, ra), (ib, rb) in zip(recs0, [r for r in recs if r is not None]):
@@ -326,3 +327,34 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
         assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
         if rec_a is not None:
             assert torch.equal(rec_a[0], rec_b[0]) and torch.equal(rec_a[1], rec_b[1]) and torch.equal(rec_a[2], rec_b[2])
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_stream_runner_batches_a_clips_frames_per_launch(gpu, graph):
+    """`records()` in the grades whose heads are batch invariant (fp16: one-pass KernelHead kernel): a 5-frame clip goes through
+    neck -> KernelHead -> decode 3 + 2 frames per launch, and every frame's record (segment ids, boxes, labels, embeddings) is still
+    the per-frame loop's bit for bit; so are the head outputs themselves"""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(34)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    frames = [tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base) for f in range(5)]
+    meta = [Hh.img_meta(H8, W8)]
+    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph)
+    assert runner.clip_batch(frames) == 3 and runner.clip_batch(frames[:2]) == 2 and runner.clip_batch(frames[:1]) == 1
+    got = runner.records(frames)
+    assert sorted(runner._slots[0]["g"]) == [3] and sorted(runner._slots[1]["g"]) == [2]
+    nrec = 0
+    for x, (ids_a, rec_a) in zip(frames, got):
+        ids_b, rec_b = pipe.simple_test(x, meta, records_only=True)
+        assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
+        assert rec_a is None or all(torch.equal(u, v) for u, v in zip(rec_a, rec_b))
+        nrec += rec_a is not None
+    assert nrec > 0
+    # the batched head outputs against one frame per launch
+    xb = tuple(torch.cat([f[l] for f in frames[:3]], 0) for l in range(4))
+    ob = [t.clone() for t in runner._heads_device(runner._slots[0], xb)]
+    for b in range(3):
+        o1 = runner._heads_device(runner._slots[0], frames[b])
+        assert all(torch.equal(u[b:b + 1], v) for u, v in zip(ob, o1))
