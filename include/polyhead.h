@@ -378,6 +378,13 @@ int ph_upsample2x_bwd(const float* grad_out, float* grad_in, int64_t planes, int
  * paste   : pan = newid[ids]; depth_final = newid[ids] > 0 ? rescale(act_depth[ids]) : rescale(act_depth0).
  * from_probs != 0: act_* are already full-resolution [K][Ho][Wo] maps (no resampling) -- the integer
  * semantics in isolation. The accept loop between argmax and paste (:500-533) is host logic. */
+/* select  : the segment candidates of kernel_update.py:428-434 / :448-459 on the device, for B frames: the top max_per_img
+ *           (query, thing class) pairs of cls_scores [B][N][L] (post-sigmoid) in descending order, then the stuff queries'
+ *           own-class scores (the diagonal of the [N - num_proposals] x [L - num_thing_classes] block) in descending order;
+ *           q_idx / labels / scores [B][out_batch_stride], K = max_per_img + stuff entries each.  Ties: ascending index. */
+int ph_panoptic_select(const float* cls_scores, int64_t cls_batch_stride, int B, int N, int L, int num_proposals,
+                       int num_thing_classes, int max_per_img, int32_t* q_idx, int32_t* labels, float* scores,
+                       int64_t out_batch_stride, void* stream);
 int ph_panoptic_activate(const void* mask_up, const void* depth_up, int dtype, const float* depth_init_up,
                          const int32_t* q_idx, int K, int h2, int w2, int depth_mode /*0 sigmoid, 1 monodepth*/,
                          float* act_mask, float* act_depth, float* act_depth0, void* stream);

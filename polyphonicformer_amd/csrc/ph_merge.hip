@@ -261,6 +261,69 @@ __global__ __launch_bounds__(256) void k_pan_paste(const int* __restrict__ ids, 
     }
 }
 
+// ---- segment selection on the device (kernel_update.py:428-434, :448-459): the top max_per_img (query, thing class) pairs by score,
+// descending, then the stuff queries' own-class scores, descending -- what panoptic.select_segments computes on the host from a D2H
+// copy of the class scores.  With this kernel the merge up to the histograms has no host step, so a frame loop can queue it right
+// behind the decode (video.VideoStreamRunner captures it into the heads' HIP graph).  Rank by counting: candidate i's position is
+// the number of candidates that sort before it, ties by ascending flat index (the reference's topk / sort leave the order among
+// EQUAL scores unspecified), NaN first like torch.  One workgroup per 256 thing candidates (all keys in LDS) + one for the stuff.
+__device__ __forceinline__ uint32_t select_key(float v) {
+    if (v != v) return 0xFFFFFFFFu;
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_pan_select(const float* __restrict__ cls, int64_t cls_stride, int L, int num_proposals,
+                                                    int num_thing, int nstuff, int max_per_img, int32_t* __restrict__ q,
+                                                    int32_t* __restrict__ labels, float* __restrict__ scores, int64_t out_stride) {
+    extern __shared__ uint32_t keys[];
+    const int b = blockIdx.y, T = num_proposals * num_thing, nb_thing = (T + 255) / 256;
+    cls += (int64_t)b * cls_stride;
+    q += (int64_t)b * out_stride; labels += (int64_t)b * out_stride; scores += (int64_t)b * out_stride;
+    if ((int)blockIdx.x < nb_thing) {
+        for (int j = threadIdx.x; j < T; j += blockDim.x) keys[j] = select_key(cls[(int64_t)(j / num_thing) * L + j % num_thing]);
+        __syncthreads();
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= T) return;
+        const uint32_t ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < T; ++j) rank += (keys[j] > ki || (keys[j] == ki && j < i)) ? 1 : 0;
+        if (rank < max_per_img) {
+            q[rank] = i / num_thing;
+            labels[rank] = i % num_thing;
+            scores[rank] = cls[(int64_t)(i / num_thing) * L + i % num_thing];
+        }
+    } else {
+        for (int j = threadIdx.x; j < nstuff; j += blockDim.x) keys[j] = select_key(cls[(int64_t)(num_proposals + j) * L + num_thing + j]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nstuff; i += blockDim.x) {
+            const uint32_t ki = keys[i];
+            int rank = 0;
+            for (int j = 0; j < nstuff; ++j) rank += (keys[j] > ki || (keys[j] == ki && j < i)) ? 1 : 0;
+            q[max_per_img + rank] = num_proposals + i;
+            labels[max_per_img + rank] = num_thing + i;
+            scores[max_per_img + rank] = cls[(int64_t)(num_proposals + i) * L + num_thing + i];
+        }
+    }
+}
+
+extern "C" int ph_panoptic_select(const float* cls_scores, int64_t cls_batch_stride, int B, int N, int L, int num_proposals,
+                                  int num_thing_classes, int max_per_img, int32_t* q_idx, int32_t* labels, float* scores,
+                                  int64_t out_batch_stride, void* stream) {
+    PH_CHECK_ARG(cls_scores && q_idx && labels && scores && B > 0, "null pointer or empty batch");
+    PH_CHECK_ARG(num_proposals > 0 && num_proposals <= N && num_thing_classes > 0 && num_thing_classes <= L, "bad head geometry");
+    const int T = num_proposals * num_thing_classes;
+    const int nstuff = (N - num_proposals) < (L - num_thing_classes) ? (N - num_proposals) : (L - num_thing_classes);   // the diagonal
+    PH_CHECK_ARG(max_per_img > 0 && max_per_img <= T && T <= 16384 && nstuff >= 0 && nstuff <= 16384, "max_per_img / candidates out of range");
+    PH_CHECK_ARG(out_batch_stride >= max_per_img + nstuff, "output stride too small");
+    const int nb_thing = (T + 255) / 256;
+    const size_t lds = (size_t)(T > nstuff ? T : nstuff) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_pan_select, dim3(nb_thing + (nstuff > 0 ? 1 : 0), B), dim3(256), lds, (hipStream_t)stream, cls_scores,
+                       cls_batch_stride, L, num_proposals, num_thing_classes, nstuff, max_per_img, q_idx, labels, scores, out_batch_stride);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
 static int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));

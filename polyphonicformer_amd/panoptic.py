@@ -153,3 +153,80 @@ def get_panoptic_device(head, cls_scores, mask_preds, depth_preds, depth_init, i
     """the same with the three result maps left on the DEVICE (int32 ids, fp32 depth_basic, depth_final) for callers that
     go on working there -- the video association step needs the id map on the GPU, not on the host"""
     return merge_on_device(*_activated(head, cls_scores, mask_preds, depth_preds, depth_init, img_meta))
+
+
+class DeviceMerge:
+    """The merge's device half for B frames of one head with NO host step up to the two pixel histograms: candidate selection
+    (`ph_panoptic_select` instead of a D2H of the class scores + torch.topk on the host), activation and argmax are queued behind
+    the decode -- `begin` is pure kernel launches on static buffers, so `video.VideoStreamRunner` captures it into the heads' HIP
+    graph and the merge's first 0.25 ms of device work run on the heads' stream, under the previous frame's host path.  One small
+    D2H (`download`: candidates + histograms, 5 K ints per frame) feeds `finish` = accept loop (host, as in the reference) + paste.
+    Same kernels and the same values as `get_panoptic_device`; the candidate ORDER among exactly equal scores is by ascending index
+    here and whatever torch.topk / torch.sort give there (unspecified in the reference too)."""
+
+    def __init__(self, head, cls_scores, mask_preds, depth_preds, depth_init, img_meta):
+        if not head.merge_joint:
+            raise NotImplementedError               # as the reference (:467-468)
+        self.head, dev = head, mask_preds.device
+        B, N, L = cls_scores.shape
+        _, _, h2, w2 = mask_preds.shape
+        cfg = head.test_cfg
+        self.B, self.N, self.L, self.h2, self.w2 = B, N, L, h2, w2
+        self.K = K = cfg.max_per_img + min(N - head.num_proposals, L - head.num_thing_classes)
+        codes = {torch.float32: _lib.PH_OUT_F32, torch.bfloat16: _lib.PH_OUT_BF16, torch.float16: _lib.PH_OUT_F16}
+        if mask_preds.dtype != depth_preds.dtype or mask_preds.dtype not in codes:
+            raise _lib.PolyheadError("mask/depth logits must both be fp32, both bf16 or both fp16")
+        self.dt = codes[mask_preds.dtype]
+        self.mode = DEPTH_MODES[head.mask_head[-1].depth_act_mode]
+        self.geom, self.out_hw = _geom((h2, w2), img_meta)
+        Ho, Wo = self.out_hw
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self.pack = e((B, 5 * K), torch.int32)              # per frame: q | labels | scores (fp32 bits) | counts [2][K]
+        self.host = torch.empty((B, 5 * K), dtype=torch.int32, pin_memory=True)
+        self.act_mask, self.act_depth = e((B, K, h2, w2), torch.float32), e((B, K, h2, w2), torch.float32)
+        self.act_d0, self.ids = e((B, h2, w2), torch.float32), e((B, Ho, Wo), torch.int32)
+        self._keep = None
+
+    def begin(self, cls_scores, mask_preds, depth_preds, depth_init):
+        """cls_scores [B,N,L] (post-sigmoid), mask_preds / depth_preds [B,N,2H,2W] logits, depth_init [B,1,2H,2W]: launches only"""
+        lib, K, s = _lib.load(), self.K, _lib.stream_ptr
+        cls = cls_scores.detach().float().contiguous()
+        m, d, d0 = mask_preds.contiguous(), depth_preds.contiguous(), depth_init.float().contiguous()
+        self._keep = (cls, m, d, d0)                        # alive until the launches have run (static under graph capture)
+        i32 = lambda t, off: C.c_void_p(t.data_ptr() + 4 * off)
+        _lib.check(lib.ph_panoptic_select(_lib.ptr(cls), self.N * self.L, self.B, self.N, self.L, self.head.num_proposals,
+                                          self.head.num_thing_classes, self.head.test_cfg.max_per_img, i32(self.pack, 0), i32(self.pack, K),
+                                          i32(self.pack, 2 * K), 5 * K, s()), "ph_panoptic_select")
+        esz = m.element_size()
+        plane = self.N * self.h2 * self.w2
+        for b in range(self.B):
+            row = b * 5 * K
+            _lib.check(lib.ph_panoptic_activate(C.c_void_p(m.data_ptr() + b * plane * esz), C.c_void_p(d.data_ptr() + b * plane * esz), self.dt,
+                                                _lib.ptr(d0[b]), i32(self.pack, row), K, self.h2, self.w2, self.mode, _lib.ptr(self.act_mask[b]),
+                                                _lib.ptr(self.act_depth[b]), _lib.ptr(self.act_d0[b]), s()), "ph_panoptic_activate")
+            _lib.check(lib.ph_panoptic_argmax(_lib.ptr(self.act_mask[b]), i32(self.pack, row + 2 * K), K, self.geom, 0, _lib.ptr(self.ids[b]),
+                                              i32(self.pack, row + 3 * K), s()), "ph_panoptic_argmax")
+
+    def download(self):
+        """candidates + histograms to pinned host memory, asynchronously on the current stream (not part of a captured graph)"""
+        self.host.copy_(self.pack, non_blocking=True)
+
+    def finish(self, b=0):
+        """frame b, after the caller has synchronised with `download`: accept loop -> paste.  Returns what `merge_on_device` returns"""
+        lib, K, dev = _lib.load(), self.K, self.pack.device
+        h = self.host[b].numpy()
+        scores = torch.from_numpy(h[2 * K:3 * K].view(np.float32).copy())
+        labels = torch.from_numpy(h[K:2 * K].astype(np.int64))
+        cnt = h[3 * K:].reshape(2, K)
+        merge_cfg = self.head.test_cfg.merge_stuff_thing
+        newid, info = accept_loop(scores, labels, cnt[0], cnt[1], self.head.num_thing_classes, merge_cfg.instance_score_thr,
+                                  merge_cfg.overlap_thr)
+        nid = torch.from_numpy(newid).pin_memory().to(dev, non_blocking=True)
+        Ho, Wo = self.out_hw
+        pan = torch.empty((Ho, Wo), dtype=torch.int32, device=dev)
+        d_basic = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
+        d_final = torch.empty((Ho, Wo), dtype=torch.float32, device=dev)
+        _lib.check(lib.ph_panoptic_paste(_lib.ptr(self.ids[b]), _lib.ptr(nid), _lib.ptr(self.act_depth[b]), _lib.ptr(self.act_d0[b]), self.geom,
+                                         0, _lib.ptr(pan), _lib.ptr(d_basic), _lib.ptr(d_final), _lib.stream_ptr()), "ph_panoptic_paste")
+        return pan, info, d_basic, d_final
+

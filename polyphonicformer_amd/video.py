@@ -473,8 +473,12 @@ class VideoStreamRunner:
     results still in flight, oldest first.  `pipelined=False`: one slot, results one frame late (round 4's first form).
     Weights are packed at capture time: call `reset()` after changing them."""
 
-    def __init__(self, pipe, img_meta, graph=True, pipelined=True):
+    def __init__(self, pipe, img_meta, graph=True, pipelined=True, device_select=None):
+        import os
         self.pipe, self.metas, self.use_graph, self.pipelined = pipe, [img_meta], graph, pipelined
+        # the merge's candidate selection + activation + argmax queued behind the decode on the heads' stream (panoptic.DeviceMerge),
+        # inside the graph; False = the module API's form (class scores to the host, torch.topk there)
+        self.device_select = (not os.environ.get("PH_VIDEO_HOST_SELECT")) if device_select is None else device_select
         self.reset()
 
     def reset(self):
@@ -524,23 +528,35 @@ class VideoStreamRunner:
         main = torch.cuda.current_stream()
         B = len(frames)
         sl["cur"] = B
+        from . import panoptic as Pn
         if not self.use_graph:
             x = frames[0] if B == 1 else tuple(torch.cat([f[l] for f in frames], 0) for l in range(len(frames[0])))
-            sl["g"][B] = dict(x=x, graph=None, outs=self._heads_device(sl, x))
+            outs = self._heads_device(sl, x)
+            dm = (sl["g"].get(B) or {}).get("dm")
+            if self.device_select:
+                dm = dm or Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
+                dm.begin(*outs)
+                dm.download()
+            sl["g"][B] = dict(x=x, graph=None, outs=outs, dm=dm)
             sl["done"] = torch.cuda.Event()
             sl["done"].record(main)
             return
         st = sl["g"].get(B)
         if st is None:
-            st = sl["g"][B] = dict(x=tuple(t.new_empty((B,) + tuple(t.shape[1:])) for t in frames[0]), graph=None, outs=None)
+            st = sl["g"][B] = dict(x=tuple(t.new_empty((B,) + tuple(t.shape[1:])) for t in frames[0]), graph=None, outs=None, dm=None)
             for b, f in enumerate(frames):
                 for d, t in zip(st["x"], f):
                     d[b:b + 1].copy_(t)
-            self._heads_device(sl, st["x"])                 # warm-up outside the capture: plans, packs, kernel attributes
+            outs = self._heads_device(sl, st["x"])          # warm-up outside the capture: plans, packs, kernel attributes
+            if self.device_select:
+                st["dm"] = Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
+                st["dm"].begin(*outs)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 st["outs"] = self._heads_device(sl, st["x"])
+                if st["dm"] is not None:
+                    st["dm"].begin(*st["outs"])
             st["graph"] = g
         for f in frames:
             if len(f) != len(st["x"]) or any(tuple(d.shape[1:]) != tuple(t.shape[1:]) or d.dtype != t.dtype for d, t in zip(st["x"], f)):
@@ -554,6 +570,8 @@ class VideoStreamRunner:
         with torch.cuda.stream(sl["stream"]):
             sl["stream"].wait_event(ready)
             st["graph"].replay()
+            if st["dm"] is not None:
+                st["dm"].download()
             sl["done"] = torch.cuda.Event()
             sl["done"].record(sl["stream"])
 
@@ -568,7 +586,11 @@ class VideoStreamRunner:
         from . import panoptic as Pn
         sl = self._slots[i]
         torch.cuda.current_stream().wait_event(sl["done"])
-        cls, mask_up, depth_up, depth_init = sl["g"][sl["cur"]]["outs"]
+        st = sl["g"][sl["cur"]]
+        if st["dm"] is not None:
+            sl["done"].synchronize()                         # candidates + histograms are in pinned memory
+            return st["dm"].finish(b)
+        cls, mask_up, depth_up, depth_init = st["outs"]
         return Pn.get_panoptic_device(sl["roi"], cls[b], mask_up[b], depth_up[b], depth_init[b], self.metas[0])
 
     def _finish(self, i):

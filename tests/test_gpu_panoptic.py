@@ -117,6 +117,42 @@ def test_argmax_x4_form_equals_the_generic_kernel(gpu, shape, monkeypatch):
     assert int(outs[0][1][0].sum()) == Ho * Wo and int(outs[0][0].min()) >= 0
 
 
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_device_select_and_device_merge_equal_the_host_form(gpu, case):
+    """ph_panoptic_select = panoptic.select_segments (torch.topk / sort on the host) on the golden class scores, for a batch of two
+    frames; panoptic.DeviceMerge (select -> activate -> argmax with no host step, then accept + paste) = get_panoptic_device:
+    ids, segment lists and depth maps identical"""
+    from polyphonicformer_amd import _lib
+    z = _golden(case)
+    cls, m_up, d_up, d0_up, meta = _case(z, case)
+    # (the fixtures hold exactly equal scores, whose order torch.topk / sort leave open: a small ramp breaks the ties for this test)
+    cls = (cls.double() * 0.98 + 1e-6 * torch.arange(cls.numel(), dtype=torch.float64).reshape(cls.shape)).float()
+    cls2 = torch.stack([cls, cls.flip(0).roll(3, 1) * 0.5 + 0.25 * cls])               # a second, different frame
+    N, L = cls.shape
+    K = CFG["Nq"] + min(N - CFG["Nq"], L - CFG["n_thing"])
+    lib = _lib.load()
+    out = torch.full((2, 3, K), -1, dtype=torch.int32, device=gpu)
+    c = cls2.to(gpu).contiguous()
+    i32 = lambda off: Pn.C.c_void_p(out.data_ptr() + 4 * off)
+    _lib.check(lib.ph_panoptic_select(_lib.ptr(c), N * L, 2, N, L, CFG["Nq"], CFG["n_thing"], CFG["Nq"], i32(0), i32(K), i32(2 * K), 3 * K,
+                                      _lib.stream_ptr()), "select")
+    o = out.cpu()
+    for b in range(2):
+        q, lab, sc = Pn.select_segments(cls2[b], CFG["Nq"], CFG["n_thing"], CFG["Nq"])
+        assert len(q) == K and len(set(sc.tolist())) == K                              # no exact ties in the fixture
+        assert torch.equal(o[b, 0].long(), q) and torch.equal(o[b, 1].long(), lab) and torch.equal(o[b, 2].view(torch.float32), sc)
+    # the whole merge, two frames per launch
+    mm, dd, d0 = (torch.stack([t, t.flip(-1)]).to(gpu) for t in (m_up, d_up, d0_up))
+    dm = Pn.DeviceMerge(_Head, c, mm, dd, d0, meta)
+    dm.begin(c, mm, dd, d0)
+    dm.download()
+    torch.cuda.synchronize()
+    for b in range(2):
+        pan, info, d_basic, d_final = dm.finish(b)
+        pan2, info2, d_basic2, d_final2 = Pn.get_panoptic_device(_Head, c[b], mm[b], dd[b], d0[b], meta)
+        assert torch.equal(pan, pan2) and info == info2 and torch.equal(d_basic, d_basic2) and torch.equal(d_final, d_final2)
+
+
 def test_simple_test_whole_path_golden(gpu):
     """KernelHead.simple_test_rpn -> KernelUpdateIterHead.simple_test exactly as Polyphonic.simple_test
     (polyphonic_former.py:145-161) against the reference's golden panoptic outputs."""

@@ -284,8 +284,8 @@ def test_affinity_beyond_the_fused_kernels_limits(gpu):
         assert not a.is_cuda and a.shape == (n, m) and torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("graph,pipelined", [(True, True), (True, False), (False, True)])
-def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
+@pytest.mark.parametrize("graph,pipelined,device_select", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined, device_select):
     """video.VideoStreamRunner (round 4: heads from one HIP graph per slot, two slots so that frame t's heads run under frame
     t - 1's merge / association, id map kept on the device, result maps downloaded on a side stream) against
     `VideoFramePipeline.simple_test` frame by frame on a 5-frame clip at cfg3's full size: semantic, track-id and depth maps
@@ -300,7 +300,7 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined):
     pipe.init_tracker()
     want = [pipe.simple_test(x, meta)[0] for x in frames]
     pipe.init_tracker()
-    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph, pipelined=pipelined)
+    runner = V.VideoStreamRunner(pipe, meta[0], graph=graph, pipelined=pipelined, device_select=device_select)
     got = []
     for x in frames:
         r = runner.push(tuple(t.clone() for t in x))
