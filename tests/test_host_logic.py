@@ -179,6 +179,19 @@ def test_accept_loop_matches_reference_segments(case):
     assert np.array_equal(pan, z[f"{case}_pan"])
 
 
+def test_accept_loop_compares_the_score_threshold_in_double_precision():
+    """kernel_update.py:503 tests `total_scores[k].item() < instance_score_thr`: the fp32 score widened to a Python float against
+    the threshold as written -- a thing whose score is fp32(0.7) = 0.69999998... is BELOW 0.7 and rejected; rounding the threshold to
+    fp32 first (what numpy does with a float32 array and a Python scalar) would keep it"""
+    from polyphonicformer_amd import panoptic as Pn
+    sc = torch.tensor([0.9, 0.7, 0.7, 0.5], dtype=torch.float32)               # 0.7 -> 0.699999988 in fp32
+    lab = torch.tensor([0, 1, 9, 2])                                            # index 2 is stuff (>= 8 thing classes): not thresholded
+    newid, info = Pn.accept_loop(sc, lab, np.array([10, 10, 10, 10]), np.array([10, 10, 10, 10]), 8, 0.7, 0.5)
+    assert newid.tolist() == [1, 0, 2, 0] and [s["category_id"] for s in info] == [0, 9]
+    newid, _ = Pn.accept_loop(sc, lab, np.array([10, 10, 10, 10]), np.array([10, 10, 10, 10]), 8, float(np.float32(0.7)), 0.5)
+    assert newid.tolist() == [1, 2, 3, 0]                                       # threshold = the fp32 value itself: not below it
+
+
 def test_fp16_config_key_switches_both_heads():
     """the reference's only mixed-precision hook is the config's `fp16` key (tools/test.py:202-204: wrap_fp16_model): heads
     built from a detector config that carries it run at their fp16 grades, without it at the parity grade"""

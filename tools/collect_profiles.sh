@@ -6,7 +6,10 @@ TAG=${1:-run}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 if [ "${ALL_LEGS:-1}" = 1 ]; then python bench.py --all-legs > $OUT/bench_all_legs.json 2> $OUT/bench_all_legs.err; fi
-python bench.py --workload cfg4 --steps 10 --warmup 2 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
+python bench.py --workload cfg4 --steps 40 --warmup 4 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
+python bench.py --workload cfg4 --steps 40 --warmup 4 --clip-frames 8 > $OUT/bench_cfg4_clip8.json 2> $OUT/bench_cfg4_clip8.err
+python tools/video_trace.py 96 > $OUT/v_video_runner_time.txt 2> $OUT/v_video.err; python tools/video_trace.py 96 seq >> $OUT/v_video_runner_time.txt 2>> $OUT/v_video.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/v -o v -- python tools/video_trace.py 48 seq > $OUT/v_video_one_slot_traced.txt 2>> $OUT/v_video.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -o d -- python bench.py --no-cpu-baseline --no-kernel-head --no-neck > $OUT/d_bench.json 2> $OUT/d.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py --streams 1 --frames 24 --no-cpu-baseline --no-kernel-head --no-neck > $OUT/e_bench.json 2> $OUT/e.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q -o q -- python tools/query_time.py 64 > $OUT/q_query64.txt 2> $OUT/q.err
