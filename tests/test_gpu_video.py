@@ -24,6 +24,25 @@ def test_segment_boxes_golden(gpu):
     assert rois2[-1].abs().sum() == 0 and ext2[-1].tolist() == [-1.0, -1.0, 10.0, 10.0]
 
 
+@pytest.mark.parametrize("shape", [(96, 160), (61, 157), (33, 8), (40, 1000)])
+def test_segment_boxes_vs_oracle_both_run_lengths(gpu, shape):
+    """the statistics kernels take 8 consecutive pixels per thread when the width allows it and one otherwise; both against the
+    oracle's per-mask boxes on blobs, single pixels, segments that touch every border and ids that do not occur"""
+    H, W = shape
+    pan, info, _, _ = Hh.video_case(seed=H + W, H=H, W=W, nseg=12)
+    pan[0, :] = 13                                       # a one-row segment across the whole width (all of it complete runs)
+    pan[-1, -1] = 14                                     # a single pixel in the last run
+    pan[:, 0] = 15                                       # a one-column segment: every run it touches is mixed
+    nseg = 17                                            # 16 and 17 do not occur
+    masks = torch.stack([torch.from_numpy(pan == s) for s in range(1, nseg + 1)])
+    rois, ext = T.segment_boxes(torch.from_numpy(pan).to(gpu), nseg)
+    occ = masks.flatten(1).any(1)
+    ref_rois, ref_ext = VO.mask_stat_boxes(masks[occ]).clamp(min=0), VO.mask_extent_boxes(masks[occ])      # RoIs are clamped at 0
+    assert torch.allclose(rois.cpu()[occ][:, 1:], ref_rois.float(), atol=2e-3), float((rois.cpu()[occ][:, 1:] - ref_rois).abs().max())
+    assert torch.equal(ext.cpu()[occ], ref_ext.float())
+    assert rois.cpu()[~occ].abs().sum() == 0 and ext.cpu()[~occ].tolist() == [[-1.0, -1.0, 10.0, 10.0]] * int((~occ).sum())
+
+
 @pytest.mark.parametrize("prec", [_lib.PH_PREC_SPLIT, _lib.PH_PREC_BF16])
 def test_roi_align_fpn_vs_oracle(gpu, prec):
     # a 960 x 1600 image: boxes from 30 px to 900 px so that all four FPN levels are used, some touching the borders
