@@ -455,6 +455,20 @@ int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, f
 int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B, void* stream);
 int ph_gn_sum_planes(const float* const* ys, const float* const* stats, const float* const* gammas, const float* const* betas,
                      int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec, void* stream);
+/* ph_gn_sum_cplanes: ph_gn_sum_planes with the result as CHANNEL planes [P][B][256][HWp] (zero in [HW, HWp)), the input format of
+ * ph_neck_out_convs: conv_pred + the two aux convs (semantic_fpn.py:156-178,223-231; each 1x1 conv + GN + ReLU of the level sum)
+ * in two passes over that sum -- statistics by recomputation, then normalise + ReLU + store -- without an fp32 conv output in
+ * memory.  in_channels_last != 0: the sum is ph_gn_sum_planes' [P][B][HW][256] instead (a 64-pixel tile is 32 KiB of consecutive
+ * bytes and its B fragments are plain 16-byte LDS reads: no transposition anywhere -- the form NeckPlan uses).
+ * wplanes: 16-bit planes [P][3][256][256] (out, in) of the three conv weights; gn_affine fp32 [3][2][256];
+ * out_planes_m: 16-bit planes [P][B][256][HWp] and / or out_f32_m: fp32 NCHW [B][256][HW], at least one per map;
+ * workspace: ph_khead_workspace_bytes(B, HW, groups). */
+int ph_gn_sum_cplanes(const float* const* ys, const float* const* stats, const float* const* gammas, const float* const* betas,
+                      int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec, void* stream);
+int ph_neck_out_convs(const uint16_t* in_planes, int in_channels_last, const uint16_t* wplanes, const float* gn_affine, int groups,
+                      float eps, uint16_t* out_planes0, uint16_t* out_planes1, uint16_t* out_planes2, float* out_f32_0,
+                      float* out_f32_1, float* out_f32_2, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec,
+                      void* stream);
 int ph_gn_apply(const float* y, const float* stats /* nullable */, const float* gamma, const float* beta, int groups, int mode,
                 int accumulate, uint16_t* planes /* nullable */, float* outf /* nullable */, int B, int H, int W, int prec,
                 void* stream);

@@ -81,7 +81,9 @@ template <int E> __device__ __forceinline__ uint32_t f2e_pk(float a, float b) { 
 // upsample's 965 MB of output per launch went from 5.4 to 6.9 TB/s with them (stores no longer allocate in L2 / MALL)
 // cache policy of the LDS-DMA feature streams (aux operand of global_load_lds on gfx950: 1 = sc0, 2 = nt, 16 = sc1):
 // nt | sc1 measured pool 197 -> 181 us, dynconv bits 102 -> 94 us against the default policy; sc1 alone is slower
+#ifndef PH_CPOL_STREAM      // -DPH_CPOL_STREAM=0: default policy (tools/mall_probe.py)
 #define PH_CPOL_STREAM 18
+#endif
 typedef unsigned ph_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_nt16(void* p, uint4 v) { __builtin_nontemporal_store(ph_u32x4{v.x, v.y, v.z, v.w}, (ph_u32x4*)p); }
 __device__ __forceinline__ void st_nt16(void* p, float4 v) {

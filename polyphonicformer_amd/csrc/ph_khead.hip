@@ -133,6 +133,36 @@ __device__ __forceinline__ void kh_store_tile_planes(const uint4 (&q)[PA][4], ui
         for (int it = 0; it < 4; ++it)
             *(uint4*)(lds + p * 256 * KH_LDT + (it * 64 + (tid >> 3)) * KH_LDT + (tid & 7) * 8) = q[p][it];
 }
+// INFMT 3 -- ONE input in channels-last planes [PA][B][HW][256] (the neck's level sum, ph_gn_sum_planes): a tile of 64 pixels is
+// 32 KiB of consecutive bytes per plane (4 x 16 bytes per thread, fully coalesced), kept in LDS as [64 px][256 + 8] so that the
+// B fragment of a k-step -- 8 consecutive channels of one pixel per lane -- is ONE ds_read_b128 (16 lanes of a group on 16
+// distinct 16-byte slots: pixel pitch 132 dwords), no transposing read.  Pixels past the map are zero.
+constexpr int KH_NLDP = 256 + 8;
+template <int PA>
+__device__ __forceinline__ void kh_load_tile_nhwc(uint4 (&q)[PA][4], const uint16_t* __restrict__ planes, int64_t iplane,
+                                                  int64_t HW, int64_t px0, int tid, bool more) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * KH_THREADS;
+        const int64_t px = px0 + (idx >> 5);
+        const bool ok = more && px < HW;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            q[p][it] = make_uint4(0, 0, 0, 0);
+            if (ok) q[p][it] = ld_nt16(planes + p * iplane + px * 256 + (idx & 31) * 8);
+        }
+    }
+}
+template <int PA>
+__device__ __forceinline__ void kh_store_tile_nhwc(const uint4 (&q)[PA][4], uint16_t* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * KH_THREADS;
+            *(uint4*)(lds + p * 256 * KH_LDT + (idx >> 5) * KH_NLDP + (idx & 31) * 8) = q[p][it];
+        }
+}
 // staging registers of one tile in either input format
 template <int PA, int INFMT, int E> struct KhStage {
     float v[8][4];
@@ -149,6 +179,14 @@ template <int PA, int E> struct KhStage<PA, 2, E> {
     __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t, int64_t) const { kh_store_tile_planes<PA>(q, lds, tid); }
 };
 
+template <int PA, int E> struct KhStage<PA, 3, E> {
+    uint4 q[PA][4];
+    __device__ __forceinline__ void load(const KHArgs& a, int m, int b, int64_t px0, int tid, bool more) {
+        kh_load_tile_nhwc<PA>(q, a.fp[m] + (int64_t)b * a.HW * 256, (int64_t)a.B * a.HW * 256, a.HW, px0, tid, more);
+    }
+    __device__ __forceinline__ void store(uint16_t* lds, int tid, int64_t, int64_t) const { kh_store_tile_nhwc<PA>(q, lds, tid); }
+};
+
 template <int PA>
 __device__ __forceinline__ void kh_load_a(uint4 (&af)[PA][16], const uint16_t* __restrict__ w, int64_t w_plane, int wave,
                                           int lane) {
@@ -161,7 +199,8 @@ __device__ __forceinline__ void kh_load_a(uint4 (&af)[PA][16], const uint16_t* _
 }
 
 // acc[32 rows of A][32 px of column tile ct] over K = 256 channels of the LDS tile
-template <int PA, int E>
+// NH: the tile is the channels-last image [64 px][KH_NLDP] (INFMT 3) instead of [256 c][KH_LDT]
+template <int PA, int E, bool NH = false>
 __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uint16_t* lds, int ct, int lane) {
     const int g = lane >> 5, i16 = lane & 15, gi = (lane >> 4) & 1;
     f32x16_t acc;
@@ -172,6 +211,10 @@ __device__ __forceinline__ f32x16_t kh_gemm(const uint4 (&af)[PA][16], const uin
         uint4 bf[PA];
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
+            if constexpr (NH) {
+                bf[p] = *(const uint4*)(lds + p * 256 * KH_LDT + (ct * 32 + (lane & 31)) * KH_NLDP + ks * 16 + g * 8);
+                continue;
+            }
             const uint16_t* a0 = lds + p * 256 * KH_LDT + (ks * 16 + g * 8 + (i16 >> 2)) * KH_LDT + ct * 32 + gi * 16 + (i16 & 3) * 4;
             const uint2 lo = lds_read_tr16(a0);
             const uint2 hi = lds_read_tr16(a0 + 4 * KH_LDT);
@@ -211,7 +254,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
         stg.load(a, m, b, (int64_t)(t + 1) * KH_T, tid, t + 1 < t1);   // in flight during the MFMAs
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x16_t acc = kh_gemm<PA, E>(af, lds, ct, lane);
+            const f32x16_t acc = kh_gemm<PA, E, INFMT == 3>(af, lds, ct, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s1[r] += acc[r]; s2[r] += acc[r] * acc[r]; }
         }
@@ -379,7 +422,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
         float vals[2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const f32x16_t acc = kh_gemm<PA, E>(af, lds, ct, lane);
+            const f32x16_t acc = kh_gemm<PA, E, INFMT == 3>(af, lds, ct, lane);
             const int64_t px = px0 + ct * 32 + (lane & 31);
             const bool inside = px < a.HW;
 #pragma unroll
@@ -557,10 +600,11 @@ struct KhFused {                  // the static 1x1 convs of the fused entry poi
     const unsigned* run_if;       // optional device predicate of every launch
 };
 
+// f32o (nullable): plain mode -- three independent maps (no x = sem + loc), fp32 NCHW output f32o[m] of every map that has one
 static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplanes, const float* gn_affine, int groups, float eps,
                   uint16_t* const outp[3], const uint16_t* add1, uint16_t* sum1, float* x_f32, float* dfe_f32,
                   const KhFused* fu, void* workspace, size_t workspace_bytes, int B, int64_t HW, int prec, void* stream,
-                  const char* fn) {
+                  const char* fn, float* const* f32o = nullptr) {
     if (!(B > 0 && HW > 0 && groups > 0 && 256 % groups == 0)) { ph_set_error("%s: bad size", fn); return PH_EINVAL; }
     if (!(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16)) {
         ph_set_error("%s: prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16", fn);
@@ -589,7 +633,9 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
             KH_ALL(0), KH_ALL(1), KH_ALL(2),
 #define KH_F16(F) (const void*)k_khead_stats<1, F, PH_E_F16>, (const void*)k_khead_apply<1, 0, F, PH_E_F16>, \
     (const void*)k_khead_apply<1, 1, F, PH_E_F16>, (const void*)k_khead_apply<1, 2, F, PH_E_F16>
-            KH_F16(0), KH_F16(1), KH_F16(2)
+            KH_F16(0), KH_F16(1), KH_F16(2),
+            (const void*)k_khead_stats<1, 3>, (const void*)k_khead_stats<2, 3>, (const void*)k_khead_stats<1, 3, PH_E_F16>,
+            (const void*)k_khead_apply<1, 0, 3>, (const void*)k_khead_apply<2, 0, 3>, (const void*)k_khead_apply<1, 0, 3, PH_E_F16>
 #undef KH_F16
 #undef KH_ALL
         };
@@ -609,7 +655,8 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
         a.w[m] = wplanes + (size_t)m * 256 * 256;
         a.partial[m] = partial + (size_t)m * B * nwg * 256 * 2;
     }
-    const int fmt = in_planes ? 2 : ((HW % 4) == 0 ? 1 : 0);      // kernel input format: fp32 scalar / fp32 x4 / bf16 planes
+    const int fmt = in_planes == 2 ? 3 : in_planes ? 2 : ((HW % 4) == 0 ? 1 : 0);      // kernel input format: fp32 scalar / fp32 x4 / channel planes / channels-last planes
+    if (fmt == 3 && !f32o) { ph_set_error("%s: channels-last input only in plain mode", fn); return PH_EINVAL; }
 #define KH_LAUNCH(K, G, L, ...)                                                                      \
     do {                                                                                             \
         if (f16 && fmt == 0) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 0, PH_E_F16>), G, block, L, s, a);      \
@@ -622,8 +669,16 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
         else if (fmt == 1) hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 1>), G, block, L, s, a);          \
         else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 2>), G, block, L, s, a);                        \
     } while (0)
+    // channels-last input (plain mode only: the neck's output convs): its own two instantiations per grade
+#define KH_LAUNCH3(K, G, L, ...)                                                                          \
+    do {                                                                                                  \
+        if (f16) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 3, PH_E_F16>), G, block, L, s, a);               \
+        else if (PA == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__, 3>), G, block, L, s, a);                \
+        else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 3>), G, block, L, s, a);                             \
+    } while (0)
     // pass 1: the three maps in one launch, then one finalize over the 3 * B (map, frame) pairs
-    KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
+    if (fmt == 3) KH_LAUNCH3(k_khead_stats, dim3(nwg, B, 3), lds);
+    else KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
     hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps, a.run_if);
     // pass 2: loc ; sem (+ x = sem + loc, loc read back from the planes the first launch wrote) ; depth
     for (int m = 0; m < 3; ++m) {
@@ -640,6 +695,7 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
         a.f32_sum = m == 1 ? x_f32 : nullptr;
         a.w2 = nullptr; a.out2b = nullptr; a.blocks_out = nullptr; a.blocks_in = nullptr;
         int add = m == 1 ? 1 : 0;
+        if (f32o) { a.add_planes = nullptr; a.sum_planes = nullptr; a.f32_sum = nullptr; a.f32 = f32o[m]; add = 0; }
         if (fu) {
             a.w2 = fu->w2[m];
             a.m2_tiles = (fu->n2[m] + 31) / 32;
@@ -665,11 +721,13 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
         }
         a.w2_lds = (PA == 1 && a.w2 && lds_apply + (size_t)a.m2_tiles * 16 * 1024 <= 160 * 1024) ? 1 : 0;
         const size_t lds_m = lds_apply + (a.w2_lds ? (size_t)a.m2_tiles * 16 * 1024 : 0);
-        if (add == 2) KH_LAUNCH(k_khead_apply, grid, lds_m, 2);
+        if (fmt == 3) KH_LAUNCH3(k_khead_apply, grid, lds_m, 0);
+        else if (add == 2) KH_LAUNCH(k_khead_apply, grid, lds_m, 2);
         else if (add == 1) KH_LAUNCH(k_khead_apply, grid, lds_m, 1);
         else KH_LAUNCH(k_khead_apply, grid, lds_m, 0);
     }
 #undef KH_LAUNCH
+#undef KH_LAUNCH3
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -685,6 +743,23 @@ extern "C" int ph_khead_conv_gn(const float* f0, const float* f1, const float* f
     uint16_t* outp[3] = {loc_planes, sem_planes, dfe_planes};
     return kh_run(fm, 0, wplanes, gn_affine, groups, eps, outp, loc_planes, x_planes, x_f32, dfe_f32, nullptr, workspace,
                   workspace_bytes, B, HW, prec, stream, __func__);
+}
+
+// The three output convs of the neck (SemanticFPNWrapper conv_pred + 2 aux convs, semantic_fpn.py:156-178,223-231: each a
+// 1x1 conv + GroupNorm + ReLU of the SAME level sum) with the two passes above: statistics from a recompute pass, then
+// normalise + ReLU + store.  Against k_conv_nhwc + k_gn_finalize + k_gn_apply per map (fp32 NHWC conv output written, read
+// back, converted) each map moves 16.8 MB of input per pass and its output instead of 16.8 + 33.5 + 33.5 + output MB per frame.
+extern "C" int ph_neck_out_convs(const uint16_t* in_planes, int in_channels_last, const uint16_t* wplanes, const float* gn_affine,
+                                 int groups, float eps, uint16_t* out_planes0, uint16_t* out_planes1, uint16_t* out_planes2,
+                                 float* out_f32_0, float* out_f32_1, float* out_f32_2, void* workspace, size_t workspace_bytes,
+                                 int B, int64_t HW, int prec, void* stream) {
+    PH_CHECK_ARG(in_planes && wplanes && gn_affine && workspace, "null pointer");
+    PH_CHECK_ARG((out_planes0 || out_f32_0) && (out_planes1 || out_f32_1) && (out_planes2 || out_f32_2), "every map needs an output");
+    const void* fm[3] = {in_planes, in_planes, in_planes};
+    uint16_t* outp[3] = {out_planes0, out_planes1, out_planes2};
+    float* f32o[3] = {out_f32_0, out_f32_1, out_f32_2};
+    return kh_run(fm, in_channels_last ? 2 : 1, wplanes, gn_affine, groups, eps, outp, nullptr, nullptr, nullptr, nullptr, nullptr,
+                  workspace, workspace_bytes, B, HW, prec, stream, __func__, f32o);
 }
 
 // ph_khead_fused with (a) a device predicate -- every launch returns at once when *run_if == 0 (null: always run) -- and (b)

@@ -598,6 +598,105 @@ __global__ __launch_bounds__(256) void k_gn_sum_planes(const GnSumArgs a, int nl
     }
 }
 
+// the same level sum, written as the decode path's CHANNEL planes [P][B][256][HWp] (zero in [HW, HWp)) through an LDS transpose
+// (k_gn_to_cplanes' tile: 64 pixels x 256 channels, whole 1 KiB pixel vectors in, 128-byte runs of 64 pixels per channel row out):
+// the input format of the 1x1 conv + GroupNorm + ReLU kernels of ph_khead.hip, which the three output convs of the neck reuse
+// (ph_neck_out_convs: their GroupNorm statistics come from a recompute pass instead of an fp32 round trip of the conv output)
+template <int PA, int E = PH_E_BF16>
+__global__ __launch_bounds__(256) void k_gn_sum_cplanes(const GnSumArgs a, int nlev, int groups, uint16_t* __restrict__ planes,
+                                                        int B, int64_t HW, int64_t HWp, int tiles_per_wg) {
+    extern __shared__ float tt[];                                 // [256][65]
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 63) * 4, pq = threadIdx.x >> 6;
+    const int cpg = 256 / groups;
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        sc[l] = make_float4(0.f, 0.f, 0.f, 0.f); sh[l] = sc[l];
+        if (l >= nlev) continue;
+        float s_[4], h_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* st = a.stats[l] + ((int64_t)b * groups + (c4 + e) / cpg) * 2;
+            s_[e] = st[1] * a.gamma[l][c4 + e];
+            h_[e] = a.beta[l][c4 + e] - st[0] * s_[e];
+        }
+        sc[l] = make_float4(s_[0], s_[1], s_[2], s_[3]);
+        sh[l] = make_float4(h_[0], h_[1], h_[2], h_[3]);
+    }
+    const int piece = threadIdx.x & 7, r0 = threadIdx.x >> 3;       // 32 channel rows per pass, 8 x 16 B per row
+    const int64_t oplane = (int64_t)B * 256 * HWp;
+    const int64_t ntiles = HWp / 64;
+    for (int ti = 0; ti < tiles_per_wg; ++ti) {
+        const int64_t tile = (int64_t)blockIdx.x * tiles_per_wg + ti;
+        if (tile >= ntiles) break;
+        const int64_t p0 = tile * 64;
+        if (ti) __syncthreads();                                  // the previous tile has been read out of LDS
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int pl = k * 4 + pq;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + pl < HW) {
+                uint4 q[4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l)        // all level loads in flight together
+                    if (l < nlev) q[l] = ld_nt16(a.y[l] + ((int64_t)b * HW + p0 + pl) * 256 + c4);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {      // level order 0, 1, 2, 3 like Python's sum()
+                    if (l < nlev) {
+                        const float4 o = gn_relu4(make_float4(__uint_as_float(q[l].x), __uint_as_float(q[l].y), __uint_as_float(q[l].z), __uint_as_float(q[l].w)), sc[l], sh[l], true);
+                        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                    }
+                }
+            }
+            tt[(c4 + 0) * 65 + pl] = acc.x; tt[(c4 + 1) * 65 + pl] = acc.y; tt[(c4 + 2) * 65 + pl] = acc.z; tt[(c4 + 3) * 65 + pl] = acc.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 32 + r0;
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f2e_split<E>(tt[row * 65 + piece * 8 + e], hi[e], lo[e]);
+            uint16_t* d = planes + ((int64_t)b * 256 + row) * HWp + p0 + piece * 8;
+            *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+            if (PA == 2) *(uint4*)(d + oplane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+        }
+    }
+}
+
+extern "C" int ph_gn_sum_cplanes(const float* const* ys, const float* const* stats, const float* const* gammas,
+                                 const float* const* betas, int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec,
+                                 void* stream) {
+    PH_CHECK_ARG(ys && stats && gammas && betas && planes && nlev >= 1 && nlev <= 4 && B > 0 && B <= 65535 && HW > 0, "bad pointer or size");
+    PH_CHECK_ARG(groups > 0 && 256 % groups == 0, "bad group count");
+    PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
+    GnSumArgs a;
+    for (int l = 0; l < 4; ++l) {
+        const int k = l < nlev ? l : 0;
+        a.y[l] = ys[k]; a.stats[l] = stats[k]; a.gamma[l] = gammas[k]; a.beta[l] = betas[k];
+    }
+    const int64_t HWp = ph_hw_padded(HW), ntiles = HWp / 64;
+    int tpw = (int)((ntiles * B + 2047) / 2048);            // ~2048 workgroups: the 4-level affine set-up is amortised over the tiles
+    if (tpw < 1) tpw = 1;
+    if (const char* e = getenv("PH_GNSUM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), B);
+    const size_t lds = 256 * 65 * sizeof(float);
+    static const bool once = [&] {
+        (void)hipFuncSetAttribute((const void*)k_gn_sum_cplanes<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_gn_sum_cplanes<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_gn_sum_cplanes<1, PH_E_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        return true;
+    }();
+    (void)once;
+    hipStream_t s = (hipStream_t)stream;
+    if (prec == PH_PREC_F16) hipLaunchKernelGGL((k_gn_sum_cplanes<1, PH_E_F16>), grid, dim3(256), lds, s, a, nlev, groups, planes, B, HW, HWp, tpw);
+    else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_cplanes<1>, grid, dim3(256), lds, s, a, nlev, groups, planes, B, HW, HWp, tpw);
+    else hipLaunchKernelGGL(k_gn_sum_cplanes<2>, grid, dim3(256), lds, s, a, nlev, groups, planes, B, HW, HWp, tpw);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
 extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stats, const float* const* gammas,
                                 const float* const* betas, int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec,
                                 void* stream) {

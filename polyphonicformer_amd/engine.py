@@ -626,6 +626,26 @@ def gn_sum_planes(ys, stats, pks, groups, planes, B, HW, prec):
                                     _lib.ptr(planes), B, HW, prec, _lib.stream_ptr()), "ph_gn_sum_planes")
 
 
+def gn_sum_cplanes(ys, stats, pks, groups, planes, B, HW, prec):
+    """the level sum as channel planes [P,B,256,HWp] (ph_neck_out_convs' input)"""
+    lib = _lib.load()
+    n = len(ys)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.ph_gn_sum_cplanes(arr(ys), arr(stats), arr([p["gamma"] for p in pks]), arr([p["beta"] for p in pks]), n, groups,
+                                     _lib.ptr(planes), B, HW, prec, _lib.stream_ptr()), "ph_gn_sum_cplanes")
+
+
+def neck_out_convs(planes, channels_last, wplanes, gn_affine, groups, out_planes, out_f32, ws, B, HW, prec, eps=1e-5):
+    """conv_pred + 2 aux convs (1x1 conv + GN + ReLU each) of the level sum `planes` ([P,B,HW,256] when channels_last, else channel
+    planes [P,B,256,HWp]); out_planes / out_f32: lists of 3 (None: not wanted)"""
+    lib = _lib.load()
+    op = out_planes if out_planes is not None else [None] * 3
+    of = out_f32 if out_f32 is not None else [None] * 3
+    _lib.check(lib.ph_neck_out_convs(_lib.ptr(planes), 1 if channels_last else 0, _lib.ptr(wplanes), _lib.ptr(gn_affine), groups, eps,
+                                     _lib.ptr(op[0]), _lib.ptr(op[1]), _lib.ptr(op[2]), _lib.ptr(of[0]), _lib.ptr(of[1]), _lib.ptr(of[2]),
+                                     _lib.ptr(ws), ws.numel() * ws.element_size(), B, HW, prec, _lib.stream_ptr()), "ph_neck_out_convs")
+
+
 class NeckPlan:
     """buffers + launch sequence of SemanticFPNWrapper.forward for one (B, level shapes): channels-last bf16 planes
     between the convs, fp32 channels-last conv outputs (one per level for the fused level sum), three fp32 NCHW outputs"""
@@ -669,6 +689,15 @@ class NeckPlan:
                                     y=e((B, n_small, 256), torch.float32), stats=e((B, 256, 2), torch.float32),
                                     partial=e((lib.ph_conv_nhwc_partial_floats(B, self.Ho, self.Wo),), torch.float32)))
         self._streams = None                                       # created on first use; not part of a copy of the plan
+        # Round 4: the three output convs (conv_pred + 2 aux convs) as stats / apply passes over the level sum in channel planes
+        # (ph_neck_out_convs) instead of conv -> fp32 NHWC -> finalize -> apply per map.  PH_NECK_OUT2=0: the per-map form.
+        self.out2 = _os.environ.get("PH_NECK_OUT2", "1") != "0"
+        self.sc = self.ws2 = None
+        self.out2_cplanes = _os.environ.get("PH_NECK_OUT2", "1") == "2"
+        if self.out2:
+            if self.out2_cplanes:
+                self.sc = e((P, B, 256, hw_padded(self.Ho * self.Wo)), torch.int16)
+            self.ws2 = e((lib.ph_khead_workspace_bytes(B, self.Ho * self.Wo, 32) // 4 + 64,), torch.float32)
 
     def __getstate__(self):
         d = dict(self.__dict__)
@@ -722,12 +751,22 @@ class NeckPlan:
             shared = dict(xa=self.xa, xb=self.xb, y=self.y, stats=self.stats, partial=self.partial)
             for lvl in range(4):
                 self._tower(lvl, feats[lvl], pk, groups, posenc if lvl == pos_level else None, shared)
-        # sum over levels of ReLU(GN(.)) straight to conv input planes, then conv_pred / aux convs -> fp32 NCHW
-        gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
         if to_planes and self.pouts is None:
             P = 2 if prec == _lib.PH_PREC_SPLIT else 1
             self.pouts = [torch.empty((P, B, 256, hw_padded(self.Ho * self.Wo)), dtype=torch.int16, device=self.xa.device)
                           for _ in range(3)]
+        if self.out2 and len(pk["outs"]) == 3 and groups == 32:
+            # level sum (channels-last planes, as before); statistics pass (three maps in one launch) + finalize + one apply launch
+            # per map.  PH_NECK_OUT2=2: through channel planes (ph_gn_sum_cplanes; the transposing sum is 0.2 ms slower per 16 frames)
+            if self.out2_cplanes:
+                gn_sum_cplanes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.sc, B, self.Ho * self.Wo, prec)
+            else:
+                gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
+            neck_out_convs(self.sc if self.out2_cplanes else self.xb, not self.out2_cplanes, pk["outs_w"], pk["outs_gn"], groups,
+                           self.pouts if to_planes else None, None if to_planes else self.outs, self.ws2, B, self.Ho * self.Wo, prec)
+            return self.pouts if to_planes else self.outs
+        # sum over levels of ReLU(GN(.)) straight to conv input planes, then conv_pred / aux convs -> fp32 NCHW
+        gn_sum_planes(self.ys, self.lstats, [pk["levels"][l][-1] for l in range(4)], groups, self.xb, B, self.Ho * self.Wo, prec)
         for i, c in enumerate(pk["outs"]):
             self._conv_gn(self.xb, c, self.Ho, self.Wo, groups, self.y, self.stats)
             if to_planes:       # bf16 channel planes, the decode path's feature format (KernelHead hand-off)

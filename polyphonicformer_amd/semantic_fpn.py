@@ -112,7 +112,14 @@ class SemanticFPNWrapper(nn.Module):
                 return dict(wp=wp, gamma=m.gn.weight.detach().float().contiguous().to(dev),
                             beta=m.gn.bias.detach().float().contiguous().to(dev), k=m.ksize, s=m.stride)
             lv = [[one(getattr(l, f"conv{j}")) for j in range(l.n)] for l in self.convs_all_levels]
-            self._packs[key] = dict(levels=lv, outs=[one(self.conv_pred)] + [one(a) for a in self.aux_convs])
+            outs = [self.conv_pred] + list(self.aux_convs)
+            pk = dict(levels=lv, outs=[one(m) for m in outs])
+            if len(outs) == 3:      # the three output convs as [out][in] planes + GN affine: the operands of ph_neck_out_convs
+                w3 = torch.stack([m.conv.weight.detach().to("cpu", torch.float64).reshape(256, 256) for m in outs], 0)
+                pk["outs_w"] = E._planes_of(w3, P, prec == _lib.PH_PREC_F16).to(dev)                      # [P,3,256,256]
+                pk["outs_gn"] = torch.stack([torch.stack([m.gn.weight.detach().float(), m.gn.bias.detach().float()], 0)
+                                             for m in outs], 0).contiguous().to(dev)                       # [3,2,256]
+            self._packs[key] = pk
         return self._packs[key]
 
     def _posenc(self, H, W, dev):

@@ -128,6 +128,48 @@ def _state():
     return Hh.seeded_fill({k: tuple(v) for k, v in keys.items()}, 31)
 
 
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT])
+@pytest.mark.parametrize("channels_last", [True, False])
+@pytest.mark.parametrize("H,W", [(5, 7), (8, 16), (3, 70)])
+def test_neck_out_convs(gpu, prec, channels_last, H, W):
+    """ph_neck_out_convs (round 4): conv_pred + 2 aux convs = 1x1 conv + GroupNorm(32) + ReLU of one level sum, statistics from a
+    recompute pass -- against torch on the 16-bit operands the kernel sees; plane and fp32 NCHW outputs; both input layouts"""
+    g = torch.Generator().manual_seed(11)
+    B, HW = 2, H * W
+    P, f16 = (2 if prec == _lib.PH_PREC_SPLIT else 1), prec == _lib.PH_PREC_F16
+    dec = (lambda p: p[0].view(torch.float16).double()) if f16 else _planes_to_float
+    s = F.relu(torch.randn(B, 256, H, W, generator=g)) * 2.0                                   # a level sum is >= 0
+    w = torch.randn(3, 256, 256, generator=g) * 0.05
+    gn = torch.stack([1.0 + 0.2 * torch.randn(3, 256, generator=g), 0.1 * torch.randn(3, 256, generator=g)], 1).contiguous()   # [3,2,256]
+    wpl = E._planes_of(w.double(), P, f16)
+    wq = dec(wpl)
+    sp_cl = E._planes_of(s.double().permute(0, 2, 3, 1).reshape(B, HW, 256), P, f16)           # [P,B,HW,256]
+    sq = dec(sp_cl).reshape(B, H, W, 256).permute(0, 3, 1, 2)
+    HWp = E.hw_padded(HW)
+    if channels_last:
+        sp = sp_cl.to(gpu)
+    else:
+        sp = torch.zeros((P, B, 256, HWp), dtype=torch.int16)
+        sp[..., :HW] = sp_cl.reshape(P, B, HW, 256).permute(0, 1, 3, 2)
+        sp = sp.to(gpu)
+    lib = _lib.load()
+    ws = torch.empty((lib.ph_khead_workspace_bytes(B, HW, 32) // 4 + 64,), dtype=torch.float32, device=gpu)
+    outp = [torch.full((P, B, 256, HWp), 0x7F7F, dtype=torch.int16, device=gpu) for _ in range(3)]
+    outf = [torch.full((B, 256, H, W), float("nan"), device=gpu) for _ in range(3)]
+    # maps 0 and 2: both output kinds at once; map 1: planes only in one call, fp32 only in the other
+    E.neck_out_convs(sp, channels_last, wpl.to(gpu), gn.to(gpu), 32, outp, [outf[0], None, outf[2]], ws, B, HW, prec)
+    E.neck_out_convs(sp, channels_last, wpl.to(gpu), gn.to(gpu), 32, [outp[0], None, outp[2]], outf, ws, B, HW, prec)
+    tol = 2e-5 if prec == _lib.PH_PREC_SPLIT else 1e-4       # fp32 accumulation of exact products (+ dropped lo*lo terms)
+    otol = {_lib.PH_PREC_SPLIT: 2e-5, _lib.PH_PREC_BF16: 4e-3, _lib.PH_PREC_F16: 5e-4}[prec]   # rounding of the plane outputs
+    for m in range(3):
+        y = F.conv2d(sq, wq[m].reshape(256, 256, 1, 1))
+        ref = F.relu(F.group_norm(y, 32, gn[m, 0].double(), gn[m, 1].double(), 1e-5))
+        assert Hh.rel_err(outf[m].cpu().double(), ref) < tol, m
+        pl = outp[m].cpu()
+        assert Hh.rel_err(dec(pl)[..., :HW].reshape(B, 256, H, W), ref) < otol, m
+        assert int(pl[..., HW:].abs().max()) == 0 if HWp > HW else True                        # planes are zero padded
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_neck_vs_reference_golden(gpu, precision):
     sd = _state()

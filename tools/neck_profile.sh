@@ -8,10 +8,10 @@ cd $R
 python - <<PY
 import csv, json, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/nk/**/nk_kernel_stats.csv", recursive=True)[0])))
-nfwd = [int(r["Calls"]) for r in rows if "k_gn_sum_planes" in r["Name"]][0]      # one launch per forward
+nfwd = [int(r["Calls"]) for r in rows if "k_gn_sum_planes" in r["Name"] or "k_gn_sum_cplanes" in r["Name"]][0]      # one launch per forward
 tot = 0
 for r in rows:
-    if "nhwc" in r["Name"] or "gn_" in r["Name"]:
+    if "nhwc" in r["Name"] or "gn_" in r["Name"] or "k_khead" in r["Name"]:
         us = int(r["TotalDurationNs"]) // (1000 * nfwd)
         tot += us
         print(r["Name"][:70].ljust(70), str(int(r["Calls"]) // nfwd).rjust(3), "x", str(round(float(r["AverageNs"]) / 1e3, 1)).rjust(8), str(us).rjust(6), "us/forward")
