@@ -143,7 +143,10 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     using G = ConvGeo<KS, S, PA>;
     constexpr int CH = G::CH, LDP = G::LDP, IR = G::IR, IC = G::IC, PAD = KS / 2;
     constexpr int KSTEPS_TOTAL = KS * KS * 256 / 16;
-    constexpr int DEPTH = 4;                                                // B fragments requested this many k-steps ahead
+#ifndef CV_DEPTH
+#define CV_DEPTH 4
+#endif
+    constexpr int DEPTH = CV_DEPTH;                                         // B fragments requested this many k-steps ahead
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -691,7 +691,9 @@ class NeckPlan:
         self._streams = None                                       # created on first use; not part of a copy of the plan
         # Round 4: the three output convs (conv_pred + 2 aux convs) as stats / apply passes over the level sum in channel planes
         # (ph_neck_out_convs) instead of conv -> fp32 NHWC -> finalize -> apply per map.  PH_NECK_OUT2=0: the per-map form.
-        self.out2 = _os.environ.get("PH_NECK_OUT2", "1") != "0"
+        # one-plane grades only: with hi / lo planes the recompute pass is three MFMAs per product and costs more than the fp32
+        # round trip it removes (whole head 19.1 -> 20.4 ms per 16 frames at the parity grade, same box)
+        self.out2 = _os.environ.get("PH_NECK_OUT2", "1") != "0" and (P == 1 or _os.environ.get("PH_NECK_OUT2") == "3")
         self.sc = self.ws2 = None
         self.out2_cplanes = _os.environ.get("PH_NECK_OUT2", "1") == "2"
         if self.out2:
