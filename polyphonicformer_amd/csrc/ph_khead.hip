@@ -15,6 +15,7 @@
 // weight rows, bf16 planes) in registers.  The fp32 input tile is converted to bf16 plane(s) while it
 // is staged into LDS as [256 c][64 px] and read back with ds_read_b64_tr_b16 (same recipe as ph_conv).
 #include "ph_common.h"
+#include <stdlib.h>
 
 constexpr int KH_T = 64;
 constexpr int KH_LDT = KH_T + 32;       // row stride 48 dwords: the transposing reads are bank-conflict free
@@ -46,6 +47,13 @@ struct KHArgs {
     uint16_t* blocks_out;         // optional: this map as per-(frame, wave, tile) register-layout blocks (see kh_block)
     const uint16_t* blocks_in;    // ADD == 2: the map to add, in that form
     int w2_lds;                   // 1: the fragments are copied to LDS once per workgroup (bf16 precision, <= 6 row tiles)
+    // plain3 (ph_neck_out_convs): the three maps of ONE input in one apply launch, 1-D XCD-aware grid -- the three workgroups
+    // that read the same tiles sit on the same XCD in consecutive slots, so the input crosses HBM once and L2 three times
+    int plain3, nwg;
+    uint16_t* planes3[3];
+    float* f32o3[3];
+    const float* gn3;             // [3][2][256]
+    const float* stats3;          // [3][B][groups][2]
     int B, groups, tiles_per_wg;
     int64_t HW, HWp;
 };
@@ -361,16 +369,30 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
     uint16_t* rows = lds + wave * 32 * KH_LDT;                       // this wave's channel rows (plane p: + p * 256 * KH_LDT)
-    const int b = blockIdx.y;
+    int b = blockIdx.y, bx = blockIdx.x, m = 0;
+    const float *gamma = a.gamma, *beta = a.beta, *stats = a.stats;
+    uint16_t* oplanes = a.planes;
+    float* of32 = a.f32;
+    if (ADD == 0 && a.plain3) {
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int grp = (slot / 3) * 8 + xcd;                        // (frame, tile range) groups dealt round-robin to the XCDs
+        if (grp >= a.nwg * a.B) return;
+        m = slot - (slot / 3) * 3;
+        b = grp / a.nwg;
+        bx = grp - b * a.nwg;
+        gamma = a.gn3 + m * 512; beta = gamma + 256;
+        stats = a.stats3 + (int64_t)m * a.B * a.groups * 2;
+        oplanes = a.planes3[m]; of32 = a.f32o3[m];
+    }
     if (a.run_if && *a.run_if == 0) return;
     const int cpg = 256 / a.groups;
     const int64_t oplane = (int64_t)a.B * 256 * a.HWp;
     // per-channel affine of the normalisation (rstd*gamma, beta - mean*rstd*gamma) in LDS
     float2* ss = (float2*)(lds + PA * 256 * KH_LDT);                 // [256]
     for (int ch = tid; ch < 256; ch += KH_THREADS) {
-        const float* st = a.stats + ((int64_t)b * a.groups + ch / cpg) * 2;
+        const float* st = stats + ((int64_t)b * a.groups + ch / cpg) * 2;
         const float mean = st[0], rstd = st[1];
-        ss[ch] = make_float2(rstd * a.gamma[ch], a.beta[ch] - mean * rstd * a.gamma[ch]);
+        ss[ch] = make_float2(rstd * gamma[ch], beta[ch] - mean * rstd * gamma[ch]);
     }
     // bf16 precision: the A fragments of the second GEMM live in LDS behind the tile (<= 96 KiB); split precision
     // (two planes of everything) and more than 192 rows read them from L2
@@ -384,12 +406,12 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
     }
     constexpr bool HOIST = (PA == 1);   // bf16 precision: the 64 weight registers stay resident across the tiles
     uint4 af[PA][16];
-    if (HOIST) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+    if (HOIST) kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
     const int ntiles = (int)(a.HWp / KH_T);
-    const int t0 = blockIdx.x * a.tiles_per_wg;
+    const int t0 = bx * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     KhStage<PA, INFMT, E> stg;
-    stg.load(a, 0, b, (int64_t)t0 * KH_T, tid, t0 < t1);
+    stg.load(a, m, b, (int64_t)t0 * KH_T, tid, t0 < t1);
     for (int t = t0; t < t1; ++t) {
         const int64_t px0 = (int64_t)t * KH_T;
         const int64_t row0 = ((int64_t)b * 256 + wave * 32) * a.HWp + px0;       // this wave's first channel row, tile start
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
         stg.store(lds, tid, a.HW, px0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        stg.load(a, 0, b, px0 + KH_T, tid, t + 1 < t1);                            // next tile in flight during this one
+        stg.load(a, m, b, px0 + KH_T, tid, t + 1 < t1);                            // next tile in flight during this one
         __builtin_amdgcn_sched_barrier(0);
         uint4 addv[PA][4];
         uint32_t addb[PA][2][8];
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                     for (int rp = 0; rp < 8; ++rp)
                         addb[p][ct][rp] = *(const uint32_t*)(a.blocks_in + p * oplane + blk + ((ct * 8 + rp) * 64 + lane) * 2);
         }
-        if (!HOIST) kh_load_a<PA>(af, a.w[0], a.w_plane, wave, lane);
+        if (!HOIST) kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
         float vals[2][16];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -431,8 +453,8 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
                 float v = fmaxf(acc[r] * af2.x + af2.y, 0.f);
                 if (!inside) v = 0.f;                                    // planes are zero padded
                 vals[ct][r] = v;
-                if (a.f32 && inside) {
-                    float* ub = a.f32 + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;   // uniform
+                if (of32 && inside) {
+                    float* ub = of32 + ((int64_t)b * 256 + wave * 32 + (r & 3) + 8 * (r >> 2)) * a.HW + px0 + ct * 32;   // uniform
                     ub[(uint32_t)(4 * g * a.HW + (lane & 31))] = v;
                 }
             }
@@ -508,10 +530,10 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_apply(const KHArgs a) {
             kh_wave_sync();
         }
         kh_vals_to_rows<PA, E>(vals, rows, lane);
-        if (a.planes) {
+        if (oplanes) {
             kh_wave_sync();
 #pragma unroll
-            for (int p = 0; p < PA; ++p) kh_flush_rows(rows + p * 256 * KH_LDT, a.planes + p * oplane, row0, a.HWp, lane);
+            for (int p = 0; p < PA; ++p) kh_flush_rows(rows + p * 256 * KH_LDT, oplanes + p * oplane, row0, a.HWp, lane);
         }
         if (a.w2) {
             // second GEMM: rows of the static 1x1 conv (init_kernels / conv_seg / conv_direct_depth, kernel_head.py:256,295,285)
@@ -680,6 +702,21 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     if (fmt == 3) KH_LAUNCH3(k_khead_stats, dim3(nwg, B, 3), lds);
     else KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
     hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps, a.run_if);
+    static const bool plain3_on = [] { const char* e = getenv("PH_NECK_APPLY3"); return !(e && e[0] == '0'); }();   // 0: one launch per map (A/B)
+    if (f32o && plain3_on) {
+        // plain mode: the three maps in ONE apply launch (see KHArgs::plain3)
+        a.plain3 = 1; a.nwg = nwg; a.gn3 = gn_affine; a.stats3 = stats;
+        for (int m = 0; m < 3; ++m) {
+            a.planes3[m] = outp[m]; a.f32o3[m] = f32o[m];
+            a.f[m] = (const float*)fm[m]; a.fp[m] = (const uint16_t*)fm[m]; a.w[m] = wplanes + (size_t)m * 256 * 256;
+        }
+        a.w2 = nullptr; a.out2b = nullptr; a.blocks_out = nullptr; a.blocks_in = nullptr; a.w2_lds = 0;
+        const dim3 g3((unsigned)(((nwg * B + 7) / 8) * 8 * 3));
+        if (fmt == 3) KH_LAUNCH3(k_khead_apply, g3, lds_apply, 0);
+        else KH_LAUNCH(k_khead_apply, g3, lds_apply, 0);
+        PH_CHECK_LAUNCH();
+        return PH_OK;
+    }
     // pass 2: loc ; sem (+ x = sem + loc, loc read back from the planes the first launch wrote) ; depth
     for (int m = 0; m < 3; ++m) {
         a.f[0] = (const float*)fm[m];
