@@ -107,6 +107,7 @@ SIGNATURES = {
     "ph_nhwc_ingest": (C.c_int, [_P, _P, _P, _I, _L, _I, _P]),
     "ph_conv_nhwc_partial_floats": (C.c_size_t, [_I, _I, _I]),
     "ph_conv_nhwc_workgroups": (C.c_int, [_I, _I, _I, _I, _I]),
+    "ph_conv_nhwc_workgroups_b": (C.c_int, [_I, _I, _I, _I, _I, _I]),
     "ph_conv_nhwc": (C.c_int, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ph_gn_finalize": (C.c_int, [_P, _P, _I, _I, _L, C.c_float, _I, _P]),
     "ph_gn_sum_planes": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -119,11 +119,13 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 // Roofline: MFMA (2*9*256*256 flop per output pixel); L2 weight stream = 1.18 MB per 128 output pixels.
 constexpr int CV_TW = 64;
 
-template <int KS, int S, int PA> struct ConvGeo {
+template <int KS, int S, int PA, int TH_ = (PA == 1 ? 4 : 2)> struct ConvGeo {
     // output rows per workgroup: 4 for the double-buffered single-plane kernels (one workgroup per CU, 128 accumulator
     // VGPRs per wave, every weight fragment feeds 8 MFMAs; stride 2 takes 16-channel chunks so that two 9-row patches
-    // fit in LDS), 2 otherwise
-    static constexpr int TH = (PA == 1) ? 4 : 2;
+    // fit in LDS), 2 otherwise -- and, round 4, 2 for the single-plane kernels when 4-row tiles would leave CUs idle (one
+    // frame per launch, the video loop: a 128 x 256 map is 128 four-row tiles, and a tile's 144 k-steps are a serial
+    // chain of ~35 us whatever the map size; two-row tiles are twice the workgroups at half the chain)
+    static constexpr int TH = TH_;
     static constexpr int MT = TH * 2;                                              // 32-pixel M tiles per wave
     static constexpr int IR = (TH - 1) * S + KS, IC = (CV_TW - 1) * S + KS;       // input patch rows / cols
     static constexpr int CH = (S == 1) ? 64 : (PA == 1 ? 16 : 32);                 // channels per LDS stage
@@ -136,11 +138,11 @@ template <int KS, int S, int PA> struct ConvGeo {
     static constexpr int PLANE = IR * ICS * LDP;                                   // elements per precision plane
 };
 
-template <int PA, int KS, int S, int E = PH_E_BF16>
+template <int PA, int KS, int S, int E = PH_E_BF16, int TH_ = (PA == 1 ? 4 : 2)>
 __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ X, int64_t x_plane,
                                                    const uint16_t* __restrict__ Wp, int64_t w_plane, float* __restrict__ Y,
                                                    float* __restrict__ partial, int B, int H, int W, int Ho, int Wo) {
-    using G = ConvGeo<KS, S, PA>;
+    using G = ConvGeo<KS, S, PA, TH_>;
     constexpr int CH = G::CH, LDP = G::LDP, IR = G::IR, IC = G::IC, PAD = KS / 2;
     constexpr int KSTEPS_TOTAL = KS * KS * 256 / 16;
 #ifndef CV_DEPTH
@@ -301,12 +303,22 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     }
 }
 
-static int conv_th(int ksize, int stride, int prec) { return prec == PH_PREC_SPLIT ? 2 : 4; }      // one-plane formats: 4-row tiles
+// one-plane formats: 4-row tiles, unless those are fewer than one per CU over the whole launch (then 2-row tiles)
+static int conv_th(int Ho, int Wo, int prec, int B) {
+    if (prec == PH_PREC_SPLIT) return 2;
+    static const int force = [] { const char* e = getenv("PH_CONV_TH"); return e ? atoi(e) : 0; }();     // 2 / 4: A/B timing
+    if (force == 2 || force == 4) return force;
+    const int64_t n4 = (int64_t)B * ((Wo + CV_TW - 1) / CV_TW) * ((Ho + 3) / 4);
+    return n4 < 256 ? 2 : 4;
+}
 
 // workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
-extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {
-    const int th = conv_th(ksize, stride, prec);
+extern "C" int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B) {
+    const int th = conv_th(Ho, Wo, prec, B);
     return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + th - 1) / th);
+}
+extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {       // launches of >= 256 four-row tiles
+    return ph_conv_nhwc_workgroups_b(ksize, stride, Ho, Wo, prec, 1 << 20);
 }
 
 // upper bound over all instantiations (2-row tiles)
@@ -321,21 +333,25 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    const int th = conv_th(ksize, stride, prec);
+    const int th = conv_th(Ho, Wo, prec, B);
     const dim3 grid((Wo + CV_TW - 1) / CV_TW, (Ho + th - 1) / th, B);
     const int64_t x_plane = (int64_t)B * H * W * 256;
     hipStream_t s = (hipStream_t)stream;
-#define PH_CV(PA, KS, S, EE)                                                                                             \
+#define PH_CV_T(PA, KS, S, EE, TT)                                                                                       \
     do {                                                                                                                 \
-        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA>::PLANE * sizeof(uint16_t);                \
+        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA, TT>::PLANE * sizeof(uint16_t);            \
         static const bool once = [&] {                                                                                   \
-            (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S, EE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                         \
             return true;                                                                                                 \
         }();                                                                                                             \
         (void)once;                                                                                                      \
-        hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S, EE>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
+        hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S, EE, TT>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
                            B, H, W, Ho, Wo);                                                                             \
+    } while (0)
+#define PH_CV(PA, KS, S, EE)                                                                                             \
+    do {                                                                                                                 \
+        if (PA == 1 && th == 4) PH_CV_T(PA, KS, S, EE, 4); else PH_CV_T(PA, KS, S, EE, 2);                               \
     } while (0)
     if (prec == PH_PREC_BF16) {
         if (ksize == 1) PH_CV(1, 1, 1, PH_E_BF16); else if (stride == 1) PH_CV(1, 3, 1, PH_E_BF16); else PH_CV(1, 3, 2, PH_E_BF16);
@@ -345,6 +361,7 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
         if (ksize == 1) PH_CV(2, 1, 1, PH_E_BF16); else if (stride == 1) PH_CV(2, 3, 1, PH_E_BF16); else PH_CV(2, 3, 2, PH_E_BF16);
     }
 #undef PH_CV
+#undef PH_CV_T
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

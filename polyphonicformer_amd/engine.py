@@ -713,7 +713,7 @@ class NeckPlan:
         k, s = pk["k"], pk["s"]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
         conv_nhwc(xp, pk, y, partial, B, H, W, prec)
-        nwg = _lib.load().ph_conv_nhwc_workgroups(k, s, Ho, Wo, prec)
+        nwg = _lib.load().ph_conv_nhwc_workgroups_b(k, s, Ho, Wo, prec, B)
         gn_finalize(partial, stats, nwg, groups, Ho * Wo, B)
         return Ho, Wo
 

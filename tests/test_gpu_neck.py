@@ -23,8 +23,9 @@ def _planes_to_float(p):
 
 
 @pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT])
-@pytest.mark.parametrize("k,s,H,W", [(3, 1, 6, 70), (3, 2, 9, 131), (1, 1, 5, 64), (3, 1, 2, 3)])
+@pytest.mark.parametrize("k,s,H,W", [(3, 1, 6, 70), (3, 2, 9, 131), (1, 1, 5, 64), (3, 1, 2, 3), (3, 1, 64, 1024), (3, 2, 72, 2048)])
 def test_conv_nhwc(gpu, prec, k, s, H, W):
+    # the small maps take the 2-row tiles (fewer than 256 four-row tiles per launch), the last two the 4-row tiles (bf16 grade)
     g = torch.Generator().manual_seed(7)
     B, P = 2, (2 if prec == _lib.PH_PREC_SPLIT else 1)
     x = torch.randn(B, 256, H, W, generator=g)
@@ -45,7 +46,7 @@ def test_conv_nhwc(gpu, prec, k, s, H, W):
     got = y.cpu().reshape(B, Ho, Wo, 256).permute(0, 3, 1, 2).double()
     tol = 1e-5 if prec == _lib.PH_PREC_BF16 else 5e-5       # exact products of the bf16 operands / dropped lo*lo terms
     assert Hh.rel_err(got, ref) < tol
-    nwg = lib.ph_conv_nhwc_workgroups(k, s, Ho, Wo, prec)
+    nwg = lib.ph_conv_nhwc_workgroups_b(k, s, Ho, Wo, prec, B)
     pr = partial.cpu()[:B * nwg * 512].reshape(B, nwg, 256, 2).double().sum(1)   # the buffer is sized for the upper bound
     assert Hh.rel_err(pr[..., 0], got.sum((2, 3))) < 1e-4 and Hh.rel_err(pr[..., 1], (got * got).sum((2, 3))) < 1e-4
     stats = torch.empty((B, 32, 2), dtype=torch.float32, device=gpu)
