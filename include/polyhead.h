@@ -463,7 +463,9 @@ int ph_gn_sum_planes(const float* const* ys, const float* const* stats, const fl
  * bytes and its B fragments are plain 16-byte LDS reads: no transposition anywhere -- the form NeckPlan uses).
  * wplanes: 16-bit planes [P][3][256][256] (out, in) of the three conv weights; gn_affine fp32 [3][2][256];
  * out_planes_m: 16-bit planes [P][B][256][HWp] and / or out_f32_m: fp32 NCHW [B][256][HW], at least one per map;
- * workspace: ph_khead_workspace_bytes(B, HW, groups). */
+ * workspace: ph_neck_out_convs_workspace_bytes(B, HW, groups).  Up to 3 frames per launch a frame's outputs are bit-identical to
+ * those of a one-frame launch (tile runs and summation order do not depend on B). */
+size_t ph_neck_out_convs_workspace_bytes(int B, int64_t HW, int groups);
 int ph_gn_sum_cplanes(const float* const* ys, const float* const* stats, const float* const* gammas, const float* const* betas,
                       int nlev, int groups, uint16_t* planes, int B, int64_t HW, int prec, void* stream);
 int ph_neck_out_convs(const uint16_t* in_planes, int in_channels_last, const uint16_t* wplanes, const float* gn_affine, int groups,

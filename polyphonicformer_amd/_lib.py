@@ -114,6 +114,7 @@ SIGNATURES = {
                                    _I, _I, _P, _I, _L, _I, _P]),
     "ph_gn_sum_cplanes": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     _I, _I, _P, _I, _L, _I, _P]),
+    "ph_neck_out_convs_workspace_bytes": (C.c_size_t, [_I, _L, _I]),
     "ph_neck_out_convs": (C.c_int, [_P, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_gn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),

@@ -603,12 +603,19 @@ static int kh_tiles_per_wg(int64_t HWp, int B) {
     return tpw;
 }
 
-extern "C" size_t ph_khead_workspace_bytes(int B, int64_t HW, int groups) {
+// plain mode (the neck's output convs): up to 3 frames per launch the tile runs are those of a ONE-frame launch, so that a
+// frame's partial sums -- and with them every bit of its outputs -- do not depend on how many frames share the launch (the
+// video runner batches a clip's frames 2-3 per launch and promises the bits of the per-frame loop)
+static int kh_tiles_per_wg_plain(int64_t HWp, int B) { return kh_tiles_per_wg(HWp, B <= 3 ? 1 : B); }
+
+static size_t kh_ws_bytes(int B, int64_t HW, int groups, bool plain) {
     const int64_t HWp = ph_hw_padded(HW);
-    const int tpw = kh_tiles_per_wg(HWp, B);
+    const int tpw = plain ? kh_tiles_per_wg_plain(HWp, B) : kh_tiles_per_wg(HWp, B);
     const int nwg = (int)((HWp / KH_T + tpw - 1) / tpw);
     return (size_t)3 * B * nwg * 256 * 2 * sizeof(float) + (size_t)3 * B * groups * 2 * sizeof(float);
 }
+extern "C" size_t ph_khead_workspace_bytes(int B, int64_t HW, int groups) { return kh_ws_bytes(B, HW, groups, false); }
+extern "C" size_t ph_neck_out_convs_workspace_bytes(int B, int64_t HW, int groups) { return kh_ws_bytes(B, HW, groups, true); }
 
 struct KhFused {                  // the static 1x1 convs of the fused entry point (all null for ph_khead_conv_gn)
     const uint16_t* w2[3];
@@ -634,13 +641,13 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
     }
     const bool f16 = prec == PH_PREC_F16;      // ONE fp16 plane of everything (weights packed as fp16 by the caller; plane inputs must be fp16)
     if (B > 65535) { ph_set_error("%s: B must be <= 65535", fn); return PH_EINVAL; }
-    if (workspace_bytes < ph_khead_workspace_bytes(B, HW, groups)) {
+    if (workspace_bytes < kh_ws_bytes(B, HW, groups, f32o != nullptr)) {
         ph_set_error("%s: workspace too small", fn);
         return PH_EWORKSPACE;
     }
     const int PA = prec == PH_PREC_SPLIT ? 2 : 1;
     const int64_t HWp = ph_hw_padded(HW);
-    const int tpw = kh_tiles_per_wg(HWp, B);
+    const int tpw = f32o ? kh_tiles_per_wg_plain(HWp, B) : kh_tiles_per_wg(HWp, B);
     const int nwg = (int)((HWp / KH_T + tpw - 1) / tpw);
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;

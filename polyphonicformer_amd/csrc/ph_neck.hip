@@ -308,8 +308,12 @@ static int conv_th(int Ho, int Wo, int prec, int B) {
     if (prec == PH_PREC_SPLIT) return 2;
     static const int force = [] { const char* e = getenv("PH_CONV_TH"); return e ? atoi(e) : 0; }();     // 2 / 4: A/B timing
     if (force == 2 || force == 4) return force;
-    const int64_t n4 = (int64_t)B * ((Wo + CV_TW - 1) / CV_TW) * ((Ho + 3) / 4);
-    return n4 < 256 ? 2 : 4;
+    // up to 3 frames per launch the choice follows the FRAME's tile count alone: the video runner batches a clip's frames 2-3 per
+    // launch and promises every frame the bits of the one-frame launch (the tile form fixes the summation order of the GroupNorm
+    // partial sums); at 2-3 frames the two forms cost the same over a forward (large maps 77 / 83 us, small ones 52 / 36)
+    const int64_t t4 = (int64_t)((Wo + CV_TW - 1) / CV_TW) * ((Ho + 3) / 4);
+    if (B <= 3) return t4 < 256 ? 2 : 4;
+    return B * t4 < 256 ? 2 : 4;
 }
 
 // workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output

@@ -699,7 +699,7 @@ class NeckPlan:
         if self.out2:
             if self.out2_cplanes:
                 self.sc = e((P, B, 256, hw_padded(self.Ho * self.Wo)), torch.int16)
-            self.ws2 = e((lib.ph_khead_workspace_bytes(B, self.Ho * self.Wo, 32) // 4 + 64,), torch.float32)
+            self.ws2 = e((lib.ph_neck_out_convs_workspace_bytes(B, self.Ho * self.Wo, 32) // 4 + 64,), torch.float32)
 
     def __getstate__(self):
         d = dict(self.__dict__)

@@ -558,6 +558,11 @@ class VideoStreamRunner:
                 if st["dm"] is not None:
                     st["dm"].begin(*st["outs"])
             st["graph"] = g
+            # the graph replays the plans' device buffers: KernelHead / KernelUpdateIterHead keep ONE plan and drop it when the
+            # batch size changes (a clip's last chunk), so the graph holds its own references -- without them a later replay wrote
+            # into freed blocks (harmless while the allocator kept them mapped; a memory fault once it had not: clips of 3 + 3 + 2)
+            neck = getattr(sl["rpn"], "localization_fpn", None)
+            st["plans"] = [dict(m._plans) for m in (sl["rpn"], sl["roi"], neck) if m is not None and hasattr(m, "_plans")]
         for f in frames:
             if len(f) != len(st["x"]) or any(tuple(d.shape[1:]) != tuple(t.shape[1:]) or d.dtype != t.dtype for d, t in zip(st["x"], f)):
                 raise ValueError("VideoStreamRunner: the FPN levels changed shape / dtype; one runner serves one stream of equally "
@@ -664,7 +669,13 @@ class VideoStreamRunner:
         if grade not in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) or os.environ.get("PH_KHEAD_TWOPASS"):
             return 1
         H, W = frames[0][1].shape[-2:]                        # the decode runs at stride 8
-        ok = lambda B: E.default_nsplit(B, H * W) == E.default_nsplit(1, H * W) and (B * H >= 512) == (H >= 512)
+        lib = _lib.load()
+        # ... and the neck's conv tiles (2-row / 4-row by launch size, ph_conv_nhwc_workgroups_b) those of the one-frame launch
+        same_tiles = lambda B: all(lib.ph_conv_nhwc_workgroups_b(3, s, (h + s - 1) // s, (w + s - 1) // s, grade, B) ==
+                                   lib.ph_conv_nhwc_workgroups_b(3, s, (h + s - 1) // s, (w + s - 1) // s, grade, 1)
+                                   for (h, w), s in [(tuple(frames[0][0].shape[-2:]), 2)] +
+                                   [((H >> k, W >> k), 1) for k in range(3)] + [((H >> 1, W >> 1), 1), ((H, W), 1)])
+        ok = lambda B: E.default_nsplit(B, H * W) == E.default_nsplit(1, H * W) and (B * H >= 512) == (H >= 512) and same_tiles(B)
         for B in range(max(1, min(cap, len(frames))), 1, -1):
             if ok(B):
                 return B

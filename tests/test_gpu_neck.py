@@ -154,7 +154,7 @@ def test_neck_out_convs(gpu, prec, channels_last, H, W):
         sp[..., :HW] = sp_cl.reshape(P, B, HW, 256).permute(0, 1, 3, 2)
         sp = sp.to(gpu)
     lib = _lib.load()
-    ws = torch.empty((lib.ph_khead_workspace_bytes(B, HW, 32) // 4 + 64,), dtype=torch.float32, device=gpu)
+    ws = torch.empty((lib.ph_neck_out_convs_workspace_bytes(B, HW, 32) // 4 + 64,), dtype=torch.float32, device=gpu)
     outp = [torch.full((P, B, 256, HWp), 0x7F7F, dtype=torch.int16, device=gpu) for _ in range(3)]
     outf = [torch.full((B, 256, H, W), float("nan"), device=gpu) for _ in range(3)]
     # maps 0 and 2: both output kinds at once; map 1: planes only in one call, fp32 only in the other

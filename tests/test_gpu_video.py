@@ -377,3 +377,26 @@ def test_stream_runner_batches_a_clips_frames_per_launch(gpu, graph):
     for b in range(3):
         o1 = runner._heads_device(runner._slots[0], frames[b])
         assert all(torch.equal(u[b:b + 1], v) for u, v in zip(ob, o1))
+
+
+def test_stream_runner_clip_of_3_3_2_replays_graphs_whose_plans_were_replaced(gpu):
+    """an 8-frame clip = launches of 3 + 3 + 2 frames: slot 0 captures a 3-frame graph, then a 2-frame one -- KernelHead and
+    KernelUpdateIterHead keep ONE plan and drop the 3-frame plan there -- and the NEXT clip replays the 3-frame graph.  The graph
+    holds its plans (round 4: without that reference the replay wrote into freed device memory; a GPU memory fault in
+    `bench.py --workload cfg4 --clip-frames 8`).  Two clips, every record against the per-frame module API."""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(35)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    meta = [Hh.img_meta(H8, W8)]
+    runner = V.VideoStreamRunner(pipe, meta[0], graph=True)
+    for clip in range(2):
+        frames = [tuple(torch.roll(t, (8 * clip + f, 2 * f), dims=(2, 3)) for t in base) for f in range(8)]
+        got = runner.records(frames)
+        assert sorted(runner._slots[0]["g"]) == [2, 3] and sorted(runner._slots[1]["g"]) == [3]
+        torch.cuda.empty_cache()                      # freed blocks really go back to the driver
+        for x, (ids_a, rec_a) in zip(frames, got):
+            ids_b, rec_b = pipe.simple_test(x, meta, records_only=True)
+            assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
+            assert rec_a is None or all(torch.equal(u, v) for u, v in zip(rec_a, rec_b))
