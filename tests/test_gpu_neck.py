@@ -131,12 +131,12 @@ def _state():
 
 @pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT])
 @pytest.mark.parametrize("channels_last", [True, False])
-@pytest.mark.parametrize("H,W", [(5, 7), (8, 16), (3, 70)])
-def test_neck_out_convs(gpu, prec, channels_last, H, W):
+@pytest.mark.parametrize("H,W,B", [(5, 7, 2), (8, 16, 2), (3, 70, 2), (9, 200, 5)])
+def test_neck_out_convs(gpu, prec, channels_last, H, W, B):
     """ph_neck_out_convs (round 4): conv_pred + 2 aux convs = 1x1 conv + GroupNorm(32) + ReLU of one level sum, statistics from a
     recompute pass -- against torch on the 16-bit operands the kernel sees; plane and fp32 NCHW outputs; both input layouts"""
     g = torch.Generator().manual_seed(11)
-    B, HW = 2, H * W
+    HW = H * W                 # B = 5: more than 3 frames (tile runs sized by the batch), 29 tiles per frame, a ragged last tile
     P, f16 = (2 if prec == _lib.PH_PREC_SPLIT else 1), prec == _lib.PH_PREC_F16
     dec = (lambda p: p[0].view(torch.float16).double()) if f16 else _planes_to_float
     s = F.relu(torch.randn(B, 256, H, W, generator=g)) * 2.0                                   # a level sum is >= 0
