@@ -6,7 +6,7 @@ import torch
 import bench
 from polyphonicformer_amd import engine as E
 
-wl = bench.WORKLOADS["cfg2"]
+wl = bench.WORKLOADS[os.environ.get("PH_QT_WORKLOAD", "cfg2")]
 dev = torch.device("cuda:0")
 N = wl["Nq"] + wl["n_stuff"]
 frames = [int(a) for a in sys.argv[1:]] or [24, 48, 64, 96]
