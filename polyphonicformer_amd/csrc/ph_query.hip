@@ -1039,49 +1039,61 @@ __global__ __launch_bounds__(NTHREADS) void k_query_pre2(const QArgs2 aa) {
     };
 
     // ---- step 0: pooled feature u = fixed-order sum of the split-K partials, pixel counts ------------------------
+    // Round 4: 32 threads per row with 8 columns each (all 512 threads work on the 16 rows of a one-frame launch, where half of
+    // them idled) and the partials of 8 pixel ranges in flight per trip instead of 4 (16: spills in the wide forms): the sum is a chain of dependent L2 round
+    // trips -- 19 of the kernel's 56 us at one frame per launch (nsplit = 32; PH_QUERY_TIMELINE) -- and the order of the
+    // additions per element (pixel range 0, 1, 2, ...) is unchanged, so every result keeps its bits.
     {
-        const int r = tid >> 4, cb = (tid & 15) * 16;
-        for (int rr = r; rr < ROWS; rr += NTHREADS / 16) {
+        const int r = tid >> 5, cb = (tid & 31) * 8;
+        for (int rr = r; rr < ROWS; rr += NTHREADS / 32) {
             const int row = row0 + rr;
-            float u[16];
+            float u[8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = 0.f;
+            for (int e = 0; e < 8; ++e) u[e] = 0.f;
             int c = 0;
             if (row < Npad) {
                 if (a.pcount) {
                     // the pooling kernel counted the set bits of its pixel range: nsplit integers per row instead of HWp / 32 words
-                    for (int s0 = tid & 15; s0 < a.nsplit; s0 += 16) c += a.pcount[((int64_t)b * a.nsplit + s0) * Npad + row];
+                    for (int s0 = tid & 31; s0 < a.nsplit; s0 += 32) c += a.pcount[((int64_t)b * a.nsplit + s0) * Npad + row];
                 } else {
                     const uint4* bw = (const uint4*)(a.bits + ((int64_t)b * Npad + row) * (a.HWp / 32));
                     const int nq = (int)(a.HWp / 128);
-                    for (int w0 = tid & 15; w0 < nq; w0 += 128) {
+                    for (int w0 = tid & 31; w0 < nq; w0 += 256) {
                         uint4 q[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) q[j] = w0 + 16 * j < nq ? bw[w0 + 16 * j] : make_uint4(0, 0, 0, 0);
+                        for (int j = 0; j < 8; ++j) q[j] = w0 + 32 * j < nq ? bw[w0 + 32 * j] : make_uint4(0, 0, 0, 0);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) c += __popc(q[j].x) + __popc(q[j].y) + __popc(q[j].z) + __popc(q[j].w);
                     }
                 }
-                for (int s0 = 0; s0 < a.nsplit; s0 += 4) {
-                    float4 v[4][4];
+                constexpr int TRIP = NRT == 1 ? 16 : 8;          // 16-row workgroups have the registers for 16 ranges per trip
+                for (int s0 = 0; s0 < a.nsplit; s0 += TRIP) {
+                    float4 v[TRIP][2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TRIP; ++j) {
                         const float* p = a.partial + (((int64_t)b * a.nsplit + s0 + j) * Npad + row) * 512 + br * 256 + cb;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 2; ++e)
                             v[j][e] = s0 + j < a.nsplit ? *(const float4*)(p + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < TRIP; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < 2; ++e) {
                             u[4 * e] += v[j][e].x; u[4 * e + 1] += v[j][e].y; u[4 * e + 2] += v[j][e].z; u[4 * e + 3] += v[j][e].w;
                         }
                 }
             }
-            put16(rr, cb, u);
-            c = (int)wave_group16_sum((float)c);          // exact: counts < 2^24
-            if ((tid & 15) == 0) cnt[rr] = (float)c;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                uint32_t h0, l0, h1, l1;
+                f2bf_split(u[e], h0, l0); f2bf_split(u[e + 1], h1, l1);
+                *(uint32_t*)(act + rr * LDA + cb + e) = pack2(h0, h1);
+                if (PA == 2) *(uint32_t*)(act + PLANE + rr * LDA + cb + e) = pack2(l0, l1);
+            }
+            float cf = wave_group16_sum((float)c);       // exact: counts < 2^24
+            cf += __shfl_xor(cf, 16);
+            if ((tid & 31) == 0) cnt[rr] = cf;
         }
     }
     __syncthreads();
