@@ -173,3 +173,14 @@ def param_versions(module):
         mods = [m for m in module.modules()]
         module.__dict__["_ph_modules"] = mods
     return tuple(p._version for m in mods for p in m._parameters.values() if p is not None)
+
+
+def named_params(module):
+    """dict(module.named_parameters()) without re-discovering the module tree: a cached list of (prefix, sub-module) pairs, their
+    live `_parameters` dicts read on every call (a replaced Parameter object is seen; these heads never grow).  The training
+    forward asks once per stage and head: 1 641 `named_parameters` generator steps, 1.3 ms per step (round 4 host profile)."""
+    mods = module.__dict__.get("_ph_named_modules")
+    if mods is None:
+        mods = [(n + "." if n else "", m) for n, m in module.named_modules()]
+        module.__dict__["_ph_named_modules"] = mods
+    return {pre + k: p for pre, m in mods for k, p in m._parameters.items() if p is not None}

@@ -200,7 +200,7 @@ def stage_forward(head, x, dfe, k, m, q):
     """KernelUpdateHead.forward (kernel_update_head.py:212-353) in training form.  x, dfe [B, C, H, W] (gradients flow),
     k / q [B, N, C] kernels and depth kernels, m [B, N, H, W] mask logits (used through the hard mask only).
     -> cls [B, N, L], mask [B, N, H, W], obj [B, N, C], depth [B, N, H, W], dobj [B, N, C]"""
-    P = dict(head.named_parameters())
+    P = _lib.named_params(head)
     Wt, bt = P["feat_transform.conv.weight"].flatten(1), P["feat_transform.conv.bias"]
     Wd, bd = P["feat_depth_transform.conv.weight"].flatten(1), P["feat_depth_transform.conv.bias"]
     cnt = hard_count(m)[..., None]
@@ -231,7 +231,7 @@ def _tower(P, name, f, groups):
 
 def rpn_forward(head, feats):
     """KernelHead._decode_init_proposals after the neck (kernel_head.py:245-336), training form (no stuff rows)"""
-    P = dict((n, p) for n, p in head.named_parameters() if not n.startswith("localization_fpn."))
+    P = dict((n, p) for n, p in _lib.named_params(head).items() if not n.startswith("localization_fpn."))
     groups = head.norm_cfg.get("num_groups", 32)
     loc = _tower(P, "loc_convs.0", feats[0], groups)
     sem = _tower(P, "seg_convs.0", feats[1], groups)
@@ -351,7 +351,7 @@ def rpn_outputs(h, r):
     mask_preds, k, q = r["mask_preds"], r["proposal"], r["depth_proposal"]
     if h.cat_stuff_mask:
         mask_preds = torch.cat([mask_preds, r["seg_preds"][:, nt:L]], dim=1)
-        stuff = dict(h.named_parameters())["conv_seg.weight"][nt:L].flatten(1)
+        stuff = _lib.named_params(h)["conv_seg.weight"][nt:L].flatten(1)
         k = torch.cat([k, stuff[None].expand(B, -1, -1)], dim=1)
     N = k.shape[1]
     return k, mask_preds, q.expand(B, N, -1)
@@ -457,7 +457,7 @@ class TrainStep:
         return False
 
     def parameters(self):
-        return [p for n, p in self.rpn.named_parameters() if not n.startswith("localization_fpn.")] + list(self.roi.parameters())
+        return [p for n, p in _lib.named_params(self.rpn).items() if not n.startswith("localization_fpn.")] + list(_lib.named_params(self.roi).values())
 
     def forward_backward(self, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, backward=True):
         feats = [f.detach().float().contiguous().requires_grad_(True) for f in feats]
