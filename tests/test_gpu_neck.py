@@ -171,6 +171,32 @@ def test_neck_out_convs(gpu, prec, channels_last, H, W, B):
         assert int(pl[..., HW:].abs().max()) == 0 if HWp > HW else True                        # planes are zero padded
 
 
+@pytest.mark.parametrize("B", [3, 8])
+def test_neck_output_stage_forms_agree_at_full_size(gpu, B):
+    """cfg2's FPN sizes, fp16 grade, 3 frames (one stream, frame-sized tile runs) and 8 frames (the four tower streams, batch-sized
+    tile runs): the recompute output stage (ph_neck_out_convs) against the per-map conv -> finalize -> apply form on the same
+    plan -- fp32 NCHW outputs to summation order, plane outputs to one rounding of the 16-bit format"""
+    torch.manual_seed(2)
+    m = NECKS.build(dict(type="SemanticFPNWrapper", in_channels=256, feat_channels=256, out_channels=256, start_level=0, end_level=3,
+                         upsample_times=2, positional_encoding=dict(type="SinePositionalEncoding", num_feats=128, normalize=True),
+                         cat_coors=False, cat_coors_level=3, fuse_by_cat=False, return_list=False, num_aux_convs=2,
+                         norm_cfg=dict(type="GN", num_groups=32, requires_grad=True)))
+    m.init_weights(); m.eval().to(gpu); m.set_precision("fp16")
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(B, 256, 256 >> i, 512 >> i, generator=g).to(gpu) for i in range(4)]
+    for planes in (False, True):
+        run = (lambda: m.forward_planes(feats)) if planes else (lambda: m(feats))
+        new = [o.clone() for o in run()]
+        plan = next(iter(m._plans.values()))
+        assert plan.out2 and plan.multi == (B >= 4)
+        plan.out2 = False
+        old = [o.clone() for o in run()]
+        plan.out2 = True
+        dec = (lambda t: t[0].view(torch.float16).float()) if planes else (lambda t: t)
+        for a, b in zip(new, old):
+            assert Hh.rel_err(dec(a).cpu(), dec(b).cpu()) < (1e-3 if planes else 1e-6)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_neck_vs_reference_golden(gpu, precision):
     sd = _state()
