@@ -232,6 +232,33 @@ def video_fixture():
     print("[video] segments:", len(info), "embed norm:", float(emb.norm(dim=1).mean()))
 
 
+def cfg1_fixture(ns):
+    """BASELINE.json configs[0] at its EXACT shape: one 256x512 frame -> 32x64 stride-8 map, 100 + 11 queries, ONE update stage,
+    fp32 on the CPU: KernelHead post-neck -> simple_test_mask_preds of the reference.  Weights = seeded_fill over the key set of
+    the S = 1 heads (regenerated by the tests from `cfg1_state_keys` = the sorted key list), inputs = neck_inputs(NSEED + 1)."""
+    cfg = dict(Hh.FULL, S=1)
+    ih, kh, sd, shapes = build(ns, cfg)
+    B, H, W, C = 1, 32, 64, cfg["C"]
+    N = cfg["Nq"] + cfg["n_stuff"]
+    metas = [Hh.img_meta(H * 8, W * 8)]
+    feats = Hh.neck_inputs(NSEED + 1, B, C, H, W)
+    (pf, xf, mp, _, seg, df, dp, dpr, _) = kh.simple_test_rpn(feats, metas)
+    r = ih._mask_forward(0, xf, pf, mp, metas, dpr.expand(-1, N, -1, -1), dp, df)
+    o4 = ih.simple_test_mask_preds(xf, pf, mp, None, metas, depth_preds=dpr, depth_feats=df, depth_proposal=dp)
+    assert np.array_equal(np_(o4[2]), np_(r["mask_preds"])) and np.array_equal(np_(o4[3]), np_(r["scaled_mask_preds"]))
+    meta = dict(cfg=cfg, B=B, H=H, W=W, N=N, wseed=WSEED, nseed=NSEED + 1, torch=torch.__version__)
+    np.savez_compressed(
+        os.path.join(OUT, "cfg1.npz"), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+        keys_json=np.frombuffer(json.dumps({k: list(v) for k, v in sorted(shapes.items())}).encode(), dtype=np.uint8),
+        kh_mask_preds=np_(mp), kh_proposal=np_(pf.reshape(B, N, C)), kh_depth_pred=np_(dpr),
+        obj=np_(o4[0].reshape(B, N, C)), cls=np_(o4[1]), mask=np_(o4[2]),
+        # the x2-upsampled maps: every third row / column (both phases of the period-2 bilinear stencil) + two checksums
+        mask_up_s=np_(o4[3][..., 0::3, 0::3]), depth_up_s=np_(r["scaled_depth_preds"][..., 0::3, 0::3]),
+        mask_up_sum=np.array([float(o4[3].double().sum()), float(o4[3].double().abs().sum())]),
+        depth_up_sum=np.array([float(r["scaled_depth_preds"].double().sum()), float(r["scaled_depth_preds"].double().abs().sum())]))
+    print("[cfg1] 32x64, N = 111, S = 1: mask std", float(o4[2].std()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = R.load_reference()
@@ -243,6 +270,7 @@ def main():
         ("d", 24, 48, Hh.img_meta(93, 187, pad_to=(100, 200), ori=(140, 281))),
         ("e", 19, 37, Hh.img_meta(70, 141, pad_to=(75, 150), ori=(53, 107))),
     ])
+    cfg1_fixture(ns)
     run_family(ns, Hh.MINI, "mini", B=2, H=6, W=10, store_all=True)
     shapes = run_family(ns, Hh.FULL, "full", B=2, H=8, W=16, store_all=False)
     with open(os.path.join(OUT, "full_state_keys.json"), "w") as f:

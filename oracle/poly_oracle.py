@@ -169,7 +169,8 @@ def _conv_gn_relu(sd, name, f, groups):
 
 
 def kernel_head_post_neck(sd, f0, f1, f2, num_thing_classes, num_classes, groups=32, prefix="",
-                          cat_stuff_mask=True):
+                          cat_stuff_mask=True, hard_mask=None):
+    """`hard_mask` (tests only): {0,1} [B, Nth, H, W] used INSTEAD of binarize(m_th) in the object pooling (see update_stage)."""
     p = prefix
     B = f0.shape[0]
     loc = _conv_gn_relu(sd, p + "loc_convs.0", f0, groups)           # :250-251
@@ -180,7 +181,8 @@ def kernel_head_post_neck(sd, f0, f1, f2, num_thing_classes, num_classes, groups
     dpr = F.conv2d(dfe, sd[p + "conv_direct_depth.weight"], sd[p + "conv_direct_depth.bias"])  # :285
     seg = F.conv2d(sem, sd[p + "conv_seg.weight"], sd[p + "conv_seg.bias"])                    # :295
     x = sem + loc                                                    # :303
-    obj = torch.einsum("bnhw,bchw->bnc", binarize(m_th), x)          # :314-320 (use_binary)
+    Mth = binarize(m_th) if hard_mask is None else hard_mask.to(m_th.dtype)
+    obj = torch.einsum("bnhw,bchw->bnc", Mth, x)                     # :314-320 (use_binary)
     Nth, C = W_init.shape[:2]
     k0 = W_init[None].expand(B, Nth, C, 1, 1) + obj.view(B, Nth, C, 1, 1)   # :299-300,324-326
     dker = sd[p + "conv_direct_depth.weight"][None].expand(B, 1, C, 1, 1)    # :286-289
@@ -277,12 +279,16 @@ def get_panoptic(cls_scores, mask_up, depth_up, depth_init_up, img_meta, num_pro
 # --------------------------------------------------------------------------------------------
 # whole path, as Polyphonic.simple_test wires it (polyphonic/polyphonic_former.py:145-161)
 # --------------------------------------------------------------------------------------------
-def run_head(sd, feats, S, num_thing_classes, num_classes, heads=8, groups=32):
+def run_head(sd, feats, S, num_thing_classes, num_classes, heads=8, groups=32, hard_masks=None):
+    """`hard_masks` (tests only): the S hard masks [B, N, H, W] of another implementation's run; stage s pools with
+    hard_masks[s], KernelHead's object pooling with the thing rows of hard_masks[0] (the same binarisation of m_th)."""
+    nth = sd["rpn_head.init_kernels.weight"].shape[0]
     kh = kernel_head_post_neck(sd, feats[0], feats[1], feats[2], num_thing_classes, num_classes,
-                               groups, prefix="rpn_head.")
+                               groups, prefix="rpn_head.",
+                               hard_mask=None if hard_masks is None else hard_masks[0][:, :nth])
     out = iter_head_mask_preds(sd, S, kh["x_feats"], kh["proposal_feats"], kh["mask_preds"],
                                kh["depth_proposal"], kh["depth_feats"], heads,
-                               prefix="roi_head.mask_head.")
+                               prefix="roi_head.mask_head.", hard_masks=hard_masks)
     out["kernel_head"] = kh
     return out
 

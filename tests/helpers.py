@@ -84,6 +84,17 @@ def needed_atol(a, b, rtol):
     return float(d.max().clamp_min(0.0) / b.abs().max().clamp_min(1e-30))
 
 
+def unpack_hard_masks(dev_bits, N, H, W):
+    """`DecodePlan.debug_bits` (the bit words [B, Npad, HWp / 32] every stage of a device run pooled with) as {0, 1}
+    fp32 tensors [B, N, H, W]: what the oracle takes as `hard_masks=` so that a free-running comparison follows the
+    DEVICE's hard decisions and measures arithmetic at 1e-3, whatever pixel flipped"""
+    out = []
+    for b in dev_bits:
+        u = np.unpackbits(b.cpu().numpy().view("uint32").view("uint8"), axis=-1, bitorder="little")[:, :N, :H * W]
+        out.append(torch.from_numpy(u.astype("float32")).reshape(b.shape[0], N, H, W))
+    return out
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

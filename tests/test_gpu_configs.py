@@ -167,25 +167,38 @@ def test_cfg5_teacher_forced_and_free_running(gpu, precision):
     head, sd = _head_and_sd(wl, precision, gpu, seed=5, out_dtype=torch.float16 if precision == "fp16" else torch.float32)
     inp = bench.synth_inputs(wl, 1, seed=14)
     _teacher_forced(head, sd, wl, inp, gpu, TOL[precision])
-    # free running through simple_test_mask_preds
+    # free running through simple_test_mask_preds, on IDENTICAL inputs: the 16-bit grades get features already rounded to
+    # their plane format (what cfg5 "fp16" means; for `mixed` / `mixed16` / `bf16` the bf16 plane the ingest would produce),
+    # the oracle gets the same rounded values.  The run records the hard masks every stage pooled with, the oracle follows
+    # them: every output at the mode's per-stage tolerance (1e-3 for all but the all-bf16 grade) whatever pixel flipped
+    # (no blanket 5e-2, a real bound for mixed16), the per-stage flip rates bounded separately.
     N = wl["Nq"] + wl["n_stuff"]
-    ref = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"])
+    rd = PLANE_DT[precision]
+    if rd is not None:
+        inp["x"], inp["dfe"] = inp["x"].to(rd).float(), inp["dfe"].to(rd).float()
     g = {k: v.to(gpu) for k, v in inp.items()}
     metas = [Hh.img_meta(375, 1242, pad_to=(384, 1248))]
+    plan = head._plan(1, N, wl["H"], wl["W"], gpu)
+    plan.debug_bits = []
     obj, cls, mask, mask_up = head.simple_test_mask_preds(g["x"], g["k0"].reshape(1, N, 256, 1, 1), g["m0"], None, metas,
                                                           depth_feats=g["dfe"], depth_proposal=g["q0"].reshape(1, N, 256, 1, 1))
+    torch.cuda.synchronize()
     assert mask_up.shape == (1, N, 96, 312) and obj.shape == (1, N, 256, 1, 1)
-    flips = ((mask.float().cpu() > 0) != (ref["mask"] > 0)).float().mean().item()
-    e = {n: Hh.rel_err(t.float().cpu(), r) for n, t, r in (("obj", obj.reshape(1, N, 256), ref["obj"]), ("cls", cls, ref["cls"]),
-                                                            ("mask", mask, ref["mask"]), ("mask_up", mask_up, ref["mask_up"]))}
-    print(f"cfg5 free-running {precision}: flip rate {flips:.2e}, rel err {e}")
-    if precision in ("fp32", "fp16"):      # fp16 = cfg5 as specified: fp16 planes / kernels / logits, S = 3, N = 253
-        assert flips < (1e-3 if precision == "fp32" else 5e-3)
-        assert max(e.values()) < (1e-3 if flips == 0 else 5e-2)
-    elif precision in ("mixed", "mixed16"):      # fp32 inputs are rounded to one bf16 plane by the ingest: input rounding, not arithmetic
-        assert flips < 2e-2 and e["obj"] < 0.1
-    else:
-        assert flips < 0.05 and e["obj"] < 0.1
+    plan = next(iter(head._plans.values()))
+    hard, plan.debug_bits = Hh.unpack_hard_masks(plan.debug_bits, N, wl["H"], wl["W"]), None
+    assert len(hard) == wl["S"]
+    refs = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"], return_stages=True)
+    stage_flips = [float((hard[0] != O.binarize(inp["m0"])).float().mean())] + \
+                  [float((hard[s + 1] != O.binarize(refs["stages"][s]["mask"])).float().mean()) for s in range(wl["S"] - 1)]
+    refc = O.iter_head_mask_preds(sd, wl["S"], inp["x"], inp["k0"], inp["m0"], inp["q0"], inp["dfe"], hard_masks=hard)
+    e = {n: Hh.rel_err(t.float().cpu(), r) for n, t, r in (("obj", obj.reshape(1, N, 256), refc["obj"]), ("cls", cls, refc["cls"]),
+                                                            ("mask", mask, refc["mask"]), ("mask_up", mask_up, refc["mask_up"]),
+                                                            ("depth_up", plan.depth_up, refc["depth_up"]))}
+    print(f"cfg5 free-running {precision}: flip rate per stage input {[f'{f:.1e}' for f in stage_flips]}, "
+          f"rel err vs the oracle on the device's hard masks", {k: f"{v:.1e}" for k, v in e.items()})
+    assert stage_flips[0] == 0.0                                   # binarising the given logits is exact
+    assert max(stage_flips) < {"fp32": 1e-3, "bf16": 5e-2}.get(precision, 5e-3)
+    assert max(e.values()) < TOL_IDENT[precision], e
 
 
 def test_api_outputs_survive_the_next_call(gpu):

@@ -144,3 +144,31 @@ def test_whole_path_panoptic(tag):
     pan, info, _, _ = O.get_panoptic(out["cls"][0], out["mask_up"][0], out["depth_up"][0], d0_up[0],
                                      meta, cfg["Nq"], cfg["n_thing"], cfg["Nq"])
     assert np.array_equal(pan, z["pan_geo2"])
+
+
+def cfg1_case():
+    """(meta, weights, post-neck inputs, golden) of tests/golden/cfg1.npz: BASELINE configs[0] at its exact shape"""
+    z = Hh.load_golden("cfg1.npz")
+    m = _meta(z)
+    shapes = json.loads(bytes(z["keys_json"]).decode())
+    sd = Hh.seeded_fill(shapes, m["wseed"])
+    feats = Hh.neck_inputs(m["nseed"], m["B"], m["cfg"]["C"], m["H"], m["W"])
+    return m, sd, feats, z
+
+
+def test_cfg1_exact_shape_oracle_vs_reference():
+    """cfg1 = one 256x512 frame (32x64 map), N = 100 + 11, S = 1, fp32 CPU: the restatement against the reference's
+    KernelHead -> simple_test_mask_preds at exactly that shape"""
+    m, sd, feats, z = cfg1_case()
+    cfg = m["cfg"]
+    out = O.run_head(sd, feats, 1, cfg["n_thing"], cfg["n_thing"] + cfg["n_stuff"], cfg["heads"], cfg["groups"])
+    kh = out["kernel_head"]
+    B, N = m["B"], m["N"]
+    assert Hh.rel_err(kh["mask_preds"], z["kh_mask_preds"]) < TOL
+    assert Hh.rel_err(kh["proposal_feats"].reshape(B, N, -1), z["kh_proposal"]) < TOL
+    assert Hh.rel_err(kh["depth_pred"], z["kh_depth_pred"]) < TOL
+    for k in ("obj", "cls", "mask"):
+        assert Hh.rel_err(out[k], z[k]) < 1e-4, k
+    assert Hh.rel_err(out["mask_up"][..., 0::3, 0::3], z["mask_up_s"]) < 1e-4
+    assert Hh.rel_err(out["depth_up"][..., 0::3, 0::3], z["depth_up_s"]) < 1e-4
+    assert abs(float(out["mask_up"].double().abs().sum()) / z["mask_up_sum"][1] - 1) < 1e-5
