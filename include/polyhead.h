@@ -449,8 +449,9 @@ int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int gro
  *                  without an fp32 sum buffer); ys / stats / gammas / betas are HOST arrays of `nlev` device pointers. */
 int ph_nhwc_ingest(const float* src, const float* add /* nullable */, uint16_t* dst, int B, int64_t HW, int prec, void* stream);
 size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo);                     /* upper bound, any instantiation */
-int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec);  /* `nwg` for ph_gn_finalize (launches of >= 256 tiles) */
-int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B);   /* the same for a launch of B frames: small launches take 2-row tiles */
+/* `nwg` for ph_gn_finalize = workgroups per frame of the ph_conv_nhwc launch of B frames (small launches take 2-row tiles, so
+   the count depends on B; the B-less ph_conv_nhwc_workgroups of rounds 3-4 is removed: it was wrong for small launches) */
+int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B);
 int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize, int stride,
                  int B, int H, int W, int prec, void* stream);
 int ph_gn_finalize(const float* partial, float* stats, int nwg, int groups, int64_t HW, float eps, int B, void* stream);

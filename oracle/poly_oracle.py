@@ -243,7 +243,7 @@ def merge_from_probs(P, D, scores, labels, D0, num_thing_classes, instance_score
     for kk in order.tolist():                                        # :500
         cls = int(labels[kk])
         isthing = cls < num_thing_classes
-        if isthing and float(scores[kk]) < instance_score_thr:       # :503
+        if isthing and bool(scores[kk] < instance_score_thr):        # :503 (0-dim fp32 tensor vs Python scalar: an fp32 comparison)
             continue
         mask = ids == kk                                             # :506
         area = int(mask.sum())

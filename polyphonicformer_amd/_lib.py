@@ -106,7 +106,6 @@ SIGNATURES = {
     "ph_gn_relu_cl": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _I, _I, _P]),
     "ph_nhwc_ingest": (C.c_int, [_P, _P, _P, _I, _L, _I, _P]),
     "ph_conv_nhwc_partial_floats": (C.c_size_t, [_I, _I, _I]),
-    "ph_conv_nhwc_workgroups": (C.c_int, [_I, _I, _I, _I, _I]),
     "ph_conv_nhwc_workgroups_b": (C.c_int, [_I, _I, _I, _I, _I, _I]),
     "ph_conv_nhwc": (C.c_int, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ph_gn_finalize": (C.c_int, [_P, _P, _I, _I, _L, C.c_float, _I, _P]),
@@ -163,24 +162,36 @@ def stream_ptr():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+def _tree(module):
+    """cached [(prefix, sub-module)] of `module`, re-discovered when the tree changed: the signature is the identity of every
+    cached module's direct children (a replaced / added / removed sub-module -- `head.fc_cls = nn.Linear(...)`,
+    `rpn_head.localization_fpn = None` -- changes it).  ~100 dict reads per call instead of a generator walk."""
+    c = module.__dict__.get("_ph_tree")
+    if c is not None:
+        sig = tuple(id(ch) for _, m in c[1] for ch in m._modules.values())
+        if sig == c[0]:
+            return c[1]
+    mods = [(n + "." if n else "", m) for n, m in module.named_modules()]
+    module.__dict__["_ph_tree"] = (tuple(id(ch) for _, m in mods for ch in m._modules.values()), mods)
+    return mods
+
+
 def param_versions(module):
     """the `_version` counters of every parameter of `module` -- the cache key of the packed device weights (an in-place
-    update such as load_state_dict / an optimizer step bumps them).  Walks a cached list of the sub-MODULES and reads their
-    live `_parameters` dicts (a replaced Parameter object is seen; a sub-module added after the first call is not -- these
-    heads never grow): `module.parameters()` re-discovers the module tree on every call, 0.8 ms per video frame."""
-    mods = module.__dict__.get("_ph_modules")
-    if mods is None:
-        mods = [m for m in module.modules()]
-        module.__dict__["_ph_modules"] = mods
-    return tuple(p._version for m in mods for p in m._parameters.values() if p is not None)
+    update such as load_state_dict / an optimizer step bumps them; a replaced Parameter or sub-module is seen through the
+    live `_parameters` dicts / `_tree`'s signature; the id of each Parameter is part of the key for that reason).
+    `module.parameters()` re-discovers the module tree on every call, 0.8 ms per video frame."""
+    return tuple((id(p), p._version) for _, m in _tree(module) for p in m._parameters.values() if p is not None)
 
 
 def named_params(module):
-    """dict(module.named_parameters()) without re-discovering the module tree: a cached list of (prefix, sub-module) pairs, their
-    live `_parameters` dicts read on every call (a replaced Parameter object is seen; these heads never grow).  The training
-    forward asks once per stage and head: 1 641 `named_parameters` generator steps, 1.3 ms per step (round 4 host profile)."""
-    mods = module.__dict__.get("_ph_named_modules")
-    if mods is None:
-        mods = [(n + "." if n else "", m) for n, m in module.named_modules()]
-        module.__dict__["_ph_named_modules"] = mods
-    return {pre + k: p for pre, m in mods for k, p in m._parameters.items() if p is not None}
+    """dict(module.named_parameters()) without re-discovering the module tree on every call (`_tree`); like
+    `named_parameters`, a Parameter shared by two modules appears once, under its first name.  The training forward asks once
+    per stage and head: 1 641 `named_parameters` generator steps, 1.3 ms per step (round 4 host profile)."""
+    out, seen = {}, set()
+    for pre, m in _tree(module):
+        for k, p in m._parameters.items():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out[pre + k] = p
+    return out

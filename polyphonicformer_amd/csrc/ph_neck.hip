@@ -321,9 +321,8 @@ extern "C" int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, 
     const int th = conv_th(Ho, Wo, prec, B);
     return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + th - 1) / th);
 }
-extern "C" int ph_conv_nhwc_workgroups(int ksize, int stride, int Ho, int Wo, int prec) {       // launches of >= 256 four-row tiles
-    return ph_conv_nhwc_workgroups_b(ksize, stride, Ho, Wo, prec, 1 << 20);
-}
+// (round 5: the B-less `ph_conv_nhwc_workgroups` is REMOVED -- it answered for launches of >= 256 four-row tiles only and
+// handed ph_gn_finalize a wrong count and partial stride on small launches; a stale caller now fails at link / dlsym time)
 
 // upper bound over all instantiations (2-row tiles)
 extern "C" size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo) {

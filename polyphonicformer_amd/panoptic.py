@@ -42,9 +42,9 @@ def accept_loop(scores, labels, area, orig, num_thing_classes, instance_score_th
     sc, lab = scores.numpy(), labels.numpy()
     area, orig = np.asarray(area, dtype=np.int64), np.asarray(orig, dtype=np.int64)
     isthing = lab < num_thing_classes
-    # :503 compares `total_scores[k].item()` -- the fp32 score as a Python float -- with the threshold in DOUBLE precision
-    # (numpy would round the threshold to fp32 first: different for a score that equals fp32(thr) < thr)
-    keep = ~(isthing & (sc.astype(np.float64) < float(instance_score_thr)))  # :503
+    # :503 is `total_scores[k] < merge_cfg.instance_score_thr`: a 0-dim fp32 TENSOR against a Python scalar, which torch
+    # evaluates in fp32 (the scalar is rounded to the tensor's dtype) -- a thing scoring exactly fp32(0.7) is NOT below 0.7
+    keep = ~(isthing & (sc.astype(np.float32) < np.float32(instance_score_thr)))  # :503
     keep &= (area > 0) & (orig > 0)                                          # :510
     with np.errstate(divide="ignore", invalid="ignore"):
         keep &= ~((area / np.where(orig > 0, orig, 1)) < overlap_thr)        # :511 (python float division, as there)

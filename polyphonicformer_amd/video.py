@@ -530,7 +530,9 @@ class VideoStreamRunner:
         sl["cur"] = B
         from . import panoptic as Pn
         if not self.use_graph:
-            x = frames[0] if B == 1 else tuple(torch.cat([f[l] for f in frames], 0) for l in range(len(frames[0])))
+            # slot-owned copies in this path too (torch.cat copies; one frame is cloned): RoIAlign reads the levels one push
+            # later, and the contract is that the caller may reuse its tensors once push() returns
+            x = tuple(t.clone() for t in frames[0]) if B == 1 else tuple(torch.cat([f[l] for f in frames], 0) for l in range(len(frames[0])))
             outs = self._heads_device(sl, x)
             dm = (sl["g"].get(B) or {}).get("dm")
             if self.device_select:
@@ -664,7 +666,9 @@ class VideoStreamRunner:
         differences, not bit identity).  `PH_VIDEO_CLIP_BATCH=1` restores one frame per launch."""
         import os
         from . import _lib, engine as E
-        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "4"))
+        # default 3: the neck's output-stage tile runs and conv tiles are fixed per FRAME up to 3 frames per launch (csrc/ph_neck.hip
+        # conv_th, ph_khead.hip kh_tiles_per_wg_plain); a larger cap is honoured only through the checks below
+        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "3"))
         grade = E.KHEAD_PREC.get(getattr(self.pipe.rpn_head, "precision", None))
         if grade not in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) or os.environ.get("PH_KHEAD_TWOPASS"):
             return 1

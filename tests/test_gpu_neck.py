@@ -23,11 +23,14 @@ def _planes_to_float(p):
 
 
 @pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_SPLIT])
-@pytest.mark.parametrize("k,s,H,W", [(3, 1, 6, 70), (3, 2, 9, 131), (1, 1, 5, 64), (3, 1, 2, 3), (3, 1, 64, 1024), (3, 2, 72, 2048)])
-def test_conv_nhwc(gpu, prec, k, s, H, W):
-    # the small maps take the 2-row tiles (fewer than 256 four-row tiles per launch), the last two the 4-row tiles (bf16 grade)
+@pytest.mark.parametrize("k,s,H,W,B", [(3, 1, 6, 70, 2), (3, 2, 9, 131, 2), (1, 1, 5, 64, 2), (3, 1, 2, 3, 2), (3, 1, 64, 1024, 2),
+                                       (3, 2, 72, 2048, 2), (3, 1, 6, 70, 1), (3, 1, 32, 64, 1), (3, 1, 48, 512, 5)])
+def test_conv_nhwc(gpu, prec, k, s, H, W, B):
+    # the small maps take the 2-row tiles (fewer than 256 four-row tiles per launch), the large ones the 4-row tiles (bf16 grade);
+    # B = 1 on a small map and B = 5 (where the choice follows the LAUNCH's tile count): the partial-sum layout ph_gn_finalize
+    # reads is the one ph_conv_nhwc_workgroups_b(..., B) describes (the B-less query is removed)
     g = torch.Generator().manual_seed(7)
-    B, P = 2, (2 if prec == _lib.PH_PREC_SPLIT else 1)
+    P = 2 if prec == _lib.PH_PREC_SPLIT else 1
     x = torch.randn(B, 256, H, W, generator=g)
     w = torch.randn(256, 256, k, k, generator=g) * 0.05
     xp = torch.empty((P, B, H * W, 256), dtype=torch.int16, device=gpu)

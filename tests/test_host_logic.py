@@ -179,17 +179,25 @@ def test_accept_loop_matches_reference_segments(case):
     assert np.array_equal(pan, z[f"{case}_pan"])
 
 
-def test_accept_loop_compares_the_score_threshold_in_double_precision():
-    """kernel_update.py:503 tests `total_scores[k].item() < instance_score_thr`: the fp32 score widened to a Python float against
-    the threshold as written -- a thing whose score is fp32(0.7) = 0.69999998... is BELOW 0.7 and rejected; rounding the threshold to
-    fp32 first (what numpy does with a float32 array and a Python scalar) would keep it"""
+def test_accept_loop_compares_the_score_threshold_in_fp32():
+    """kernel_update.py:503 tests `total_scores[k] < merge_cfg.instance_score_thr`: a 0-dim fp32 tensor against a Python scalar,
+    which torch evaluates in fp32 -- a thing whose score is exactly fp32(0.7) = 0.69999998... is NOT below 0.7 and is kept (ADVICE r04;
+    a double-precision comparison would drop it).  The oracle's loop and the product's vectorised form agree with torch."""
     from polyphonicformer_amd import panoptic as Pn
+    from oracle import poly_oracle as O
     sc = torch.tensor([0.9, 0.7, 0.7, 0.5], dtype=torch.float32)               # 0.7 -> 0.699999988 in fp32
+    assert not bool(sc[1] < 0.7)                                               # torch's own answer: the reference's arithmetic
     lab = torch.tensor([0, 1, 9, 2])                                            # index 2 is stuff (>= 8 thing classes): not thresholded
     newid, info = Pn.accept_loop(sc, lab, np.array([10, 10, 10, 10]), np.array([10, 10, 10, 10]), 8, 0.7, 0.5)
-    assert newid.tolist() == [1, 0, 2, 0] and [s["category_id"] for s in info] == [0, 9]
-    newid, _ = Pn.accept_loop(sc, lab, np.array([10, 10, 10, 10]), np.array([10, 10, 10, 10]), 8, float(np.float32(0.7)), 0.5)
-    assert newid.tolist() == [1, 2, 3, 0]                                       # threshold = the fp32 value itself: not below it
+    assert newid.tolist() == [1, 2, 3, 0] and [s["category_id"] for s in info] == [0, 1, 9]
+    newid, _ = Pn.accept_loop(sc, lab, np.array([10, 10, 10, 10]), np.array([10, 10, 10, 10]), 8, 0.7000001, 0.5)
+    assert newid.tolist() == [1, 0, 2, 0]                                       # a threshold above fp32(0.7): below it, rejected
+    # the oracle's sequential loop on disjoint one-pixel masks gives the same ids
+    P = torch.zeros(4, 1, 4)
+    for k in range(4):
+        P[k, 0, k] = 1.0
+    pan, oinfo, _ = O.merge_from_probs(P, torch.zeros(4, 1, 4), sc, lab, torch.zeros(1, 4), 8, 0.7, 0.5)
+    assert pan.reshape(-1).tolist() == [1, 2, 3, 0] and [s["category_id"] for s in oinfo] == [0, 1, 9]
 
 
 def test_fp16_config_key_switches_both_heads():
@@ -233,7 +241,20 @@ def test_param_versions_sees_in_place_updates_and_replaced_parameters():
         m[1].bias.add_(1.0)
     assert _lib.param_versions(m) != v1
     m2 = copy.deepcopy(m)
-    assert m2.__dict__["_ph_modules"][0] is m2 and m2.__dict__["_ph_modules"][1] is m2[0]
     with torch.no_grad():
         m2[0].weight.mul_(2.0)
     assert _lib.param_versions(m2) != _lib.param_versions(m)
+    assert _lib._tree(m2)[0][1] is m2 and _lib._tree(m2)[1][1] is m2[0]
+    # a REPLACED or ADDED sub-module is seen (the cached tree is keyed on the identity of every module's children),
+    # and a Parameter shared by two modules is listed once, like nn.Module.named_parameters
+    v2 = _lib.param_versions(m)
+    old = set(map(id, _lib.named_params(m).values()))
+    m[0] = torch.nn.Linear(4, 4)
+    assert _lib.param_versions(m) != v2
+    assert id(m[0].weight) in set(map(id, _lib.named_params(m).values())) - old
+    m.add_module("extra", torch.nn.Linear(4, 2))
+    assert "extra.weight" in _lib.named_params(m) and len(_lib.param_versions(m)) == 6
+    m.extra.weight = m[0].weight if m.extra.weight.shape == m[0].weight.shape else m.extra.weight
+    tied = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    tied[1].weight = tied[0].weight
+    assert list(_lib.named_params(tied)) == [n for n, _ in tied.named_parameters()]
