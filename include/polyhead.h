@@ -368,6 +368,47 @@ int ph_map_x_map_t_nsplit(int B, int M, int64_t HW);
 int ph_map_x_map_t(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
                   int binarize_g, void* stream);
 int ph_upsample2x_bwd(const float* grad_out, float* grad_in, int64_t planes, int H, int W, void* stream);
+/* round 5: _ex forms.  rows_x_map: bias [B][M] (nullable) added to every pixel of row m -- the scalar bias of a folded dynamic
+ * kernel, kernel_update_head.py:317-329 --, accumulate != 0: Y += (a second gradient contribution into the same map).
+ * map_x_mapT: rowsum [B][M] = sum_p G[b][m][p] (binarised: the pixel count of each hard mask; otherwise the gradient of a dynamic
+ * kernel's scalar bias), rs_partial [B][nsplit][M] its per-split scratch; both null or both given.
+ * hard_count: out[r] = #{p : sigmoid(logits[r][p]) > 0.5}. */
+int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
+                     int64_t HW, int binarize_x, const float* bias, int accumulate, void* stream);
+int ph_map_x_map_t_ex(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
+                      int binarize_g, float* rs_partial, float* rowsum, void* stream);
+int ph_hard_count(const float* logits, float* out, int64_t rows, int64_t HW, void* stream);
+
+/* ---- N4, device half: the QUERY SIDE of one KernelUpdateHead stage in TRAINING mode (csrc/ph_qtrain.hip) -------------------
+ * Replaces what autograd records for kernel_update_head.py:245-288 (KernelUpdator x2, funcs/kernel_updator.py:55-93; mmcv
+ * MultiheadAttention + LayerNorm x2; FFN + LayerNorm x2; cls_fcs / mask_fcs / depth_regs + fc_cls / fc_mask / fc_depth) and its
+ * backward.  Rows r = b * N + n of 256 features; two branches (0 mask, 1 depth).  fp32 in, fp32 out, fp32 MFMA products.
+ * params: HOST array [2][PH_QTRAIN_NPARAM] of DEVICE pointers to the fp32 parameters as nn.Parameter stores them ([out][in]
+ * weights), per branch in this order (mask-branch names; the depth branch: *_depth, depth_regs / fc_depth for 34-38, 39-43 null):
+ *   0 feat_transform.conv.weight  1 .bias | kernel_update_conv: 2 dynamic_layer.weight 3 .bias 4 input_layer.weight 5 .bias
+ *   6 input_gate.weight 7 .bias 8 update_gate.weight 9 .bias 10 input_norm_in.weight 11 .bias 12 norm_in.weight 13 .bias
+ *   14 norm_out.weight 15 .bias 16 input_norm_out.weight 17 .bias 18 fc_layer.weight 19 .bias 20 fc_norm.weight 21 .bias |
+ *   22 attention.attn.in_proj_weight 23 in_proj_bias 24 out_proj.weight 25 out_proj.bias 26 attention_norm.weight 27 .bias |
+ *   28 ffn.layers.0.0.weight 29 .bias 30 ffn.layers.1.weight 31 .bias 32 ffn_norm.weight 33 .bias |
+ *   34 mask_fcs.0.weight 35 mask_fcs.1.weight 36 mask_fcs.1.bias 37 fc_mask.weight 38 fc_mask.bias |
+ *   39 cls_fcs.0.weight 40 cls_fcs.1.weight 41 cls_fcs.1.bias 42 fc_cls.weight 43 fc_cls.bias
+ * forward : pooled [2][R][256] = the hard-mask pooling of x / depth_feats BEFORE feat_transform (folded: pooling is linear in it),
+ *           cnt [R] = pixels of each hard mask, k [R][256] kernels, q [R][256] depth kernels (the kernel k.detach() is added inside,
+ *           :250).  Writes cls [R][L], kern [2][R][256] = fc_mask / fc_depth outputs folded with feat_transform's weight,
+ *           kbias [2][R] = their product with its bias, obj [2][R][256] = the updated kernels; `saved` (ph_qtrain_saved_floats)
+ *           keeps the pre-normalisation rows, activations and attention probabilities the backward needs.
+ * backward: gradients w.r.t. cls, kern, kbias, obj in; writes grads [2][PH_QTRAIN_NPARAM] (HOST array of device pointers, each
+ *           the size of its parameter; every one is overwritten, none accumulated), g_pooled [2][R][256], g_k, g_q [R][256].
+ *           `scratch`: ph_qtrain_scratch_floats.  Fixed summation orders throughout (no atomics). */
+#define PH_QTRAIN_NPARAM 44
+size_t ph_qtrain_saved_floats(int B, int N, int L, int F);
+size_t ph_qtrain_scratch_floats(int B, int N, int L, int F);
+int ph_qtrain_forward(const float* const* params, const float* pooled, const float* cnt, const float* k, const float* q, float* cls,
+                      float* kern, float* kbias, float* obj, float* saved, int B, int N, int L, int F, void* stream);
+int ph_qtrain_backward(const float* const* params, const float* pooled, const float* cnt, const float* k, const float* q,
+                       const float* saved, const float* g_cls, const float* g_kern, const float* g_kbias, const float* g_obj,
+                       float* const* grads, float* g_pooled, float* g_k, float* g_q, float* scratch, int B, int N, int L, int F,
+                       void* stream);
 
 /* ---- A16-A18: panoptic merge (kernel_update.py:421-535, kernel_update_head.py:593-626) -------
  * geom = {sh, sw, Hb, Wb, h, w, Ho, Wo}: stride-4 source size, batch_input_shape, img_shape, ori_shape.

@@ -108,7 +108,7 @@ def update_stage(sd, pre, x, k, m, q, dfe, heads=8, hard_mask_thr=0.5, hard_mask
     M = binarize(m, hard_mask_thr) if hard_mask is None else hard_mask.to(m.dtype)   # :236-238
     u = torch.einsum("bnhw,bchw->bnc", M, xt)                        # :241
     ud = torch.einsum("bnhw,bchw->bnc", M, dt)                       # :242
-    q = q + k                                                        # :250
+    q = q + k.detach()                                               # :250 (`.detach()`: no gradient into the mask kernel; same values)
     o = kernel_updator(sd, pre + "kernel_update_conv", u, k)         # :252
     od = kernel_updator(sd, pre + "kernel_update_conv_depth", ud, q)  # :253
     o = _ln(sd, pre + "attention_norm", mha_self(sd, pre + "attention", o, heads))                # :259

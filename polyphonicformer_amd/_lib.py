@@ -89,6 +89,13 @@ SIGNATURES = {
     "ph_map_x_map_t_nsplit": (C.c_int, [_I, _I, _L]),
     "ph_map_x_map_t": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "ph_upsample2x_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P]),
+    "ph_rows_x_map_ex": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _I, _L, _I, _P, _I, _P]),
+    "ph_map_x_map_t_ex": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _P, _P]),
+    "ph_hard_count": (C.c_int, [_P, _P, _L, _L, _P]),
+    "ph_qtrain_saved_floats": (C.c_size_t, [_I, _I, _I, _I]),
+    "ph_qtrain_scratch_floats": (C.c_size_t, [_I, _I, _I, _I]),
+    "ph_qtrain_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ph_qtrain_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ph_panoptic_select": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "ph_panoptic_activate": (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ph_panoptic_argmax": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32), _I, _P, _P, _P]),

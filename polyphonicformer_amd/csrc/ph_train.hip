@@ -48,9 +48,12 @@ __device__ __forceinline__ float binz(float z) { return z > PH_BIN_THR ? 1.f : 0
 // (4, 10), one pass per 160 rows; (2, 20) = all of up to 320 rows in one pass for the binarised map operand (160 accumulator
 // registers either way).
 // A: [B or 1][Mpad][lda] fp32, Mpad % 16 == 0, lda % 8 == 0, zero padded (the caller pads: it is a few hundred KB).
+// epilogue extras (round 5): bias [B][M] added to every pixel of row m (the scalar bias of a folded dynamic kernel), and
+// accumulate: Y += (a second gradient contribution lands in the buffer the first one wrote, no ATen add over the map)
 template <bool BIN, int CT, int RT>
 __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
-                                                       const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
+                                                       const float* __restrict__ X, float* __restrict__ Y, int64_t HW,
+                                                       const float* __restrict__ bias, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
@@ -109,7 +112,12 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = (mt0 + r) * 16 + g * 4 + i;
-                    if (m < M && p < HW) __builtin_nontemporal_store(acc[r][t][i], &Yb[(int64_t)m * HW + p]);
+                    if (m < M && p < HW) {
+                        float v = acc[r][t][i];
+                        if (bias) v += bias[(int64_t)b * M + m];
+                        if (accumulate) v += Yb[(int64_t)m * HW + p];
+                        __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
+                    }
                 }
             }
         }
@@ -128,7 +136,8 @@ constexpr int RX2_PITCH = 272;             // uint16 elements per LDS row: 256 p
 
 template <bool BIN, bool VEC>
 __global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
-                                                           const float* __restrict__ X, float* __restrict__ Y, int64_t HW) {
+                                                           const float* __restrict__ X, float* __restrict__ Y, int64_t HW,
+                                                           const float* __restrict__ bias, int accumulate) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[2][32][RX2_PITCH];            // [hi | lo][k][px]
     constexpr int RT = 5, CT = 4;                                  // per wave: 8 waves = 2 row halves x 4 pixel quarters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wave = wv & 3, wr = wv >> 2;
@@ -222,7 +231,12 @@ __global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = (mt0 + r) * 16 + g * 4 + i;
-                    if (m < M && p < HW) __builtin_nontemporal_store(acc[r][t][i], &Yb[(int64_t)m * HW + p]);
+                    if (m < M && p < HW) {
+                        float v = acc[r][t][i];
+                        if (bias) v += bias[(int64_t)b * M + m];
+                        if (accumulate) v += Yb[(int64_t)m * HW + p];
+                        __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
+                    }
                 }
             }
         }
@@ -241,9 +255,11 @@ constexpr int MXM_ROWS = 448;               // 160 rows of G + 256 rows of X, ro
 constexpr int MXM_PITCH = 40;              // uint16 elements per LDS row: 32 pixels + 16 bytes of padding
 constexpr int MXM_LOADS = MXM_ROWS / 64;   // float4 loads per thread and step (row = tid / 8 + 64 j, 4 pixels at (tid % 8) * 4)
 
+// rs_partial (nullable, round 5): [B][nsplit][M] row sums of G over the split's pixels, from the staging threads' own fp32
+// loads (binarised: the pixel COUNT of each hard mask; otherwise the gradient of a dynamic kernel's scalar bias)
 template <bool VEC, bool BIN>
 __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
-                                                       int M, int K, int64_t HW, int64_t chunk) {
+                                                       int M, int K, int64_t HW, int64_t chunk, float* __restrict__ rs_partial) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[2][MXM_ROWS][MXM_PITCH];     // [hi | lo][row][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -255,6 +271,7 @@ __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G,
     const int r0 = tid >> 3, p4 = (tid & 7) * 4;
     // row j of this thread: LDS row r0 + 32 j; rows < 160 are G rows m0 + .., the others X rows
     float4 st[MXM_LOADS];
+    float rsum[3] = {0.f, 0.f, 0.f};            // G rows r0, r0 + 64, r0 + 128 of this pass
     auto fetch = [&](int64_t p) {
 #pragma unroll
         for (int j = 0; j < MXM_LOADS; ++j) {
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G,
                 }
             }
             st[j] = v;
+            if (j < 3 && isg) rsum[j] += (v.x + v.y) + (v.z + v.w);
         }
     };
     auto stash = [&]() {
@@ -334,6 +352,29 @@ __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G,
                 if (r < nrt && m < M && k < K) out[(int64_t)m * K + k] = acc[r][t][i];
             }
         }
+    if (rs_partial) {           // the 8 threads of a row are 8 adjacent lanes: xor-1/2/4 butterfly, lane 0 of the group writes
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float v = rsum[j];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            const int row = r0 + 64 * j, m = m0 + row;
+            if ((tid & 7) == 0 && row < MXM_RT * 16 && m < M) rs_partial[((int64_t)b * nsplit + s) * M + m] = v;
+        }
+    }
+}
+
+// the number of pixels of each hard mask, [rows]: one wave per row (used where no pooling pass delivers it)
+__global__ __launch_bounds__(256) void k_hard_count(const float* __restrict__ z, float* __restrict__ out, int64_t rows, int64_t HW) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* p = z + r * HW;
+    int n = 0;
+    for (int64_t i = threadIdx.x & 63; i < HW; i += 64) n += p[i] > PH_BIN_THR ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) out[r] = (float)n;
 }
 
 __global__ __launch_bounds__(256) void k_sum_splits(const float* __restrict__ partial, float* __restrict__ out, int nsplit, int64_t MK, int B) {
@@ -385,8 +426,8 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict_
 
 }  // namespace
 
-extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
-                             int64_t HW, int binarize_x, void* stream) {
+extern "C" int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
+                                int64_t HW, int binarize_x, const float* bias /* [B][M] or null */, int accumulate, void* stream) {
     PH_CHECK_ARG(A && X && Y && B > 0 && M > 0 && K > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG(Mpad % 16 == 0 && Mpad >= M && lda % 8 == 0 && lda >= K && (a_batch_stride % 4) == 0, "A must be zero padded: rows to 16, row stride to 8");
     PH_CHECK_ARG(((uintptr_t)A & 15) == 0, "A must be 16-byte aligned");
@@ -394,15 +435,27 @@ extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, in
     hipStream_t s = (hipStream_t)stream;
 #define PH_RXM(BIN, CT, RT)                                                                                               \
     hipLaunchKernelGGL((k_rows_x_map<BIN, CT, RT>), dim3((unsigned)((HW + 64 * CT - 1) / (64 * CT)), B, (tiles + RT - 1) / RT), \
-                       dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW)
+                       dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate)
     if (binarize_x) {           // the map operand staged through LDS (one comparison per element, 16-byte loads)
         const dim3 grid((unsigned)((HW + 255) / 256), B, (tiles + 9) / 10);
         if ((HW % 4) == 0 && ((uintptr_t)X & 15) == 0)
-            hipLaunchKernelGGL((k_rows_x_map_lds<true, true>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, true>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate);
         else
-            hipLaunchKernelGGL((k_rows_x_map_lds<true, false>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW);
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, false>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate);
     } else PH_RXM(false, 4, 10);
 #undef PH_RXM
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
+                             int64_t HW, int binarize_x, void* stream) {
+    return ph_rows_x_map_ex(A, a_batch_stride, lda, Mpad, M, K, X, Y, B, HW, binarize_x, nullptr, 0, stream);
+}
+
+extern "C" int ph_hard_count(const float* logits, float* out, int64_t rows, int64_t HW, void* stream) {
+    PH_CHECK_ARG(logits && out && rows > 0 && HW > 0, "bad pointer or size");
+    hipLaunchKernelGGL(k_hard_count, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, out, rows, HW);
     PH_CHECK_LAUNCH();
     return PH_OK;
 }
@@ -416,15 +469,17 @@ extern "C" int ph_map_x_map_t_nsplit(int B, int M, int64_t HW) {
     return (int)want;
 }
 
-extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial /* [B][nsplit][M][K] */, float* out /* [B][M][K] */, int B,
-                             int M, int K, int64_t HW, int nsplit, int binarize_g, void* stream) {
+extern "C" int ph_map_x_map_t_ex(const float* G, const float* X, float* partial /* [B][nsplit][M][K] */, float* out /* [B][M][K] */, int B,
+                                int M, int K, int64_t HW, int nsplit, int binarize_g, float* rs_partial /* [B][nsplit][M] or null */,
+                                float* rowsum /* [B][M] or null */, void* stream) {
+    PH_CHECK_ARG((rs_partial == nullptr) == (rowsum == nullptr), "rs_partial and rowsum go together");
     PH_CHECK_ARG(G && X && partial && out && B > 0 && M > 0 && K > 0 && K <= 256 && HW > 0 && nsplit >= 1, "bad pointer or size (K <= 256)");
     int64_t chunk = (HW + nsplit - 1) / nsplit;
     chunk = (chunk + 31) / 32 * 32;
     const bool vec = (HW % 4) == 0 && (((uintptr_t)G | (uintptr_t)X) & 15) == 0;
     const dim3 grid(nsplit, B, ((M + 15) / 16 + MXM_RT - 1) / MXM_RT);
     hipStream_t s = (hipStream_t)stream;
-#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(512), 0, s, G, X, partial, M, K, HW, chunk)
+#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(512), 0, s, G, X, partial, M, K, HW, chunk, rs_partial)
     if (vec) { if (binarize_g) PH_MXM(true, true); else PH_MXM(true, false); }
     else { if (binarize_g) PH_MXM(false, true); else PH_MXM(false, false); }
 #undef PH_MXM
@@ -432,7 +487,16 @@ extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial /* 
     const int64_t MK = (int64_t)M * K;
     hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((MK * B + 255) / 256)), dim3(256), 0, s, partial, out, nsplit, MK, B);
     PH_CHECK_LAUNCH();
+    if (rowsum) {
+        hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)(((int64_t)M * B + 255) / 256)), dim3(256), 0, s, rs_partial, rowsum, nsplit, (int64_t)M, B);
+        PH_CHECK_LAUNCH();
+    }
     return PH_OK;
+}
+
+extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
+                             int binarize_g, void* stream) {
+    return ph_map_x_map_t_ex(G, X, partial, out, B, M, K, HW, nsplit, binarize_g, nullptr, nullptr, stream);
 }
 
 extern "C" int ph_upsample2x_bwd(const float* grad_out /* [planes][2H][2W] */, float* grad_in /* [planes][H][W] */, int64_t planes, int H,

@@ -21,6 +21,7 @@ How the work is split on the MI355X:
 
 The result is checked against the reference's own forward + autograd backward (tests/golden/train_step.npz:
 every loss, the objective and the gradient of every parameter and of the three input maps)."""
+import ctypes as C
 import math
 
 import torch
@@ -39,24 +40,33 @@ def _gpu32(t, name):
 
 
 # ---- raw calls -------------------------------------------------------------------------------------------------------------
-def rows_x_map(A, X, binarize_x=False):
-    """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p];  A [B or 1, M, K], X [B, K, *spatial] -> [B, M, *spatial]"""
+def rows_x_map(A, X, binarize_x=False, bias=None, out=None, accumulate=False):
+    """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p] (+ bias[b, m]);  A [B or 1, M, K], X [B, K, *spatial] -> [B, M, *spatial].
+    `out` + accumulate: Y += (a gradient contribution added where an earlier one already lies)"""
     X = _gpu32(X, "X")
     B, K = X.shape[:2]
     HW = X[0, 0].numel()
     Ab, M, Ka = A.shape
     assert Ka == K and Ab in (1, B), (A.shape, X.shape)
     Mpad, lda = (M + 15) // 16 * 16, (K + 7) // 8 * 8
-    Ap = torch.zeros((Ab, Mpad, lda), dtype=torch.float32, device=X.device)
-    Ap[:, :M, :K] = A.detach()
-    Y = torch.empty((B, M) + tuple(X.shape[2:]), dtype=torch.float32, device=X.device)
-    _lib.check(_lib.load().ph_rows_x_map(_lib.ptr(Ap), Mpad * lda if Ab > 1 else 0, lda, Mpad, M, K, _lib.ptr(X), _lib.ptr(Y), B, HW,
-                                         int(binarize_x), _lib.stream_ptr()), "ph_rows_x_map")
+    if Mpad == M and lda == K and A.is_contiguous() and A.dtype == torch.float32:
+        Ap = A.detach()
+    else:
+        Ap = torch.zeros((Ab, Mpad, lda), dtype=torch.float32, device=X.device)
+        Ap[:, :M, :K] = A.detach()
+    Y = torch.empty((B, M) + tuple(X.shape[2:]), dtype=torch.float32, device=X.device) if out is None else out
+    assert Y.is_contiguous() and Y.numel() == B * M * HW and (out is not None or not accumulate)
+    if bias is not None:
+        bias = bias.detach().contiguous().float()
+        assert bias.numel() == B * M
+    _lib.check(_lib.load().ph_rows_x_map_ex(_lib.ptr(Ap), Mpad * lda if Ab > 1 else 0, lda, Mpad, M, K, _lib.ptr(X), _lib.ptr(Y), B, HW,
+                                            int(binarize_x), _lib.ptr(bias), int(accumulate), _lib.stream_ptr()), "ph_rows_x_map")
     return Y
 
 
-def map_x_mapT(G, X, binarize_g=False):
-    """O[b, m, k] = sum_p G[b, m, p] X[b, k, p];  G [B, M, *spatial], X [B, K, *spatial] -> [B, M, K]"""
+def map_x_mapT(G, X, binarize_g=False, out=None, rowsum=None):
+    """O[b, m, k] = sum_p G[b, m, p] X[b, k, p];  G [B, M, *spatial], X [B, K, *spatial] -> [B, M, K].
+    rowsum [B, M] (optional): sum_p G[b, m, p] from the same pass (binarised: the hard masks' pixel counts)"""
     G, X = _gpu32(G, "G"), _gpu32(X, "X")
     B, M = G.shape[:2]
     K = X.shape[1]
@@ -65,10 +75,23 @@ def map_x_mapT(G, X, binarize_g=False):
     lib = _lib.load()
     ns = lib.ph_map_x_map_t_nsplit(B, M, HW)
     part = torch.empty((B, ns, M, K), dtype=torch.float32, device=X.device)
-    out = torch.empty((B, M, K), dtype=torch.float32, device=X.device)
-    _lib.check(lib.ph_map_x_map_t(_lib.ptr(G), _lib.ptr(X), _lib.ptr(part), _lib.ptr(out), B, M, K, HW, ns, int(binarize_g),
-                                 _lib.stream_ptr()), "ph_map_x_map_t")
+    if out is None:
+        out = torch.empty((B, M, K), dtype=torch.float32, device=X.device)
+    assert out.is_contiguous() and out.numel() == B * M * K
+    rsp = None
+    if rowsum is not None:
+        assert rowsum.is_contiguous() and rowsum.numel() == B * M and rowsum.dtype == torch.float32
+        rsp = torch.empty((B, ns, M), dtype=torch.float32, device=X.device)
+    _lib.check(lib.ph_map_x_map_t_ex(_lib.ptr(G), _lib.ptr(X), _lib.ptr(part), _lib.ptr(out), B, M, K, HW, ns, int(binarize_g),
+                                    _lib.ptr(rsp), _lib.ptr(rowsum), _lib.stream_ptr()), "ph_map_x_map_t")
     return out
+
+
+def pool_hard_counts(m, x, dfe, pooled, cnt):
+    """pooled[0] = sum_p M x, pooled[1] = sum_p M depth_feats (M = the hard masks of the logits m), cnt = pixels per mask:
+    kernel_update_head.py:236-242 with feat_transform folded out (train._Stage)"""
+    map_x_mapT(m, x, binarize_g=True, out=pooled[0], rowsum=cnt)
+    map_x_mapT(m, dfe, binarize_g=True, out=pooled[1])
 
 
 # ---- differentiable map-sized operations -------------------------------------------------------------------------------------
@@ -160,68 +183,169 @@ def hard_count(logits):
     return (logits.detach() > BIN_THR).flatten(2).sum(-1).float()
 
 
-# ---- the query side (rows), under autograd -------------------------------------------------------------------------------------
-def _lin(P, name, x, bias=True):
-    return F.linear(x, P[name + ".weight"], P[name + ".bias"] if bias else None)
+# ---- one KernelUpdateHead stage: ONE autograd node, forward and backward in libpolyhead ---------------------------------------
+def _qt_names():
+    """parameter names in the order of include/polyhead.h's PH_QTRAIN table: (mask branch [44], depth branch [39])"""
+    def upd(u):
+        return [f"{u}.dynamic_layer.weight", f"{u}.dynamic_layer.bias", f"{u}.input_layer.weight", f"{u}.input_layer.bias",
+                f"{u}.input_gate.weight", f"{u}.input_gate.bias", f"{u}.update_gate.weight", f"{u}.update_gate.bias",
+                f"{u}.input_norm_in.weight", f"{u}.input_norm_in.bias", f"{u}.norm_in.weight", f"{u}.norm_in.bias",
+                f"{u}.norm_out.weight", f"{u}.norm_out.bias", f"{u}.input_norm_out.weight", f"{u}.input_norm_out.bias",
+                f"{u}.fc_layer.weight", f"{u}.fc_layer.bias", f"{u}.fc_norm.weight", f"{u}.fc_norm.bias"]
+
+    def rest(sfx):
+        return [f"attention{sfx}.attn.in_proj_weight", f"attention{sfx}.attn.in_proj_bias", f"attention{sfx}.attn.out_proj.weight",
+                f"attention{sfx}.attn.out_proj.bias", f"attention_norm{sfx}.weight", f"attention_norm{sfx}.bias",
+                f"ffn{sfx}.layers.0.0.weight", f"ffn{sfx}.layers.0.0.bias", f"ffn{sfx}.layers.1.weight", f"ffn{sfx}.layers.1.bias",
+                f"ffn_norm{sfx}.weight", f"ffn_norm{sfx}.bias"]
+    mask = (["feat_transform.conv.weight", "feat_transform.conv.bias"] + upd("kernel_update_conv") + rest("") +
+            ["mask_fcs.0.weight", "mask_fcs.1.weight", "mask_fcs.1.bias", "fc_mask.weight", "fc_mask.bias",
+             "cls_fcs.0.weight", "cls_fcs.1.weight", "cls_fcs.1.bias", "fc_cls.weight", "fc_cls.bias"])
+    depth = (["feat_depth_transform.conv.weight", "feat_depth_transform.conv.bias"] + upd("kernel_update_conv_depth") + rest("_depth") +
+             ["depth_regs.0.weight", "depth_regs.1.weight", "depth_regs.1.bias", "fc_depth.weight", "fc_depth.bias"])
+    return mask, depth
 
 
-def _ln(P, name, x):
-    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], LN_EPS)
+QT_MASK_NAMES, QT_DEPTH_NAMES = _qt_names()
+QT_NPARAM = 44
+assert len(QT_MASK_NAMES) == QT_NPARAM and len(QT_DEPTH_NAMES) == 39
 
 
-def _updator(P, name, u, k):
-    """KernelUpdator.forward (funcs/kernel_updator.py:55-93), conv_kernel_size = 1"""
-    Cf = P[name + ".input_gate.weight"].shape[0]
-    p = _lin(P, name + ".dynamic_layer", u)
-    i = _lin(P, name + ".input_layer", k)
-    gate = i[..., :Cf] * p[..., :Cf]
-    ig = _ln(P, name + ".input_norm_in", _lin(P, name + ".input_gate", gate)).sigmoid()
-    ug = _ln(P, name + ".norm_in", _lin(P, name + ".update_gate", gate)).sigmoid()
-    f = ug * _ln(P, name + ".norm_out", p[..., -Cf:]) + ig * _ln(P, name + ".input_norm_out", i[..., -Cf:])
-    return F.relu(_ln(P, name + ".fc_norm", _lin(P, name + ".fc_layer", f)))
+def _ptr_table(tensors_mask, tensors_depth):
+    """HOST array [2][44] of device pointers (the depth branch has no classification tower: 5 nulls)"""
+    arr = (C.c_void_p * (2 * QT_NPARAM))()
+    for i, t in enumerate(tensors_mask):
+        arr[i] = t.data_ptr()
+    for i, t in enumerate(tensors_depth):
+        arr[QT_NPARAM + i] = t.data_ptr()
+    return arr
 
 
-def _self_attention(P, name, t, heads):
-    """mmcv MultiheadAttention (identity added) around nn.MultiheadAttention with q = k = v (kernel_update_head.py:259)"""
-    B, N, C = t.shape
-    d = C // heads
-    q, k, v = F.linear(t, P[name + ".attn.in_proj_weight"], P[name + ".attn.in_proj_bias"]).split(C, dim=-1)
-    q = q.view(B, N, heads, d).transpose(1, 2) * (1.0 / math.sqrt(d))
-    k, v = k.view(B, N, heads, d).transpose(1, 2), v.view(B, N, heads, d).transpose(1, 2)
-    a = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B, N, C)
-    return t + F.linear(a, P[name + ".attn.out_proj.weight"], P[name + ".attn.out_proj.bias"])
+_QT_SCRATCH = {}
 
 
-def _ffn(P, name, t):
-    return t + _lin(P, name + ".layers.1", F.relu(_lin(P, name + ".layers.0.0", t)))
+def _qt_scratch(dev, n):
+    """the backward's scratch (a few tens of MB): one buffer per device, reused by every stage and step -- the stages'
+    backwards run one after the other on the same stream"""
+    t = _QT_SCRATCH.get(dev)
+    if t is None or t.numel() < n:
+        t = _QT_SCRATCH[dev] = torch.empty((n,), dtype=torch.float32, device=dev)
+    return t
+
+
+class _Stage(torch.autograd.Function):
+    """KernelUpdateHead.forward (kernel_update_head.py:212-353) in training form as ONE autograd node: hard-mask pooling of
+    x / depth_feats (`ph_map_x_map_t`, feat_transform folded), the whole query side (`ph_qtrain_forward`: updators, attention,
+    FFN, towers -- csrc/ph_qtrain.hip), the two dynamic convolutions (`ph_rows_x_map`); backward likewise
+    (`ph_qtrain_backward` + the transposed map products).  No gradient through the hard masks (piecewise constant)."""
+
+    @staticmethod
+    def forward(ctx, meta, x, dfe, k, m, q, *params):
+        lib = _lib.load()
+        x, dfe, m = _gpu32(x, "x"), _gpu32(dfe, "depth_feats"), _gpu32(m, "mask_preds")
+        k, q = _gpu32(k, "proposal_feat"), _gpu32(q, "depth_proposal")
+        params = [p.detach() for p in params]
+        pm, pd = params[:QT_NPARAM], params[QT_NPARAM:]
+        B, N, Cc = k.shape
+        L, F = meta["L"], meta["F"]
+        dev, R = x.device, B * N
+        pooled = torch.empty((2, B, N, Cc), dtype=torch.float32, device=dev)
+        cnt = torch.empty((B, N), dtype=torch.float32, device=dev)
+        pool_hard_counts(m, x, dfe, pooled, cnt)
+        cls = torch.empty((B, N, L), dtype=torch.float32, device=dev)
+        kern = torch.empty((2, B, N, Cc), dtype=torch.float32, device=dev)
+        kbias = torch.empty((2, B, N), dtype=torch.float32, device=dev)
+        obj = torch.empty((2, B, N, Cc), dtype=torch.float32, device=dev)
+        saved = torch.empty((lib.ph_qtrain_saved_floats(B, N, L, F),), dtype=torch.float32, device=dev)
+        ptab = _ptr_table(pm, pd)
+        _lib.check(lib.ph_qtrain_forward(ptab, _lib.ptr(pooled), _lib.ptr(cnt), _lib.ptr(k), _lib.ptr(q), _lib.ptr(cls), _lib.ptr(kern),
+                                         _lib.ptr(kbias), _lib.ptr(obj), _lib.ptr(saved), B, N, L, F, _lib.stream_ptr()),
+                   "ph_qtrain_forward")
+        mask = rows_x_map(kern[0], x, bias=kbias[0])                   # = conv(feat_transform(x), fc_mask(...)) (:317-322)
+        depth = rows_x_map(kern[1], dfe, bias=kbias[1])
+        ctx.meta, ctx.params = meta, params
+        ctx.save_for_backward(x, dfe, m, k, q, pooled, cnt, kern, saved)
+        return cls, mask, obj[0], depth, obj[1]
+
+    @staticmethod
+    def backward(ctx, gcls, gmask, gobj, gdepth, gdobj):
+        lib = _lib.load()
+        x, dfe, m, k, q, pooled, cnt, kern, saved = ctx.saved_tensors
+        params, meta = ctx.params, ctx.meta
+        pm, pd = params[:QT_NPARAM], params[QT_NPARAM:]
+        B, N, Cc = k.shape
+        L, F = meta["L"], meta["F"]
+        dev = x.device
+        gmask, gdepth = _gpu32(gmask, "grad"), _gpu32(gdepth, "grad")
+        # the dynamic convolutions: d kernels (+ d bias = row sums of the map gradient), d maps
+        gkern = torch.empty((2, B, N, Cc), dtype=torch.float32, device=dev)
+        gkbias = torch.empty((2, B, N), dtype=torch.float32, device=dev)
+        map_x_mapT(gmask, x, out=gkern[0], rowsum=gkbias[0])
+        map_x_mapT(gdepth, dfe, out=gkern[1], rowsum=gkbias[1])
+        need_x, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gx = rows_x_map(kern[0].transpose(1, 2), gmask) if need_x else None
+        gd = rows_x_map(kern[1].transpose(1, 2), gdepth) if need_d else None
+        gobj2 = torch.stack([_gpu32(gobj, "grad"), _gpu32(gdobj, "grad")], 0)
+        # the query side
+        sizes = meta["sizes"]
+        gflat = torch.empty((meta["total"],), dtype=torch.float32, device=dev)
+        gtab = (C.c_void_p * (2 * QT_NPARAM))()
+        base = gflat.data_ptr()
+        for i, off in enumerate(meta["offsets"]):
+            if off >= 0:
+                gtab[i] = base + 4 * off
+        g_pooled = torch.empty_like(pooled)
+        gk, gq = torch.empty_like(k), torch.empty_like(q)
+        scratch = _qt_scratch(dev, lib.ph_qtrain_scratch_floats(B, N, L, F))
+        _lib.check(lib.ph_qtrain_backward(_ptr_table(pm, pd), _lib.ptr(pooled), _lib.ptr(cnt), _lib.ptr(k), _lib.ptr(q), _lib.ptr(saved),
+                                          _lib.ptr(_gpu32(gcls, "grad")), _lib.ptr(gkern), _lib.ptr(gkbias), _lib.ptr(gobj2), gtab,
+                                          _lib.ptr(g_pooled), _lib.ptr(gk), _lib.ptr(gq), _lib.ptr(scratch), B, N, L, F,
+                                          _lib.stream_ptr()), "ph_qtrain_backward")
+        # the pooling: d map[c, p] += sum_n d pooled[n, c] M[n, p]
+        if need_x:
+            rows_x_map(g_pooled[0].transpose(1, 2), m, binarize_x=True, out=gx, accumulate=True)
+        if need_d:
+            rows_x_map(g_pooled[1].transpose(1, 2), m, binarize_x=True, out=gd, accumulate=True)
+        pgrads = []
+        for i, off in enumerate(meta["offsets"]):
+            if off >= 0:
+                pgrads.append(gflat[off:off + sizes[i]].view(meta["shapes"][i]))
+        return (None, gx, gd, gk, None, gq) + tuple(pgrads)
+
+
+def _stage_meta(head):
+    """per-head constants of `_Stage`: parameter order, sizes and offsets of the flat gradient buffer (cached on the module)"""
+    P = _lib.named_params(head)
+    c = head.__dict__.get("_ph_stage_meta")
+    plist = [P[n] for n in QT_MASK_NAMES] + [P[n] for n in QT_DEPTH_NAMES]
+    key = tuple(id(p) for p in plist)
+    if c is None or c["key"] != key:
+        for p in plist:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.PolyheadError("training forward: fp32 contiguous parameters only")
+        offsets, sizes, shapes, off = [], [], [], 0
+        for i in range(2 * QT_NPARAM):
+            j = i if i < QT_NPARAM else i - QT_NPARAM
+            have = i < QT_NPARAM or j < len(QT_DEPTH_NAMES)
+            if not have:
+                offsets.append(-1); sizes.append(0); shapes.append(None)
+                continue
+            p = plist[i if i < QT_NPARAM else QT_NPARAM + j]
+            offsets.append(off); sizes.append(p.numel()); shapes.append(tuple(p.shape))
+            off += (p.numel() + 3) // 4 * 4
+        c = dict(key=key, L=head.num_classes, F=P["ffn.layers.0.0.weight"].shape[0], offsets=offsets, sizes=sizes, shapes=shapes, total=off)
+        if P["fc_cls.weight"].shape[0] != c["L"] or P["feat_transform.conv.weight"].shape[:2] != (256, 256) or head.attention.attn.num_heads != 8:
+            raise NotImplementedError("training forward: 256 channels, 8 heads, fc_cls of num_classes rows (the shipped configuration)")
+        head.__dict__["_ph_stage_meta"] = c
+    return c, plist
 
 
 def stage_forward(head, x, dfe, k, m, q):
     """KernelUpdateHead.forward (kernel_update_head.py:212-353) in training form.  x, dfe [B, C, H, W] (gradients flow),
     k / q [B, N, C] kernels and depth kernels, m [B, N, H, W] mask logits (used through the hard mask only).
     -> cls [B, N, L], mask [B, N, H, W], obj [B, N, C], depth [B, N, H, W], dobj [B, N, C]"""
-    P = _lib.named_params(head)
-    Wt, bt = P["feat_transform.conv.weight"].flatten(1), P["feat_transform.conv.bias"]
-    Wd, bd = P["feat_depth_transform.conv.weight"].flatten(1), P["feat_depth_transform.conv.bias"]
-    cnt = hard_count(m)[..., None]
-    u = pool_hard(m, x) @ Wt.t() + cnt * bt               # = einsum(hard mask, feat_transform(x)) (:225,241)
-    ud = pool_hard(m, dfe) @ Wd.t() + cnt * bd
-    q = q + k.detach()                                    # :250
-    o = _updator(P, "kernel_update_conv", u, k)
-    od = _updator(P, "kernel_update_conv_depth", ud, q)
-    heads = head.attention.attn.num_heads
-    o = _ln(P, "attention_norm", _self_attention(P, "attention", o, heads))
-    od = _ln(P, "attention_norm_depth", _self_attention(P, "attention_depth", od, heads))
-    o = _ln(P, "ffn_norm", _ffn(P, "ffn", o))
-    od = _ln(P, "ffn_norm_depth", _ffn(P, "ffn_depth", od))
-    cls_feat = F.relu(_ln(P, "cls_fcs.1", _lin(P, "cls_fcs.0", o, bias=False)))
-    mask_feat = F.relu(_ln(P, "mask_fcs.1", _lin(P, "mask_fcs.0", o, bias=False)))
-    dep_feat = _ln(P, "depth_regs.1", _lin(P, "depth_regs.0", od, bias=False))
-    cls = _lin(P, "fc_cls", cls_feat)
-    kmask, kdep = _lin(P, "fc_mask", mask_feat), _lin(P, "fc_depth", dep_feat)
-    mask = dynconv(kmask @ Wt, x) + (kmask @ bt)[..., None, None]         # = conv(feat_transform(x), kmask) (:317-322)
-    depth = dynconv(kdep @ Wd, dfe) + (kdep @ bd)[..., None, None]
-    return cls, mask, o, depth, od
+    meta, plist = _stage_meta(head)
+    return _Stage.apply(meta, x, dfe, k, m, q.expand_as(k), *plist)
 
 
 def _tower(P, name, f, groups):
