@@ -369,14 +369,27 @@ int ph_map_x_map_t(const float* G, const float* X, float* partial, float* out, i
                   int binarize_g, void* stream);
 int ph_upsample2x_bwd(const float* grad_out, float* grad_in, int64_t planes, int H, int W, void* stream);
 /* round 5: _ex forms.  rows_x_map: bias [B][M] (nullable) added to every pixel of row m -- the scalar bias of a folded dynamic
- * kernel, kernel_update_head.py:317-329 --, accumulate != 0: Y += (a second gradient contribution into the same map).
+ * kernel, kernel_update_head.py:317-329 --, add [B][M][HW] (nullable, may be Y itself): Y = A X + add (a second gradient
+ * contribution lands where the first one lies).
  * map_x_mapT: rowsum [B][M] = sum_p G[b][m][p] (binarised: the pixel count of each hard mask; otherwise the gradient of a dynamic
  * kernel's scalar bias), rs_partial [B][nsplit][M] its per-split scratch; both null or both given.
  * hard_count: out[r] = #{p : sigmoid(logits[r][p]) > 0.5}. */
 int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
-                     int64_t HW, int binarize_x, const float* bias, int accumulate, void* stream);
+                     int64_t HW, int binarize_x, const float* bias, const float* add, void* stream);
 int ph_map_x_map_t_ex(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
-                      int binarize_g, float* rs_partial, float* rowsum, void* stream);
+                      int binarize_g, float* rs_partial, float* rowsum, int sum_batch, void* stream);
+/* GroupNorm + ReLU of a ConvModule in training mode, fp32 NCHW (csrc/ph_gntrain.hip; kernel_head.py:250-278, semantic_fpn.py:75-178).
+ * fwd: out = relu(GN(y)); out_sum = out + add (both null or both given: KernelHead's x_feats = sem + loc); stats [B][groups][2]
+ *      (mean, rstd) kept for the backward; partial: B * groups * ph_gn_train_nsplit(HW, C / groups) * 2 doubles of scratch.
+ * bwd: dy = dyA (+ dyB) masked by out > 0 (recomputed from y); dx, dgamma [C], dbeta [C] are overwritten;
+ *      partial: B * C * ph_gn_train_bwd_nsplit(HW) * 2 doubles of scratch.  sum_batch != 0 in ph_map_x_map_t_ex: out [M][K] and
+ *      rowsum [M] are summed over the images as well (the gradient of a static 1x1 kernel and of its bias). */
+int ph_gn_train_nsplit(int64_t HW, int cpg);
+int ph_gn_train_bwd_nsplit(int64_t HW);
+int ph_gn_train_fwd(const float* y, const float* gamma, const float* beta, int groups, float eps, const float* add, float* out,
+                    float* out_sum, float* stats, double* partial, int B, int C, int64_t HW, void* stream);
+int ph_gn_train_bwd(const float* y, const float* stats, const float* gamma, const float* beta, int groups, const float* dyA,
+                    const float* dyB, float* dx, float* dgamma, float* dbeta, double* partial, int B, int C, int64_t HW, void* stream);
 int ph_hard_count(const float* logits, float* out, int64_t rows, int64_t HW, void* stream);
 
 /* ---- N4, device half: the QUERY SIDE of one KernelUpdateHead stage in TRAINING mode (csrc/ph_qtrain.hip) -------------------

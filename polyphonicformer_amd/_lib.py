@@ -89,8 +89,12 @@ SIGNATURES = {
     "ph_map_x_map_t_nsplit": (C.c_int, [_I, _I, _L]),
     "ph_map_x_map_t": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P]),
     "ph_upsample2x_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P]),
-    "ph_rows_x_map_ex": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _I, _L, _I, _P, _I, _P]),
-    "ph_map_x_map_t_ex": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _P, _P]),
+    "ph_rows_x_map_ex": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _I, _L, _I, _P, _P, _P]),
+    "ph_map_x_map_t_ex": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _P, _I, _P]),
+    "ph_gn_train_nsplit": (C.c_int, [_L, _I]),
+    "ph_gn_train_bwd_nsplit": (C.c_int, [_L]),
+    "ph_gn_train_fwd": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
+    "ph_gn_train_bwd": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "ph_hard_count": (C.c_int, [_P, _P, _L, _L, _P]),
     "ph_qtrain_saved_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "ph_qtrain_scratch_floats": (C.c_size_t, [_I, _I, _I, _I]),

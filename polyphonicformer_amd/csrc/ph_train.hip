@@ -49,11 +49,11 @@ __device__ __forceinline__ float binz(float z) { return z > PH_BIN_THR ? 1.f : 0
 // registers either way).
 // A: [B or 1][Mpad][lda] fp32, Mpad % 16 == 0, lda % 8 == 0, zero padded (the caller pads: it is a few hundred KB).
 // epilogue extras (round 5): bias [B][M] added to every pixel of row m (the scalar bias of a folded dynamic kernel), and
-// accumulate: Y += (a second gradient contribution lands in the buffer the first one wrote, no ATen add over the map)
+// add [B][M][HW] (may be Y itself: a second gradient contribution lands where the first one lies, no ATen add over the map)
 template <bool BIN, int CT, int RT>
 __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
                                                        const float* __restrict__ X, float* __restrict__ Y, int64_t HW,
-                                                       const float* __restrict__ bias, int accumulate) {
+                                                       const float* __restrict__ bias, const float* add) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
                     if (m < M && p < HW) {
                         float v = acc[r][t][i];
                         if (bias) v += bias[(int64_t)b * M + m];
-                        if (accumulate) v += Yb[(int64_t)m * HW + p];
+                        if (add) v += add[((int64_t)b * M + m) * HW + p];
                         __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
                     }
                 }
@@ -137,7 +137,7 @@ constexpr int RX2_PITCH = 272;             // uint16 elements per LDS row: 256 p
 template <bool BIN, bool VEC>
 __global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict__ A, int64_t a_batch_stride, int lda, int Mpad, int M, int K,
                                                            const float* __restrict__ X, float* __restrict__ Y, int64_t HW,
-                                                           const float* __restrict__ bias, int accumulate) {
+                                                           const float* __restrict__ bias, const float* add) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[2][32][RX2_PITCH];            // [hi | lo][k][px]
     constexpr int RT = 5, CT = 4;                                  // per wave: 8 waves = 2 row halves x 4 pixel quarters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wave = wv & 3, wr = wv >> 2;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict_
                     if (m < M && p < HW) {
                         float v = acc[r][t][i];
                         if (bias) v += bias[(int64_t)b * M + m];
-                        if (accumulate) v += Yb[(int64_t)m * HW + p];
+                        if (add) v += add[((int64_t)b * M + m) * HW + p];
                         __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
                     }
                 }
@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict_
 }  // namespace
 
 extern "C" int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
-                                int64_t HW, int binarize_x, const float* bias /* [B][M] or null */, int accumulate, void* stream) {
+                                int64_t HW, int binarize_x, const float* bias /* [B][M] or null */, const float* add /* [B][M][HW], may alias Y, or null */,
+                                void* stream) {
     PH_CHECK_ARG(A && X && Y && B > 0 && M > 0 && K > 0 && HW > 0, "bad pointer or size");
     PH_CHECK_ARG(Mpad % 16 == 0 && Mpad >= M && lda % 8 == 0 && lda >= K && (a_batch_stride % 4) == 0, "A must be zero padded: rows to 16, row stride to 8");
     PH_CHECK_ARG(((uintptr_t)A & 15) == 0, "A must be 16-byte aligned");
@@ -435,13 +436,13 @@ extern "C" int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda,
     hipStream_t s = (hipStream_t)stream;
 #define PH_RXM(BIN, CT, RT)                                                                                               \
     hipLaunchKernelGGL((k_rows_x_map<BIN, CT, RT>), dim3((unsigned)((HW + 64 * CT - 1) / (64 * CT)), B, (tiles + RT - 1) / RT), \
-                       dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate)
+                       dim3(256), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, add)
     if (binarize_x) {           // the map operand staged through LDS (one comparison per element, 16-byte loads)
         const dim3 grid((unsigned)((HW + 255) / 256), B, (tiles + 9) / 10);
         if ((HW % 4) == 0 && ((uintptr_t)X & 15) == 0)
-            hipLaunchKernelGGL((k_rows_x_map_lds<true, true>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate);
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, true>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, add);
         else
-            hipLaunchKernelGGL((k_rows_x_map_lds<true, false>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, accumulate);
+            hipLaunchKernelGGL((k_rows_x_map_lds<true, false>), grid, dim3(512), 0, s, A, a_batch_stride, lda, Mpad, M, K, X, Y, HW, bias, add);
     } else PH_RXM(false, 4, 10);
 #undef PH_RXM
     PH_CHECK_LAUNCH();
@@ -450,7 +451,7 @@ extern "C" int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda,
 
 extern "C" int ph_rows_x_map(const float* A, int64_t a_batch_stride, int lda, int Mpad, int M, int K, const float* X, float* Y, int B,
                              int64_t HW, int binarize_x, void* stream) {
-    return ph_rows_x_map_ex(A, a_batch_stride, lda, Mpad, M, K, X, Y, B, HW, binarize_x, nullptr, 0, stream);
+    return ph_rows_x_map_ex(A, a_batch_stride, lda, Mpad, M, K, X, Y, B, HW, binarize_x, nullptr, nullptr, stream);
 }
 
 extern "C" int ph_hard_count(const float* logits, float* out, int64_t rows, int64_t HW, void* stream) {
@@ -471,7 +472,8 @@ extern "C" int ph_map_x_map_t_nsplit(int B, int M, int64_t HW) {
 
 extern "C" int ph_map_x_map_t_ex(const float* G, const float* X, float* partial /* [B][nsplit][M][K] */, float* out /* [B][M][K] */, int B,
                                 int M, int K, int64_t HW, int nsplit, int binarize_g, float* rs_partial /* [B][nsplit][M] or null */,
-                                float* rowsum /* [B][M] or null */, void* stream) {
+                                float* rowsum /* [B][M] or null */, int sum_batch /* out [M][K], rowsum [M]: summed over the images too */,
+                                void* stream) {
     PH_CHECK_ARG((rs_partial == nullptr) == (rowsum == nullptr), "rs_partial and rowsum go together");
     PH_CHECK_ARG(G && X && partial && out && B > 0 && M > 0 && K > 0 && K <= 256 && HW > 0 && nsplit >= 1, "bad pointer or size (K <= 256)");
     int64_t chunk = (HW + nsplit - 1) / nsplit;
@@ -485,10 +487,12 @@ extern "C" int ph_map_x_map_t_ex(const float* G, const float* X, float* partial 
 #undef PH_MXM
     PH_CHECK_LAUNCH();
     const int64_t MK = (int64_t)M * K;
-    hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((MK * B + 255) / 256)), dim3(256), 0, s, partial, out, nsplit, MK, B);
+    // sum_batch (the gradient of a STATIC 1x1 kernel): the B * nsplit records are one run of splits
+    const int sB = sum_batch ? 1 : B, sN = sum_batch ? nsplit * B : nsplit;
+    hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((MK * sB + 255) / 256)), dim3(256), 0, s, partial, out, sN, MK, sB);
     PH_CHECK_LAUNCH();
     if (rowsum) {
-        hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)(((int64_t)M * B + 255) / 256)), dim3(256), 0, s, rs_partial, rowsum, nsplit, (int64_t)M, B);
+        hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)(((int64_t)M * sB + 255) / 256)), dim3(256), 0, s, rs_partial, rowsum, sN, (int64_t)M, sB);
         PH_CHECK_LAUNCH();
     }
     return PH_OK;
@@ -496,7 +500,7 @@ extern "C" int ph_map_x_map_t_ex(const float* G, const float* X, float* partial 
 
 extern "C" int ph_map_x_map_t(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
                              int binarize_g, void* stream) {
-    return ph_map_x_map_t_ex(G, X, partial, out, B, M, K, HW, nsplit, binarize_g, nullptr, nullptr, stream);
+    return ph_map_x_map_t_ex(G, X, partial, out, B, M, K, HW, nsplit, binarize_g, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int ph_upsample2x_bwd(const float* grad_out /* [planes][2H][2W] */, float* grad_in /* [planes][H][W] */, int64_t planes, int H,

@@ -5,27 +5,24 @@ What `PolyphonicFormer.forward_train` runs after `extract_feat` (polyphonic_form
 
     rpn_head.forward_train -> roi_head.forward_train -> objective = sum of the entries whose key contains 'loss' -> backward
 
-How the work is split on the MI355X:
+How the work is split on the MI355X (round 5: every tensor operation of the step that touches a map or a weight is a
+libpolyhead kernel, forward and backward; torch is the autograd bookkeeping between four kinds of nodes):
 
-  * everything that is map-sized runs in libpolyhead, forward AND backward: every 1x1 convolution (static or
-    dynamic kernels), the hard-mask pooling, the x2 upsamples (`ph_rows_x_map`, `ph_map_x_map_t`, `ph_upsample2x`,
-    `ph_upsample2x_bwd`, csrc/ph_train.hip) and the losses with their gradients w.r.t. the predictions
-    (csrc/ph_loss.hip).  They are `torch.autograd.Function`s here, each with a hand-written backward.
-    `feat_transform` is folded as in the inference path (pooling and the dynamic convolution are linear in it),
-    so a stage makes two pooling and two dynamic-convolution passes over the maps and nothing else.
-  * the query side -- [B * N, 256] rows: KernelUpdator, attention, FFN, the fc towers -- is expressed with the
-    library's dense GEMMs and row-wise ops under autograd.  It is 4 MB of weights against a few thousand rows;
-    the fused inference kernels (csrc/ph_query.hip) keep no intermediates, so the training forward re-evaluates
-    it op by op.  GroupNorm + ReLU of the three KernelHead towers likewise.
-  * the discrete parts (Hungarian assignment, sampling, targets) are the ones `forward_train` already uses.
+  * `_Rpn`: KernelHead after the neck -- three 1x1 conv + GroupNorm + ReLU towers, x = sem + loc, the static 1x1 convs,
+    the hard-mask pooling (csrc/ph_train.hip products, csrc/ph_gntrain.hip GroupNorm forward / backward);
+  * `_Stage` (one per KernelUpdateHead): hard-mask pooling, the whole query side -- KernelUpdator x2, attention + LN x2,
+    FFN + LN x2, the fc towers, 4 MB of weights against a few hundred rows -- as ONE forward and ONE backward call
+    (csrc/ph_qtrain.hip: fp32-MFMA job tables, 19 + 21 launches), the two dynamic convolutions; `feat_transform` is folded
+    as in the inference path (pooling and the dynamic convolution are linear in it), gradients included;
+  * `_Upsample2x`; `_Objective`: a head's or stage's losses with d(losses)/d(predictions) from the loss kernels
+    (csrc/ph_loss.hip);
+  * the discrete parts (Hungarian assignment on the host, targets) in between.
 
 The result is checked against the reference's own forward + autograd backward (tests/golden/train_step.npz:
 every loss, the objective and the gradient of every parameter and of the three input maps)."""
 import ctypes as C
-import math
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib, engine as E, losses as Lo
 
@@ -40,9 +37,9 @@ def _gpu32(t, name):
 
 
 # ---- raw calls -------------------------------------------------------------------------------------------------------------
-def rows_x_map(A, X, binarize_x=False, bias=None, out=None, accumulate=False):
-    """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p] (+ bias[b, m]);  A [B or 1, M, K], X [B, K, *spatial] -> [B, M, *spatial].
-    `out` + accumulate: Y += (a gradient contribution added where an earlier one already lies)"""
+def rows_x_map(A, X, binarize_x=False, bias=None, out=None, accumulate=False, add=None):
+    """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p] (+ bias[b, m]) (+ add[b, m, p]);  A [B or 1, M, K], X [B, K, *spatial] ->
+    [B, M, *spatial].  `out` + accumulate: Y += (a gradient contribution added where an earlier one already lies)"""
     X = _gpu32(X, "X")
     B, K = X.shape[:2]
     HW = X[0, 0].numel()
@@ -55,18 +52,24 @@ def rows_x_map(A, X, binarize_x=False, bias=None, out=None, accumulate=False):
         Ap = torch.zeros((Ab, Mpad, lda), dtype=torch.float32, device=X.device)
         Ap[:, :M, :K] = A.detach()
     Y = torch.empty((B, M) + tuple(X.shape[2:]), dtype=torch.float32, device=X.device) if out is None else out
-    assert Y.is_contiguous() and Y.numel() == B * M * HW and (out is not None or not accumulate)
+    assert Y.is_contiguous() and Y.numel() == B * M * HW and (out is not None or not accumulate) and not (accumulate and add is not None)
+    if accumulate:
+        add = Y
+    elif add is not None:
+        add = _gpu32(add, "add")
+        assert add.numel() == Y.numel()
     if bias is not None:
         bias = bias.detach().contiguous().float()
         assert bias.numel() == B * M
     _lib.check(_lib.load().ph_rows_x_map_ex(_lib.ptr(Ap), Mpad * lda if Ab > 1 else 0, lda, Mpad, M, K, _lib.ptr(X), _lib.ptr(Y), B, HW,
-                                            int(binarize_x), _lib.ptr(bias), int(accumulate), _lib.stream_ptr()), "ph_rows_x_map")
+                                            int(binarize_x), _lib.ptr(bias), _lib.ptr(add), _lib.stream_ptr()), "ph_rows_x_map")
     return Y
 
 
-def map_x_mapT(G, X, binarize_g=False, out=None, rowsum=None):
+def map_x_mapT(G, X, binarize_g=False, out=None, rowsum=None, sum_batch=False):
     """O[b, m, k] = sum_p G[b, m, p] X[b, k, p];  G [B, M, *spatial], X [B, K, *spatial] -> [B, M, K].
-    rowsum [B, M] (optional): sum_p G[b, m, p] from the same pass (binarised: the hard masks' pixel counts)"""
+    rowsum [B, M] (optional): sum_p G[b, m, p] from the same pass (binarised: the hard masks' pixel counts).
+    sum_batch: summed over the images too -> [M, K] / rowsum [M] (the gradient of a static kernel and of its bias)"""
     G, X = _gpu32(G, "G"), _gpu32(X, "X")
     B, M = G.shape[:2]
     K = X.shape[1]
@@ -75,15 +78,16 @@ def map_x_mapT(G, X, binarize_g=False, out=None, rowsum=None):
     lib = _lib.load()
     ns = lib.ph_map_x_map_t_nsplit(B, M, HW)
     part = torch.empty((B, ns, M, K), dtype=torch.float32, device=X.device)
+    Bo = 1 if sum_batch else B
     if out is None:
-        out = torch.empty((B, M, K), dtype=torch.float32, device=X.device)
-    assert out.is_contiguous() and out.numel() == B * M * K
+        out = torch.empty((M, K) if sum_batch else (B, M, K), dtype=torch.float32, device=X.device)
+    assert out.is_contiguous() and out.numel() == Bo * M * K
     rsp = None
     if rowsum is not None:
-        assert rowsum.is_contiguous() and rowsum.numel() == B * M and rowsum.dtype == torch.float32
+        assert rowsum.is_contiguous() and rowsum.numel() == Bo * M and rowsum.dtype == torch.float32
         rsp = torch.empty((B, ns, M), dtype=torch.float32, device=X.device)
     _lib.check(lib.ph_map_x_map_t_ex(_lib.ptr(G), _lib.ptr(X), _lib.ptr(part), _lib.ptr(out), B, M, K, HW, ns, int(binarize_g),
-                                    _lib.ptr(rsp), _lib.ptr(rowsum), _lib.stream_ptr()), "ph_map_x_map_t")
+                                    _lib.ptr(rsp), _lib.ptr(rowsum), int(sum_batch), _lib.stream_ptr()), "ph_map_x_map_t")
     return out
 
 
@@ -95,42 +99,6 @@ def pool_hard_counts(m, x, dfe, pooled, cnt):
 
 
 # ---- differentiable map-sized operations -------------------------------------------------------------------------------------
-class _Conv1x1(torch.autograd.Function):
-    """Y = A . X per image (F.conv2d with 1x1 kernels: static when A has batch 1, dynamic otherwise)"""
-
-    @staticmethod
-    def forward(ctx, A, X):
-        ctx.save_for_backward(A, X)
-        return rows_x_map(A, X)
-
-    @staticmethod
-    def backward(ctx, gY):
-        A, X = ctx.saved_tensors
-        gA = gX = None
-        if ctx.needs_input_grad[0]:
-            gA = map_x_mapT(gY, X)                                   # [B, M, K]: dL/dA[m, k] = sum_p gY[m, p] X[k, p]
-            if A.shape[0] == 1:
-                gA = gA.sum(0, keepdim=True)
-        if ctx.needs_input_grad[1]:
-            gX = rows_x_map(A.transpose(1, 2), gY)                   # dL/dX[k, p] = sum_m A[m, k] gY[m, p]
-        return gA, gX
-
-
-class _PoolHard(torch.autograd.Function):
-    """O[b, n, c] = sum_p [sigmoid(logits[b, n, p]) > 0.5] X[b, c, p]; no gradient through the hard mask
-    (kernel_update_head.py:236-242, kernel_head.py:314-320)"""
-
-    @staticmethod
-    def forward(ctx, logits, X):
-        ctx.save_for_backward(logits)
-        return map_x_mapT(logits, X, binarize_g=True)
-
-    @staticmethod
-    def backward(ctx, gO):
-        (logits,) = ctx.saved_tensors
-        return None, rows_x_map(gO.transpose(1, 2), logits, binarize_x=True)   # dL/dX[c, p] = sum_n gO[n, c] M[n, p]
-
-
 class _Upsample2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
@@ -163,24 +131,7 @@ class _Objective(torch.autograd.Function):
         return (None, None) + tuple(g * t for t in ctx.saved_tensors)
 
 
-def conv1x1(X, weight, bias=None):
-    """F.conv2d(X, weight [O, C, 1, 1], bias) on libpolyhead"""
-    Y = _Conv1x1.apply(weight.reshape(1, weight.shape[0], -1), X)
-    return Y if bias is None else Y + bias.reshape(1, -1, 1, 1)
-
-
-def dynconv(kernels, X):
-    """per-image 1x1 convolution with predicted kernels [B, N, C] (kernel_update_head.py:317-329)"""
-    return _Conv1x1.apply(kernels, X)
-
-
-pool_hard = _PoolHard.apply
 upsample2x = _Upsample2x.apply
-
-
-def hard_count(logits):
-    """number of foreground pixels of each hard mask, [B, N] (the bias term of the folded feat_transform)"""
-    return (logits.detach() > BIN_THR).flatten(2).sum(-1).float()
 
 
 # ---- one KernelUpdateHead stage: ONE autograd node, forward and backward in libpolyhead ---------------------------------------
@@ -348,25 +299,102 @@ def stage_forward(head, x, dfe, k, m, q):
     return _Stage.apply(meta, x, dfe, k, m, q.expand_as(k), *plist)
 
 
-def _tower(P, name, f, groups):
-    y = conv1x1(f, P[name + ".conv.weight"])
-    return F.relu(F.group_norm(y, groups, P[name + ".gn.weight"], P[name + ".gn.bias"], 1e-5))
+# ---- KernelHead after the neck: ONE autograd node -----------------------------------------------------------------------------
+def gn_relu_fwd(y, gamma, beta, groups, add=None, eps=1e-5):
+    """relu(GroupNorm(y)) of a ConvModule, fp32 NCHW (`ph_gn_train_fwd`) -> (out, out + add or None, stats [B, groups, 2])"""
+    lib = _lib.load()
+    B, Cc = y.shape[:2]
+    HW = y[0, 0].numel()
+    out = torch.empty_like(y)
+    osum = torch.empty_like(y) if add is not None else None
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=y.device)
+    part = torch.empty((B * groups * lib.ph_gn_train_nsplit(HW, Cc // groups) * 2,), dtype=torch.float64, device=y.device)
+    _lib.check(lib.ph_gn_train_fwd(_lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), groups, eps, _lib.ptr(add), _lib.ptr(out), _lib.ptr(osum),
+                                   _lib.ptr(stats), _lib.ptr(part), B, Cc, HW, _lib.stream_ptr()), "ph_gn_train_fwd")
+    return out, osum, stats
+
+
+def gn_relu_bwd(y, stats, gamma, beta, groups, dyA, dyB=None):
+    """backward of `gn_relu_fwd` for dy = dyA (+ dyB) -> (dx, dgamma, dbeta)"""
+    lib = _lib.load()
+    B, Cc = y.shape[:2]
+    HW = y[0, 0].numel()
+    dx = torch.empty_like(y)
+    dg = torch.empty((2, Cc), dtype=torch.float32, device=y.device)
+    part = torch.empty((B * Cc * lib.ph_gn_train_bwd_nsplit(HW) * 2,), dtype=torch.float64, device=y.device)
+    _lib.check(lib.ph_gn_train_bwd(_lib.ptr(y), _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), groups, _lib.ptr(dyA), _lib.ptr(dyB),
+                                   _lib.ptr(dx), _lib.ptr(dg[0]), _lib.ptr(dg[1]), _lib.ptr(part), B, Cc, HW, _lib.stream_ptr()),
+               "ph_gn_train_bwd")
+    return dx, dg[0], dg[1]
+
+
+RPN_NAMES = ["loc_convs.0.conv.weight", "loc_convs.0.gn.weight", "loc_convs.0.gn.bias",
+             "seg_convs.0.conv.weight", "seg_convs.0.gn.weight", "seg_convs.0.gn.bias",
+             "depth_convs.0.conv.weight", "depth_convs.0.gn.weight", "depth_convs.0.gn.bias",
+             "init_kernels.weight", "conv_seg.weight", "conv_seg.bias", "conv_direct_depth.weight", "conv_direct_depth.bias"]
+
+
+class _Rpn(torch.autograd.Function):
+    """KernelHead._decode_init_proposals after the neck (kernel_head.py:245-326), training form, as ONE autograd node: three
+    1x1 conv + GroupNorm + ReLU towers (`ph_rows_x_map`, `ph_gn_train_fwd`), x = sem + loc from the same pass that normalises
+    sem, the static 1x1 convs with their biases in the epilogue, the hard-mask pooling; backward by hand: every second gradient
+    contribution enters a kernel as an operand (no map-sized ATen add), static-kernel gradients are summed over the batch inside
+    the split reduction."""
+
+    @staticmethod
+    def forward(ctx, groups, f0, f1, f2, *params):
+        f = [_gpu32(t, "post-neck map") for t in (f0, f1, f2)]
+        P = [p.detach() for p in params]
+        W = [P[0].flatten(1), P[3].flatten(1), P[6].flatten(1)]
+        B = f[0].shape[0]
+        y = [rows_x_map(W[t][None], f[t]) for t in range(3)]
+        loc, _, st0 = gn_relu_fwd(y[0], P[1], P[2], groups)
+        sem, x, st1 = gn_relu_fwd(y[1], P[4], P[5], groups, add=loc)                   # x = sem + loc (:303)
+        dfe, _, st2 = gn_relu_fwd(y[2], P[7], P[8], groups)
+        W_init, W_seg, w_dd = P[9].flatten(1), P[10].flatten(1), P[12].flatten(1)
+        mask_preds = rows_x_map(W_init[None], loc)                                      # :256
+        seg_preds = rows_x_map(W_seg[None], sem, bias=P[11][None].expand(B, -1))        # :295
+        depth_pred = rows_x_map(w_dd[None], dfe, bias=P[13][None].expand(B, -1))        # :285
+        proposal = map_x_mapT(mask_preds, x, binarize_g=True)                           # :314-320 (use_binary)
+        proposal += W_init[None]                                                        # :299-300,324-326
+        ctx.groups, ctx.P = groups, P
+        ctx.save_for_backward(f[0], f[1], f[2], y[0], y[1], y[2], st0, st1, st2, loc, sem, dfe, x, mask_preds)
+        return proposal, x, mask_preds, seg_preds, dfe, depth_pred
+
+    @staticmethod
+    def backward(ctx, g_prop, g_x, g_mp, g_seg, g_dfe, g_dp):
+        f0, f1, f2, y0, y1, y2, st0, st1, st2, loc, sem, dfe, x, mask_preds = ctx.saved_tensors
+        P, groups = ctx.P, ctx.groups
+        g_prop, g_x, g_mp, g_seg, g_dfe, g_dp = [_gpu32(t, "grad") for t in (g_prop, g_x, g_mp, g_seg, g_dfe, g_dp)]
+        W_init, W_seg, w_dd = P[9].flatten(1), P[10].flatten(1), P[12].flatten(1)
+        # d / d x: what arrives + the pooling's share (d pooled^T M), in one pass; sem and loc both receive it
+        gxs = rows_x_map(g_prop.transpose(1, 2), mask_preds, binarize_x=True, add=g_x)
+        dy = [rows_x_map(W_init.t()[None], g_mp), rows_x_map(W_seg.t()[None], g_seg), rows_x_map(w_dd.t()[None], g_dp)]
+        gy0, dg0, db0 = gn_relu_bwd(y0, st0, P[1], P[2], groups, dy[0], gxs)
+        gy1, dg1, db1 = gn_relu_bwd(y1, st1, P[4], P[5], groups, dy[1], gxs)
+        gy2, dg2, db2 = gn_relu_bwd(y2, st2, P[7], P[8], groups, dy[2], g_dfe)
+        gW_init = map_x_mapT(g_mp, loc, sum_batch=True)
+        gW_init += g_prop.sum(0)
+        L = W_seg.shape[0]
+        gb_seg = torch.empty((L,), dtype=torch.float32, device=x.device)
+        gW_seg = map_x_mapT(g_seg, sem, rowsum=gb_seg, sum_batch=True)
+        gb_dd = torch.empty((1,), dtype=torch.float32, device=x.device)
+        gw_dd = map_x_mapT(g_dp, dfe, rowsum=gb_dd, sum_batch=True)
+        gf, gW = [], []
+        for t, (gy, ft) in enumerate(((gy0, f0), (gy1, f1), (gy2, f2))):
+            gf.append(rows_x_map(P[3 * t].flatten(1).t()[None], gy) if ctx.needs_input_grad[1 + t] else None)
+            gW.append(map_x_mapT(gy, ft, sum_batch=True).view(P[3 * t].shape))
+        return (None, gf[0], gf[1], gf[2], gW[0], dg0, db0, gW[1], dg1, db1, gW[2], dg2, db2, gW_init.view(P[9].shape),
+                gW_seg.view(P[10].shape), gb_seg, gw_dd.view(P[12].shape), gb_dd)
 
 
 def rpn_forward(head, feats):
     """KernelHead._decode_init_proposals after the neck (kernel_head.py:245-336), training form (no stuff rows)"""
-    P = dict((n, p) for n, p in _lib.named_params(head).items() if not n.startswith("localization_fpn."))
+    P = _lib.named_params(head)
+    plist = [P[n] for n in RPN_NAMES]
     groups = head.norm_cfg.get("num_groups", 32)
-    loc = _tower(P, "loc_convs.0", feats[0], groups)
-    sem = _tower(P, "seg_convs.0", feats[1], groups)
-    dfe = _tower(P, "depth_convs.0", feats[2], groups)
-    W_init = P["init_kernels.weight"]
-    mask_preds = conv1x1(loc, W_init)
-    depth_pred = conv1x1(dfe, P["conv_direct_depth.weight"], P["conv_direct_depth.bias"])
-    seg_preds = conv1x1(sem, P["conv_seg.weight"], P["conv_seg.bias"])
-    x = sem + loc
+    proposal, x, mask_preds, seg_preds, dfe, depth_pred = _Rpn.apply(groups, feats[0], feats[1], feats[2], *plist)
     B = x.shape[0]
-    proposal = W_init.flatten(1)[None] + pool_hard(mask_preds, x)                              # :299-300,314-326
     depth_proposal = P["conv_direct_depth.weight"].flatten(1)[None].expand(B, 1, -1)           # :286-289
     return dict(proposal=proposal, x=x, mask_preds=mask_preds, seg_preds=seg_preds, dfe=dfe, depth_proposal=depth_proposal,
                 depth_pred=depth_pred)

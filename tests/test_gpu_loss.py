@@ -368,31 +368,33 @@ def test_train_step_vs_reference(gpu, golden, path):
     worst = ("", 0.0)
     named = [("rpn_head." + n, p) for n, p in rpn.named_parameters()] + [("roi_head." + n, p) for n, p in roi.named_parameters()]
     assert len(named) == sum(k.startswith("g_") for k in z.files)
-    def cmp(got, ref):
-        # norm and the strided entries to 1e-3 (entries relative to the largest of them); the plain sum of all entries is a
-        # cancellation of up to 5e5 terms and only sanity-checked against the norm
+    def cmp(got, ref, n):
+        # norm and the strided entries to 1e-3 (entries relative to the largest of them).  The plain sum of all n entries is a
+        # cancellation of up to 5e5 terms: |sum a - sum b| <= sqrt(n) ||a - b||, so it is normalised by sqrt(n) ||b|| -- the
+        # figure a COHERENT relative error of every entry would show (gated at 1e-4; round 5: the previous form divided by
+        # ||b|| alone and a 4e-5 coherent deviation of a 256 x 256 tensor tripped its 1e-2)
         e_norm = abs(got[0] - ref[0]) / max(ref[0], 1e-30)
         e_ent = float(np.abs(got[2:] - ref[2:]).max() / max(np.abs(ref[2:]).max(), 1e-30))
-        e_sum = abs(got[1] - ref[1]) / max(ref[0], 1e-30)
+        e_sum = abs(got[1] - ref[1]) / max(ref[0] * np.sqrt(n), 1e-30)
         return e_norm, e_ent, e_sum
 
     over = []
     for name, p in named:
         assert p.grad is not None, name
-        e = cmp(_digest(p.grad, 64), z["g_" + name])
+        e = cmp(_digest(p.grad, 64), z["g_" + name], p.numel())
         if max(e[:2]) > worst[1]:
             worst = (name, max(e[:2]))
         if e[1] >= 1e-3:
             over.append((name, e))
-        assert e[0] < 1e-3 and e[1] < 1e-2 and e[2] < 1e-2, (name, e)
+        assert e[0] < 1e-3 and e[1] < 1e-2 and e[2] < 1e-4, (name, e)
     # a ReLU / hard-mask decision that sits on its threshold moves single entries of a bias gradient by one row's
     # contribution: allowed on a handful of tensors, never on the norms (all < 1e-3 above)
     print("tensors with an entry off by more than 1e-3 of the largest sampled entry:", over)
     assert len(over) <= 3, over
     for i, gf in enumerate(gfeat):
-        e = cmp(_digest(gf, 4096), z[f"gfeat{i}"])
+        e = cmp(_digest(gf, 4096), z[f"gfeat{i}"], gf.numel())
         print("d objective / d post-neck map", i, e)
-        assert e[0] < 1e-3 and e[1] < 1e-3 and e[2] < 1e-2, (i, e)
+        assert e[0] < 1e-3 and e[1] < 1e-3 and e[2] < 1e-4, (i, e)
     print("parameter gradients vs reference autograd: worst", worst, "over", len(named), "tensors")
 
 

@@ -114,3 +114,70 @@ def test_stage_node_is_deterministic(gpu):
         runs.append([o.detach().clone() for o in out] + [kk.grad.clone()] + [p.grad.clone() for p in head.parameters()])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,W,L,nt", [(2, 8, 16, 19, 8), (3, 7, 11, 19, 8), (1, 16, 24, 133, 80)])
+def test_rpn_node_vs_oracle_autograd(gpu, B, H, W, L, nt):
+    """KernelHead after the neck in training form (`train._Rpn`: towers with GroupNorm + ReLU, static convs, x = sem + loc,
+    hard-mask pooling) against the oracle's `kernel_head_post_neck` under torch autograd: the six outputs and the gradient of
+    every parameter and of the three input maps for random cotangents (ragged 7 x 11: no 16-byte aligned rows)"""
+    import polyphonicformer_amd.kernel_head  # noqa: F401
+    kh = HEADS.build(dict(type="KernelHead", num_proposals=100, num_classes=L, num_thing_classes=nt, num_stuff_classes=L - nt,
+                          in_channels=256, out_channels=256, cat_stuff_mask=True, feat_downsample_stride=2, feat_refine=False,
+                          use_binary=True, proposal_feats_with_obj=True, loss_seg=dict(type="FocalLoss", use_sigmoid=True),
+                          loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True), localization_fpn=None))
+    sd = Hh.seeded_fill({k: tuple(v.shape) for k, v in kh.state_dict().items()}, 77 + B)
+    kh.load_state_dict(sd)
+    kh.to(gpu)
+    feats = Hh.neck_inputs(5 + B, B, 256, H, W)
+    g = torch.Generator().manual_seed(B)
+    names = ("proposal", "x", "mask_preds", "seg_preds", "dfe", "depth_pred")
+    okeys = ("proposal_feats", "x_feats", "mask_preds", "seg_preds", "depth_feats", "depth_pred")
+    with torch.enable_grad():
+        w = {k_: v.clone().requires_grad_(True) for k_, v in sd.items()}
+        cf = [f.clone().requires_grad_(True) for f in feats]
+        r = O.kernel_head_post_neck(w, *cf, nt, L, 32, cat_stuff_mask=False)
+        ref = [r[k_].reshape(B, 100, 256) if k_ == "proposal_feats" else r[k_] for k_ in okeys]
+        cot = [torch.randn(t.shape, generator=g) * (0.05 if t.dim() == 4 else 1.0) for t in ref]
+        sum((a * c).sum() for a, c in zip(ref, cot)).backward()
+        df = [f.to(gpu).requires_grad_(True) for f in feats]
+        for p in kh.parameters():
+            p.grad = None
+        out = T.rpn_forward(kh, df)
+        sum((out[n] * c.to(gpu)).sum() for n, c in zip(names, cot)).backward()
+    torch.cuda.synchronize()
+    err = {n: Hh.rel_err(out[n].detach().cpu(), a.detach()) for n, a in zip(names, ref)}
+    print("rpn node forward vs oracle:", {k_: f"{v:.1e}" for k_, v in err.items()})
+    assert max(err.values()) < 2e-5, err
+    gerr = {i: Hh.rel_err(df[i].grad.cpu(), cf[i].grad) for i in range(3)}
+    perr = {n: Hh.rel_err(p.grad.cpu(), w[n].grad) for n, p in kh.named_parameters()}
+    print("input gradients:", {k_: f"{v:.1e}" for k_, v in gerr.items()}, "parameter gradients:", {k_: f"{v:.1e}" for k_, v in perr.items()})
+    assert max(gerr.values()) < 1e-4 and max(perr.values()) < 1e-4
+
+
+def test_map_product_epilogues(gpu):
+    """round 5 options of the two map products against torch: row bias, add source (also in place), row sums, batch sums"""
+    g = torch.Generator().manual_seed(0)
+    for B, M, K, H, W in ((2, 37, 256, 6, 10), (3, 160, 100, 5, 7)):
+        A, X = torch.randn(B, M, K, generator=g).to(gpu), torch.randn(B, K, H, W, generator=g).to(gpu)
+        bias, add = torch.randn(B, M, generator=g).to(gpu), torch.randn(B, M, H, W, generator=g).to(gpu)
+        ref = torch.einsum("bmk,bkhw->bmhw", A.double(), X.double())
+        y = T.rows_x_map(A, X, bias=bias, add=add)
+        assert Hh.rel_err(y.cpu(), (ref + bias.double()[..., None, None] + add.double()).cpu()) < 2e-5
+        y2 = add.clone()
+        T.rows_x_map(A, X, out=y2, accumulate=True)
+        assert Hh.rel_err(y2.cpu(), (ref + add.double()).cpu()) < 2e-5
+        if K <= 256:
+            Gm = torch.randn(B, M, H, W, generator=g).to(gpu)
+            Xk = torch.randn(B, K, H, W, generator=g).to(gpu)
+            rs = torch.empty((B, M), device=gpu)
+            o = T.map_x_mapT(Gm, Xk, rowsum=rs)
+            assert Hh.rel_err(o.cpu(), torch.einsum("bmhw,bkhw->bmk", Gm.double(), Xk.double()).cpu()) < 2e-5
+            assert Hh.rel_err(rs.cpu(), Gm.double().sum((2, 3)).cpu()) < 1e-5
+            rs1 = torch.empty((M,), device=gpu)
+            o1 = T.map_x_mapT(Gm, Xk, rowsum=rs1, sum_batch=True)
+            assert o1.shape == (M, K) and Hh.rel_err(o1.cpu(), torch.einsum("bmhw,bkhw->mk", Gm.double(), Xk.double()).cpu()) < 2e-5
+            assert Hh.rel_err(rs1.cpu(), Gm.double().sum((0, 2, 3)).cpu()) < 1e-5
+            cnt = torch.empty((B, M), device=gpu)
+            T.map_x_mapT(Gm, Xk, binarize_g=True, rowsum=cnt)
+            assert torch.equal(cnt.cpu(), (Gm > 1.5 * 2.0 ** -24).flatten(2).sum(-1).float().cpu())
