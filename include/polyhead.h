@@ -392,6 +392,33 @@ int ph_gn_train_bwd(const float* y, const float* stats, const float* gamma, cons
                     const float* dyB, float* dx, float* dgamma, float* dbeta, double* partial, int B, int C, int64_t HW, void* stream);
 int ph_hard_count(const float* logits, float* out, int64_t rows, int64_t HW, void* stream);
 
+/* ---- N4: targets + losses + d(losses)/d(predictions) of one head / stage in ONE call, from DESCRIPTORS (csrc/ph_loss.hip) ------
+ * Replaces `get_targets` + `loss` of both heads on the training path (kernel_update_head.py:355-591, kernel_head.py:456-698): every
+ * target / weight row the reference materialises is a ground-truth mask, the image's valid map, its depth map, ones or zeros,
+ * so rows are described by device POINTERS (int64 addresses of fp32 rows of HW pixels):
+ *   pos_rows int32 [P] (rows with a label in [0, L)), pos_u8 [B*N]; tptr / wptr int64 [B*N]: mask target / weight row (0 = zeros);
+ *   depth items grouped per prediction row: dstart int32 [depth_rows + 1], dit_t (target row), dit_w (weight row; 1 = ones),
+ *   dit_s (scale; the weight is scale * row, and the reference's `* (gt_depth > 0)` is the kernel's own `0 < target < 80`);
+ *   labels int64 [B*N], label_w fp32 [B*N][L] (nullable together with cls_score: KernelHead has no classification);
+ *   KernelHead only: seg_pred [B][seg_L][HW] with the paint lists of the dense semantic target (kernel_head.py:590-605):
+ *   sstart int32 [B + 1], sit_m (mask row), sit_l (class), painted in order over background = seg_L.
+ * mask_pred [B][N][HW]; depth_pred [depth_rows][HW] (KernelHead: the ONE direct depth map per image, all its items summed).
+ * losses [8] (device): loss_depth, loss_cls, mask BCE, dice, rank, seg focal, pos_acc, number of labelled seg pixels -- weighted as
+ * the reference's loss modules weight them.  g_* nullable all together: d(sum of the losses)/d(prediction), overwritten.
+ * Loss values and gradient coefficients are formed on the device (fp64, fixed order): no host round trip inside the call. */
+typedef struct {
+    int32_t B, N, L, P, depth_rows, seg_L, has_rank, ignore, depth_mode;
+    int64_t HW;
+    float lw_mask, lw_dice, dice_eps, lw_rank, lw_depth, dw_si, dw_sq, dw_abs, lw_cls, cls_gamma, cls_alpha, cls_avg, lw_seg, seg_gamma,
+        seg_alpha;
+} ph_loss_cfg;
+size_t ph_train_losses_scratch_bytes(const ph_loss_cfg* cfg);
+int ph_train_losses(const ph_loss_cfg* cfg, const float* mask_pred, const float* cls_score, const float* depth_pred,
+                    const float* seg_pred, const int32_t* pos_rows, const uint8_t* pos_u8, const int64_t* tptr, const int64_t* wptr,
+                    const int32_t* dstart, const int64_t* dit_t, const int64_t* dit_w, const float* dit_s, const int64_t* labels,
+                    const float* label_w, const int32_t* sstart, const int64_t* sit_m, const int32_t* sit_l, float* losses,
+                    float* g_mask, float* g_cls, float* g_depth, float* g_seg, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- N4, device half: the QUERY SIDE of one KernelUpdateHead stage in TRAINING mode (csrc/ph_qtrain.hip) -------------------
  * Replaces what autograd records for kernel_update_head.py:245-288 (KernelUpdator x2, funcs/kernel_updator.py:55-93; mmcv
  * MultiheadAttention + LayerNorm x2; FFN + LayerNorm x2; cls_fcs / mask_fcs / depth_regs + fc_cls / fc_mask / fc_depth) and its

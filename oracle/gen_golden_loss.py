@@ -292,6 +292,14 @@ def train_step_fixture(name="train_step.npz", B=2, H=8, W=16, gt_counts=(5, 8), 
             setattr(st, k, reg.build(dict(c)))
     kh.train()
     ih.train()
+    # round 5: the HARD MASKS the reference pools with at every stage (sigmoid(mask_preds) > 0.5 of each stage's input,
+    # kernel_update_head.py:236-238; KernelHead's own pooling uses the first num_proposals rows of stage 0's, kernel_head.py:314-317).
+    # A logit within rounding of the threshold is a coin flip for any other implementation (this fixture has one at +2.3e-5);
+    # the GPU test hands these decisions to the device path so that what it compares is arithmetic, and bounds the flips.
+    hard = {}
+    for si, st in enumerate(ih.mask_head):
+        st.register_forward_pre_hook(lambda mod, args, kwargs, si=si: hard.__setitem__(si, (args[2].detach().sigmoid() > 0.5).numpy()),
+                                     with_kwargs=True)
     feats = [f.requires_grad_(True) for f in Hh.neck_inputs(G.NSEED, B, cfg["C"], H, W)]
     gts = train_gt(gt_seed, B, 2 * H, 2 * W, cfg["n_thing"], cfg["n_stuff"], list(gt_counts))
     metas = [Hh.img_meta(H * 8, W * 8) for _ in range(B)]
@@ -326,6 +334,10 @@ def train_step_fixture(name="train_step.npz", B=2, H=8, W=16, gt_counts=(5, 8), 
     for i, f in enumerate(feats):
         out[f"gfeat{i}"] = grad_digest(f.grad, 4096)
     out["no_grad_json"] = np.frombuffer(json.dumps(none).encode(), dtype=np.uint8)
+    assert sorted(hard) == list(range(S))
+    for si in range(S):
+        out[f"hard{si}"] = np.packbits(hard[si].reshape(-1))
+        out[f"hard{si}_shape"] = np.asarray(hard[si].shape, dtype=np.int64)
     print("total", float(total), "params with grad", sum(k.startswith("g_") for k in out), "without", none)
     print({k: round(float(v), 4) for k, v in losses.items()})
     np.savez_compressed(os.path.join(OUT, name), **out)

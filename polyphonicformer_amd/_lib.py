@@ -96,6 +96,8 @@ SIGNATURES = {
     "ph_gn_train_fwd": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "ph_gn_train_bwd": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "ph_hard_count": (C.c_int, [_P, _P, _L, _L, _P]),
+    "ph_train_losses_scratch_bytes": (C.c_size_t, [_P]),
+    "ph_train_losses": (C.c_int, [_P] * 24 + [_Z, _P]),
     "ph_qtrain_saved_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "ph_qtrain_scratch_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "ph_qtrain_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

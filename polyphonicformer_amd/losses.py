@@ -537,3 +537,292 @@ def rpn_get_targets(head, sampling_results, gt_mask, rpn_train_cfg, concat=True,
     if concat:
         cols = [None if c[0] is None else (torch.stack(c, 0) if k == 4 else torch.cat(c, 0)) for k, c in enumerate(cols)]
     return tuple(cols)
+
+
+# =================================================================================================================================
+# Round 5: the training path's targets + losses from DESCRIPTORS (csrc/ph_loss.hip `ph_train_losses`; include/polyhead.h).
+# `get_targets` / `loss` above stay what the reference's API exposes (materialised [rows][H][W] targets, bit for bit); the
+# heads' `forward_train` -- `train.rpn_forward_train` / `train.roi_forward_train` -- no longer goes through them: the Hungarian
+# result lives on the host, every target row is a ground-truth row that already lies in HBM, so the host writes pointer tables
+# (numpy, ~100 us), uploads them in one copy and ONE C call evaluates the head's or stage's losses and gradients.
+# =================================================================================================================================
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+class LossCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "L", "P", "depth_rows", "seg_L", "has_rank", "ignore", "depth_mode")] + \
+               [("HW", C.c_int64)] + \
+               [(n, C.c_float) for n in ("lw_mask", "lw_dice", "dice_eps", "lw_rank", "lw_depth", "dw_si", "dw_sq", "dw_abs", "lw_cls",
+                                         "cls_gamma", "cls_alpha", "cls_avg", "lw_seg", "seg_gamma", "seg_alpha")]
+
+
+class StepGT:
+    """one training step's ground truth where the descriptors point: per image contiguous fp32 masks [G, H, W] (hardened when
+    `hard_target`), stuff masks [S, H, W], the valid map (any mask set: kernel_head.py:415, kernel_update.py:238), the depth
+    map; labels / stuff classes also on the host; the zero-padded stack [B, Gmax, H, W] the batched assignment reads"""
+
+    def __init__(self, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, hard_target):
+        B = len(gt_masks)
+        dev = gt_masks[0].device
+        f = lambda t: t.detach().float().contiguous()
+        self.masks = [f(m.bool()) if hard_target else f(m) for m in gt_masks]
+        self.has_sem = gt_sem_seg is not None and gt_sem_cls is not None
+        self.sem = [f(s) for s in gt_sem_seg] if self.has_sem else [self.masks[0][:0]] * B
+        self.H, self.W = self.masks[0].shape[-2:]
+        HW = self.HW = self.H * self.W
+        self.G = [int(m.shape[0]) for m in self.masks]
+        self.S = [int(s.shape[0]) for s in self.sem]
+        valid = torch.zeros((B, self.H, self.W), dtype=torch.float32, device=dev)
+        for i in range(B):
+            for t in (self.masks[i], self.sem[i]):
+                if t.shape[0]:
+                    valid[i] += t.ne(0).any(dim=0)
+        self.valid = (valid > 0).float()
+        if isinstance(gt_depth, (list, tuple)):
+            gt_depth = torch.stack([d.reshape(self.H, self.W) for d in gt_depth])
+        self.depth = None if gt_depth is None else f(gt_depth.to(dev)).reshape(B, HW)
+        # host copies of the small integer lists (ONE synchronising read per step)
+        lab = torch.cat([l.reshape(-1).long() for l in gt_labels] + ([c.reshape(-1).long() for c in gt_sem_cls] if self.has_sem else []))
+        lab = lab.cpu().numpy()
+        o = np.cumsum([0] + self.G + (self.S if self.has_sem else []))
+        self.labels_h = [lab[o[i]:o[i + 1]] for i in range(B)]
+        self.sem_cls_h = [lab[o[B + i]:o[B + i + 1]] for i in range(B)] if self.has_sem else [np.zeros(0, np.int64)] * B
+        self.labels_dev = [l.reshape(-1).long() for l in gt_labels]
+        self.Gmax = max(self.G + [0])
+        self.pad = torch.zeros((B, max(self.Gmax, 1), self.H, self.W), dtype=torch.float32, device=dev)
+        for i in range(B):
+            if self.G[i]:
+                self.pad[i, :self.G[i]] = self.masks[i]
+        self.mask_base = np.array([m.data_ptr() for m in self.masks], dtype=np.int64)
+        self.sem_base = np.array([s.data_ptr() for s in self.sem], dtype=np.int64)
+        self.valid_base = self.valid.data_ptr() + 4 * HW * np.arange(B, dtype=np.int64)
+        self.depth_base = None if self.depth is None else self.depth.data_ptr() + 4 * HW * np.arange(B, dtype=np.int64)
+        self.B = B
+
+
+def assign_batch(assigner, pred, cls_pred, gt):
+    """the Hungarian assignment of B images from ONE `ph_match_sums` pass and ONE device -> host copy (funcs/assigner.py:363-542
+    per image).  pred [B, Np, H, W] detached mask logits, cls_pred [B, Np, n_thing] or None.  -> per image (pred indices
+    ascending, matched gt indices) as numpy arrays.  Configurations the batched algebra does not cover (DepthCost with a weight,
+    topk > 1) are refused by the caller."""
+    from .assigner import MatchSums, _hungarian
+    B, Np = pred.shape[:2]
+    out = [(np.zeros(0, np.int64), np.zeros(0, np.int64))] * B
+    if gt.Gmax == 0:
+        return out
+    s = MatchSums(pred, gt.pad, gt.valid)
+    cost = 0
+    a = assigner
+    if a.cls_cost.weight != 0 and cls_pred is not None:
+        cc = a.cls_cost
+        p = cls_pred.sigmoid()
+        neg = -(1 - p + cc.eps).log() * (1 - cc.alpha) * p.pow(cc.gamma)
+        pos = -(p + cc.eps).log() * cc.alpha * (1 - p).pow(cc.gamma)
+        lab = torch.zeros((B, gt.Gmax), dtype=torch.long, device=pred.device)
+        for i in range(B):
+            if gt.G[i]:
+                lab[i, :gt.G[i]] = gt.labels_dev[i]
+        idx = lab[:, None, :].expand(B, Np, gt.Gmax)
+        cost = cost + (pos.gather(2, idx) - neg.gather(2, idx)) * cc.weight
+    if a.mask_cost.weight != 0:
+        V = s.V[:, None, None]
+        cost = cost + (-(s.A + (V - s.S[:, :, None] - s.T[:, None, :] + s.A)) / V * a.mask_cost.weight)
+    if a.dice_cost.weight != 0:
+        e = a.dice_cost.eps
+        cost = cost + (-(2 * s.A) / ((s.Q + e)[:, :, None] + (s.C + e)[:, None, :]) * a.dice_cost.weight)
+    cost = cost.detach().cpu().numpy()
+    for i in range(B):
+        if gt.G[i]:
+            r, c = _hungarian(torch.from_numpy(cost[i, :, :gt.G[i]]), 1)
+            order = np.argsort(r, kind="stable")
+            out[i] = (np.asarray(r)[order].astype(np.int64), np.asarray(c)[order].astype(np.int64))
+    return out
+
+
+class LossDesc:
+    """the pointer tables of one head / stage on the device (one upload) + what the host knows about them"""
+
+    def __init__(self, dev, sections):
+        off, total = {}, 0
+        for k, a in sections.items():
+            off[k] = total
+            total += (a.nbytes + 15) // 16 * 16
+        buf = np.zeros(max(total, 16), dtype=np.uint8)
+        for k, a in sections.items():
+            buf[off[k]:off[k] + a.nbytes] = a.view(np.uint8).reshape(-1)
+        self.blob = torch.from_numpy(buf).to(dev, non_blocking=True)
+        base = self.blob.data_ptr()
+        self.ptr = {k: C.c_void_p(base + o) for k, o in off.items()}
+        self.n = {k: a.size for k, a in sections.items()}
+
+
+def build_desc(head, gt, assigns, num_proposals, cfg, roi):
+    """roi=True : KernelUpdateHead._get_target_single (kernel_update_head.py:443-531) for B images: N = num_proposals + stuff rows
+    roi=False: KernelHead._get_target_single (kernel_head.py:571-647): N = num_proposals rows, dense semantic target, the depth
+    items of an image all on its ONE direct depth map"""
+    B, HW = gt.B, gt.HW
+    L, ns, nt = head.num_classes, head.num_stuff_classes, head.num_thing_classes
+    Np = num_proposals
+    N = Np + ns if (roi and gt.has_sem) else Np
+    R = B * N
+    pw = 1.0 if cfg.pos_weight <= 0 else float(cfg.pos_weight)
+    HW4 = 4 * HW
+    tptr, wptr = np.zeros(R, np.int64), np.zeros(R, np.int64)
+    labels = np.full(R, L, np.int64)
+    pos_u8 = np.zeros(R, np.uint8)
+    label_w = np.zeros((R, L), np.float32) if roi else None
+    d_row, d_t, d_w, d_s = [], [], [], []
+    s_cnt, s_m, s_l = [0], [], []
+    for b in range(B):
+        r0 = b * N
+        pi, gi = assigns[b]
+        rows = r0 + pi
+        wptr[r0:r0 + Np] = gt.valid_base[b]
+        tptr[rows] = gt.mask_base[b] + gi * HW4
+        labels[rows] = gt.labels_h[b][gi]
+        pos_u8[rows] = 1
+        if roi:
+            label_w[r0:r0 + Np, :(nt if gt.has_sem else L)] = 1.0
+            label_w[rows, :(nt if gt.has_sem else L)] = pw
+        sc = gt.sem_cls_h[b]
+        srow = None
+        if roi and gt.has_sem:
+            label_w[r0 + Np + np.arange(ns), nt + np.arange(ns)] = 1.0
+            if len(sc):
+                srow = r0 + Np + (sc - nt)
+                tptr[srow] = gt.sem_base[b] + np.arange(len(sc), dtype=np.int64) * HW4
+                wptr[srow] = gt.valid_base[b]
+                labels[srow] = sc
+                pos_u8[srow] = 1
+        if gt.depth_base is not None:
+            dp = int(gt.depth_base[b])
+            if roi:
+                last = r0 + N - 1
+                for r, w in zip(rows.tolist(), (gt.mask_base[b] + gi * HW4).tolist()):
+                    if r != last:
+                        d_row.append(r); d_t.append(dp); d_w.append(w); d_s.append(pw)
+                if srow is not None:
+                    for k, r in enumerate(srow.tolist()):
+                        if r != last:
+                            d_row.append(r); d_t.append(dp); d_w.append(int(gt.sem_base[b]) + k * HW4); d_s.append(pw)
+                d_row.append(last); d_t.append(dp); d_w.append(1); d_s.append(1.0)          # the direct depth row (:525-528)
+            else:
+                for w in (gt.mask_base[b] + gi * HW4).tolist():
+                    d_row.append(b); d_t.append(dp); d_w.append(w); d_s.append(pw)
+                if gt.has_sem:
+                    for k in range(len(sc)):
+                        d_row.append(b); d_t.append(dp); d_w.append(int(gt.sem_base[b]) + k * HW4); d_s.append(pw)
+        if not roi:         # dense semantic target: the stuff masks in order, then the assigned thing masks in order (:590-605)
+            if gt.has_sem:
+                for k in range(len(sc)):
+                    s_m.append(int(gt.sem_base[b]) + k * HW4); s_l.append(int(sc[k]))
+            for w, l in zip((gt.mask_base[b] + gi * HW4).tolist(), gt.labels_h[b][gi].tolist()):
+                s_m.append(w); s_l.append(int(l))
+            s_cnt.append(len(s_m))
+    depth_rows = R if roi else B
+    d_row = np.asarray(d_row, np.int64)
+    order = np.argsort(d_row, kind="stable")
+    dstart = np.zeros(depth_rows + 1, np.int32)
+    if len(d_row):
+        np.add.at(dstart, d_row + 1, 1)
+    dstart = np.cumsum(dstart).astype(np.int32)
+    pos_rows = np.nonzero(pos_u8)[0].astype(np.int32)
+    sec = dict(tptr=tptr, wptr=wptr, labels=labels, pos_u8=pos_u8, pos_rows=pos_rows if len(pos_rows) else np.zeros(1, np.int32), dstart=dstart,
+               dit_t=np.asarray(d_t, np.int64)[order] if len(d_row) else np.zeros(1, np.int64),
+               dit_w=np.asarray(d_w, np.int64)[order] if len(d_row) else np.zeros(1, np.int64),
+               dit_s=np.asarray(d_s, np.float32)[order] if len(d_row) else np.zeros(1, np.float32))
+    if roi:
+        sec["label_w"] = label_w.reshape(-1)
+    else:
+        sec.update(sstart=np.asarray(s_cnt, np.int32), sit_m=np.asarray(s_m if s_m else [0], np.int64), sit_l=np.asarray(s_l if s_l else [0], np.int32))
+    d = LossDesc(gt.valid.device, sec)
+    d.B, d.N, d.R, d.P, d.depth_rows, d.roi, d.has_depth = B, N, R, int(len(pos_rows)), depth_rows, roi, gt.depth_base is not None
+    d.gt = gt              # keeps the ground-truth tensors the pointers address alive
+    return d
+
+
+_LOSS_SCRATCH = {}
+
+
+def fused_losses(head, desc, mask_pred, cls_score, depth_pred, seg_pred, with_grads=True):
+    """`ph_train_losses` for one head / stage: -> (dict of weighted losses as the reference names them, grads or None).
+    mask_pred [B, N, H, W]; cls_score [B, N, L] (roi) / None; depth_pred [B, N, H, W] (roi) / [B, 1, H, W] (KernelHead's direct
+    map) / None; seg_pred [B, L, H, W] (KernelHead) / None"""
+    lib, dev = _lib.load(), mask_pred.device
+    B, N, H, W = mask_pred.shape
+    assert (B, N) == (desc.B, desc.N)
+    HW, L = H * W, head.num_classes
+    roi = desc.roi
+    mp = _f32(mask_pred)
+    cs = _f32(cls_score).reshape(B * N, L) if cls_score is not None else None
+    have_depth = depth_pred is not None and desc.has_depth
+    dp = _f32(depth_pred) if have_depth else mp                 # a valid pointer either way; without items nothing is read
+    sp = _f32(seg_pred) if seg_pred is not None else None
+    c = LossCfg()
+    c.B, c.N, c.L, c.P, c.depth_rows, c.HW = B, N, L, desc.P, desc.depth_rows, HW
+    c.seg_L = sp.shape[1] if sp is not None else 0
+    lr = head.loss_rank
+    c.has_rank, c.ignore = int(lr is not None), int(head.ignore_label)
+    c.lw_mask, c.lw_dice, c.dice_eps = head.loss_mask.loss_weight, head.loss_dice.loss_weight, head.loss_dice.eps
+    c.lw_rank = lr.loss_weight if lr is not None else 0.0
+    ld = head.loss_depth
+    if have_depth:
+        c.depth_mode = DEPTH_MODES[ld.depth_act_mode]
+        c.lw_depth = ld.loss_weight
+        c.dw_si, c.dw_sq, c.dw_abs = [float(v) for v in ld.weight]
+    if cs is not None:
+        lc = head.loss_cls
+        from .dist import reduce_mean
+        import torch.distributed as tdist
+        npos = float(desc.P)
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(_REDUCE_GROUP[-1]) > 1:
+            # gloo groups (the CPU tests) reduce host tensors, RCCL groups device tensors
+            on = dev if tdist.get_backend(_REDUCE_GROUP[-1]) == "nccl" else "cpu"
+            npos = float(reduce_mean(torch.tensor(npos, device=on), _REDUCE_GROUP[-1]))
+        c.lw_cls, c.cls_gamma, c.cls_alpha, c.cls_avg = lc.loss_weight, lc.gamma, lc.alpha, max(npos, 1.0)
+    else:
+        c.cls_avg = 1.0
+    if sp is not None:
+        ls = head.loss_seg
+        if not ls.use_sigmoid:
+            raise NotImplementedError("libpolyhead: loss_seg is the shipped sigmoid FocalLoss (polyphonic_former.py:73-78)")
+        c.lw_seg, c.seg_gamma, c.seg_alpha = ls.loss_weight, ls.gamma, ls.alpha
+    nb = lib.ph_train_losses_scratch_bytes(C.byref(c))
+    scratch = _LOSS_SCRATCH.get(dev)
+    if scratch is None or scratch.numel() < nb:
+        scratch = _LOSS_SCRATCH[dev] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    out = torch.empty((8,), dtype=torch.float32, device=dev)
+    g = None
+    if with_grads:
+        g = dict(mask_pred=torch.empty_like(mp), depth_pred=torch.empty_like(dp) if have_depth else None,
+                 cls_score=torch.empty_like(cs) if cs is not None else None, seg_preds=torch.empty_like(sp) if sp is not None else None)
+    P = desc.ptr
+    gd = g["depth_pred"] if (g and have_depth) else (torch.empty_like(dp) if g else None)
+    if not have_depth:        # no depth items: an empty item table (dstart all zero) -- the kernel reads nothing
+        pass
+    _lib.check(lib.ph_train_losses(C.byref(c), _lib.ptr(mp), _lib.ptr(cs), _lib.ptr(dp), _lib.ptr(sp), P["pos_rows"], P["pos_u8"], P["tptr"],
+                                   P["wptr"], P["dstart"], P["dit_t"], P["dit_w"], P["dit_s"], P["labels"] if cs is not None else None,
+                                   P.get("label_w") if cs is not None else None, P.get("sstart") if sp is not None else None,
+                                   P.get("sit_m") if sp is not None else None, P.get("sit_l") if sp is not None else None, _lib.ptr(out),
+                                   _lib.ptr(g["mask_pred"]) if g else None, _lib.ptr(g["cls_score"]) if (g and cs is not None) else None,
+                                   _lib.ptr(gd), _lib.ptr(g["seg_preds"]) if (g and sp is not None) else None, _lib.ptr(scratch),
+                                   scratch.numel(), _lib.stream_ptr()), "ph_train_losses")
+    losses = {}
+    if have_depth:
+        losses["loss_depth"] = out[0]
+    if roi:
+        losses["loss_cls"], losses["pos_acc"] = out[1], out[6]
+        keys = ("loss_rpn_mask", "loss_rpn_dice", "loss_rank") if desc.P else ("loss_mask", "loss_dice", "loss_rank")
+    else:
+        keys = ("loss_rpn_mask", "loss_rpn_dice", "loss_rpn_rank") if desc.P else ("loss_rpn_mask", "loss_rpn_dice", "loss_rank")
+    losses[keys[0]], losses[keys[1]] = out[2], out[3]
+    if lr is not None:
+        losses[keys[2]] = out[4]
+    if sp is not None:
+        losses["loss_rpn_seg"] = out[5]
+    if g is not None:
+        g = dict(mask_pred=g["mask_pred"].reshape(B, N, H, W), cls_score=None if cs is None else g["cls_score"].reshape(B, N, L),
+                 depth_pred=None if not have_depth else g["depth_pred"], seg_preds=g["seg_preds"])
+    return losses, g

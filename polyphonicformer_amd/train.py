@@ -36,6 +36,13 @@ def _gpu32(t, name):
     return t.detach().contiguous().float()
 
 
+# Test aid (None in production): `hard_mask_hook(site, logits) -> logits` is consulted wherever the training forward is about to
+# BINARISE mask logits for pooling -- site = the KernelHead module or the KernelUpdateHead stage module.  The tests hand the
+# reference's hard decisions in (+-1 logits) so that a comparison with the reference's gradients measures arithmetic, not a logit
+# that sits within rounding of the threshold (the inference tests do the converse: the oracle follows the device's hard masks).
+hard_mask_hook = None
+
+
 # ---- raw calls -------------------------------------------------------------------------------------------------------------
 def rows_x_map(A, X, binarize_x=False, bias=None, out=None, accumulate=False, add=None):
     """Y[b, m, p] = sum_k A[b, m, k] X[b, k, p] (+ bias[b, m]) (+ add[b, m, p]);  A [B or 1, M, K], X [B, K, *spatial] ->
@@ -194,6 +201,8 @@ class _Stage(torch.autograd.Function):
     def forward(ctx, meta, x, dfe, k, m, q, *params):
         lib = _lib.load()
         x, dfe, m = _gpu32(x, "x"), _gpu32(dfe, "depth_feats"), _gpu32(m, "mask_preds")
+        if hard_mask_hook is not None:
+            m = _gpu32(hard_mask_hook(meta["module"](), m), "mask_preds")
         k, q = _gpu32(k, "proposal_feat"), _gpu32(q, "depth_proposal")
         params = [p.detach() for p in params]
         pm, pd = params[:QT_NPARAM], params[QT_NPARAM:]
@@ -284,7 +293,9 @@ def _stage_meta(head):
             p = plist[i if i < QT_NPARAM else QT_NPARAM + j]
             offsets.append(off); sizes.append(p.numel()); shapes.append(tuple(p.shape))
             off += (p.numel() + 3) // 4 * 4
-        c = dict(key=key, L=head.num_classes, F=P["ffn.layers.0.0.weight"].shape[0], offsets=offsets, sizes=sizes, shapes=shapes, total=off)
+        import weakref
+        c = dict(key=key, L=head.num_classes, F=P["ffn.layers.0.0.weight"].shape[0], offsets=offsets, sizes=sizes, shapes=shapes, total=off,
+                 module=weakref.ref(head))
         if P["fc_cls.weight"].shape[0] != c["L"] or P["feat_transform.conv.weight"].shape[:2] != (256, 256) or head.attention.attn.num_heads != 8:
             raise NotImplementedError("training forward: 256 channels, 8 heads, fc_cls of num_classes rows (the shipped configuration)")
         head.__dict__["_ph_stage_meta"] = c
@@ -342,7 +353,7 @@ class _Rpn(torch.autograd.Function):
     the split reduction."""
 
     @staticmethod
-    def forward(ctx, groups, f0, f1, f2, *params):
+    def forward(ctx, groups, site, f0, f1, f2, *params):
         f = [_gpu32(t, "post-neck map") for t in (f0, f1, f2)]
         P = [p.detach() for p in params]
         W = [P[0].flatten(1), P[3].flatten(1), P[6].flatten(1)]
@@ -355,10 +366,11 @@ class _Rpn(torch.autograd.Function):
         mask_preds = rows_x_map(W_init[None], loc)                                      # :256
         seg_preds = rows_x_map(W_seg[None], sem, bias=P[11][None].expand(B, -1))        # :295
         depth_pred = rows_x_map(w_dd[None], dfe, bias=P[13][None].expand(B, -1))        # :285
-        proposal = map_x_mapT(mask_preds, x, binarize_g=True)                           # :314-320 (use_binary)
+        hard_src = mask_preds if hard_mask_hook is None else _gpu32(hard_mask_hook(site, mask_preds), "mask_preds")
+        proposal = map_x_mapT(hard_src, x, binarize_g=True)                             # :314-320 (use_binary)
         proposal += W_init[None]                                                        # :299-300,324-326
         ctx.groups, ctx.P = groups, P
-        ctx.save_for_backward(f[0], f[1], f[2], y[0], y[1], y[2], st0, st1, st2, loc, sem, dfe, x, mask_preds)
+        ctx.save_for_backward(f[0], f[1], f[2], y[0], y[1], y[2], st0, st1, st2, loc, sem, dfe, x, hard_src)
         return proposal, x, mask_preds, seg_preds, dfe, depth_pred
 
     @staticmethod
@@ -382,9 +394,9 @@ class _Rpn(torch.autograd.Function):
         gw_dd = map_x_mapT(g_dp, dfe, rowsum=gb_dd, sum_batch=True)
         gf, gW = [], []
         for t, (gy, ft) in enumerate(((gy0, f0), (gy1, f1), (gy2, f2))):
-            gf.append(rows_x_map(P[3 * t].flatten(1).t()[None], gy) if ctx.needs_input_grad[1 + t] else None)
+            gf.append(rows_x_map(P[3 * t].flatten(1).t()[None], gy) if ctx.needs_input_grad[2 + t] else None)
             gW.append(map_x_mapT(gy, ft, sum_batch=True).view(P[3 * t].shape))
-        return (None, gf[0], gf[1], gf[2], gW[0], dg0, db0, gW[1], dg1, db1, gW[2], dg2, db2, gW_init.view(P[9].shape),
+        return (None, None, gf[0], gf[1], gf[2], gW[0], dg0, db0, gW[1], dg1, db1, gW[2], dg2, db2, gW_init.view(P[9].shape),
                 gW_seg.view(P[10].shape), gb_seg, gw_dd.view(P[12].shape), gb_dd)
 
 
@@ -393,7 +405,7 @@ def rpn_forward(head, feats):
     P = _lib.named_params(head)
     plist = [P[n] for n in RPN_NAMES]
     groups = head.norm_cfg.get("num_groups", 32)
-    proposal, x, mask_preds, seg_preds, dfe, depth_pred = _Rpn.apply(groups, feats[0], feats[1], feats[2], *plist)
+    proposal, x, mask_preds, seg_preds, dfe, depth_pred = _Rpn.apply(groups, head, feats[0], feats[1], feats[2], *plist)
     B = x.shape[0]
     depth_proposal = P["conv_direct_depth.weight"].flatten(1)[None].expand(B, 1, -1)           # :286-289
     return dict(proposal=proposal, x=x, mask_preds=mask_preds, seg_preds=seg_preds, dfe=dfe, depth_proposal=depth_proposal,
@@ -454,7 +466,23 @@ def _valid_pixels(gt_masks_i, gt_sem_seg_i):
     return v.float()
 
 
-def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, want_grads=False):
+def _fast_assign_ok(assigner, sampler):
+    """the batched descriptor path covers the shipped training configuration: one-to-one Hungarian matching on class / mask / dice
+    costs (DepthCost weight 0, polyphonic_former.py:170-192) and the pseudo sampler"""
+    from .assigner import _MaskAssignerBase, MaskPseudoSampler
+    return (isinstance(assigner, _MaskAssignerBase) and assigner.topk == 1 and isinstance(sampler, MaskPseudoSampler)
+            and (assigner.depth_cost is None or assigner.depth_cost.weight == 0))
+
+
+def _step_gt(cache, hard, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth):
+    if cache is None:
+        cache = {}
+    if hard not in cache:
+        cache[hard] = Lo.StepGT(gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, hard)
+    return cache[hard]
+
+
+def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, want_grads=False, gt_cache=None):
     """KernelHead.forward_train, kernel_head.py:349-454, on the three post-neck maps (gradients flow into `feats` when they
     require them).  Returns (losses, r): `losses` = the reference's dict with the 'loss' entries attached to the graph
     (`_attach`), `depth_dense` logged only (base.py:198 leaves it out of the objective); r = the differentiable training-
@@ -463,12 +491,32 @@ def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_s
     check_rpn_topology(h)
     if h.assigner is None:
         raise ValueError("forward_train needs train_cfg (assigner / sampler)")
+    gt_raw = gt_masks
     if h.hard_target:                     # local to the rpn side, as in the reference (kernel_head.py:400-403)
         gt_masks = [m.bool().float() for m in gt_masks]
     r = rpn_forward(h, feats)
     up = (lambda t: upsample2x(t)) if h.feat_downsample_stride == 2 else (lambda t: t)
     smask, sseg, sdep0 = up(r["mask_preds"]), up(r["seg_preds"]), up(r["depth_pred"])         # :364-398
     N = h.num_proposals + h.num_stuff_classes
+    if _fast_assign_ok(h.assigner, h.sampler):
+        # round 5: batched assignment (one pixel pass + one D2H for all images), targets as pointer tables, ONE loss call
+        gt = _step_gt(gt_cache, bool(h.hard_target), gt_raw, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth)
+        assigns = Lo.assign_batch(h.assigner, smask.detach(), None, gt)
+        desc = Lo.build_desc(h, gt, assigns, h.num_proposals, h.train_cfg, roi=False)
+        kept = {}
+
+        def fn(mp, sp, dp):
+            ls, g = Lo.fused_losses(h, desc, mp, None, dp, sp, with_grads=True)
+            kept.update(mask_pred=g["mask_pred"], seg_preds=g["seg_preds"], depth_pred=g["depth_pred"])
+            return ls, (g["mask_pred"], g["seg_preds"], g["depth_pred"])
+
+        values = {}
+        total = _Objective.apply(fn, values, smask, sseg, sdep0)
+        losses = _attach(values, total)
+        losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)              # :438-442, logged only
+        if want_grads:
+            losses["_grads"] = kept
+        return losses, r
     sdep = sdep0.detach().expand(-1, N, -1, -1)
     srs = []
     for i in range(len(img_metas)):                                                           # :411-426
@@ -510,7 +558,7 @@ def rpn_outputs(h, r):
 
 
 def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
-                      want_grads=False):
+                      want_grads=False, gt_cache=None):
     """KernelUpdateIterHead.forward_train, kernel_update.py:159-280.  x, dfe [B, C, H, W]; k / q [B, N, C] kernels and depth
     kernels; mask_preds [B, N, H, W]; depth_pred [B, 1, H, W].  Every stage: forward in training form, the Hungarian
     assignment on the previous stage's detached predictions, pseudo sampling, targets, the stage's losses as one autograd
@@ -526,6 +574,9 @@ def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_ma
         raise NotImplementedError("libpolyhead: mask_upsample_stride must be 1 or 2")
     scale = (lambda t: upsample2x(t)) if up == 2 else (lambda t: t)
     prev_mask = scale(mask_preds.detach()).detach()                                           # :179-191
+    if all(_fast_assign_ok(a, sm) for a, sm in zip(ih.mask_assigner, ih.mask_sampler)):
+        return _roi_forward_train_fast(ih, x, dfe, k, mask_preds, q, prev_mask, scale, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
+                                       want_grads, gt_cache)
     prev_depth = scale(depth_pred.detach().expand(-1, N, -1, -1).contiguous()).detach()
     prev_cls = [None] * B                                                                      # :193-196
     if ih.hard_target:
@@ -575,6 +626,48 @@ def roi_forward_train(ih, x, dfe, k, mask_preds, q, depth_pred, img_metas, gt_ma
     return losses, (k, cls, m, smask)
 
 
+def _roi_forward_train_fast(ih, x, dfe, k, mask_preds, q, prev_mask, scale, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth, want_grads,
+                            gt_cache):
+    """the stage loop of `roi_forward_train` on the batched / descriptor path (round 5): per stage ONE `_Stage` node, two
+    upsamples, one batched assignment (`ph_match_sums` over all images + one D2H + the host Hungarian solves), one pointer-table
+    upload and ONE loss call (`ph_train_losses`).  No sampler gathers, no materialised targets: every target row is a row of the
+    step's ground truth (`losses.StepGT`).  The previous stage's depth predictions only feed the DepthCost, whose weight is 0
+    on this path, so they are not formed."""
+    B = k.shape[0]
+    Np, nt = ih.num_proposals, ih.num_thing_classes
+    gt = _step_gt(gt_cache, bool(ih.hard_target), gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth)
+    total, m, values, grads, assigns, prev_cls = 0.0, mask_preds, {}, [], None, None
+    cls = smask = None
+    for s in range(ih.num_stages):
+        head = ih.mask_head[s]
+        check_stage_topology(head)
+        cls, m, k, depth, q = stage_forward(head, x, dfe, k, m, q)
+        smask, sdepth = scale(m), scale(depth)                                                 # training: every stage (:131)
+        if s < ih.assign_stages:
+            c = None if prev_cls is None else prev_cls[:, :Np, :nt]
+            assigns = Lo.assign_batch(ih.mask_assigner[s], prev_mask[:, :Np], c, gt)           # :231-251
+        desc = Lo.build_desc(head, gt, assigns, Np, ih.train_cfg[s], roi=True)
+        kept = {}
+
+        def fn(cs, mp, dp, head=head, desc=desc, kept=kept):
+            ls, g = Lo.fused_losses(head, desc, mp, cs, dp, None, with_grads=True)
+            kept.update(g)
+            return ls, (g["cls_score"], g["mask_pred"], g["depth_pred"])
+
+        box = {}
+        w = ih.stage_loss_weights[s]
+        obj = _Objective.apply(fn, box, cls, smask, sdepth)
+        total = total + (obj if w == 1 else w * obj)
+        for key, v in box.items():
+            values[f"s{s}_{key}"] = v if w == 1 else v * w
+        grads.append(kept)
+        prev_mask, prev_cls = smask.detach(), cls.detach()                                     # :273-276
+    losses = _attach(values, total)
+    if want_grads:
+        losses["_grads"] = grads
+    return losses, (k, cls, m, smask)
+
+
 # ---- the step ------------------------------------------------------------------------------------------------------------------
 class TrainStep:
     """rpn_head: KernelHead, roi_head: KernelUpdateIterHead, both built with train_cfg.  `forward_backward` evaluates one
@@ -617,10 +710,12 @@ class TrainStep:
             if not f.is_cuda:
                 raise _lib.PolyheadError("the post-neck maps must live on the GPU: libpolyhead has no CPU path")
         with torch.enable_grad(), Lo.reduce_group(self.group):
-            rpn_losses, r = rpn_forward_train(self.rpn, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth)
+            gt_cache = {}                                   # the step's ground truth (losses.StepGT), shared by the two heads
+            rpn_losses, r = rpn_forward_train(self.rpn, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_sem_cls, gt_depth,
+                                              gt_cache=gt_cache)
             k, mask_preds, q = rpn_outputs(self.rpn, r)
             losses, _ = roi_forward_train(self.roi, r["x"], r["dfe"], k, mask_preds, q, r["depth_pred"], img_metas, gt_masks, gt_labels,
-                                          gt_sem_seg, gt_sem_cls, gt_depth)
+                                          gt_sem_seg, gt_sem_cls, gt_depth, gt_cache=gt_cache)
             losses.update(rpn_losses)                       # polyphonic_former.py:126
             total = parse_losses(losses)
             if backward:
