@@ -379,11 +379,24 @@ int ph_rows_x_map_ex(const float* A, int64_t a_batch_stride, int lda, int Mpad, 
 int ph_map_x_map_t_ex(const float* G, const float* X, float* partial, float* out, int B, int M, int K, int64_t HW, int nsplit,
                       int binarize_g, float* rs_partial, float* rowsum, int sum_batch, void* stream);
 /* GroupNorm + ReLU of a ConvModule in training mode, fp32 NCHW (csrc/ph_gntrain.hip; kernel_head.py:250-278, semantic_fpn.py:75-178).
- * fwd: out = relu(GN(y)); out_sum = out + add (both null or both given: KernelHead's x_feats = sem + loc); stats [B][groups][2]
+ * fwd: out = relu(GN(y)) (nullable when out_sum is given); out_sum = out + add (both null or both given: KernelHead's
+ *      x_feats = sem + loc, the neck's sum over its towers); stats [B][groups][2]
  *      (mean, rstd) kept for the backward; partial: B * groups * ph_gn_train_nsplit(HW, C / groups) * 2 doubles of scratch.
  * bwd: dy = dyA (+ dyB) masked by out > 0 (recomputed from y); dx, dgamma [C], dbeta [C] are overwritten;
  *      partial: B * C * ph_gn_train_bwd_nsplit(HW) * 2 doubles of scratch.  sum_batch != 0 in ph_map_x_map_t_ex: out [M][K] and
  *      rowsum [M] are summed over the images as well (the gradient of a static 1x1 kernel and of its bias). */
+/* 3x3 convolutions of SemanticFPNWrapper's towers in training (fp32 NCHW, csrc/ph_train.hip; semantic_fpn.py:75-150):
+ * conv3x3_taps : W [M][K][3][3] <-> tap-major [9][M][K] (transpose: [9][K][M]; flip: tap 8 - t -- together the operand of the input
+ *                gradient of a stride-1 conv); to_weight != 0 runs the inverse (a tap-major weight gradient back to [M][K][3][3]).
+ * conv3x3_train: Y [B][M][Ho][Wo] = sum_tap taps[tap] X[.., src_tap(.)], X [B][K][Hi][Wi]; mode 0: forward with `stride` (also the
+ *                input gradient of a stride-1 conv with flipped / transposed taps), mode 1: input gradient of the stride-2 conv
+ *                (X = dL/dY [Hi][Wi], Y = dL/dX [Ho][Wo], taps transposed, NOT flipped).
+ * conv3x3_wgrad: tap-major dW [9][M][K] summed over the batch; partial: B * nsplit * M * K floats (nsplit: ph_map_x_map_t_nsplit). */
+int ph_conv3x3_taps(const float* W, float* taps, int M, int K, int transpose, int flip, int to_weight, void* stream);
+int ph_conv3x3_train(const float* taps, int M, int K, const float* X, float* Y, int B, int Hi, int Wi, int Ho, int Wo, int stride,
+                     int mode, void* stream);
+int ph_conv3x3_wgrad(const float* dY, const float* X, float* partial, float* taps_out, int B, int M, int K, int Hi, int Wi, int Ho,
+                     int Wo, int stride, int nsplit, void* stream);
 int ph_gn_train_nsplit(int64_t HW, int cpg);
 int ph_gn_train_bwd_nsplit(int64_t HW);
 int ph_gn_train_fwd(const float* y, const float* gamma, const float* beta, int groups, float eps, const float* add, float* out,

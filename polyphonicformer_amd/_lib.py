@@ -91,6 +91,9 @@ SIGNATURES = {
     "ph_upsample2x_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P]),
     "ph_rows_x_map_ex": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _I, _L, _I, _P, _P, _P]),
     "ph_map_x_map_t_ex": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _P, _I, _P]),
+    "ph_conv3x3_taps": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ph_conv3x3_train": (C.c_int, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ph_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ph_gn_train_nsplit": (C.c_int, [_L, _I]),
     "ph_gn_train_bwd_nsplit": (C.c_int, [_L]),
     "ph_gn_train_fwd": (C.c_int, [_P, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _I, _I, _L, _P]),

@@ -96,13 +96,13 @@ __global__ __launch_bounds__(GT_T) void k_gnt_apply(const float* __restrict__ y,
     const float sc = gamma[c] * rstd, sh = beta[c] - mean * sc;
     const float* p = y + bc * HW;
     const float* a = add ? add + bc * HW : nullptr;
-    float* o = out + bc * HW;
+    float* o = out ? out + bc * HW : nullptr;            // null: only the sum is wanted (a level of the neck's tower sum)
     float* o2 = out_sum ? out_sum + bc * HW : nullptr;
     if (VEC) {
         for (int64_t i = ((int64_t)blockIdx.x * GT_T + threadIdx.x) * 4; i < HW; i += (int64_t)gridDim.x * GT_T * 4) {
             const float4 v = *(const float4*)(p + i);
             const float4 r = make_float4(fmaxf(v.x * sc + sh, 0.f), fmaxf(v.y * sc + sh, 0.f), fmaxf(v.z * sc + sh, 0.f), fmaxf(v.w * sc + sh, 0.f));
-            *(float4*)(o + i) = r;
+            if (o) *(float4*)(o + i) = r;
             if (o2) {
                 const float4 w = *(const float4*)(a + i);
                 *(float4*)(o2 + i) = make_float4(r.x + w.x, r.y + w.y, r.z + w.z, r.w + w.w);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(GT_T) void k_gnt_apply(const float* __restrict__ y,
     } else {
         for (int64_t i = (int64_t)blockIdx.x * GT_T + threadIdx.x; i < HW; i += (int64_t)gridDim.x * GT_T) {
             const float r = fmaxf(p[i] * sc + sh, 0.f);
-            o[i] = r;
+            if (o) o[i] = r;
             if (o2) o2[i] = r + a[i];
         }
     }
@@ -245,7 +245,7 @@ extern "C" int ph_gn_train_nsplit(int64_t HW, int cpg) { return slices(HW * cpg)
 
 extern "C" int ph_gn_train_fwd(const float* y, const float* gamma, const float* beta, int groups, float eps, const float* add, float* out,
                                float* out_sum, float* stats, double* partial, int B, int C, int64_t HW, void* stream) {
-    PH_CHECK_ARG(y && gamma && beta && out && stats && partial && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "bad pointer or size");
+    PH_CHECK_ARG(y && gamma && beta && (out || out_sum) && stats && partial && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "bad pointer or size");
     PH_CHECK_ARG((add == nullptr) == (out_sum == nullptr), "add and out_sum go together");
     const int cpg = C / groups, ns = ph_gn_train_nsplit(HW, cpg);
     hipStream_t s = (hipStream_t)stream;

@@ -124,6 +124,123 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
     }
 }
 
+// ---- 3x3 convolution as nine shifted rows-x-map products (round 5: the training forward / backward of the neck's towers) ------
+// Y[b][m][q] = sum_tap sum_k A[tap][m][k] X[b][k][src_tap(q)], zero where src falls outside the input.  The map operand of
+// k_rows_x_map is read with 4-byte loads whose address each lane computes itself, so a tap is nothing but another address:
+//   mode 0 (forward, stride s, pad 1): q = (oy, ox) of the Ho x Wo output, src = (oy s + dy - 1, ox s + dx - 1) of the Hi x Wi input;
+//          also the input gradient of a stride-1 conv (A = flipped, transposed taps, X = dL/dY);
+//   mode 1 (input gradient of the stride-2 conv): q = (iy, ix) of the Ho x Wo = INPUT-resolution map, src = ((iy + 1 - dy) / 2,
+//          (ix + 1 - dx) / 2) of the Hi x Wi gradient map where both numerators are even and in range.
+// A: [9][Mpad][lda] fp32, zero padded like k_rows_x_map's.  Grid (pixel tiles, B, m passes); accumulators stay in registers over
+// the nine taps (one pass over X per m pass, X re-reads of the taps hit L2).
+template <int CT, int RT>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_rows(const float* __restrict__ A, int lda, int Mpad, int M, int K, const float* __restrict__ X,
+                                                         float* __restrict__ Y, int Hi, int Wi, int Ho, int Wo, int stride, int mode) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int64_t HWo = (int64_t)Ho * Wo, HWi = (int64_t)Hi * Wi;
+    const int64_t p0 = (int64_t)blockIdx.x * (64 * CT) + wave * (16 * CT);
+    if (p0 >= HWo) return;
+    const int mt0 = blockIdx.z * RT;
+    const int nrt = min(RT, Mpad / 16 - mt0);
+    const float* Xb = X + (int64_t)b * K * HWi;
+    f32x4_t acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[r][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int oy[CT], ox[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int64_t p = p0 + t * 16 + c;
+        oy[t] = p < HWo ? (int)(p / Wo) : -100000;
+        ox[t] = (int)(p % Wo);
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        int64_t src[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            int sy, sx;
+            bool ok;
+            if (mode == 0) {
+                sy = oy[t] * stride + dy - 1; sx = ox[t] * stride + dx - 1;
+                ok = oy[t] >= 0 && sy >= 0 && sy < Hi && sx >= 0 && sx < Wi;
+            } else {
+                const int ny = oy[t] + 1 - dy, nx = ox[t] + 1 - dx;
+                sy = ny >> 1; sx = nx >> 1;
+                ok = oy[t] >= 0 && ny >= 0 && nx >= 0 && !(ny & 1) && !(nx & 1) && sy < Hi && sx < Wi;
+            }
+            src[t] = ok ? (int64_t)sy * Wi + sx : -1;
+        }
+        const float* At = A + (int64_t)tap * Mpad * lda + (int64_t)mt0 * 16 * lda;
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            Frag xb[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + g * 8 + e;
+                    v[e] = (k < K && src[t] >= 0) ? Xb[(int64_t)k * HWi + src[t]] : 0.f;
+                }
+                xb[t] = split8(v);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (r < nrt) {
+                    const int k = k0 + g * 8;
+                    float v[8];
+                    if (k < lda) {
+                        const float4* sp = (const float4*)(At + (int64_t)(r * 16 + c) * lda + k);
+                        const float4 q0 = sp[0], q1 = sp[1];
+                        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                    }
+                    const Frag a = split8(v);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[r][t] = mfma3(a, xb[t], acc[r][t]);
+                }
+            }
+        }
+    }
+    float* Yb = Y + (int64_t)b * M * HWo;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (r < nrt) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int64_t p = p0 + t * 16 + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = (mt0 + r) * 16 + g * 4 + i;
+                    if (m < M && p < HWo) __builtin_nontemporal_store(acc[r][t][i], &Yb[(int64_t)m * HWo + p]);
+                }
+            }
+        }
+    }
+}
+
+// taps[tap][a][b] <- W[m][k][dy][dx]:  transpose == 0: (a, b) = (m, k), tap = dy * 3 + dx  (forward / weight-gradient order);
+//                                      transpose != 0: (a, b) = (k, m), tap = 8 - (dy * 3 + dx)  (input gradient of a stride-1 conv;
+//                                      with flip == 0 the tap order is kept: the stride-2 input gradient indexes taps itself)
+__global__ __launch_bounds__(256) void k_conv3x3_taps(const float* __restrict__ W, float* __restrict__ taps, int M, int K, int transpose, int flip,
+                                                      int to_weight) {
+    const int64_t n = (int64_t)M * K * 9;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i % 9);
+        const int64_t mk = i / 9;
+        const int k = (int)(mk % K), m = (int)(mk / K);
+        const int tap = flip ? 8 - t : t;
+        const int64_t j = transpose ? ((int64_t)tap * K + k) * M + m : ((int64_t)tap * M + m) * K + k;
+        if (to_weight) ((float*)W)[i] = taps[j];        // the inverse: tap-major gradient -> [m][k][3][3]
+        else taps[j] = W[i];
+    }
+}
+
 // ---- rows x map, map operand staged through LDS -------------------------------------------------------------------------------
 // The direct form above reads the map operand with 4-byte loads (its contiguous axis is the output pixel, the MFMA wants 8
 // consecutive k per lane).  Here a [32 k][256 px] step is loaded with 16-byte accesses, split to hi / lo bf16 and stored to LDS
@@ -257,9 +374,13 @@ constexpr int MXM_LOADS = MXM_ROWS / 64;   // float4 loads per thread and step (
 
 // rs_partial (nullable, round 5): [B][nsplit][M] row sums of G over the split's pixels, from the staging threads' own fp32
 // loads (binarised: the pixel COUNT of each hard mask; otherwise the gradient of a dynamic kernel's scalar bias)
+// shift (round 5, the weight gradient of a 3x3 tap): X is a [K][Hi][Wi] map read at src_tap(q) for every pixel q of G's Ho x Wo map
+struct TapShift {
+    int on, Hi, Wi, Wo, stride, dy, dx;
+};
 template <bool VEC, bool BIN>
 __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ partial,
-                                                       int M, int K, int64_t HW, int64_t chunk, float* __restrict__ rs_partial) {
+                                                       int M, int K, int64_t HW, int64_t chunk, float* __restrict__ rs_partial, const TapShift sh) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[2][MXM_ROWS][MXM_PITCH];     // [hi | lo][row][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -267,7 +388,8 @@ __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G,
     const int m0 = blockIdx.z * (MXM_RT * 16);
     const int64_t pa = s * chunk, pe = min(HW, pa + chunk);
     const float* Gb = G + ((int64_t)b * M + m0) * HW;
-    const float* Xb = X + (int64_t)b * K * HW;
+    const int64_t HWx = sh.on ? (int64_t)sh.Hi * sh.Wi : HW;
+    const float* Xb = X + (int64_t)b * K * HWx;
     const int r0 = tid >> 3, p4 = (tid & 7) * 4;
     // row j of this thread: LDS row r0 + 32 j; rows < 160 are G rows m0 + .., the others X rows
     float4 st[MXM_LOADS];
@@ -281,7 +403,20 @@ __global__ __launch_bounds__(512) void k_map_x_mapT(const float* __restrict__ G,
             const bool ok = isg ? (m0 + rr < M) : (rr < K);
             const float* src = (isg ? Gb : Xb) + (int64_t)rr * HW + p + p4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
+            if (ok && sh.on && !isg) {          // a tap of a 3x3 conv: every pixel of the step computes its own source address
+                const float* xr = Xb + (int64_t)rr * HWx;
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t q = p + p4 + u;
+                    e[u] = 0.f;
+                    if (q < pe) {
+                        const int sy = (int)(q / sh.Wo) * sh.stride + sh.dy - 1, sx = (int)(q % sh.Wo) * sh.stride + sh.dx - 1;
+                        if (sy >= 0 && sy < sh.Hi && sx >= 0 && sx < sh.Wi) e[u] = xr[(int64_t)sy * sh.Wi + sx];
+                    }
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            } else if (ok) {
                 if (VEC) { if (p + p4 < pe) v = *(const float4*)src; }      // pe, HW multiples of 4 here
                 else {
                     if (p + p4 + 0 < pe) v.x = src[0];
@@ -382,9 +517,18 @@ __global__ __launch_bounds__(256) void k_sum_splits(const float* __restrict__ pa
     if (i >= MK * B) return;
     const int64_t b = i / MK, j = i - b * MK;
     const float* p = partial + b * nsplit * MK + j;
-    float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += p[(int64_t)s * MK];       // fixed order: run-to-run identical
-    out[i] = acc;
+    // fixed order (run-to-run identical): four interleaved partial sums so that 8 loads are in flight per thread -- the plain
+    // one-accumulator loop read the 40 MB of a cfg2 pooling pass at 1 TB/s (39 us per call, 1.1 ms per training step)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        const float v0 = p[(int64_t)(s + 0) * MK], v1 = p[(int64_t)(s + 1) * MK], v2 = p[(int64_t)(s + 2) * MK], v3 = p[(int64_t)(s + 3) * MK];
+        const float v4 = p[(int64_t)(s + 4) * MK], v5 = p[(int64_t)(s + 5) * MK], v6 = p[(int64_t)(s + 6) * MK], v7 = p[(int64_t)(s + 7) * MK];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+    }
+    for (; s < nsplit; ++s) a0 += p[(int64_t)s * MK];
+    out[i] = (a0 + a1) + (a2 + a3);
 }
 
 // ---- transpose of the x2 bilinear upsample -----------------------------------------------------------------------------------------
@@ -481,7 +625,8 @@ extern "C" int ph_map_x_map_t_ex(const float* G, const float* X, float* partial 
     const bool vec = (HW % 4) == 0 && (((uintptr_t)G | (uintptr_t)X) & 15) == 0;
     const dim3 grid(nsplit, B, ((M + 15) / 16 + MXM_RT - 1) / MXM_RT);
     hipStream_t s = (hipStream_t)stream;
-#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(512), 0, s, G, X, partial, M, K, HW, chunk, rs_partial)
+    const TapShift sh{};
+#define PH_MXM(V, Bn) hipLaunchKernelGGL((k_map_x_mapT<V, Bn>), grid, dim3(512), 0, s, G, X, partial, M, K, HW, chunk, rs_partial, sh)
     if (vec) { if (binarize_g) PH_MXM(true, true); else PH_MXM(true, false); }
     else { if (binarize_g) PH_MXM(false, true); else PH_MXM(false, false); }
 #undef PH_MXM
@@ -510,6 +655,51 @@ extern "C" int ph_upsample2x_bwd(const float* grad_out /* [planes][2H][2W] */, f
     int64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_upsample2x_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad_out, grad_in, planes, H, W);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// ---- 3x3 convolution of the neck's towers in training (semantic_fpn.py:75-150: ConvModule 3x3, padding 1, stride 1 or 2, no bias) --
+extern "C" int ph_conv3x3_taps(const float* W /* [M][K][3][3] */, float* taps /* [9][..][..] */, int M, int K, int transpose, int flip,
+                               int to_weight, void* stream) {
+    PH_CHECK_ARG(W && taps && M > 0 && K > 0, "bad pointer or size");
+    const int64_t n = (int64_t)M * K * 9;
+    hipLaunchKernelGGL(k_conv3x3_taps, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, taps, M,
+                       K, transpose, flip, to_weight);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+extern "C" int ph_conv3x3_train(const float* taps /* [9][M][K], M % 16 == 0, K % 8 == 0 */, int M, int K, const float* X, float* Y, int B, int Hi,
+                                int Wi, int Ho, int Wo, int stride, int mode, void* stream) {
+    PH_CHECK_ARG(taps && X && Y && B > 0 && M > 0 && K > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bad pointer or size");
+    PH_CHECK_ARG(M % 16 == 0 && K % 8 == 0 && ((uintptr_t)taps & 15) == 0, "M % 16, K % 8 (the shipped towers: 256 x 256)");
+    PH_CHECK_ARG((mode == 0 && (stride == 1 || stride == 2)) || (mode == 1 && stride == 2), "mode 0: stride 1 / 2 forward; mode 1: stride-2 input gradient");
+    const int64_t HWo = (int64_t)Ho * Wo;
+    constexpr int CT = 4, RT = 8;
+    hipLaunchKernelGGL((k_conv3x3_rows<CT, RT>), dim3((unsigned)((HWo + 64 * CT - 1) / (64 * CT)), B, (M / 16 + RT - 1) / RT), dim3(256), 0,
+                       (hipStream_t)stream, taps, K, M, M, K, X, Y, Hi, Wi, Ho, Wo, stride, mode);
+    PH_CHECK_LAUNCH();
+    return PH_OK;
+}
+
+// dW taps [9][M][K] = sum_b sum_q dY[b][m][q] X[b][k][src_tap(q)]  (nine shifted map x map^T products, summed over the batch)
+extern "C" int ph_conv3x3_wgrad(const float* dY /* [B][M][Ho][Wo] */, const float* X /* [B][K][Hi][Wi] */, float* partial, float* taps_out, int B,
+                                int M, int K, int Hi, int Wi, int Ho, int Wo, int stride, int nsplit, void* stream) {
+    PH_CHECK_ARG(dY && X && partial && taps_out && B > 0 && M > 0 && K > 0 && K <= 256 && nsplit >= 1, "bad pointer or size (K <= 256)");
+    const int64_t HW = (int64_t)Ho * Wo;
+    int64_t chunk = (HW + nsplit - 1) / nsplit;
+    chunk = (chunk + 31) / 32 * 32;
+    const bool vec = (HW % 4) == 0 && ((uintptr_t)dY & 15) == 0;
+    const dim3 grid(nsplit, B, ((M + 15) / 16 + MXM_RT - 1) / MXM_RT);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t MK = (int64_t)M * K;
+    for (int tap = 0; tap < 9; ++tap) {
+        const TapShift sh{1, Hi, Wi, Wo, stride, tap / 3, tap % 3};
+        if (vec) hipLaunchKernelGGL((k_map_x_mapT<true, false>), grid, dim3(512), 0, s, dY, X, partial, M, K, HW, chunk, (float*)nullptr, sh);
+        else hipLaunchKernelGGL((k_map_x_mapT<false, false>), grid, dim3(512), 0, s, dY, X, partial, M, K, HW, chunk, (float*)nullptr, sh);
+        hipLaunchKernelGGL(k_sum_splits, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, s, partial, taps_out + tap * MK, nsplit * B, MK, 1);
+    }
     PH_CHECK_LAUNCH();
     return PH_OK;
 }

@@ -71,7 +71,6 @@ class KernelHead(nn.Module):
         self.precision = "fp32"
         self.emit_fp32_features = True     # the reference API returns x_feats / depth_feats as fp32 NCHW tensors
         self.logit_dtype = torch.float32   # mask_preds / seg_preds / depth_pred; torch.float16 halves their bytes (one-pass form)
-        self.frozen_neck_ok = False        # forward_train with this package's (non-differentiable) neck: only when it is frozen
         self._pack, self._plans = None, {}
         self.assigner = self.sampler = None
         if self.train_cfg:                 # kernel_head.py:134-140
@@ -176,25 +175,16 @@ class KernelHead(nn.Module):
         backward of every map-sized product), the 'loss' entries of the returned dict are attached to one autograd node, and
         the tensors handed on to the roi head stay on the graph -- mmdet's `_parse_losses` + `backward()`
         (mmdet/models/detectors/base.py:176-199) work on the result unchanged.  `img`: the three post-neck maps (gradients
-        flow into them when they require them).  With this package's neck as `localization_fpn` the call RAISES unless the neck is
-        frozen and `frozen_neck_ok` is set: that neck has no backward, and the reference trains neck / FPN / backbone through
-        this method.  `with_grads=True` adds losses['_grads'] = d(sum of the 'loss' entries) / d(scaled mask, seg
+        flow into them when they require them) or, with `localization_fpn` set, the four FPN levels: the neck then runs its
+        differentiable form (`train.neck_forward_train`) and is trained through this method like the reference's (round 5; the
+        `frozen_neck_ok` escape hatch of rounds 3-4 is gone).  `with_grads=True` adds losses['_grads'] = d(sum of the 'loss' entries) / d(scaled mask, seg
         and direct depth predictions)."""
         from . import train as T
         if self.assigner is None:
             raise ValueError("forward_train needs train_cfg (assigner / sampler)")
         neck = self.localization_fpn
-        if neck is not None and not getattr(neck, "differentiable", True) and not self.frozen_neck_ok:
-            # ADVICE r03: this package's SemanticFPNWrapper runs its inference kernels on detached weight packs -- under mmdet's
-            # backward() the neck, the FPN and the backbone would silently receive NO gradient, where the reference trains them
-            # through rpn_head.forward_train (polyphonic_former.py:97-110).  Refuse instead of training something else.
-            if any(p.requires_grad for p in neck.parameters()) or any(torch.is_tensor(t) and t.requires_grad for t in img):
-                raise NotImplementedError(
-                    "KernelHead.forward_train: localization_fpn is libpolyhead's SemanticFPNWrapper, which has no backward -- its "
-                    "parameters / the FPN inputs require gradients and would not get any.  Train on the post-neck maps "
-                    "(localization_fpn=None, a differentiable neck in front), or freeze the neck (requires_grad_(False) on it, "
-                    "detached FPN inputs) and set rpn_head.frozen_neck_ok = True.")
-        feats = neck(img) if neck is not None else list(img)
+        with torch.enable_grad():      # the neck's differentiable form (SemanticFPNWrapper under autograd): it is trained from here
+            feats = neck(img) if neck is not None else list(img)
         if not isinstance(feats, (list, tuple)) or len(feats) != 3:
             raise NotImplementedError("with_depth needs the neck's three maps (kernel_head.py:272-276)")
         for f in feats:

@@ -55,8 +55,11 @@ def sine_positional_encoding(H, W, num_feats, temperature=10000, scale=2 * math.
 
 
 class SemanticFPNWrapper(nn.Module):
-    # inference kernels on detached weight packs: no autograd graph (KernelHead.forward_train refuses to "train" through it)
-    differentiable = False
+    # round 5: under autograd (grad mode on and a parameter or an input that requires grad) `forward` runs the differentiable
+    # fp32 form (`train.neck_forward_train`: 3x3 conv / GroupNorm + ReLU / upsample nodes with hand-written backward), so
+    # KernelHead.forward_train trains the neck -- and through its input gradients the FPN and the backbone -- as the reference does
+    # (polyphonic_former.py:97-110).  Without autograd: the inference kernels on packed 16-bit weights, as before.
+    differentiable = True
 
     def __init__(self, in_channels, feat_channels, out_channels, start_level, end_level, cat_coors=False,
                  positional_encoding=None, cat_coors_level=3, fuse_by_cat=False, return_list=False, upsample_times=3,
@@ -141,6 +144,13 @@ class SemanticFPNWrapper(nn.Module):
     def forward(self, inputs, _planes=False):
         x0 = inputs[0]
         E._require_gpu(x0, "inputs[0]")
+        if not _planes and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                                        any(torch.is_tensor(t) and t.requires_grad for t in inputs[:4])):
+            from . import train as T
+            outs = T.neck_forward_train(self, inputs)
+            if self.num_aux_convs > 0:
+                return outs
+            return [outs[0]] if self.return_list else outs[0]
         dev, B = x0.device, x0.shape[0]
         pk, prec, G = self._pack(dev), E.KHEAD_PREC[self.precision], self.groups
         shapes = tuple(tuple(t.shape[-2:]) for t in inputs[:4])

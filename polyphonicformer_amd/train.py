@@ -311,12 +311,12 @@ def stage_forward(head, x, dfe, k, m, q):
 
 
 # ---- KernelHead after the neck: ONE autograd node -----------------------------------------------------------------------------
-def gn_relu_fwd(y, gamma, beta, groups, add=None, eps=1e-5):
+def gn_relu_fwd(y, gamma, beta, groups, add=None, eps=1e-5, want_out=True):
     """relu(GroupNorm(y)) of a ConvModule, fp32 NCHW (`ph_gn_train_fwd`) -> (out, out + add or None, stats [B, groups, 2])"""
     lib = _lib.load()
     B, Cc = y.shape[:2]
     HW = y[0, 0].numel()
-    out = torch.empty_like(y)
+    out = torch.empty_like(y) if (want_out or add is None) else None
     osum = torch.empty_like(y) if add is not None else None
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=y.device)
     part = torch.empty((B * groups * lib.ph_gn_train_nsplit(HW, Cc // groups) * 2,), dtype=torch.float64, device=y.device)
@@ -410,6 +410,139 @@ def rpn_forward(head, feats):
     depth_proposal = P["conv_direct_depth.weight"].flatten(1)[None].expand(B, 1, -1)           # :286-289
     return dict(proposal=proposal, x=x, mask_preds=mask_preds, seg_preds=seg_preds, dfe=dfe, depth_proposal=depth_proposal,
                 depth_pred=depth_pred)
+
+
+# ---- SemanticFPNWrapper in training: the neck's forward as differentiable libpolyhead nodes (round 5) ------------------------------
+class _Conv3x3(torch.autograd.Function):
+    """F.conv2d(X, W [M, K, 3, 3], stride, padding 1) on `ph_conv3x3_train` (nine shifted rows-x-map products); backward: the input
+    gradient is the same kernel on flipped / transposed taps (stride 2: its transposed-stride mode), the weight gradient nine
+    shifted map x map^T products summed over the batch (`ph_conv3x3_wgrad`)"""
+
+    @staticmethod
+    def _taps(W, transpose, flip):
+        M, K = W.shape[:2]
+        t = torch.empty((9, K, M) if transpose else (9, M, K), dtype=torch.float32, device=W.device)
+        _lib.check(_lib.load().ph_conv3x3_taps(_lib.ptr(W), _lib.ptr(t), M, K, int(transpose), int(flip), 0, _lib.stream_ptr()), "ph_conv3x3_taps")
+        return t
+
+    @staticmethod
+    def forward(ctx, X, W, stride):
+        X, Wd = _gpu32(X, "X"), _gpu32(W, "W")
+        B, K, Hi, Wi = X.shape
+        M = Wd.shape[0]
+        Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+        Y = torch.empty((B, M, Ho, Wo), dtype=torch.float32, device=X.device)
+        _lib.check(_lib.load().ph_conv3x3_train(_lib.ptr(_Conv3x3._taps(Wd, False, False)), M, K, _lib.ptr(X), _lib.ptr(Y), B, Hi, Wi, Ho, Wo,
+                                                stride, 0, _lib.stream_ptr()), "ph_conv3x3_train")
+        ctx.stride = stride
+        ctx.save_for_backward(X, Wd)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        X, W = ctx.saved_tensors
+        lib, s = _lib.load(), ctx.stride
+        gY = _gpu32(gY, "grad")
+        B, K, Hi, Wi = X.shape
+        M, Ho, Wo = W.shape[0], gY.shape[2], gY.shape[3]
+        gX = gW = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            if s == 1:
+                _lib.check(lib.ph_conv3x3_train(_lib.ptr(_Conv3x3._taps(W, True, True)), K, M, _lib.ptr(gY), _lib.ptr(gX), B, Ho, Wo, Hi, Wi, 1, 0,
+                                                _lib.stream_ptr()), "ph_conv3x3_train(dgrad)")
+            else:
+                _lib.check(lib.ph_conv3x3_train(_lib.ptr(_Conv3x3._taps(W, True, False)), K, M, _lib.ptr(gY), _lib.ptr(gX), B, Ho, Wo, Hi, Wi, 2, 1,
+                                                _lib.stream_ptr()), "ph_conv3x3_train(dgrad, stride 2)")
+        if ctx.needs_input_grad[1]:
+            ns = lib.ph_map_x_map_t_nsplit(B, M, Ho * Wo)
+            part = torch.empty((B, ns, M, K), dtype=torch.float32, device=X.device)
+            taps = torch.empty((9, M, K), dtype=torch.float32, device=X.device)
+            _lib.check(lib.ph_conv3x3_wgrad(_lib.ptr(gY), _lib.ptr(X), _lib.ptr(part), _lib.ptr(taps), B, M, K, Hi, Wi, Ho, Wo, s, ns,
+                                            _lib.stream_ptr()), "ph_conv3x3_wgrad")
+            gW = torch.empty_like(W)
+            _lib.check(lib.ph_conv3x3_taps(_lib.ptr(gW), _lib.ptr(taps), M, K, 0, 0, 1, _lib.stream_ptr()), "ph_conv3x3_taps")
+        return gX, gW, None
+
+
+class _GNReLU(torch.autograd.Function):
+    """relu(GroupNorm(y)) (+ add: the running sum over the neck's towers, semantic_fpn.py:217-220) -- csrc/ph_gntrain.hip"""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, add):
+        y = _gpu32(y, "y")
+        g, b = gamma.detach(), beta.detach()
+        out, osum, stats = gn_relu_fwd(y, g, b, groups, add=None if add is None else _gpu32(add, "add"), want_out=False)
+        ctx.groups, ctx.has_add = groups, add is not None
+        ctx.save_for_backward(y, stats, g, b)
+        return out if add is None else osum
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, stats, g, b = ctx.saved_tensors
+        gout = _gpu32(gout, "grad")
+        dx, dg, db = gn_relu_bwd(y, stats, g, b, ctx.groups, gout)
+        return dx, dg, db, None, (gout if ctx.has_add else None)
+
+
+class _NeckOuts(torch.autograd.Function):
+    """conv_pred + the aux convs (semantic_fpn.py:152-178, 222-229): 1x1 conv + GroupNorm + ReLU each, on the tower sum; backward
+    in one node so that the three input-gradient contributions land in ONE buffer (the second and third as the product's add source)"""
+
+    @staticmethod
+    def forward(ctx, groups, s, *params):
+        s = _gpu32(s, "tower sum")
+        P = [p.detach() for p in params]
+        n = len(P) // 3
+        ys, sts, outs = [], [], []
+        for j in range(n):
+            y = rows_x_map(P[3 * j].flatten(1)[None], s)
+            o, _, st = gn_relu_fwd(y, P[3 * j + 1], P[3 * j + 2], groups)
+            ys.append(y); sts.append(st); outs.append(o)
+        ctx.groups, ctx.P, ctx.n = groups, P, n
+        ctx.save_for_backward(s, *ys, *sts)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        sv = ctx.saved_tensors
+        P, n, s = ctx.P, ctx.n, sv[0]
+        ys, sts = sv[1:1 + n], sv[1 + n:1 + 2 * n]
+        gs, grads = None, []
+        for j in range(n):
+            gy, dg, db = gn_relu_bwd(ys[j], sts[j], P[3 * j + 1], P[3 * j + 2], ctx.groups, _gpu32(gouts[j], "grad"))
+            if ctx.needs_input_grad[1]:
+                W = P[3 * j].flatten(1)
+                gs = rows_x_map(W.t()[None], gy) if gs is None else rows_x_map(W.t()[None], gy, out=gs, accumulate=True)
+            grads += [map_x_mapT(gy, s, sum_batch=True).view(P[3 * j].shape), dg, db]
+        return (None, gs) + tuple(grads)
+
+
+def neck_forward_train(neck, inputs):
+    """SemanticFPNWrapper.forward (funcs/semantic_fpn.py:198-235) for the shipped configuration, every operation a differentiable
+    libpolyhead node: per level 3x3 conv (level 0: stride 2) + GroupNorm + ReLU, x2 bilinear upsamples in between, the towers'
+    outputs summed inside the last GroupNorm pass of each level, conv_pred / aux convs.  fp32 NCHW, the reference's arithmetic
+    (products on hi + lo bf16 MFMA like the heads' map products).  Gradients flow to every parameter and to the four FPN inputs."""
+    G = neck.groups
+    total = None
+    for lvl, level in enumerate(neck.convs_all_levels):
+        t = inputs[lvl].float()
+        if lvl == neck.cat_coors_level and neck.pos_cfg is not None:
+            t = t + neck._posenc(t.shape[-2], t.shape[-1], t.device)[None]                    # semantic_fpn.py:202-209
+        for j in range(level.n):
+            m = getattr(level, f"conv{j}")
+            y = _Conv3x3.apply(t, m.conv.weight, m.stride)
+            last = j == level.n - 1
+            t = _GNReLU.apply(y, m.gn.weight, m.gn.bias, G, total if (last and total is not None) else None)
+            if not last:                              # levels 2, 3: an x2 upsample follows every conv but the last (:117-150)
+                t = upsample2x(t)
+        total = t
+    outs = [neck.conv_pred] + list(neck.aux_convs)
+    plist = []
+    for m in outs:
+        plist += [m.conv.weight, m.gn.weight, m.gn.bias]
+    res = _NeckOuts.apply(G, total, *plist)
+    return list(res)
 
 
 # ---- the two heads' training forwards (ONE implementation: the API methods and TrainStep both call these) --------------------
