@@ -571,6 +571,29 @@ int ph_gn_apply(const float* y, const float* stats /* nullable */, const float* 
                 int accumulate, uint16_t* planes /* nullable */, float* outf /* nullable */, int B, int H, int W, int prec,
                 void* stream);
 
+/* ---- N1: the quasi-dense embedding tracker as a native object (csrc/ph_tracker.hip; polyphonic/video/qdtrack/trackers/
+ * quasi_dense_embed_tracker.py:47-207).  Host bookkeeping in C++ (boxes, labels, ids, ages), embeddings in a device POOL of
+ * `capacity` rows of 256 floats inside `device_mem` (ph_tracker_device_bytes; owned by the caller, alive as long as the tracker).
+ * match: boxes [n][5] (x1, y1, x2, y2, score) and labels [n] on the HOST, embeds [n][256] on the DEVICE; writes the kept detections
+ * in descending-score order -- kept_out [k] (indices into the input), ids_out [k] (>= 0 track id, -1 unmatched, -2 suppressed) -- and
+ * updates the memory.  Returns k >= 0 or a negative error.  One stream synchronisation inside (the [n x m] score download).
+ * thresholds are compared in fp32 like the reference's tensors; memo_momentum / one_minus_momentum: fp32(m) and fp32(1 - m) with
+ * 1 - m evaluated in double (what `(1 - momentum) * tensor` does). */
+typedef struct {
+    float init_score_thr, obj_score_thr, match_score_thr, memo_momentum, one_minus_momentum, nms_conf_thr, nms_backdrop_iou_thr,
+        nms_class_iou_thr;
+    int32_t memo_tracklet_frames, memo_backdrop_frames, with_cats, metric;   /* metric: 0 bisoftmax, 1 softmax, 2 cosine */
+} ph_tracker_cfg;
+typedef struct ph_tracker ph_tracker;
+size_t ph_tracker_device_bytes(int capacity, int max_dets);
+ph_tracker* ph_tracker_create(const ph_tracker_cfg* cfg, void* device_mem, size_t device_bytes, int capacity, int max_dets);
+void ph_tracker_destroy(ph_tracker* t);
+void ph_tracker_reset(ph_tracker* t);
+int64_t ph_tracker_num_tracklets(const ph_tracker* t);
+int ph_tracker_rows(const ph_tracker* t);
+int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t* labels, const float* embeds_dev, int n, int64_t frame_id,
+                     int32_t* kept_out, int64_t* ids_out, void* stream);
+
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);
 int ph_selftest_mfma32(const uint16_t* a /*[32][16]*/, const uint16_t* bt /*[32][16]*/, float* d /*[32][32]*/, void* stream);

@@ -132,6 +132,13 @@ SIGNATURES = {
     "ph_neck_out_convs_workspace_bytes": (C.c_size_t, [_I, _L, _I]),
     "ph_neck_out_convs": (C.c_int, [_P, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _P]),
     "ph_gn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "ph_tracker_device_bytes": (C.c_size_t, [_I, _I]),
+    "ph_tracker_create": (C.c_void_p, [_P, _P, _Z, _I, _I]),
+    "ph_tracker_destroy": (None, [_P]),
+    "ph_tracker_reset": (None, [_P]),
+    "ph_tracker_num_tracklets": (C.c_int64, [_P]),
+    "ph_tracker_rows": (C.c_int, [_P]),
+    "ph_tracker_match": (C.c_int, [_P, _P, _P, _P, _I, _L, _P, _P, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_readbw": (C.c_int, [_P, _L, _I, _P, _P]),

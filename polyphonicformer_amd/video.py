@@ -152,12 +152,78 @@ class QuasiDenseEmbedTracker(object):
         self.memo_momentum, self.nms_conf_thr = memo_momentum, nms_conf_thr
         self.nms_backdrop_iou_thr, self.nms_class_iou_thr, self.with_cats = nms_backdrop_iou_thr, nms_class_iou_thr, with_cats
         self.match_metric = match_metric
-        self.num_tracklets = 0
+        self._num_tracklets = 0
         self.table = _TrackTable(memo_backdrop_frames)
+        self._native = None           # (handle, device memory, device): round 5, embeddings on a GPU -> csrc/ph_tracker.hip
+
+    @property
+    def num_tracklets(self):
+        if self._native is not None:
+            from . import _lib
+            return int(_lib.load().ph_tracker_num_tracklets(self._native[0]))
+        return self._num_tracklets
+
+    @num_tracklets.setter
+    def num_tracklets(self, v):
+        self._num_tracklets = v
 
     @property
     def empty(self):
+        if self._native is not None:
+            from . import _lib
+            return _lib.load().ph_tracker_rows(self._native[0]) == 0
         return len(self.table) == 0
+
+    def __del__(self):
+        nat = getattr(self, "_native", None)
+        if nat is not None:
+            try:
+                from . import _lib
+                _lib.load().ph_tracker_destroy(nat[0])
+            except Exception:
+                pass
+
+    # -- the native form (embeddings on a GPU): one C call per frame ----------------------------------------------
+    NATIVE_CAPACITY, NATIVE_MAX_DETS = 4096, 128
+    native = True                 # False: the array form below also for GPU embeddings (tests compare the two)
+
+    def _match_native(self, bboxes, labels, track_feats, frame_id):
+        """csrc/ph_tracker.hip: bookkeeping in C++, embeddings in a device pool, per frame two small uploads, six launches and
+        ONE synchronising download (the [detections x memory] scores).  Same integer ids as the array form below."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = track_feats.device
+        if self._native is None:
+            if len(self.table) or self._num_tracklets:
+                raise _lib.PolyheadError("QuasiDenseEmbedTracker: a tracker that started on CPU embeddings cannot continue on the GPU")
+
+            class Cfg(C.Structure):
+                _fields_ = [(n, C.c_float) for n in ("init_score_thr", "obj_score_thr", "match_score_thr", "memo_momentum", "one_minus_momentum",
+                                                     "nms_conf_thr", "nms_backdrop_iou_thr", "nms_class_iou_thr")] + \
+                           [(n, C.c_int32) for n in ("memo_tracklet_frames", "memo_backdrop_frames", "with_cats", "metric")]
+            c = Cfg(self.init_score_thr, self.obj_score_thr, self.match_score_thr, self.memo_momentum, 1 - self.memo_momentum, self.nms_conf_thr,
+                    self.nms_backdrop_iou_thr, self.nms_class_iou_thr, self.memo_tracklet_frames, self.memo_backdrop_frames,
+                    1 if self.with_cats else 0, {'bisoftmax': 0, 'softmax': 1, 'cosine': 2}[self.match_metric])
+            nb = lib.ph_tracker_device_bytes(self.NATIVE_CAPACITY, self.NATIVE_MAX_DETS)
+            mem = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            h = lib.ph_tracker_create(C.byref(c), _lib.ptr(mem), nb, self.NATIVE_CAPACITY, self.NATIVE_MAX_DETS)
+            if not h:
+                raise _lib.PolyheadError("ph_tracker_create failed: " + (lib.ph_last_error_string() or b"").decode())
+            self._native = (C.c_void_p(h), mem, dev)
+        if dev != self._native[2]:
+            raise _lib.PolyheadError("QuasiDenseEmbedTracker: the embeddings moved to another device mid-stream")
+        box = np.ascontiguousarray(bboxes.detach().cpu().float().numpy())
+        lab = np.ascontiguousarray(labels.detach().cpu().long().numpy())
+        emb = track_feats.detach().float().contiguous()
+        n = box.shape[0]
+        kept, ids = np.empty((max(n, 1),), dtype=np.int32), np.empty((max(n, 1),), dtype=np.int64)
+        k = lib.ph_tracker_match(self._native[0], box.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), _lib.ptr(emb), n, int(frame_id),
+                                 kept.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), _lib.stream_ptr())
+        if k < 0:
+            _lib.check(k, "ph_tracker_match")
+        kept = kept[:k].astype(np.int64)
+        return torch.from_numpy(box[kept]), torch.from_numpy(lab[kept]), torch.from_numpy(ids[:k].copy())
 
     # -- pieces of `match` ---------------------------------------------------------------------------------
     def _dedup(self, box):
@@ -233,6 +299,9 @@ class QuasiDenseEmbedTracker(object):
         return self._match(bboxes, labels, track_feats, frame_id)
 
     def _match(self, bboxes, labels, track_feats, frame_id):
+        if self.native and track_feats.is_cuda and bboxes.shape[0] <= self.NATIVE_MAX_DETS and bboxes.shape[1] == 5 and track_feats.shape[1] == 256 \
+                and (self._native is not None or (len(self.table) == 0 and self._num_tracklets == 0)):
+            return self._match_native(bboxes, labels, track_feats, frame_id)
         box_t, lab_t, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().float()   # emb: stays put
         dev = emb.device
         order = box_t[:, 4].sort(descending=True)[1].numpy()      # torch's order among equal scores (what the goldens were pinned with)
@@ -246,8 +315,8 @@ class QuasiDenseEmbedTracker(object):
             ids = self._assign(self._affinity(emb, lab, memo_emb, memo_lab).numpy(), box[:, 4], memo_ids)
         born = (ids == -1) & (box[:, 4] > np.float32(self.init_score_thr))
         k = int(born.sum())
-        ids[born] = np.arange(self.num_tracklets, self.num_tracklets + k, dtype=np.int64)
-        self.num_tracklets += k
+        ids[born] = np.arange(self._num_tracklets, self._num_tracklets + k, dtype=np.int64)
+        self._num_tracklets += k
         self._remember(ids, box, emb, lab, frame_id, iou[keep][:, keep])
         return torch.from_numpy(box), torch.from_numpy(lab), torch.from_numpy(ids)
 

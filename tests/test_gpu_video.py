@@ -256,9 +256,10 @@ def test_cfg3_two_frame_clip_end_to_end(gpu):
 
 @pytest.mark.parametrize("metric", ["bisoftmax", "softmax", "cosine"])
 def test_tracker_with_device_embeddings(gpu, metric):
-    """QuasiDenseEmbedTracker with the embeddings (detections and memory) resident on the device and the affinity matrix
-    from ph_track_affinity: the integer ids of the REFERENCE tracker (tests/golden/tracker.npz, bisoftmax) come out bit for
-    bit, every metric gives the ids of the all-host formulation, and the affinity kernel agrees with the torch formula"""
+    """QuasiDenseEmbedTracker on GPU embeddings in its two forms -- the NATIVE object (round 5, csrc/ph_tracker.hip: bookkeeping in
+    C++, embeddings in a device pool) and the array form (numpy bookkeeping, `ph_track_affinity`) -- and on the CPU: the integer ids of
+    the REFERENCE tracker (tests/golden/tracker.npz, bisoftmax) come out bit for bit from all three, every metric gives the ids of the
+    all-host formulation, boxes / labels of the kept detections are identical, and the affinity kernel agrees with the torch formula"""
     import json
     import numpy as np
     from polyphonicformer_amd import video as V
@@ -267,7 +268,9 @@ def test_tracker_with_device_embeddings(gpu, metric):
     cfg["match_metric"] = metric
     threads_before = torch.get_num_threads()
     for seed in (1, 2, 3):
+        nat_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
         dev_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
+        dev_tr.native = False
         cpu_tr = V.TRACKERS.build(dict(type="QuasiDenseEmbedTracker", **cfg))
         cnt = 1
         for f, bb, lab, emb in Hh.tracker_records(seed):
@@ -278,15 +281,44 @@ def test_tracker_with_device_embeddings(gpu, metric):
                 a = dev_tr._affinity(emb.to(gpu), lab, me, ml)
                 b = cpu_tr._affinity(emb, lab, me.cpu(), ml)
                 assert me.is_cuda and torch.allclose(a, b, rtol=1e-4, atol=1e-6), float((a - b).abs().max())
+            nbb, nlab, nids = nat_tr.match(bboxes=bb.to(gpu), labels=lab.to(gpu), track_feats=emb.to(gpu), frame_id=cnt)
             obb, olab, ids = dev_tr.match(bboxes=bb.to(gpu), labels=lab.to(gpu), track_feats=emb.to(gpu), frame_id=cnt)
             cbb, clab, cids = cpu_tr.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
             cnt += 1
             assert torch.equal(ids, cids) and torch.equal(obb, cbb) and torch.equal(olab, clab)
+            assert torch.equal(nids, cids) and torch.equal(nbb, cbb) and torch.equal(nlab, clab), (seed, f, nids.tolist(), cids.tolist())
+            assert nat_tr.num_tracklets == cpu_tr.num_tracklets and nat_tr.empty == cpu_tr.empty
             if metric == "bisoftmax":
-                r = ids + 1
+                r = nids + 1
                 r[r == -1] = 0
                 assert np.array_equal(r.numpy(), z[f"s{seed}_f{f}_ids"]), (seed, f)
+        assert nat_tr._native is not None and dev_tr._native is None
         assert dev_tr.table.emb.is_cuda and torch.get_num_threads() == threads_before      # the library leaves the thread knob alone
+
+
+def test_native_tracker_long_stream_and_timing(gpu):
+    """300 frames of a synthetic stream through the native tracker and the CPU form: identical ids throughout (slots of expired
+    tracklets and backdrops are recycled), and the native frame costs well under the 0.41 ms of round 4's host form"""
+    import time
+    from polyphonicformer_amd import video as V
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+    nat, cpu = V.QuasiDenseEmbedTracker(**cfg), V.QuasiDenseEmbedTracker(**cfg)
+    recs = [r for s_ in range(25) for r in Hh.tracker_records(100 + s_, nframes=12, nobj=40)]
+    dev_recs = [(f, bb.to(gpu), lab.to(gpu), emb.to(gpu)) for f, bb, lab, emb in recs]
+    torch.cuda.synchronize()
+    t_nat = 0.0
+    for cnt, ((f, bb, lab, emb), (_, dbb, dlab, demb)) in enumerate(zip(recs, dev_recs), 1):
+        if bb.shape[0] == 0:
+            continue
+        t0 = time.perf_counter()
+        n = nat.match(bboxes=dbb, labels=dlab, track_feats=demb, frame_id=cnt)
+        t_nat += time.perf_counter() - t0
+        c = cpu.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
+        assert torch.equal(n[2], c[2]) and torch.equal(n[0], c[0]), cnt
+    per = t_nat / len(recs) * 1e3
+    print(f"native tracker: {per:.3f} ms per frame over {len(recs)} frames ({nat.num_tracklets} tracklets born)")
+    assert nat.num_tracklets == cpu.num_tracklets and per < 0.3
 
 
 def test_affinity_beyond_the_fused_kernels_limits(gpu):
