@@ -589,43 +589,70 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
     # PH_VIDEO_EAGER=1 restores the module-API call per frame (same records, same ids)
     runner = None if os.environ.get("PH_VIDEO_EAGER") else V.VideoStreamRunner(pipe, meta[0])
 
-    def one_step(step):
-        nonlocal cnt
-        mine = [step * per_step + f for f in D.shard_frames(per_step, rank, world)]
-        recs, cnts = [], []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if runner is not None:                  # the clip's frames, two sets of heads in flight
-            outs = runner.records([_video_frame(base, f, 6) for f in mine])
+    def frames_of(step):
+        return [step * per_step + f for f in D.shard_frames(per_step, rank, world)]
+
+    def begin(step):
+        if runner is not None:                  # the clip's heads start (HIP graph replays on the slots' streams); no wait
+            runner.records_begin([_video_frame(base, f, 6) for f in frames_of(step)])
+
+    def finish(step):
+        """the records of this rank's frames of `step` (the synchronising half), packed for the all-gather"""
+        mine = frames_of(step)
+        if runner is not None:
+            outs = runner.records_end()
         else:
             outs = [pipe.simple_test(_video_frame(base, f, 6), meta, records_only=True) for f in mine]
+        recs, cnts = [], []
         for seg_ids, rec in outs:
             if rec is None:
                 rec = (torch.zeros(0, 5), torch.zeros(0, dtype=torch.int64), torch.zeros(0, 256, device=dev))
             r, n = D.pack_track_records(*[t.to(cdev) for t in rec])
             recs.append(r)
             cnts.append(n)
-        torch.cuda.synchronize()
+        return mine, recs, cnts
+
+    def gather_and_replay(mine, recs, cnts):
+        nonlocal cnt
         t1 = time.perf_counter()
         allrec = D.allgather_track_records(mine, recs, cnts, clip_frames)
         if cdev.type == "cuda":
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
         t2 = time.perf_counter()
         ids = V.replay_tracking(allrec, tracker=tracker, first_count=cnt)        # embeddings stay where the all-gather left them
         cnt += sum(1 for t in allrec if t[1].shape[0] > 0)
-        t3 = time.perf_counter()
-        return t1 - t0, t2 - t1, t3 - t2, ids
+        return t2 - t1, time.perf_counter() - t2, ids
+
+    def one_step(step):
+        """unpipelined (calibration of the components): heads -> records -> all-gather -> replay, each waited for"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        begin(step)
+        mine, recs, cnts = finish(step)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        b, c, ids = gather_and_replay(mine, recs, cnts)
+        return t1 - t0, b, c, ids
 
     for s_ in range(warmup):
         one_step(s_)
+    # components, one step at a time (what bounds the pipelined loop below)
+    calib = [one_step(warmup + s_) for s_ in range(min(steps, 6))]
+    t_heads, t_coll, t_replay = [c[0] for c in calib], [c[1] for c in calib], [c[2] for c in calib]
     tracker = V.QuasiDenseEmbedTracker(**tcfg)           # a new video for the timed steps (polyphonic_former_video.py:59-61)
     cnt = 1
     dist.barrier()
     torch.cuda.synchronize()
     t_all0 = time.perf_counter()
+    # round 5 (VERDICT r04 weak #2): the step is PIPELINED -- step k + 1's heads are started (asynchronous graph replays) before step
+    # k's records are all-gathered and the tracker replayed, so that a step costs max(heads, all-gather + replay), not their sum
+    first = warmup + len(calib)
+    begin(first)
     for s_ in range(steps):
-        a, b, c, ids = one_step(warmup + s_)
-        t_heads.append(a), t_coll.append(b), t_replay.append(c)
+        mine, recs, cnts = finish(first + s_)
+        if s_ + 1 < steps:
+            begin(first + s_ + 1)
+        _, _, ids = gather_and_replay(mine, recs, cnts)
         if collect_ids:
             ids_log.update({int(k): v.tolist() for k, v in ids.items()})
     torch.cuda.synchronize()
@@ -636,8 +663,18 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
            "clip_frames_per_rank": clip_frames, "world_size": dist.get_world_size(), "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
            "heads_merge_records_ms_per_step": round(D.barrier_and_max(med(t_heads), cdev) * 1e3, 3),
            "allgather_track_records_us_per_step": round(D.barrier_and_max(med(t_coll), cdev) * 1e6, 1),
-           "replay_tracking_ms_per_step": round(D.barrier_and_max(med(t_replay), cdev) * 1e3, 3), "precision": precision,
+           "replay_tracking_ms_per_step": round(D.barrier_and_max(med(t_replay), cdev) * 1e3, 3),
+           "replay_tracking_ms_per_frame": round(D.barrier_and_max(med(t_replay), cdev) * 1e3 / per_step, 4),
+           "step_pipelining": "step k+1's heads are started before step k's all-gather + tracker replay (ms_per_step ~ max of the two)",
+           "precision": precision,
            "frame_loop": "module API, eager launches" if runner is None else "video.VideoStreamRunner: heads replayed from one HIP graph"}
+    # what the measured components project for a node of 8 ranks (the driver's 8-GPU leg, when a node is available): every rank replays
+    # all 8 x clip frames of a step; the step is pipelined, so it costs max(heads of the own clip, all-gather + replay of all frames)
+    h, c_, r_ = out["heads_merge_records_ms_per_step"], out["allgather_track_records_us_per_step"] * 1e-3, out["replay_tracking_ms_per_frame"]
+    w8 = 8 * clip_frames
+    out["projected_world8_frames_per_s"] = round(w8 / max(h, c_ + r_ * w8) * 1e3, 1)
+    out["projected_world8_model"] = (f"8 x {clip_frames} frames / max(heads {h} ms, all-gather {round(c_, 3)} ms + {w8} frames x replay {r_} ms) -- "
+                                     "heads and replay measured on this rank; linear scaling would be 8 x this run's frames_per_s at world 1")
     if collect_ids:
         out["track_ids"] = ids_log
     return out, pipe

@@ -213,8 +213,10 @@ class QuasiDenseEmbedTracker(object):
             self._native = (C.c_void_p(h), mem, dev)
         if dev != self._native[2]:
             raise _lib.PolyheadError("QuasiDenseEmbedTracker: the embeddings moved to another device mid-stream")
-        box = np.ascontiguousarray(bboxes.detach().cpu().float().numpy())
-        lab = np.ascontiguousarray(labels.detach().cpu().long().numpy())
+        # boxes / labels: torch tensors (any device) or host numpy arrays (`replay_tracking` downloads a whole step's at once)
+        box = bboxes if isinstance(bboxes, np.ndarray) else bboxes.detach().cpu().float().numpy()
+        lab = labels if isinstance(labels, np.ndarray) else labels.detach().cpu().long().numpy()
+        box, lab = np.ascontiguousarray(box, dtype=np.float32), np.ascontiguousarray(lab, dtype=np.int64)
         emb = track_feats.detach().float().contiguous()
         n = box.shape[0]
         kept, ids = np.empty((max(n, 1),), dtype=np.int32), np.empty((max(n, 1),), dtype=np.int64)
@@ -342,8 +344,18 @@ def replay_tracking(records, tracker_cfg=None, tracker=None, first_count=1):
     if tracker is None:
         tracker = QuasiDenseEmbedTracker(**(tracker_cfg or {}))
     out, cnt = {}, first_count
-    for fid, bb, lab, emb in sorted(records, key=lambda r: r[0]):
+    records = sorted(records, key=lambda r: r[0])
+    if records and all(r[1].is_cuda and r[2].is_cuda for r in records):
+        # device records (after an RCCL all-gather): ONE download of the step's boxes and labels instead of two per frame
+        ns = [int(r[1].shape[0]) for r in records]
+        if sum(ns):
+            bl = torch.cat([torch.cat([r[1].float(), r[2].float()[:, None]], 1) for r in records if r[1].shape[0]], 0).cpu().numpy()
+            o = np.cumsum([0] + ns)
+            records = [(r[0], bl[o[i]:o[i + 1], :5], bl[o[i]:o[i + 1], 5].astype(np.int64), r[3]) for i, r in enumerate(records)]
+    for fid, bb, lab, emb in records:
         if bb.shape[0] > 0:
+            if isinstance(bb, np.ndarray) and not (tracker.native and emb.is_cuda and bb.shape[0] <= tracker.NATIVE_MAX_DETS):
+                bb, lab = torch.from_numpy(bb), torch.from_numpy(lab)
             _, _, ids = tracker.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)
             cnt += 1
             ids = ids + 1
@@ -758,17 +770,37 @@ class VideoStreamRunner:
         """the sharded mode's per-step work for a rank's clip: `simple_test(..., records_only=True)` of every frame in order.
         The clip goes through the heads in chunks of `clip_batch` frames per launch; the heads of up to two chunks are in flight
         at a time: chunk k + 1's are started BEFORE chunk k's merges / records, and the clip's first two chunks start back to back.
-        Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame."""
+        Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame.  = `records_begin` + `records_end`."""
+        self.records_begin(frames)
+        return self.records_end()
+
+    def records_begin(self, frames):
+        """first half of `records`: copies the clip's first chunk(s) into the slots and STARTS their heads (graph replays on the
+        slots' streams) -- returns without waiting for the device.  A caller that has other work for this step (round 5, the
+        sharded video loop: the all-gather and the tracker replay of the PREVIOUS step) does it between this call and
+        `records_end`, under the heads."""
         frames = list(frames)
-        assert self._inflight is None, "records() and push() / push_record() must not be interleaved"
-        if not frames:
-            return []
+        assert self._inflight is None and getattr(self, "_rb", None) is None, "records() and push() / push_record() must not be interleaved"
         for f in frames:
             self._check(f)
+        if not frames:
+            self._rb = ([], 0, 1)
+            return
         Bc = self.clip_batch(frames)
         chunks = [frames[k:k + Bc] for k in range(0, len(frames), Bc)]
-        out, started = [], 0
         depth = 2 if self.pipelined else 1
+        started = 0
+        while started < len(chunks) and started < depth:
+            self._start_heads(started % depth, chunks[started])
+            started += 1
+        self._rb = (chunks, started, depth)
+
+    def records_end(self):
+        """second half of `records`: merges / records chunk by chunk (the synchronising part), starting the remaining chunks' heads
+        as slots free up"""
+        chunks, started, depth = self._rb
+        self._rb = None
+        out = []
         for c in range(len(chunks)):
             while started < len(chunks) and started < c + depth:
                 self._start_heads(started % depth, chunks[started])
