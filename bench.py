@@ -175,7 +175,7 @@ def algorithmic_bytes(plan, kernel):
     if kernel == "ingest":
         return p.B * 256 * p.HW * 4 + feat
     if kernel == "binarize":
-        return p.B * p.N * p.HW * 4 + bits
+        return p.B * p.N * p.HW * p.m0.element_size() + bits
     return None
 
 
@@ -207,6 +207,8 @@ def mode_leg(wl, mode, dev, B, parts, fp32_inputs=False, steps=10):
     fdt = MODES[mode].feat_dtype
     if fdt is not None and not fp32_inputs:
         gin[0], gin[1] = gin[0].to(fdt), gin[1].to(fdt)
+        if out_dtype != torch.float32:
+            gin[4] = gin[4].to(out_dtype)            # 16-bit mask logits with 16-bit features (see main)
     runner.set_inputs(*gin)
     runner.capture()
     t = time_op(runner.replay, steps, warm=4)
@@ -1085,6 +1087,9 @@ def main():
     ap.add_argument("--input-dtype", default="auto", choices=["auto", "fp32", "bf16", "fp16"],
                     help="dtype of the x_feats / depth_feats inputs resident in HBM; auto = the precision's own "
                          "(bf16 NCHW tensors are the kernels' plane format, fp32 ones go through the ingest kernel)")
+    ap.add_argument("--mask-logits", default="auto", choices=["auto", "fp32"],
+                    help="dtype of the initial mask logits resident in HBM: auto = the mode's 16-bit logit format when the features are "
+                         "16-bit (what a KernelHead at that grade hands over; SURVEY 8d counts them at e_f = 2), fp32 = round 4's tensor")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4, 6, 8],
                     help="n > 1: n part-batches on n skewed HIP streams, one HIP graph (engine.DualDecodePlan)")
@@ -1152,6 +1157,11 @@ def main():
     if in_dt in ("bf16", "fp16"):
         tdt = torch.bfloat16 if in_dt == "bf16" else torch.float16
         gin[0], gin[1] = gin[0].to(tdt), gin[1].to(tdt)
+        # round 5: the initial mask logits arrive 16-bit too -- cfg2 is the bf16 configuration, SURVEY 8d's algorithmic bytes count
+        # them as N * HW * e_f with e_f = 2, and they are what KernelHead hands over at this grade (its `logit_dtype`); in the
+        # logits' own 16-bit format (the mode's output dtype).  --mask-logits fp32 restores round 4's fp32 tensor
+        if args.mask_logits == "auto" and out_dtype != torch.float32:
+            gin[4] = gin[4].to(out_dtype)
     plan.set_inputs(*gin)
     runner = plan
     if args.streams > 1:
@@ -1232,7 +1242,7 @@ def main():
                                    f"{wl['H'] * 8}x{wl['W'] * 8}, stride-8 {wl['H']}x{wl['W']}, N={N}, S={wl['S']}, "
                                    f"L={wl['n_thing'] + wl['n_stuff']}, random-init weights",
                        "frames_per_step_per_gpu": B, "hip_graph": not args.no_graph, "streams": args.streams,
-                       "feature_input_dtype": in_dt, "mask_logit_input_dtype": "fp32", "output_dtype": str(out_dtype),
+                       "feature_input_dtype": in_dt, "mask_logit_input_dtype": str(gin[4].dtype).replace("torch.", ""), "output_dtype": str(out_dtype),
                        "parity_inputs": {"bf16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads); 6.6e-3 per stage: outside the 1e-3 contract",
                                          "mixed": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 1.2e-5 per stage",
                                          "mixed16": "bf16-rounded features on both sides (oracle fed the bf16 tensors the device reads): 5.3e-4-6.6e-4 per stage; "

@@ -591,6 +591,7 @@ void ph_tracker_destroy(ph_tracker* t);
 void ph_tracker_reset(ph_tracker* t);
 int64_t ph_tracker_num_tracklets(const ph_tracker* t);
 int ph_tracker_rows(const ph_tracker* t);
+void ph_tracker_debug_times(const ph_tracker* t, double* out6);   /* accumulated host seconds per phase of `match` (csrc/ph_tracker.hip) */
 int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t* labels, const float* embeds_dev, int n, int64_t frame_id,
                      int32_t* kept_out, int64_t* ids_out, void* stream);
 

@@ -59,51 +59,59 @@ template <int E> __device__ __forceinline__ float ld_as_f32(const uint16_t* p) {
 // ---------------------------------------------------------------------------------------------
 // binarize: logits [B][N][HW] -> bits [B][Npad][HWp/32].  One wave produces two words per step
 // with __ballot (lane = pixel).  Rows >= N and pixels >= HW come out 0.
-template <typename T>
+template <typename T, int E = PH_E_F16>
 __global__ __launch_bounds__(256) void k_binarize(const T* __restrict__ logits, int64_t lbs, uint32_t* __restrict__ bits,
                                                   int B, int N, int Npad, int64_t HW, int64_t HWp, const unsigned* run_if) {
     if (run_if && *run_if == 0) return;
-    // one row (b, n) per blockIdx.y; each lane tests 4 consecutive pixels (16-byte load); a wave covers
-    // 256 px = 8 words; the 8 lanes of a word OR their nibbles together with three xor-shuffles
+    // one row (b, n) per blockIdx.y; each lane tests V consecutive pixels of ONE 16-byte load (V = 4 fp32 / 8 sixteen-bit values); a
+    // wave covers 64 V pixels = 2 V words; the 32 / V lanes of a word OR their V-bit pieces together with xor-shuffles
+    constexpr int V = 16 / (int)sizeof(T), LPW = 32 / V;              // pixels per lane, lanes per word
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.y; row < B * Npad; row += gridDim.y) {
     const int b = row / Npad, n = row - b * Npad;
     const bool live = n < N;
     const T* src = logits + (int64_t)b * lbs + (int64_t)n * HW;
     uint32_t* dst = bits + (int64_t)row * (HWp / 32);
-    const bool vec_ok = (HW & 3) == 0;
-    for (int c = blockIdx.x * 4 + wave; (int64_t)c * 256 < HWp; c += gridDim.x * 4) {
-        const int64_t px = (int64_t)c * 256 + lane * 4;
-        float v[4] = {-1.f, -1.f, -1.f, -1.f};
+    const bool vec_ok = (HW % V) == 0 && (((uintptr_t)src) & 15) == 0;
+    for (int c = blockIdx.x * 4 + wave; (int64_t)c * (64 * V) < HWp; c += gridDim.x * 4) {
+        const int64_t px = (int64_t)c * (64 * V) + lane * V;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = -1.f;
         if (live && px < HW) {
-            if (vec_ok && px + 4 <= HW) {
+            if (vec_ok && px + V <= HW) {
+                const uint4 q = ld_nt16(src + px);
                 if constexpr (sizeof(T) == 4) {
-                    const uint4 q = ld_nt16(src + px);
                     v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
                 } else {
-                    const uint2 q = ld_nt8(src + px);
-                    v[0] = h2f(q.x & 0xFFFFu); v[1] = h2f(q.x >> 16); v[2] = h2f(q.y & 0xFFFFu); v[3] = h2f(q.y >> 16);
+                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] = e2f<E>(w[e] & 0xFFFFu); v[2 * e + 1] = e2f<E>(w[e] >> 16); }
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (px + e < HW) v[e] = ld_as_f32<PH_E_F16>(src + px + e);
+                for (int e = 0; e < V; ++e) if (px + e < HW) v[e] = ld_as_f32<E>(src + px + e);
             }
         }
-        const uint32_t nib = (v[0] > PH_BIN_THR ? 1u : 0u) | (v[1] > PH_BIN_THR ? 2u : 0u) | (v[2] > PH_BIN_THR ? 4u : 0u) | (v[3] > PH_BIN_THR ? 8u : 0u);
-        uint32_t word = nib << (4 * (lane & 7));
+        uint32_t piece = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) piece |= (v[e] > PH_BIN_THR ? 1u : 0u) << e;
+        uint32_t word = piece << (V * (lane & (LPW - 1)));
         word |= __shfl_xor(word, 1);
         word |= __shfl_xor(word, 2);
-        word |= __shfl_xor(word, 4);
-        if ((lane & 7) == 0 && (int64_t)c * 256 + (lane >> 3) * 32 < HWp) dst[c * 8 + (lane >> 3)] = word;
+        if (LPW == 8) word |= __shfl_xor(word, 4);
+        const int wi = lane / LPW;                                    // word of this wave's 2 V
+        if ((lane & (LPW - 1)) == 0 && (int64_t)c * (64 * V) + wi * 32 < HWp) dst[c * (2 * V) + wi] = word;
     }
     }
 }
 
-// logits fp32 (PH_OUT_F32) or fp16 (PH_OUT_F16); run_if: optional device predicate (the launch returns at once when *run_if == 0)
+// logits fp32 (PH_OUT_F32), fp16 (PH_OUT_F16) or bf16 (PH_OUT_BF16: round 5 -- 16-bit mask logits are what a 16-bit KernelHead grade hands
+// over and what cfg2's bf16 / SURVEY 8d's N * HW * e_f "initial mask logits read" mean); run_if: optional device predicate (the launch returns at once when *run_if == 0)
 extern "C" int ph_binarize_if(const void* logits, int dtype, int64_t logits_batch_stride, uint32_t* bits, int B, int N, int64_t HW,
                               const uint32_t* run_if, void* stream) {
     PH_CHECK_ARG(logits && bits && B > 0 && N > 0 && HW > 0, "bad pointer or size");
-    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_F16, "dtype must be PH_OUT_F32 or PH_OUT_F16");
+    PH_CHECK_ARG(dtype == PH_OUT_F32 || dtype == PH_OUT_F16 || dtype == PH_OUT_BF16, "dtype must be PH_OUT_F32, PH_OUT_F16 or PH_OUT_BF16");
     PH_CHECK_ARG(logits_batch_stride == 0 || logits_batch_stride >= (int64_t)N * HW, "batch stride smaller than a frame");
     if (!logits_batch_stride) logits_batch_stride = (int64_t)N * HW;
     const int Npad = ph_n_padded(N);
@@ -118,8 +126,11 @@ extern "C" int ph_binarize_if(const void* logits, int dtype, int64_t logits_batc
     if (dtype == PH_OUT_F32)
         hipLaunchKernelGGL(k_binarize<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
                            logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
+    else if (dtype == PH_OUT_F16)
+        hipLaunchKernelGGL((k_binarize<uint16_t, PH_E_F16>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
+                           logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
     else
-        hipLaunchKernelGGL(k_binarize<uint16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
+        hipLaunchKernelGGL((k_binarize<uint16_t, PH_E_BF16>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits,
                            logits_batch_stride, bits, B, N, Npad, HW, HWp, (const unsigned*)run_if);
     PH_CHECK_LAUNCH();
     return PH_OK;

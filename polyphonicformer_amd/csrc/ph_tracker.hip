@@ -13,6 +13,7 @@
 //     -> the greedy walk in C++ -> one small upload -> one update launch (EMA / copy into pool slots).
 // fp32 operations are written one per statement (no contraction) in the order the reference's tensor expressions evaluate them.
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "ph_common.h"
@@ -50,6 +51,7 @@ struct ph_tracker {
     void* d_ws;
     size_t ws_bytes;
     int max_n, max_m;
+    double tacc[6];                  // seconds spent in the phases of `match` (ph_tracker_debug_times)
     hipEvent_t uploaded;             // the last upload from the pinned table has left the host buffer
     bool pending;
 };
@@ -127,6 +129,7 @@ extern "C" ph_tracker* ph_tracker_create(const ph_tracker_cfg* cfg, void* device
         return nullptr;
     }
     t->pending = false;
+    for (double& v : t->tacc) v = 0;
     t->num_tracklets = 0;
     for (int s = capacity - 1; s >= 0; --s) t->free_slots.push_back(s);
     return t;
@@ -148,6 +151,12 @@ extern "C" void ph_tracker_reset(ph_tracker* t) {
     t->num_tracklets = 0;
 }
 
+// accumulated host seconds per phase: [0] wait for the previous frame's upload, [1] sort + de-duplication + tables, [2] launches up to
+// the score download, [3] the synchronising wait, [4] greedy walk + bookkeeping, [5] update launch
+extern "C" void ph_tracker_debug_times(const ph_tracker* t, double* out6) {
+    if (t && out6) for (int i = 0; i < 6; ++i) out6[i] = t->tacc[i];
+}
+
 extern "C" int64_t ph_tracker_num_tracklets(const ph_tracker* t) { return t ? t->num_tracklets : -1; }
 extern "C" int ph_tracker_rows(const ph_tracker* t) { return t ? (int)t->ids.size() : -1; }
 
@@ -160,7 +169,12 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     PH_CHECK_ARG(n <= t->max_n, "more detections than the tracker was created for");
     hipStream_t s = (hipStream_t)stream;
     const ph_tracker_cfg& c = t->c;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto t0 = now();
     if (t->pending) { (void)hipEventSynchronize(t->uploaded); t->pending = false; }      // the previous frame's last upload (long done)
+    auto t1 = now();
+    t->tacc[0] += secs(t0, t1);
     // ---- descending score (stable: ascending index among equal scores, torch's CPU order), de-duplication (:147-155)
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -189,6 +203,9 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     for (int i = 0; i < k; ++i) { tab[i] = kept[i]; tab[k + i] = (int32_t)labels[kept[i]]; }
     for (int j = 0; j < m; ++j) { tab[2 * k + j] = memo_slot[j]; tab[2 * k + m + j] = (int32_t)memo_lab[j]; }
     const bool need_aff = k > 0 && !table_empty && m > 0;
+    auto t2 = now();
+    t->tacc[1] += secs(t1, t2);
+    auto t3 = t2, t4 = t2;
     if (k > 0) {
         if (hipMemcpyAsync(t->d_tab, tab, (size_t)(2 * k + 2 * m) * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
             ph_set_error("ph_tracker_match: table upload failed");
@@ -201,11 +218,18 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
         const int rc = ph_track_affinity(t->d_det, t->d_tab + k, t->d_memo, t->d_tab + 2 * k + m, k, m, c.metric, c.with_cats, t->d_score, t->d_ws,
                                          t->ws_bytes, stream);
         if (rc != PH_OK) return rc;
-        if (hipMemcpyAsync(t->h_score, t->d_score, (size_t)k * m * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
+        if (hipMemcpyAsync(t->h_score, t->d_score, (size_t)k * m * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) {
             ph_set_error("ph_tracker_match: score download failed");
             return PH_ELAUNCH;
         }
+        t3 = now();
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            ph_set_error("ph_tracker_match: score download failed");
+            return PH_ELAUNCH;
+        }
+        t4 = now();
+        t->tacc[2] += secs(t2, t3);
+        t->tacc[3] += secs(t3, t4);
         // ---- greedy, in detection (score) order: best still-free column (:183-197)
         std::vector<char> taken(m, 0);
         for (int i = 0; i < k; ++i) {
@@ -267,6 +291,8 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
             }
         }
     }
+    auto t5 = now();
+    t->tacc[4] += secs(t4, t5);
     if (k > 0) {
         if (hipMemcpyAsync(t->d_tab + act_off, act, (size_t)2 * k * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
             ph_set_error("ph_tracker_match: action upload failed");
@@ -296,6 +322,7 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     }
     t->ids.resize(w); t->lab.resize(w); t->seen.resize(w); t->slot.resize(w); t->box.resize(w * 5);
     for (int i = 0; i < k; ++i) { kept_out[i] = kept[i]; ids_out[i] = ids[i]; }
+    t->tacc[5] += secs(t5, now());
     PH_CHECK_LAUNCH();
     return k;
 }

@@ -112,14 +112,14 @@ def ingest(x, prec, out=None):
 
 
 def binarize(m, out=None):
-    """fp32 mask logits [B,N,H,W] -> mask bits int32 [B,Npad,HWp/32]"""
+    """mask logits [B,N,H,W] (fp32, or fp16 / bf16 as a 16-bit KernelHead grade hands them over) -> mask bits int32 [B,Npad,HWp/32]"""
     _require_gpu(m, "mask_preds")
     B, N, H, W = m.shape
-    m = m.contiguous().float()
+    m = m.contiguous() if m.dtype in OUT_CODE else m.contiguous().float()
     if out is None:
         out = torch.empty((B, n_padded(N), hw_padded(H * W) // 32), dtype=torch.int32, device=m.device)
     lib = _lib.load()
-    _lib.check(lib.ph_binarize(_lib.ptr(m), 0, _lib.ptr(out), B, N, H * W, _lib.stream_ptr()), "ph_binarize")
+    _lib.check(lib.ph_binarize_if(_lib.ptr(m), OUT_CODE[m.dtype], 0, _lib.ptr(out), B, N, H * W, None, _lib.stream_ptr()), "ph_binarize")
     return out
 
 
@@ -302,6 +302,12 @@ class DecodePlan:
             self.dfe.copy_(dfe)
         self.k0.copy_(k0.reshape(self.B, self.N, 256))
         self.q0.copy_(q0.reshape(self.B, self.N, 256))   # materialises the stride-0 expand view
+        if m0.dtype in OUT_CODE and self.m0.dtype != m0.dtype:
+            # mask logits are binarised from the format they arrive in (16-bit: what a 16-bit KernelHead grade hands over and what
+            # cfg2's bf16 inputs mean -- half the bytes; never a rounding of fp32 logits).  A captured graph holds the old buffer:
+            # it is dropped, the owner captures again
+            self.m0 = torch.empty_like(self.m0, dtype=m0.dtype)
+            self.graph = None
         self.m0.copy_(m0)
 
     def ingest(self):
@@ -798,9 +804,12 @@ class DualDecodePlan:
 
     def set_inputs(self, x, dfe, k0, q0, m0):
         o = 0
+        before = [p.m0.dtype for p in self.halves]
         for p, n in zip(self.halves, self.sizes):
             p.set_inputs(x[o:o + n], dfe[o:o + n], k0[o:o + n], q0[o:o + n], m0[o:o + n])
             o += n
+        if before != [p.m0.dtype for p in self.halves]:
+            self.graph = None            # the parts re-allocated their mask-logit buffers: the captured graph is stale (capture again)
 
     def _issue(self, *streams):
         cur = torch.cuda.current_stream()

@@ -89,6 +89,19 @@ def test_binarize(gpu, N, H, W):
     assert full[:, N:].sum() == 0 and full[:, :, H * W:].sum() == 0
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W", [(111, 8, 16), (40, 6, 13), (153, 16, 32)])
+def test_binarize_16bit_logits(gpu, dt, N, H, W):
+    """round 5: mask logits that arrive 16-bit (a 16-bit KernelHead grade's hand-over, cfg2's bf16 inputs) are binarised from their
+    own format -- exactly `sigmoid(m.float()) > 0.5` of the 16-bit values, ragged sizes (scalar path) included"""
+    m = torch.randn(2, N, H, W, generator=torch.Generator().manual_seed(4)).to(dt)
+    m[0, 0, 0, :6] = torch.tensor([0.0, -0.0, 6e-8, -6e-8, 2.0 ** -14, -2.0 ** -14]).to(dt)
+    bits = E.binarize(m.to(gpu))
+    got = unpack_bits(bits, N, H * W)
+    assert torch.equal(got, (m.float().sigmoid() > 0.5).float().reshape(2, N, -1))
+    assert torch.equal(got, unpack_bits(E.binarize(m.float().to(gpu)), N, H * W))      # = the fp32 kernel on the same values
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("N,H,W,nsplit", [(111, 8, 16, 1), (153, 16, 32, 3), (40, 6, 13, 1), (253, 8, 48, 2)])
 def test_pool(gpu, prec, N, H, W, nsplit):
