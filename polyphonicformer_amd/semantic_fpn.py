@@ -55,7 +55,7 @@ def sine_positional_encoding(H, W, num_feats, temperature=10000, scale=2 * math.
 
 
 class SemanticFPNWrapper(nn.Module):
-    # round 5: under autograd (grad mode on and a parameter or an input that requires grad) `forward` runs the differentiable
+    # round 5: in training mode under autograd (`.train()`, grad mode on, a parameter or an input that requires grad) `forward` runs the differentiable
     # fp32 form (`train.neck_forward_train`: 3x3 conv / GroupNorm + ReLU / upsample nodes with hand-written backward), so
     # KernelHead.forward_train trains the neck -- and through its input gradients the FPN and the backbone -- as the reference does
     # (polyphonic_former.py:97-110).  Without autograd: the inference kernels on packed 16-bit weights, as before.
@@ -144,7 +144,7 @@ class SemanticFPNWrapper(nn.Module):
     def forward(self, inputs, _planes=False):
         x0 = inputs[0]
         E._require_gpu(x0, "inputs[0]")
-        if not _planes and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+        if not _planes and self.training and torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                                         any(torch.is_tensor(t) and t.requires_grad for t in inputs[:4])):
             from . import train as T
             outs = T.neck_forward_train(self, inputs)

@@ -520,8 +520,25 @@ class VideoFramePipeline:
                                          aspp_semantic=semantic_aspp_out, rescale=rescale)
 
     def simple_test(self, x, img_metas, rescale=False, records_only=False):
+        """round 5: the heads of this per-frame call replay ONE HIP graph (a one-slot `VideoStreamRunner` kept per frame geometry,
+        captured on first use from the same module calls) -- same kernels, same results, returned immediately as before; the ~70
+        launches of neck -> KernelHead -> decode cost the host one graph launch instead of 2.5 ms.  Weights are re-captured when
+        their versions change.  PH_VIDEO_API_EAGER=1: the eager launches of rounds 1-4."""
         if x[0].shape[0] != 1:
             raise NotImplementedError("video inference is one frame at a time (samples_per_gpu = 1, as in the reference)")
+        import os
+        if not records_only and x[0].is_cuda and not os.environ.get("PH_VIDEO_API_EAGER"):
+            m = img_metas[0]
+            key = (tuple(m["img_shape"]), tuple(m["ori_shape"]), tuple(m["batch_input_shape"]), tuple(tuple(t.shape) for t in x), x[0].dtype)
+            runners = self.__dict__.setdefault("_api_runners", {})
+            r = runners.get(key)
+            if r is None:
+                runners.clear()                      # one geometry at a time: a runner owns GBs of plan buffers
+                r = runners[key] = VideoStreamRunner(self, dict(m), graph=True, pipelined=False)
+            r._check_weights()
+            r._start_heads(0, [x])
+            r._finish(0)
+            return r._collect(r._downloads.pop(0))
         _, _, (panoptic_seg, segments_info), _, depth_final = self.heads(x, img_metas, rescale)[0]
         return self.assoc.step(x, panoptic_seg, segments_info, depth_final, records_only=records_only)
 
@@ -552,7 +569,8 @@ class VideoStreamRunner:
 
     `push(x)` therefore returns the result of frame t - 2 (None for the first two frames); `flush()` returns the list of the
     results still in flight, oldest first.  `pipelined=False`: one slot, results one frame late (round 4's first form).
-    Weights are packed at capture time: call `reset()` after changing them."""
+    Weights are packed at capture time; every push compares the parameters' version counters with the capture-time ones and
+    captures again (all slots) when they changed (`_check_weights`, round 5)."""
 
     def __init__(self, pipe, img_meta, graph=True, pipelined=True, device_select=None):
         import os
@@ -568,6 +586,26 @@ class VideoStreamRunner:
         self._inflight = None            # frame whose heads are running: (slot index)
         self._downloads = []             # [(event, host tensors, device sources)] oldest first
         self._n = 0
+        self._versions = None
+
+    def _weight_versions(self):
+        from . import _lib
+        return _lib.param_versions(self.pipe.rpn_head) + _lib.param_versions(self.pipe.roi_head)
+
+    def _check_weights(self):
+        """the graphs replay weight PACKS made at capture time and the second slot is a deep copy of the head
+        modules -- after load_state_dict / an optimizer step / a replaced sub-module they would silently keep the old weights.
+        The parameters' version counters are compared with the capture-time ones; on a change the frame in flight is finished
+        (with the weights it started with), the slots are dropped and the next frame captures again from the current modules."""
+        v = self._weight_versions()
+        if self._versions is None:
+            self._versions = v
+        elif v != self._versions:
+            if self._inflight is not None:
+                self._finish(self._inflight)
+                self._inflight = None
+            self._slots = []
+            self._versions = v
 
     # -- slots ---------------------------------------------------------------------------------------------------
     def _slot(self, i):
@@ -715,6 +753,7 @@ class VideoStreamRunner:
         """x: the four FPN levels of ONE frame (device tensors).  Returns the result list [{"sem", "track", "depth"}] (numpy,
         owned by the caller) of the frame pushed two calls ago (one call ago with pipelined=False), or None."""
         self._check(x)
+        self._check_weights()
         if not self.pipelined:
             self._start_heads(0, [x])
             self._finish(0)
@@ -783,6 +822,7 @@ class VideoStreamRunner:
         assert self._inflight is None and getattr(self, "_rb", None) is None, "records() and push() / push_record() must not be interleaved"
         for f in frames:
             self._check(f)
+        self._check_weights()
         if not frames:
             self._rb = ([], 0, 1)
             return

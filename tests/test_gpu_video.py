@@ -343,7 +343,7 @@ def test_affinity_beyond_the_fused_kernels_limits(gpu):
 
 
 @pytest.mark.parametrize("graph,pipelined,device_select", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
-def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined, device_select):
+def test_stream_runner_equals_the_module_api_loop(gpu, monkeypatch, graph, pipelined, device_select):
     """video.VideoStreamRunner (round 4: heads from one HIP graph per slot, two slots so that frame t's heads run under frame
     t - 1's merge / association, id map kept on the device, result maps downloaded on a side stream) against
     `VideoFramePipeline.simple_test` frame by frame on a 5-frame clip at cfg3's full size: semantic, track-id and depth maps
@@ -356,7 +356,15 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined, device_
     frames = [tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base) for f in range(5)]
     meta = [Hh.img_meta(H8, W8)]
     pipe.init_tracker()
+    monkeypatch.setenv("PH_VIDEO_API_EAGER", "1")       # the reference loop: the module API with eager launches (rounds 1-4's form)
     want = [pipe.simple_test(x, meta)[0] for x in frames]
+    monkeypatch.delenv("PH_VIDEO_API_EAGER")
+    pipe.init_tracker()
+    api = [pipe.simple_test(x, meta)[0] for x in frames]            # round 5: the module API itself replays a one-slot graph
+    assert "_api_runners" in pipe.__dict__ and len(pipe._api_runners) == 1
+    for a, b in zip(api, want):
+        for k in ("sem", "track", "depth"):
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), ("module API, graph vs eager", k)
     pipe.init_tracker()
     runner = V.VideoStreamRunner(pipe, meta[0], graph=graph, pipelined=pipelined, device_select=device_select)
     got = []
@@ -385,6 +393,53 @@ def test_stream_runner_equals_the_module_api_loop(gpu, graph, pipelined, device_
         assert ids_a == ids_b and (rec_a is None) == (rec_b is None)
         if rec_a is not None:
             assert torch.equal(rec_a[0], rec_b[0]) and torch.equal(rec_a[1], rec_b[1]) and torch.equal(rec_a[2], rec_b[2])
+
+
+def test_video_graphs_follow_weight_changes(gpu, monkeypatch):
+    """new weights in the middle of a stream (load_state_dict after the graphs were captured) -- the runner
+    (two slots: the second one a deep copy of the heads) and the module API's internal graph both capture again, and the results
+    equal the eager module-API loop's that gets the same weights at the same frame"""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu)
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(35)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    frames = [tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base) for f in range(6)]
+    meta = [Hh.img_meta(H8, W8)]
+    sd0 = {k: v.detach().clone() for k, v in pipe.roi_head.state_dict().items()}
+    sd1 = {k: (v * 1.05 if v.dtype.is_floating_point and "fc_mask" in k else v.clone()) for k, v in sd0.items()}
+
+    def loop(step):
+        pipe.roi_head.load_state_dict(sd0)
+        pipe.init_tracker()
+        out = []
+        for f, x in enumerate(frames):
+            if f == 3:
+                pipe.roi_head.load_state_dict(sd1)
+            out += step(x)
+        return out
+
+    monkeypatch.setenv("PH_VIDEO_API_EAGER", "1")
+    want = loop(lambda x: [pipe.simple_test(x, meta)[0]])
+    monkeypatch.delenv("PH_VIDEO_API_EAGER")
+    api = loop(lambda x: [pipe.simple_test(x, meta)[0]])
+    runner = V.VideoStreamRunner(pipe, meta[0])
+
+    def push(x):
+        r = runner.push(tuple(t.clone() for t in x))
+        return [] if r is None else [r[0]]
+    got = loop(push) + [r[0] for r in runner.flush()]
+    assert len(got) == len(want) == len(api) == 6
+    changed = 0
+    for f, (a, b, c) in enumerate(zip(api, got, want)):
+        for k in ("sem", "track", "depth"):
+            assert np.array_equal(a[k], c[k]), ("module API graph", f, k)
+            assert np.array_equal(b[k], c[k]), ("runner", f, k)
+    pipe.roi_head.load_state_dict(sd0)
+    pipe.init_tracker()
+    monkeypatch.setenv("PH_VIDEO_API_EAGER", "1")
+    old = pipe.simple_test(frames[4], meta)[0]
+    assert not np.array_equal(old["depth"], want[4]["depth"]) or not np.array_equal(old["sem"], want[4]["sem"])     # the new weights do change the result
 
 
 @pytest.mark.parametrize("graph", [True, False])
