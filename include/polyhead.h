@@ -453,6 +453,10 @@ int ph_train_losses(const ph_loss_cfg* cfg, const float* mask_pred, const float*
  * backward: gradients w.r.t. cls, kern, kbias, obj in; writes grads [2][PH_QTRAIN_NPARAM] (HOST array of device pointers, each
  *           the size of its parameter; every one is overwritten, none accumulated), g_pooled [2][R][256], g_k, g_q [R][256].
  *           `scratch`: ph_qtrain_scratch_floats.  Fixed summation orders throughout (no atomics). */
+/* ph_gemm32: one product of the training side's fp32-MFMA tile GEMM on its own (tests, timing): C [M][N] = A(m,k) B(k,n) (+ bias[n]);
+ * kcA / kcB != 0: the operand is k-contiguous (X [row][k] / W [out][in]), else row-contiguous ([k][row]); ksplit > 1: C [ksplit][M][ldc] */
+int ph_gemm32(const float* A, int lda, int kcA, const float* B, int ldb, int kcB, float* C, int ldc, int M, int N, int K, int ksplit,
+              const float* bias, void* stream);
 #define PH_QTRAIN_NPARAM 44
 size_t ph_qtrain_saved_floats(int B, int N, int L, int F);
 size_t ph_qtrain_scratch_floats(int B, int N, int L, int F);

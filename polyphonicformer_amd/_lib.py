@@ -101,6 +101,7 @@ SIGNATURES = {
     "ph_hard_count": (C.c_int, [_P, _P, _L, _L, _P]),
     "ph_train_losses_scratch_bytes": (C.c_size_t, [_P]),
     "ph_train_losses": (C.c_int, [_P] * 24 + [_Z, _P]),
+    "ph_gemm32": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ph_qtrain_saved_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "ph_qtrain_scratch_floats": (C.c_size_t, [_I, _I, _I, _I]),
     "ph_qtrain_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

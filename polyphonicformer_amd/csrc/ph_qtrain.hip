@@ -3,7 +3,7 @@
 // funcs/kernel_updator.py:55-93, mmcv MultiheadAttention / FFN) -- as ONE forward call that keeps what the backward needs and ONE
 // hand-written backward call that returns the gradient of every parameter and input.  The reference runs this under autograd as
 // ~120 ATen / BLAS launches per stage and direction; round 4's training step did the same through torch (hipBLASLt + ATen:
-// 70 % of its GPU time).  Here a stage's query side is 19 launches forward and 21 backward, issued from C.
+// 70 % of its GPU time).  Here a stage's query side is 19 launches forward and 22 backward, issued from C.
 //
 // Rows: R = B * N query rows of C = 256 features (row r = b * N + n), two branches (mask / depth) with separate weights that run
 // side by side in every launch (a launch = a table of independent jobs).
@@ -26,10 +26,11 @@ constexpr float QEPS = 1e-5f;      // LayerNorm eps (torch default, as the refer
 
 // ===================================================================================================================
 // the tile GEMM:  C[m][n] = sum_k A(m,k) B(k,n)  (+ second pair A2 B2) (+ bias[n]) (+ rs_row[m] rs_col[n]) (+ add[m][n])
-// 64 x 64 tile per workgroup of 4 waves (2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), 16 k per step through LDS.
+// 64 x 64 tile per workgroup of 4 waves (2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), 32 k per step through LDS (the loop is bound by
+// the latency of the next step's global loads, not by the fp32 matrix pipe: 16 k per step measured 30 us per launch on average).
 // kcA / kcB: the operand's contiguous axis is k ("k-contiguous": X[row][k], W[out][in]) or the row / column index.
 // ===================================================================================================================
-constexpr int GT = 64, GK = 16, GP = 20;       // tile edge, k per step, LDS pitch in floats (80-byte rows: 16-byte aligned)
+constexpr int GT = 64, GK = 32, GP = 36;       // tile edge, k per step (two 16-k halves), LDS pitch in floats (144-byte rows: 16-byte aligned)
 constexpr int GEMM_MAX_JOBS = 10;
 enum { GF_RELU = 1, GF_ACCUM = 2, GF_COLSUM_ACCUM = 4 };
 
@@ -41,53 +42,47 @@ struct GemmJob {
     int M, N, K, K2;
     int lda, ldb, lda2, ldb2, ldc, ldadd;
     int kcA, kcB, kcA2, kcB2;
-    int vecA, vecB, vecA2, vecB2;
+    int rowsA, KA, KB;           // extents the A / B loads may touch (default M, K, K): an operand padded to a multiple of 4 on its
+                                 // vectorised axis (d cls, L = 19 / 133 classes) is read past M / K, the other one is not
     int ksplit, flags, tiles, nt;
 };
 struct GemmBatch {
     GemmJob j[GEMM_MAX_JOBS];
 };
 
-// one [64 rows][16 k] operand tile: 4 values per thread.  kc: thread (row t >> 2, k (t & 3) * 4 + e); else (k t >> 4, rows (t & 15) * 4 + e)
-__device__ __forceinline__ float4 load_op(const float* __restrict__ P, int ld, int kc, int vec, int row0, int nrows, int k0, int kend, int t) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kc) {
-        const int row = row0 + (t >> 2), k = k0 + (t & 3) * 4;
-        if (row < nrows && k < kend) {
-            const float* src = P + (int64_t)row * ld + k;
-            if (vec && k + 3 < kend) v = *(const float4*)src;
-            else {
-                v.x = src[0];
-                if (k + 1 < kend) v.y = src[1];
-                if (k + 2 < kend) v.z = src[2];
-                if (k + 3 < kend) v.w = src[3];
-            }
-        }
-    } else {
-        const int k = k0 + (t >> 4), row = row0 + (t & 15) * 4;
-        if (k < kend && row < nrows) {
-            const float* src = P + (int64_t)k * ld + row;
-            if (vec && row + 3 < nrows) v = *(const float4*)src;
-            else {
-                v.x = src[0];
-                if (row + 1 < nrows) v.y = src[1];
-                if (row + 2 < nrows) v.z = src[2];
-                if (row + 3 < nrows) v.w = src[3];
-            }
-        }
-    }
-    return v;
+// one [64 rows][16 k] HALF of an operand tile: 4 values per thread.  kc: thread (row t >> 2, k (t & 3) * 4 + e); else (k t >> 4, rows (t & 15) * 4 + e)
+typedef unsigned qt_u4 __attribute__((ext_vector_type(4)));
+
+// One unconditional 16-byte BUFFER load per call: the descriptor's range check returns zeros for a lane whose offset is pushed
+// past the operand's end, so there is no branch and no exec masking around the load (round 5 history: per-element bounds branches
+// with scalar fallbacks compiled to 600 load instructions and 1300 branches, ~4000 cycles per 32-k step; a plain load under
+// `in ? .. : ..` still became an exec-masked branch, and ANY conditional load -- like __syncthreads()'s fence -- makes the
+// compiler's vmcnt bookkeeping fall back to vmcnt(0), which serialises the prefetch ring).  The host guarantees that a float4 is
+// wholly inside or wholly outside the operand: base 16-byte aligned, ld % 4 == 0, the vectorised axis (k when the operand is
+// k-contiguous, else its row index) a multiple of 4 long (Launcher::job checks).
+__device__ __forceinline__ float4 load_op(__amdgpu_buffer_rsrc_t rs, int ld, int kc, int row0, int nrows, int k0, int kend, int t) {
+    const int row = kc ? row0 + (t >> 2) : row0 + (t & 15) * 4;
+    const int k = kc ? k0 + (t & 3) * 4 : k0 + (t >> 4);
+    const bool in = row < nrows && k < kend;
+    const unsigned off = in ? 4u * (unsigned)(kc ? row * ld + k : k * ld + row) : 0x7FFFFFF0u;
+    const qt_u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    return make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t op_rsrc(const float* P, int ld, int kc, int nrows, int kend) {
+    // bytes the operand spans (0 for an absent second pair: every load returns zeros)
+    const long n = !P || nrows <= 0 || kend <= 0 ? 0 : (kc ? (long)(nrows - 1) * ld + kend : (long)(kend - 1) * ld + nrows) * 4;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, (int)n, 0x00020000);
 }
 
-__device__ __forceinline__ void stash_op(float* S, int kc, int t, float4 v) {
-    if (kc) *(float4*)&S[(t >> 2) * GP + (t & 3) * 4] = v;
-    else {
-        const int r = (t & 15) * 4, k = t >> 4;
-        S[(r + 0) * GP + k] = v.x;
-        S[(r + 1) * GP + k] = v.y;
-        S[(r + 2) * GP + k] = v.z;
-        S[(r + 3) * GP + k] = v.w;
-    }
+// branch-free for both layouts: element e of the thread's run goes to (row + e (1 - kc), k + e kc)
+__device__ __forceinline__ void stash_op(float* S, int kc, int t, float4 v, int half) {
+    const int r = kc ? (t >> 2) : (t & 15) * 4, k = half * 16 + (kc ? (t & 3) * 4 : (t >> 4));
+    const int step = kc ? 1 : GP;
+    float* d = S + r * GP + k;
+    d[0] = v.x;
+    d[step] = v.y;
+    d[2 * step] = v.z;
+    d[3 * step] = v.w;
 }
 
 __global__ __launch_bounds__(256) void k_gemm32(const GemmBatch gb) {
@@ -116,45 +111,82 @@ __global__ __launch_bounds__(256) void k_gemm32(const GemmBatch gb) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float4 ra, rb;
-    int rkcA = 1, rkcB = 1;
-    auto fetch = [&](int s) {
-        if (s < steps1) {
-            rkcA = J.kcA; rkcB = J.kcB;
-            ra = load_op(J.A, J.lda, J.kcA, J.vecA, m0, J.M, s * GK, J.K, t);
-            rb = load_op(J.B, J.ldb, J.kcB, J.vecB, n0, J.N, s * GK, J.K, t);
-            if (want_cs) {
-                if (J.kcA) cs[0] += (ra.x + ra.y) + (ra.z + ra.w);
-                else { cs[0] += ra.x; cs[1] += ra.y; cs[2] += ra.z; cs[3] += ra.w; }
-            }
-        } else {
-            rkcA = J.kcA2; rkcB = J.kcB2;
-            ra = load_op(J.A2, J.lda2, J.kcA2, J.vecA2, m0, J.M, (s - steps1) * GK, J.K2, t);
-            rb = load_op(J.B2, J.ldb2, J.kcB2, J.vecB2, n0, J.N, (s - steps1) * GK, J.K2, t);
+    // The loop is bound by the LATENCY of the operand loads (every launch measured ~24 us whatever its size: 8 steps x ~2.5 us with
+    // one step of prefetch), so the loads run PD steps ahead of the MFMAs through a register ring.
+    constexpr int PD = 4;
+    float4 ra[PD][2], rb[PD][2];
+    const float csw = want_cs ? 1.f : 0.f;
+    auto fetch = [&](int s, int d) {
+        const bool dead = s >= send;                       // a padding step: every lane out of range
+        const bool one = dead || s < steps1;               // uniform: first or second operand pair -- selected, not branched on
+        const int la = one ? J.lda : J.lda2, lb = one ? J.ldb : J.ldb2, kca = one ? J.kcA : J.kcA2, kcb = one ? J.kcB : J.kcB2;
+        const int kea = one ? J.KA : J.K2, keb = one ? J.KB : J.K2, kb = dead ? (1 << 28) : (one ? s : s - steps1) * GK;
+        const int ra_rows = one ? J.rowsA : J.M;
+        const float w = one && !dead ? csw : 0.f;
+        // descriptors from SELECTED scalars (a branch between two loads would make them conditional)
+        const __amdgpu_buffer_rsrc_t rsA = op_rsrc(one ? J.A : J.A2, la, kca, ra_rows, kea), rsB = op_rsrc(one ? J.B : J.B2, lb, kcb, J.N, keb);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            ra[d][hf] = load_op(rsA, la, kca, m0, ra_rows, kb + hf * 16, kea, t);
+            rb[d][hf] = load_op(rsB, lb, kcb, n0, J.N, kb + hf * 16, keb, t);
+            // column sums of the first pair's A (selects, no branch): k-contiguous -> one row per thread, else four rows
+            const float4 q = ra[d][hf];
+            cs[0] += w * (kca ? (q.x + q.y) + (q.z + q.w) : q.x);
+            cs[1] += w * (kca ? 0.f : q.y);
+            cs[2] += w * (kca ? 0.f : q.z);
+            cs[3] += w * (kca ? 0.f : q.w);
         }
     };
-    if (sbeg < send) fetch(sbeg);
-    for (int s = sbeg; s < send; ++s) {
-        __syncthreads();                      // every wave is done with the previous step's fragments
-        stash_op(As, rkcA, t, ra);
-        stash_op(Bs, rkcB, t, rb);
-        __syncthreads();
-        if (s + 1 < send) fetch(s + 1);       // in flight during the MFMAs
-        // k-slot g of MFMA e carries k = 4 g + e of the step (the same permutation for both operands)
-        const float4 a0 = *(const float4*)&As[(wm * 32 + li) * GP + lg * 4];
-        const float4 a1 = *(const float4*)&As[(wm * 32 + 16 + li) * GP + lg * 4];
-        const float4 b0 = *(const float4*)&Bs[(wn * 32 + li) * GP + lg * 4];
-        const float4 b1 = *(const float4*)&Bs[(wn * 32 + 16 + li) * GP + lg * 4];
+    // No conditional loads: steps past the end read nothing useful (every lane out of range -> zeros) and multiply zeros, so that
+    // the compiler's vmcnt bookkeeping stays exact -- with `if (s + PD < send) fetch(...)` it fell back to vmcnt(0) in front of every
+    // LDS stash and each step waited for the loads issued one step earlier (1.2 us per step).
+    const int send_p = sbeg + (send - sbeg + PD - 1) / PD * PD;
+    auto fetch_c = [&](int s, int d) { fetch(s, d); };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch_c(sbeg + d, d);
+    for (int s0 = sbeg; s0 < send_p; s0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int s = s0 + d;
+            {
+                const bool one = s < steps1;
+                const int kca = one ? J.kcA : J.kcA2, kcb = one ? J.kcB : J.kcB2;
+                // RAW barriers: __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0) -- it would drain the prefetch ring at
+                // every step.  Only LDS traffic has to be ordered here: lgkmcnt(0) + s_barrier (the register dependencies of the stash
+                // on its own slot's loads are the compiler's counted vmcnt waits).
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();     // every wave is done with the previous step's fragments
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    stash_op(As, kca, t, ra[d][hf], hf);
+                    stash_op(Bs, kcb, t, rb[d][hf], hf);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fetch_c(s + PD, d);
+                // k-slot g of MFMA e carries k = 16 hf + 4 g + e of the step (the same permutation for both operands)
 #define QT_MF(av, bv, c) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0)
-        QT_MF(a0.x, b0.x, acc[0][0]); QT_MF(a0.x, b1.x, acc[0][1]); QT_MF(a1.x, b0.x, acc[1][0]); QT_MF(a1.x, b1.x, acc[1][1]);
-        QT_MF(a0.y, b0.y, acc[0][0]); QT_MF(a0.y, b1.y, acc[0][1]); QT_MF(a1.y, b0.y, acc[1][0]); QT_MF(a1.y, b1.y, acc[1][1]);
-        QT_MF(a0.z, b0.z, acc[0][0]); QT_MF(a0.z, b1.z, acc[0][1]); QT_MF(a1.z, b0.z, acc[1][0]); QT_MF(a1.z, b1.z, acc[1][1]);
-        QT_MF(a0.w, b0.w, acc[0][0]); QT_MF(a0.w, b1.w, acc[0][1]); QT_MF(a1.w, b0.w, acc[1][0]); QT_MF(a1.w, b1.w, acc[1][1]);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 a0 = *(const float4*)&As[(wm * 32 + li) * GP + hf * 16 + lg * 4];
+                    const float4 a1 = *(const float4*)&As[(wm * 32 + 16 + li) * GP + hf * 16 + lg * 4];
+                    const float4 b0 = *(const float4*)&Bs[(wn * 32 + li) * GP + hf * 16 + lg * 4];
+                    const float4 b1 = *(const float4*)&Bs[(wn * 32 + 16 + li) * GP + hf * 16 + lg * 4];
+                    QT_MF(a0.x, b0.x, acc[0][0]); QT_MF(a0.x, b1.x, acc[0][1]); QT_MF(a1.x, b0.x, acc[1][0]); QT_MF(a1.x, b1.x, acc[1][1]);
+                    QT_MF(a0.y, b0.y, acc[0][0]); QT_MF(a0.y, b1.y, acc[0][1]); QT_MF(a1.y, b0.y, acc[1][0]); QT_MF(a1.y, b1.y, acc[1][1]);
+                    QT_MF(a0.z, b0.z, acc[0][0]); QT_MF(a0.z, b1.z, acc[0][1]); QT_MF(a1.z, b0.z, acc[1][0]); QT_MF(a1.z, b1.z, acc[1][1]);
+                    QT_MF(a0.w, b0.w, acc[0][0]); QT_MF(a0.w, b1.w, acc[0][1]); QT_MF(a1.w, b0.w, acc[1][0]); QT_MF(a1.w, b1.w, acc[1][1]);
+                }
 #undef QT_MF
+            }
+        }
     }
-    // ---- epilogue: D lane (li, lg), reg r -> row lg * 4 + r, col li of its 16 x 16 tile
+    // ---- epilogue: D lane (li, lg), reg r -> row lg * 4 + r, col li of its 16 x 16 tile.  Two passes: every load of the extras
+    // first, then the stores -- interleaved, the compiler must keep each element's loads behind the previous element's store (the
+    // pointers may alias), i.e. 16 dependent memory round trips: every launch measured ~24 us whatever its size.
     const bool first = ks == 0;
     float* Cb = J.C + (J.ksplit > 1 ? (int64_t)ks * J.M * J.ldc : 0);
+    float ov[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -163,8 +195,8 @@ __global__ __launch_bounds__(256) void k_gemm32(const GemmBatch gb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 32 + a * 16 + lg * 4 + r;
+                float v = acc[a][b][r];
                 if (m < J.M && n < J.N) {
-                    float v = acc[a][b][r];
                     if (first) {
                         if (J.bias) v += J.bias[n];
                         if (J.rs_row) v += J.rs_row[m] * J.rs_col[n];
@@ -172,15 +204,25 @@ __global__ __launch_bounds__(256) void k_gemm32(const GemmBatch gb) {
                     }
                     if (J.flags & GF_RELU) v = fmaxf(v, 0.f);
                     if (J.mask) v = J.mask[(int64_t)m * J.ldc + n] > 0.f ? v : 0.f;
-                    float* dst = Cb + (int64_t)m * J.ldc + n;
-                    if (J.flags & GF_ACCUM) v += *dst;
-                    *dst = v;
+                    if (J.flags & GF_ACCUM) v += Cb[(int64_t)m * J.ldc + n];
                 }
+                ov[a][b][r] = v;
+            }
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn * 32 + b * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + a * 16 + lg * 4 + r;
+                if (m < J.M && n < J.N) Cb[(int64_t)m * J.ldc + n] = ov[a][b][r];
             }
         }
     if (want_cs) {          // sum_k A(m, k): fixed-order reduction of the staging threads' partial sums through LDS
         __syncthreads();
-        float* red = As;    // 1024 floats of the 1280
+        float* red = As;    // 1024 floats of the 64 x 36
         if (J.kcA) red[t] = cs[0];
         else { red[t * 4 + 0] = cs[0]; red[t * 4 + 1] = cs[1]; red[t * 4 + 2] = cs[2]; red[t * 4 + 3] = cs[3]; }
         __syncthreads();
@@ -354,6 +396,14 @@ __global__ __launch_bounds__(256) void k_qt_ln_bwd(const LnArgs a, int R) {
     st4(a.dx[j] + o, ln_bwd(h, s.rstd, dy, a.gamma[j], c4));
 }
 
+// out [R][Lp] = in [R][L] with zero columns behind
+__global__ __launch_bounds__(256) void k_qt_pad_cols(const float* __restrict__ in, float* __restrict__ out, int R, int L, int Lp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * Lp) return;
+    const int r = i / Lp, c = i - r * Lp;
+    out[i] = c < L ? in[(int64_t)r * L + c] : 0.f;
+}
+
 // ---- kbias[r] = kraw[r] . bt (the scalar bias of the folded dynamic kernel) --------------------------------------------
 struct DotArgs {
     const float *x[2], *v[2];
@@ -412,6 +462,9 @@ struct AttArgs {
     float* ds[2];            // [B][8][N][N] scratch
     float* gqkv[2];          // [R][3C]
 };
+// grid (B * 8, 2 branches, ACH row chunks): a workgroup takes the query rows n = chunk, chunk + ACH, ... -- 32 workgroups of one
+// (image, head, branch) each measured 116 us forward / 160 us backward at cfg2 (2 images), latency bound on 32 of 256 CUs
+constexpr int ACH = 4;
 __global__ __launch_bounds__(512) void k_qt_attn_fwd(const AttArgs a, int N) {
     extern __shared__ float sm[];
     const int b = blockIdx.x / QHEADS, h = blockIdx.x % QHEADS, br = blockIdx.y;
@@ -428,7 +481,7 @@ __global__ __launch_bounds__(512) void k_qt_attn_fwd(const AttArgs a, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* P = a.prob[br] + ((int64_t)(b * QHEADS + h) * N) * N;
     float* pr = prow + wave * N;
-    for (int n = wave; n < N; n += 8) {
+    for (int n = blockIdx.z + ACH * wave; n < N; n += 8 * ACH) {
         float mx = -INFINITY;
         for (int j = lane; j < N; j += 64) {
             float s = 0.f;
@@ -482,7 +535,7 @@ __global__ __launch_bounds__(512) void k_qt_attn_bwd(const AttArgs a, int N) {
     float* gq = a.gqkv[br] + (int64_t)b * N * 3 * QC + h * QD;
     float* pr = prow + wave * N;
     // phase 1, one wave per query row: dP = go v^T, dS = P (dP - sum_j dP P), d q = scale * dS k
-    for (int n = wave; n < N; n += 8) {
+    for (int n = blockIdx.z + ACH * wave; n < N; n += 8 * ACH) {
         float dl = 0.f;
         for (int j = lane; j < N; j += 64) {
             float s = 0.f;
@@ -504,11 +557,29 @@ __global__ __launch_bounds__(512) void k_qt_attn_bwd(const AttArgs a, int N) {
         o += __shfl_xor(o, 32);
         if (hf == 0) gq[(int64_t)n * 3 * QC + c] = o * scale;
     }
-    __threadfence_block();      // phase 2 reads the dS rows the other waves of this workgroup wrote to global memory
+}
+
+// phase 2 (its own launch: it needs the dS rows of ALL query rows): d k[j][c] = sum_n dS[n][j] q_scaled[n][c];
+// d v[j][c] = sum_n P[n][j] go[n][c].  grid (B * 8, 2, ACH): key rows j = chunk, chunk + ACH, ...; thread = (j, quarter of c)
+__global__ __launch_bounds__(256) void k_qt_attn_bwd2(const AttArgs a, int N) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x / QHEADS, h = blockIdx.x % QHEADS, br = blockIdx.y;
+    float *q = sm, *go = q + N * AP;
+    const float* src = a.qkv[br] + (int64_t)b * N * 3 * QC + h * QD;
+    const float* gsrc = a.gatt[br] + (int64_t)b * N * QC + h * QD;
+    const float scale = 0.17677669529663687f;
+    for (int e = threadIdx.x; e < N * QD; e += 256) {
+        const int n = e >> 5, c = e & 31;
+        q[n * AP + c] = src[(int64_t)n * 3 * QC + c] * scale;
+        go[n * AP + c] = gsrc[(int64_t)n * QC + c];
+    }
     __syncthreads();
-    // phase 2: d k[j][c] = sum_n dS[n][j] q_scaled[n][c];  d v[j][c] = sum_n P[n][j] go[n][c].  thread = (j, quarter of c)
-    for (int e = threadIdx.x; e < N * 4; e += 512) {
-        const int j = e % N, cq = (e / N) * 8;
+    const float* P = a.prob[br] + ((int64_t)(b * QHEADS + h) * N) * N;
+    const float* dS = a.ds[br] + ((int64_t)(b * QHEADS + h) * N) * N;
+    float* gq = a.gqkv[br] + (int64_t)b * N * 3 * QC + h * QD;
+    const int nj = (N - blockIdx.z + ACH - 1) / ACH;                 // key rows of this chunk
+    for (int e = threadIdx.x; e < nj * 4; e += 256) {
+        const int j = blockIdx.z + ACH * (e % nj), cq = (e / nj) * 8;
         float ak[8], av[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) ak[c] = av[c] = 0.f;
@@ -560,7 +631,7 @@ struct Saved {
 };
 // offsets into the backward's scratch, per branch
 struct Scratch {
-    int64_t GKRAW, GT0, GT1, GT0P, GT1P, GO3, GT3, GZ, PART, GT2, GATT, GQKV, DS, GO1, GH, GF, GA, GB, GP, GI, GG, GU, CS_UPD,
+    int64_t GKRAW, GT0, GT1, GT0P, GT1P, GO3, GT3, GZ, PART, GT2, GATT, GQKV, DS, GO1, GH, GF, GA, GB, GP, GI, GG, GU, GCLSP, CS_UPD,
         CS_LN, per_branch;
     Scratch(int B, int N, int L, int Fd) {
         const int64_t R = (int64_t)B * N, RC = R * QC;
@@ -569,7 +640,7 @@ struct Scratch {
         GKRAW = take(RC); GT0 = take(RC); GT1 = take(RC); GT0P = take(RC); GT1P = take(RC); GO3 = take(RC); GT3 = take(RC);
         GZ = take(R * Fd); PART = take(KSPLIT * RC); GT2 = take(RC); GATT = take(RC); GQKV = take(3 * RC);
         DS = take((int64_t)B * QHEADS * N * N); GO1 = take(RC); GH = take(RC); GF = take(RC); GA = take(RC); GB = take(RC);
-        GP = take(2 * RC); GI = take(2 * RC); GG = take(RC); GU = take(RC);
+        GP = take(2 * RC); GI = take(2 * RC); GG = take(RC); GU = take(RC); GCLSP = take(R * ((L + 3) / 4 * 4));
         CS_UPD = take(8 * RC);             // the four LayerNorms of the updator
         CS_LN = take(5 * 2 * RC);          // fc_norm, attention_norm, ffn_norm, tower 0, tower 1
         per_branch = o;
@@ -583,7 +654,9 @@ struct Launcher {
     int nj = 0, maxtiles = 0;
     bool failed = false;
 
-    static int vec_ok(const float* p, int ld) { return (((uintptr_t)p & 15) == 0 && (ld % 4) == 0) ? 1 : 0; }
+    // a float4 of the operand is wholly inside or wholly outside: aligned base, ld % 4 == 0, the vectorised axis (k when the operand is
+    // k-contiguous, else its row index) a multiple of 4 long
+    static bool vec_ok(const float* p, int ld, int run) { return ((uintptr_t)p & 15) == 0 && (ld % 4) == 0 && (run % 4) == 0; }
 
     // C[M][N] = A(m,k) B(k,n): kcA / kcB as in GemmJob.  Returns the job for optional extras.
     GemmJob& job(const float* A, int lda, int kcA, const float* B, int ldb, int kcB, float* C, int ldc, int M, int N, int K) {
@@ -591,14 +664,24 @@ struct Launcher {
         GemmJob& j = gb.j[nj++];
         j = GemmJob{};
         j.A = A; j.lda = lda; j.kcA = kcA; j.B = B; j.ldb = ldb; j.kcB = kcB; j.C = C; j.ldc = ldc; j.M = M; j.N = N; j.K = K;
-        j.vecA = vec_ok(A, lda); j.vecB = vec_ok(B, ldb);
+        j.rowsA = M; j.KA = K; j.KB = K;
+        if (!vec_ok(A, lda, kcA ? K : M) || !vec_ok(B, ldb, kcB ? K : N)) failed = true;       // callers pad (see `padded`)
         j.ksplit = 1;
         j.kcA2 = j.kcB2 = 1;
         return j;
     }
     static void second(GemmJob& j, const float* A2, int lda2, int kcA2, const float* B2, int ldb2, int kcB2, int K2) {
         j.A2 = A2; j.lda2 = lda2; j.kcA2 = kcA2; j.B2 = B2; j.ldb2 = ldb2; j.kcB2 = kcB2; j.K2 = K2;
-        j.vecA2 = vec_ok(A2, lda2); j.vecB2 = vec_ok(B2, ldb2);
+    }
+    // operand A is a buffer padded on its vectorised axis (zeros behind the data): let its loads run to the padded extent
+    void padded_A(GemmJob& j, int rows_padded, int k_padded) {
+        j.rowsA = rows_padded; j.KA = k_padded;
+        if (k_padded > j.K) j.K = k_padded;
+        failed = false;
+        for (int i = 0; i < nj; ++i) {
+            const GemmJob& q = gb.j[i];
+            if (!vec_ok(q.A, q.lda, q.kcA ? q.KA : q.rowsA) || !vec_ok(q.B, q.ldb, q.kcB ? q.KB : q.N)) failed = true;
+        }
     }
     void flush() {
         if (!nj) return;
@@ -694,7 +777,7 @@ extern "C" int ph_qtrain_forward(const float* const* params, const float* pooled
         const size_t lds = (size_t)(3 * N * AP + 8 * N) * 4;
         static const hipError_t attr = hipFuncSetAttribute((const void*)k_qt_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)attr;
-        hipLaunchKernelGGL(k_qt_attn_fwd, dim3(B * QHEADS, 2), dim3(512), lds, Lh.s, a, N);
+        hipLaunchKernelGGL(k_qt_attn_fwd, dim3(B * QHEADS, 2, ACH), dim3(512), lds, Lh.s, a, N);
     }
     for (int br = 0; br < 2; ++br) Lh.job(S(br, sv.ATT), C, 1, Pm(br, P_OUT_W), C, 1, S(br, sv.PART), C, R, C, C).bias = Pm(br, P_OUT_B);
     Lh.flush();
@@ -799,8 +882,17 @@ extern "C" int ph_qtrain_backward(const float* const* params, const float* poole
         Lh.job(X(br, sc.GKRAW), C, 1, Pm(br, P_K_W), C, 0, X(br, sc.GT0), C, R, C, C);
         dweight(X(br, sc.GKRAW), C, S(br, sv.T0), C, Gd(br, P_K_W), C, C, Gd(br, P_K_B));
     }
-    Lh.job(g_cls, L, 1, Pm(0, P_CLS_W), C, 0, X(0, sc.GT1), C, R, C, L);
-    dweight(g_cls, L, S(0, sv.T1), C, Gd(0, P_CLS_W), L, C, Gd(0, P_CLS_B));
+    {   // d cls [R][L] (L = 19 / 133: no multiple of 4) goes through a zero-padded copy [R][Lp] so that every operand load of the
+        // tile GEMM is one aligned 16-byte load
+        const int Lp = (L + 3) / 4 * 4;
+        float* gcp = X(0, sc.GCLSP);
+        hipLaunchKernelGGL(k_qt_pad_cols, dim3((R * Lp + 255) / 256), dim3(256), 0, Lh.s, g_cls, gcp, R, L, Lp);
+        GemmJob& j1 = Lh.job(gcp, Lp, 1, Pm(0, P_CLS_W), C, 0, X(0, sc.GT1), C, R, C, L);
+        j1.KB = L;                                   // fc_cls.weight has L rows; d cls is padded to Lp columns of zeros
+        Lh.padded_A(j1, R, Lp);
+        GemmJob& j2 = dweight(gcp, Lp, S(0, sv.T1), C, Gd(0, P_CLS_W), L, C, Gd(0, P_CLS_B));
+        Lh.padded_A(j2, Lp, R);                      // A = d cls^T: rows (= classes) padded to Lp; stores and column sums stop at L
+    }
     Lh.flush();
     {   // R8b: tower LayerNorms (+ ReLU)
         LnArgs a{};
@@ -872,7 +964,10 @@ extern "C" int ph_qtrain_backward(const float* const* params, const float* poole
         const size_t lds = (size_t)(4 * N * AP + 8 * N) * 4;
         static const hipError_t attr = hipFuncSetAttribute((const void*)k_qt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)attr;
-        hipLaunchKernelGGL(k_qt_attn_bwd, dim3(B * QHEADS, 2), dim3(512), lds, Lh.s, a, N);
+        hipLaunchKernelGGL(k_qt_attn_bwd, dim3(B * QHEADS, 2, ACH), dim3(512), lds, Lh.s, a, N);
+        static const hipError_t attr2 = hipFuncSetAttribute((const void*)k_qt_attn_bwd2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr2;
+        hipLaunchKernelGGL(k_qt_attn_bwd2, dim3(B * QHEADS, 2, ACH), dim3(256), (size_t)(2 * N * AP) * 4, Lh.s, a, N);
     }
     // L7: in_proj; d o1 = d t2 + d qkv W_in
     for (int br = 0; br < 2; ++br) {
@@ -952,4 +1047,20 @@ extern "C" int ph_qtrain_backward(const float* const* params, const float* poole
     PH_CHECK_LAUNCH();
     if (Lh.failed) { ph_set_error("ph_qtrain_backward: a launch failed"); return PH_ELAUNCH; }
     return PH_OK;
+}
+
+// one product of the tile GEMM on its own (tests / tools/gemm32_time.py): C [M][N] = A(m, k) B(k, n) (+ bias[n]); kcA / kcB != 0: the
+// operand's contiguous axis is k (X [row][k], W [out][in]); ksplit > 1: C is [ksplit][M][ldc] partial results
+extern "C" int ph_gemm32(const float* A, int lda, int kcA, const float* B, int ldb, int kcB, float* C, int ldc, int M, int N, int K,
+                         int ksplit, const float* bias, void* stream) {
+    PH_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1, "bad pointer or size");
+    Launcher Lh;
+    Lh.s = (hipStream_t)stream;
+    Lh.R = M;
+    GemmJob& j = Lh.job(A, lda, kcA, B, ldb, kcB, C, ldc, M, N, K);
+    j.bias = bias;
+    j.ksplit = ksplit;
+    Lh.flush();
+    PH_CHECK_LAUNCH();
+    return Lh.failed ? PH_ELAUNCH : PH_OK;
 }

@@ -109,14 +109,23 @@ __global__ __launch_bounds__(256, 2) void k_rows_x_map(const float* __restrict__
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const int64_t p = p0 + t * 16 + c;
+                {
+                    // every load of the epilogue's extras before the first store of the group: interleaved, each load would wait
+                    // behind the previous store (possible aliasing) -- a dependent memory round trip per element
+                    float ev[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = (mt0 + r) * 16 + g * 4 + i;
-                    if (m < M && p < HW) {
-                        float v = acc[r][t][i];
-                        if (bias) v += bias[(int64_t)b * M + m];
-                        if (add) v += add[((int64_t)b * M + m) * HW + p];
-                        __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = (mt0 + r) * 16 + g * 4 + i;
+                        ev[i] = acc[r][t][i];
+                        if (m < M && p < HW) {
+                            if (bias) ev[i] += bias[(int64_t)b * M + m];
+                            if (add) ev[i] += add[((int64_t)b * M + m) * HW + p];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = (mt0 + r) * 16 + g * 4 + i;
+                        if (m < M && p < HW) __builtin_nontemporal_store(ev[i], &Yb[(int64_t)m * HW + p]);
                     }
                 }
             }
@@ -345,14 +354,23 @@ __global__ __launch_bounds__(512) void k_rows_x_map_lds(const float* __restrict_
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
                 const int64_t p = p0 + t * 16 + c;
+                {
+                    // every load of the epilogue's extras before the first store of the group: interleaved, each load would wait
+                    // behind the previous store (possible aliasing) -- a dependent memory round trip per element
+                    float ev[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = (mt0 + r) * 16 + g * 4 + i;
-                    if (m < M && p < HW) {
-                        float v = acc[r][t][i];
-                        if (bias) v += bias[(int64_t)b * M + m];
-                        if (add) v += add[((int64_t)b * M + m) * HW + p];
-                        __builtin_nontemporal_store(v, &Yb[(int64_t)m * HW + p]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = (mt0 + r) * 16 + g * 4 + i;
+                        ev[i] = acc[r][t][i];
+                        if (m < M && p < HW) {
+                            if (bias) ev[i] += bias[(int64_t)b * M + m];
+                            if (add) ev[i] += add[((int64_t)b * M + m) * HW + p];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = (mt0 + r) * 16 + g * 4 + i;
+                        if (m < M && p < HW) __builtin_nontemporal_store(ev[i], &Yb[(int64_t)m * HW + p]);
                     }
                 }
             }
