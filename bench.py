@@ -1216,7 +1216,7 @@ def main():
         # which cannot run inside this process: the committed summary is quoted, labelled as such, and only when the launch
         # geometry is the profiled one
         traffic, traffic_src = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")) as f:
                     pt = json.load(f)

@@ -23,6 +23,8 @@ python tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/pmc_sq_query $OUT/pmc_sq_a1 > $O
 python tools/r04_kernels.py mixed16 > $OUT/r04_kernels.json 2> $OUT/r04_kernels.err; python tools/r04_kernels.py fp16 >> $OUT/r04_kernels.json 2>> $OUT/r04_kernels.err
 python tools/a1_time.py 16 fp16 > $OUT/a1_time.json 2> $OUT/a1_time.err; PH_KHEAD_NO_FALLBACK=1 python tools/a1_time.py 16 fp16 >> $OUT/a1_time.json 2>> $OUT/a1_time.err
 if [ "${ALL_LEGS:-1}" = 1 ]; then bash tools/run_train_prof.sh $OUT > $OUT/train_prof.txt 2>&1; fi
+python tools/neck_train_time.py 2 > $OUT/neck_train_step.json 2> $OUT/neck_train.err
+python tools/gemm32_time.py > $OUT/gemm32_time.txt 2>&1
 python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -R $OUT | head -60
