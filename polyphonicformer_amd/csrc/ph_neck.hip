@@ -109,10 +109,12 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, M = output pixels, N = 256 output channels, K = KS*KS*256 ordered (tap, channel).
-// Workgroup (8 waves) = TH output rows x 64 output pixels x all 256 channels (TH = 4 or 2, ConvGeo); wave w owns
-// channels 32 w .. 32 w + 31 of all TH * 64 pixels: 2 TH 32-pixel M tiles of 32x32x16 MFMA.  Per k-step a wave reads four A
-// fragments from LDS and ONE B fragment from L2 (a 64-pixel x 64-channel wave tile needs two: the CU's 64 B/clk L1
-// request path then runs as long as the matrix pipe).  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
+// Workgroup (8 waves) = TH output rows x 64 output pixels x all 256 channels (TH = 4 or 2, ConvGeo).  Round 5: the waves
+// are arranged 2 x 4 -- wave w owns channels 64 (w & 3) .. + 63 of the output rows (w >> 2) * TH / 2 .. + TH / 2 - 1: TH
+// 32-pixel M tiles x 2 column tiles of 32x32x16 MFMA (the same 2 TH accumulators as before).  Per k-step a wave reads TH A
+// fragments from LDS (half of what the 1 x 8 arrangement read: there every A fragment was read by all 8 waves and the
+// LDS pipe ran exactly as long as the matrix pipe, 512 cycles per CU and k-step) and TWO B fragments from L2 (16 KB per CU
+// and k-step = 32 B/clk of the 64 B/clk L1 request path).  -DCV_WAVES_1X8 restores the old arrangement (A/B timing).  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
 // time ([pixel][CH + 8] bf16: the 16-byte pad makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots);
 // an A fragment is one ds_read_b128 at a pixel offset given by the tap.  Weights are pre-packed B fragments
 // ([col tile][k-step] blocks of 1 KiB, pack.pack_b32) streamed from L2, one k-step ahead.
@@ -152,20 +154,29 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);               // this wave's 32 output channels
-    constexpr int MT = G::MT;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CV_WAVES_1X8
+    constexpr int NT = 1, MT = G::MT;                                       // wave = 32 channels x all rows
+    const int wc = wv, row_base = 0;
+#else
+    constexpr int NT = 2, MT = G::TH;                                       // wave = 64 channels x half of the rows
+    const int wc = wv & 3, row_base = (wv >> 2) * (G::TH / 2);
+#endif
     const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * CV_TW;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const int m = lane & 31, kg = lane >> 5;
 
-    f32x16_t acc[MT];         // [output row * 2 + 32-pixel half]
+    f32x16_t acc[MT][NT];     // [output row (of this wave) * 2 + 32-pixel half][column tile]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const uint16_t* xb = X + (int64_t)b * H * W * 256;
-    const uint16_t* wbase = Wp + ((int64_t)wn * KSTEPS_TOTAL) * 512 + lane * 8;   // this lane's B-fragment stream
+    const uint16_t* wbase = Wp + ((int64_t)wc * NT * KSTEPS_TOTAL) * 512 + lane * 8;   // this lane's B-fragment stream(s)
+    constexpr int64_t W_NT = (int64_t)KSTEPS_TOTAL * 512;                             // next column tile
 
     // Stride-1 single-plane instantiations double-buffer the patch: chunk c + 1 travels HBM -> registers while the
     // MFMAs of chunk c run and is written to the other LDS buffer after them (one barrier per chunk).  Vector-memory
@@ -225,12 +236,14 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             return tap * 16 + (c0 >> 4) + kk;             // (tap * 256 + c0 + kk * 16) / 16
         };
-        uint4 bq[DEPTH][PA];
+        uint4 bq[DEPTH][NT][PA];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (d < NK) {
 #pragma unroll
-                for (int p = 0; p < PA; ++p) bq[d][p] = *(const uint4*)(wbase + p * w_plane + (int64_t)kstep_of(d) * 512);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) bq[d][nt][p] = *(const uint4*)(wbase + nt * W_NT + p * w_plane + (int64_t)kstep_of(d) * 512);
             }
         uint4 pre[DB ? NPRE : 1][PA];
         const bool more = DB && c0 + CH < 256;
@@ -240,12 +253,17 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
-            uint4 bcur[PA];
+            uint4 bcur[NT][PA];
 #pragma unroll
-            for (int p = 0; p < PA; ++p) bcur[p] = bq[j % DEPTH][p];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < PA; ++p) bcur[nt][p] = bq[j % DEPTH][nt][p];
             if (j + DEPTH < NK) {
 #pragma unroll
-                for (int p = 0; p < PA; ++p) bq[j % DEPTH][p] = *(const uint4*)(wbase + p * w_plane + (int64_t)kstep_of(j + DEPTH) * 512);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PA; ++p)
+                        bq[j % DEPTH][nt][p] = *(const uint4*)(wbase + nt * W_NT + p * w_plane + (int64_t)kstep_of(j + DEPTH) * 512);
             }
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             const int dy = tap / KS, dx = tap - dy * KS;
@@ -254,19 +272,21 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             for (int p = 0; p < PA; ++p)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int row = (mt >> 1) * S + dy;
+                    const int row = (row_base + (mt >> 1)) * S + dy;
                     const int px = (S == 2) ? (dx & 1) * G::HALF + (mt & 1) * 32 + m + (dx >> 1) : (mt & 1) * 32 + m + dx;
                     a[p][mt] = *(const uint4*)(cur + p * G::PLANE + (row * G::ICS + px) * LDP + kk * 16 + kg * 8);
                 }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = mfma32e<E>(a[0][mt], bcur[0], acc[mt]);
-                if (PA == 2) {
-                    acc[mt] = mfma32e<E>(a[0][mt], bcur[PA - 1], acc[mt]);
-                    acc[mt] = mfma32e<E>(a[PA - 1][mt], bcur[0], acc[mt]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = mfma32e<E>(a[0][mt], bcur[nt][0], acc[mt][nt]);
+                    if (PA == 2) {
+                        acc[mt][nt] = mfma32e<E>(a[0][mt], bcur[nt][PA - 1], acc[mt][nt]);
+                        acc[mt][nt] = mfma32e<E>(a[PA - 1][mt], bcur[nt][0], acc[mt][nt]);
+                    }
                 }
-            }
-            if (MT > 4) __builtin_amdgcn_sched_barrier(0);   // 128 accumulator VGPRs: keep the A fragments of later k-steps out
+            if (MT * NT > 4) __builtin_amdgcn_sched_barrier(0);   // 128 accumulator VGPRs: keep the A fragments of later k-steps out
         }
         if (DB) {
             if (more) {
@@ -279,28 +299,56 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     }
 
     // ---- epilogue: fp32 NHWC store (32 lanes = 128 contiguous bytes of a pixel) + GroupNorm partial sums
-    float s1 = 0.f, s2 = 0.f;
+    float s1[NT], s2[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = 0.f;
+        s2[nt] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int px = (mt & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
-            const int ox = ox0 + px, oy = oy0 + (mt >> 1);
-            if (oy < Ho && ox < Wo) {
-                const float v = acc[mt][r];
-                Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + wn * 32 + m] = v;
-                s1 += v;
-                s2 += v * v;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (mt & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
+                const int ox = ox0 + px, oy = oy0 + row_base + (mt >> 1);
+                if (oy < Ho && ox < Wo) {
+                    const float v = acc[mt][nt][r];
+                    Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + (wc * NT + nt) * 32 + m] = v;
+                    s1[nt] += v;
+                    s2[nt] += v * v;
+                }
             }
-        }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (kg == 0) {
-        const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
-        float* o = partial + (((int64_t)b * nwg + wg) * 256 + wn * 32 + m) * 2;
-        o[0] = s1;
-        o[1] = s2;
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
     }
+    const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
+#ifdef CV_WAVES_1X8
+    if (kg == 0) {
+        float* o = partial + (((int64_t)b * nwg + wg) * 256 + wc * 32 + m) * 2;
+        o[0] = s1[0];
+        o[1] = s2[0];
+    }
+#else
+    // the two row halves of a channel meet in LDS (fixed order: upper rows + lower rows)
+    float* red = (float*)lds;                             // [256 channels][2]
+    if (!DB) __syncthreads();                             // the last chunk's readers are done (DB: its closing barrier)
+    if (row_base != 0 && kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            red[((wc * NT + nt) * 32 + m) * 2 + 0] = s1[nt];
+            red[((wc * NT + nt) * 32 + m) * 2 + 1] = s2[nt];
+        }
+    }
+    __syncthreads();
+    if (row_base == 0 && kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = (wc * NT + nt) * 32 + m;
+            float* o = partial + (((int64_t)b * nwg + wg) * 256 + c) * 2;
+            o[0] = s1[nt] + red[c * 2 + 0];
+            o[1] = s2[nt] + red[c * 2 + 1];
+        }
+    }
+#endif
 }
 
 // one-plane formats: 4-row tiles, unless those are fewer than one per CU over the whole launch (then 2-row tiles)
