@@ -46,6 +46,11 @@ enum { PH_OK = 0, PH_EINVAL = -1, PH_EUNSUPPORTED = -2, PH_ELAUNCH = -3, PH_EWOR
  *                        bounded operand -- as ONE fp16 plane of weights and activations (1 MFMA, 2^-12 per operand, half the
  *                        weight stream); weights packed accordingly (pack.py), dynamic kernels out as PH_KERN_F16. */
 enum { PH_PREC_BF16 = 1, PH_PREC_BF16_KSPLIT = 2, PH_PREC_SPLIT = 3, PH_PREC_F16 = 5, PH_PREC_BF16_KF16 = 6, PH_PREC_QHYBRID = 7 };
+/* flag OR-ed into `prec` of ph_nhwc_ingest (output) and ph_conv_nhwc (input, 3x3 stride 2, one-plane formats): the planes are
+   chunk-major [frame][256 / 16][HW][16] instead of channels-last [frame][HW][256].  The stride-2 kernel stages 16 channels of
+   a 9 x 129 pixel patch at a time; from channels-last planes that is 32 bytes of every 512, i.e. a quarter of each 128-byte
+   line per stage and (the lines do not survive in L2 between stages) four times the plane's bytes from HBM. */
+enum { PH_PLANES_C16 = 0x100 };
 enum { PH_OUT_F32 = 0, PH_OUT_BF16 = 1, PH_OUT_F16 = 2 };
 enum { PH_KERN_BF16_PLANES = 0, PH_KERN_F16 = 1 };   /* ph_query_stage: format of the dynamic conv kernels it emits */
 enum { PH_GN_TO_PLANES = 0, PH_GN_UP2_PLANES = 1, PH_GN_ACCUM = 2, PH_GN_TO_NCHW = 3, PH_GN_TO_CPLANES = 4 };   /* ph_gn_apply modes */

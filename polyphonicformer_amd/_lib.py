@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
 
 PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16, PH_PREC_BF16_KF16, PH_PREC_QHYBRID = 1, 2, 3, 5, 6, 7
+PH_PLANES_C16 = 0x100            # flag on `prec` of ph_nhwc_ingest / ph_conv_nhwc: chunk-major planes [B][16][HW][16] (polyhead.h)
 PH_QUERY_WIDE = 0x100            # ph_query_stage phases flag: most rows per workgroup (launches that share the GPU)
 PH_OUT_F32, PH_OUT_BF16, PH_OUT_F16 = 0, 1, 2
 PH_KERN_BF16_PLANES, PH_KERN_F16 = 0, 1

@@ -18,7 +18,7 @@
 // fp32 NCHW [B][256][HW] (+ add[256][HW], nullable) -> bf16 NHWC planes [PA][B][HW][256]; 64 channels x 64 pixels per
 // block (256-byte runs in, whole 128-byte lines out).  A 256-channel x 32-pixel variant that writes whole 512-byte
 // pixel vectors was 50 % slower at the stride-4 level (256 rows 512 KB apart per block).
-template <int PA, int E = PH_E_BF16>
+template <int PA, int E = PH_E_BF16, bool C16 = false>
 __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ src, const float* __restrict__ add,
                                                      uint16_t* __restrict__ dst, int B, int64_t HW) {
     __shared__ float t[64][65];                       // [channel][pixel] tile
@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ s
         if (p0 + p >= HW) continue;
         uint32_t hi, lo;
         f2e_split<E>(t[tx][p], hi, lo);
-        const int64_t o = ((int64_t)b * HW + p0 + p) * 256 + c0 + tx;
+        // C16: [frame][16-channel chunk][pixel][16] (PH_PLANES_C16, the stride-2 conv's input)
+        const int64_t o = C16 ? (((int64_t)b * 16 + ((c0 + tx) >> 4)) * HW + p0 + p) * 16 + ((c0 + tx) & 15)
+                              : ((int64_t)b * HW + p0 + p) * 256 + c0 + tx;
         dst[o] = (uint16_t)hi;
         if (PA == 2) dst[o + plane] = (uint16_t)lo;
     }
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest(const float* __restrict__ s
 
 // the same tile with 16-byte accesses on both sides (HW % 4 == 0): 4 x float4 per thread in, 2 x 16 bytes (8 channels of
 // one pixel) per thread out -- a quarter / an eighth of the memory instructions of the scalar kernel above
-template <int PA, int E = PH_E_BF16>
+template <int PA, int E = PH_E_BF16, bool C16 = false>
 __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict__ src, const float* __restrict__ add,
                                                         uint16_t* __restrict__ dst, int B, int64_t HW) {
     __shared__ float t[64][65];                       // [channel][pixel] tile
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict_
         uint32_t hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f2e_split<E>(t[piece * 8 + e][px], hi[e], lo[e]);
-        uint16_t* d = dst + ((int64_t)b * HW + p0 + px) * 256 + c0 + piece * 8;
+        uint16_t* d = C16 ? dst + (((int64_t)b * 16 + ((c0 + piece * 8) >> 4)) * HW + p0 + px) * 16 + ((piece & 1) * 8)
+                          : dst + ((int64_t)b * HW + p0 + px) * 256 + c0 + piece * 8;
         *(uint4*)d = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
         if (PA == 2) *(uint4*)(d + plane) = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
     }
@@ -93,8 +96,23 @@ __global__ __launch_bounds__(256) void k_nhwc_ingest_v4(const float* __restrict_
 
 extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst, int B, int64_t HW, int prec, void* stream) {
     PH_CHECK_ARG(src && dst && B > 0 && HW > 0, "bad pointer or size");
+    const bool c16 = (prec & PH_PLANES_C16) != 0;
+    prec &= ~PH_PLANES_C16;
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
+    PH_CHECK_ARG(!c16 || prec != PH_PREC_SPLIT, "PH_PLANES_C16 output: one-plane formats only");
     const dim3 grid((unsigned)((HW + 63) / 64), 4, B);
+    if (c16) {
+        hipStream_t st = (hipStream_t)stream;
+        if (prec == PH_PREC_F16) {
+            if ((HW & 3) == 0) hipLaunchKernelGGL((k_nhwc_ingest_v4<1, PH_E_F16, true>), grid, dim3(256), 0, st, src, add, dst, B, HW);
+            else hipLaunchKernelGGL((k_nhwc_ingest<1, PH_E_F16, true>), grid, dim3(256), 0, st, src, add, dst, B, HW);
+        } else {
+            if ((HW & 3) == 0) hipLaunchKernelGGL((k_nhwc_ingest_v4<1, PH_E_BF16, true>), grid, dim3(256), 0, st, src, add, dst, B, HW);
+            else hipLaunchKernelGGL((k_nhwc_ingest<1, PH_E_BF16, true>), grid, dim3(256), 0, st, src, add, dst, B, HW);
+        }
+        PH_CHECK_LAUNCH();
+        return PH_OK;
+    }
     if (prec == PH_PREC_F16) {
         if ((HW & 3) == 0) hipLaunchKernelGGL((k_nhwc_ingest_v4<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
         else hipLaunchKernelGGL((k_nhwc_ingest<1, PH_E_F16>), grid, dim3(256), 0, (hipStream_t)stream, src, add, dst, B, HW);
@@ -109,12 +127,18 @@ extern "C" int ph_nhwc_ingest(const float* src, const float* add, uint16_t* dst,
 
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, M = output pixels, N = 256 output channels, K = KS*KS*256 ordered (tap, channel).
-// Workgroup (8 waves) = TH output rows x 64 output pixels x all 256 channels (TH = 4 or 2, ConvGeo).  Round 5: the waves
-// are arranged 2 x 4 -- wave w owns channels 64 (w & 3) .. + 63 of the output rows (w >> 2) * TH / 2 .. + TH / 2 - 1: TH
-// 32-pixel M tiles x 2 column tiles of 32x32x16 MFMA (the same 2 TH accumulators as before).  Per k-step a wave reads TH A
-// fragments from LDS (half of what the 1 x 8 arrangement read: there every A fragment was read by all 8 waves and the
-// LDS pipe ran exactly as long as the matrix pipe, 512 cycles per CU and k-step) and TWO B fragments from L2 (16 KB per CU
-// and k-step = 32 B/clk of the 64 B/clk L1 request path).  -DCV_WAVES_1X8 restores the old arrangement (A/B timing).  The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
+// Workgroup (8 waves) = TH output rows x 64 output pixels x all 256 channels (TH = 4 or 2, ConvGeo); wave w owns
+// channels 32 w .. 32 w + 31 of all TH * 64 pixels: 2 TH 32-pixel M tiles of 32x32x16 MFMA.  Per k-step a wave reads 2 TH A
+// fragments from LDS and ONE B fragment from L2.  (-DCV_WAVES_2X4: wave = 64 channels x half of the rows, half the A reads
+// and twice the B stream -- measured equal, 611 against 604 us at 128 x 256 x 16 frames: timing ablations put the A reads at
+// 46 us and the weight stream at 24 of the 604, the patch prefetch at 40 and the output stores at 60.)
+// Round 5, from those ablations: (i) the next chunk's patch is requested ONE 16-byte piece per few k-steps instead of as
+// a burst behind the first weight fragments -- vector loads of a wave retire in order, so every weight fragment requested
+// after the burst waited for all of it (stride 2: 207 of 806 us); the loads are unconditional (clamped addresses, zeros
+// selected at the LDS write) so that hipcc's vmcnt counting stays exact; (ii) the epilogue transposes each wave's
+// accumulators through LDS and stores 16 bytes per lane: a quarter of the store instructions (the tail of a workgroup is
+// store-ISSUE bound and nothing overlaps it at one workgroup per CU).
+// The input patch ((2-1)*S + KS rows x (64-1)*S + KS pixels) is staged through LDS one channel chunk at a
 // time ([pixel][CH + 8] bf16: the 16-byte pad makes the 16 lanes of a ds_read_b128 group hit 16 distinct slots);
 // an A fragment is one ds_read_b128 at a pixel offset given by the tap.  Weights are pre-packed B fragments
 // ([col tile][k-step] blocks of 1 KiB, pack.pack_b32) streamed from L2, one k-step ahead.
@@ -143,19 +167,22 @@ template <int KS, int S, int PA, int TH_ = (PA == 1 ? 4 : 2)> struct ConvGeo {
 template <int PA, int KS, int S, int E = PH_E_BF16, int TH_ = (PA == 1 ? 4 : 2)>
 __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ X, int64_t x_plane,
                                                    const uint16_t* __restrict__ Wp, int64_t w_plane, float* __restrict__ Y,
-                                                   float* __restrict__ partial, int B, int H, int W, int Ho, int Wo) {
+                                                   float* __restrict__ partial, int B, int H, int W, int Ho, int Wo, int c16) {
     using G = ConvGeo<KS, S, PA, TH_>;
     constexpr int CH = G::CH, LDP = G::LDP, IR = G::IR, IC = G::IC, PAD = KS / 2;
     constexpr int KSTEPS_TOTAL = KS * KS * 256 / 16;
 #ifndef CV_DEPTH
 #define CV_DEPTH 4
 #endif
+#ifndef CV_ABL
+#define CV_ABL 0          // timing-only ablations (wrong results): 1 no patch prefetch, 2 no weight stream, 4 no stores, 8 no A reads, 16 patch pieces from one 16 KB window, 32 no patch LDS writes
+#endif
     constexpr int DEPTH = CV_DEPTH;                                         // B fragments requested this many k-steps ahead
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef CV_WAVES_1X8
+#ifndef CV_WAVES_2X4
     constexpr int NT = 1, MT = G::MT;                                       // wave = 32 channels x all rows
     const int wc = wv, row_base = 0;
 #else
@@ -185,7 +212,41 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     constexpr bool DB = (PA == 1);
     constexpr int PIECES = CH / 8;
     constexpr int NPRE = (IR * IC * PIECES + 511) / 512;
-    auto patch_load = [&](int c0, int k, uint4 (&v)[PA]) {      // k-th piece of this thread, zero outside the image
+    // k-th 16-byte piece of this thread: ALWAYS loaded (clamped to the image and to the patch; the select happens at the
+    // LDS write), so that no branch sits between the weight-fragment loads.  Where the piece comes from and where it goes
+    // does not depend on the chunk: the index arithmetic (two divisions per piece) is done ONCE -- recomputed per chunk it
+    // was 15 % of the stride-1 kernel and 30 % of the stride-2 one (16 chunks), VALU work in front of the MFMAs.
+    int goff[DB ? NPRE : 1], loff[DB ? NPRE : 1];         // plane element offset; LDS element offset | zero flag, -1 = no piece
+    if (DB) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int idx = tid + k * 512, idc = min(idx, IR * IC * PIECES - 1);
+            const int piece = idc % PIECES, pix = idc / PIECES;
+            const int r = pix / IC, x = pix - r * IC;
+            const int iy = iy0 + r, ix = ix0 + x;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int slot = r * G::ICS + (S == 2 ? (x & 1) * G::HALF + (x >> 1) : x);
+            // PH_PLANES_C16 input (16-channel stages only): [chunk][pixel][16] -- a stage's rows are contiguous in memory
+            goff[k] = (min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)) * (c16 ? 16 : 256) + piece * 8;
+            if (CV_ABL & 16) goff[k] &= 0x1ff8;           // timing only: every piece from one 16 KB window (cache hits)
+            loff[k] = idx < IR * IC * PIECES ? ((slot * LDP + piece * 8) | (in ? 0 : 0x40000000)) : -1;
+        }
+    }
+    auto patch_load = [&](int c0, int k, uint4 (&v)[PA]) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) v[p] = *(const uint4*)(xb + p * x_plane + goff[k] + (c16 ? (int64_t)(c0 >> 4) * H * W * 16 : (int64_t)c0));
+    };
+    auto patch_put = [&](uint16_t* buf, int k, const uint4 (&v)[PA]) {
+        if (loff[k] >= 0) {
+            const bool zero = (loff[k] & 0x40000000) != 0;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                if ((CV_ABL & 32) && v[p].x != 0x12345678u) continue;     // timing only: loads awaited, no LDS write
+                *(uint4*)(buf + p * G::PLANE + (loff[k] & 0xffffff)) = zero ? make_uint4(0, 0, 0, 0) : v[p];
+            }
+        }
+    };
+    auto patch_load_cond = [&](int c0, int k, uint4 (&v)[PA]) {      // the kernels without a prefetch: only what is inside
         const int idx = tid + k * 512;
         const int piece = idx % PIECES, pix = idx / PIECES;
         const int r = pix / IC, x = pix - r * IC;
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
         for (int k = 0; k < NPRE; ++k) {
             uint4 v[PA];
             patch_load(0, k, v);
-            patch_store(lds, k, v);
+            patch_put(lds, k, v);
         }
         __syncthreads();
     }
@@ -224,7 +285,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #pragma unroll
             for (int k = 0; k < NPRE; ++k) {
                 uint4 v[PA];
-                patch_load(c0, k, v);
+                patch_load_cond(c0, k, v);
                 patch_store(lds, k, v);
             }
             __syncthreads();
@@ -247,27 +308,36 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             }
         uint4 pre[DB ? NPRE : 1][PA];
         const bool more = DB && c0 + CH < 256;
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < NPRE; ++k) patch_load(c0 + CH, k, pre[k]);
-        }
+        const int cn = min(c0 + CH, 256 - CH);            // the last chunk re-requests itself (L2 hits) rather than branch
+        constexpr int NKS = (NK - DEPTH > 1) ? NK - DEPTH : 1;   // the pieces are spread over the first NKS k-steps
+#if CV_ABL & 8
+        uint4 a[PA][MT];
+#endif
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
+#if !(CV_ABL & 8)
+            uint4 a[PA][MT];
+#endif
             uint4 bcur[NT][PA];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int p = 0; p < PA; ++p) bcur[nt][p] = bq[j % DEPTH][nt][p];
-            if (j + DEPTH < NK) {
+            if (j + DEPTH < NK && !(CV_ABL & 2)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int p = 0; p < PA; ++p)
                         bq[j % DEPTH][nt][p] = *(const uint4*)(wbase + nt * W_NT + p * w_plane + (int64_t)kstep_of(j + DEPTH) * 512);
             }
+            if (DB && !(CV_ABL & 1)) {
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k)
+                    if (k >= (j * NPRE + NKS - 1) / NKS && (k < ((j + 1) * NPRE + NKS - 1) / NKS || j == NK - 1)) patch_load(cn, k, pre[k]);
+            }
             const int tap = j / (CH / 16), kk = j - tap * (CH / 16);
             const int dy = tap / KS, dx = tap - dy * KS;
-            uint4 a[PA][MT];
+            if (!(CV_ABL & 8) || j == 0)
 #pragma unroll
             for (int p = 0; p < PA; ++p)
 #pragma unroll
@@ -292,36 +362,56 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
             if (more) {
                 uint16_t* nxt = lds + (((c0 / CH) + 1) & 1) * (PA * G::PLANE);
 #pragma unroll
-                for (int k = 0; k < NPRE; ++k) patch_store(nxt, k, pre[k]);
+                for (int k = 0; k < NPRE; ++k) patch_put(nxt, k, pre[k]);
             }
             __syncthreads();
         }
     }
 
-    // ---- epilogue: fp32 NHWC store (32 lanes = 128 contiguous bytes of a pixel) + GroupNorm partial sums
+    // ---- epilogue: GroupNorm partial sums from the accumulators; fp32 NHWC store through a per-wave LDS transposition
+    //      (C layout: a lane holds 16 pixels of ONE channel; memory wants 4 consecutive channels of one pixel per lane).  One
+    //      output row of the wave at a time: 64 pixels x 32 channels = 8 KB per wave, pixel rows swizzled by bit 2 (= kg on the
+    //      write side) so that both the 4-byte writes and the 16-byte reads touch every bank once; then 8 stores of 16 bytes
+    //      per lane (8 pixels x 128 contiguous bytes per instruction) instead of 32 of 4 bytes.
     float s1[NT], s2[NT];
+    float* tbuf = (float*)lds + wv * 2048;
+    // (the single-plane kernels: the last chunk's closing barrier has passed, the LDS is free)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         s1[nt] = 0.f;
         s2[nt] = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int row = 0; row < MT / 2; ++row) {
+            const int oy = oy0 + row_base + row;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = (mt & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
-                const int ox = ox0 + px, oy = oy0 + row_base + (mt >> 1);
-                if (oy < Ho && ox < Wo) {
-                    const float v = acc[mt][nt][r];
-                    Y[(((int64_t)b * Ho + oy) * Wo + ox) * 256 + (wc * NT + nt) * 32 + m] = v;
-                    s1[nt] += v;
-                    s2[nt] += v * v;
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;  // C layout: row = pixel, col = channel
+                    const float v = acc[row * 2 + half][nt][r];
+                    if (DB) tbuf[(px ^ kg) * 32 + m] = v;
+                    if (oy < Ho && ox0 + px < Wo) {
+                        if (!DB) Y[(((int64_t)b * Ho + oy) * Wo + ox0 + px) * 256 + (wc * NT + nt) * 32 + m] = v;
+                        s1[nt] += v;
+                        s2[nt] += v * v;
+                    }
+                }
+            if (!DB) continue;                            // (the two-plane kernels keep the direct stores below)
+            if (oy < Ho) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int P = (lane >> 3) + 8 * i;
+                    const float4 v = *(const float4*)(tbuf + (P ^ ((P >> 2) & 1)) * 32 + (lane & 7) * 4);
+                    if ((CV_ABL & 4) && v.x != 12345.f) continue;
+                    if (ox0 + P < Wo) *(float4*)(Y + (((int64_t)b * Ho + oy) * Wo + ox0 + P) * 256 + (wc * NT + nt) * 32 + (lane & 7) * 4) = v;
                 }
             }
+        }
         s1[nt] += __shfl_xor(s1[nt], 32);
         s2[nt] += __shfl_xor(s2[nt], 32);
     }
     const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
-#ifdef CV_WAVES_1X8
+#ifndef CV_WAVES_2X4
     if (kg == 0) {
         float* o = partial + (((int64_t)b * nwg + wg) * 256 + wc * 32 + m) * 2;
         o[0] = s1[0];
@@ -330,7 +420,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #else
     // the two row halves of a channel meet in LDS (fixed order: upper rows + lower rows)
     float* red = (float*)lds;                             // [256 channels][2]
-    if (!DB) __syncthreads();                             // the last chunk's readers are done (DB: its closing barrier)
+    __syncthreads();                                      // the transposition buffers are done
     if (row_base != 0 && kg == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -366,6 +456,7 @@ static int conv_th(int Ho, int Wo, int prec, int B) {
 
 // workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
 extern "C" int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B) {
+    prec &= ~PH_PLANES_C16;
     const int th = conv_th(Ho, Wo, prec, B);
     return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + th - 1) / th);
 }
@@ -381,6 +472,9 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
                             int stride, int B, int H, int W, int prec, void* stream) {
     PH_CHECK_ARG(X && Wp && Y && partial && B > 0 && H > 0 && W > 0, "bad pointer or size");
     PH_CHECK_ARG((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1), "supported: 3x3 stride 1/2, 1x1 stride 1");
+    const int c16 = (prec & PH_PLANES_C16) ? 1 : 0;
+    prec &= ~PH_PLANES_C16;
+    PH_CHECK_ARG(!c16 || (ksize == 3 && stride == 2 && prec != PH_PREC_SPLIT), "PH_PLANES_C16 input: the one-plane 3x3 stride-2 kernel only");
     PH_CHECK_ARG(prec == PH_PREC_BF16 || prec == PH_PREC_SPLIT || prec == PH_PREC_F16, "prec must be PH_PREC_BF16, PH_PREC_SPLIT or PH_PREC_F16");
     const int pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -390,7 +484,8 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
     hipStream_t s = (hipStream_t)stream;
 #define PH_CV_T(PA, KS, S, EE, TT)                                                                                       \
     do {                                                                                                                 \
-        const size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA, TT>::PLANE * sizeof(uint16_t);            \
+        size_t lds = (size_t)(PA == 1 ? 2 : 1) * PA * ConvGeo<KS, S, PA, TT>::PLANE * sizeof(uint16_t);                  \
+        if (lds < 65536) lds = 65536;                          /* the epilogue's 8 x 8 KB transposition buffers */        \
         static const bool once = [&] {                                                                                   \
             (void)hipFuncSetAttribute((const void*)k_conv_nhwc<PA, KS, S, EE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                         \
@@ -398,7 +493,7 @@ extern "C" int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_pla
         }();                                                                                                             \
         (void)once;                                                                                                      \
         hipLaunchKernelGGL((k_conv_nhwc<PA, KS, S, EE, TT>), grid, dim3(512), lds, s, X, x_plane, Wp, w_plane_elems, Y, partial, \
-                           B, H, W, Ho, Wo);                                                                             \
+                           B, H, W, Ho, Wo, c16);                                                                        \
     } while (0)
 #define PH_CV(PA, KS, S, EE)                                                                                             \
     do {                                                                                                                 \

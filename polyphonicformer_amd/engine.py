@@ -712,9 +712,9 @@ class NeckPlan:
         d["_streams"] = None               # HIP streams cannot be copied / pickled (copy.deepcopy of a module that holds a plan)
         return d
 
-    def _conv_gn(self, xp, pk, H, W, groups, y, stats, partial=None):
+    def _conv_gn(self, xp, pk, H, W, groups, y, stats, partial=None, layout=0):
         """conv + statistics; returns the conv output size"""
-        B, prec = self.B, self.prec
+        B, prec = self.B, self.prec | layout
         partial = self.partial if partial is None else partial
         k, s = pk["k"], pk["s"]
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
@@ -728,17 +728,22 @@ class NeckPlan:
         B, prec = self.B, self.prec
         H, W = self.shapes[lvl]
         xa, xb, y, stats, partial = bufs["xa"], bufs["xb"], bufs["y"], bufs["stats"], bufs["partial"]
-        nhwc_ingest(feat, posenc, prec, xa)
-        src = xa
         convs = pk["levels"][lvl]
+        # a level that starts with the stride-2 conv (level 0) hands it chunk-major planes (PH_PLANES_C16: the kernel's 16-channel
+        # stages then read whole lines; PH_NECK_C16=0: channels-last, A/B timing)
+        c16 = _lib.PH_PLANES_C16 if (convs[0]["s"] == 2 and convs[0]["k"] == 3 and prec != _lib.PH_PREC_SPLIT
+                                     and _os.environ.get("PH_NECK_C16", "1") != "0") else 0
+        nhwc_ingest(feat, posenc, prec | c16, xa)
+        src = xa
         for j, c in enumerate(convs):
+            lay = c16 if j == 0 else 0
             if j + 1 < len(convs):      # every non-final conv of levels 2 and 3 is followed by an x2 upsample
-                H, W = self._conv_gn(src, c, H, W, groups, y, stats, partial)
+                H, W = self._conv_gn(src, c, H, W, groups, y, stats, partial, lay)
                 dst = xb if src is xa else xa
                 gn_apply(y, stats, c, groups, _lib.PH_GN_UP2_PLANES, B, H, W, prec, planes=dst)
                 H, W, src = 2 * H, 2 * W, dst
             else:
-                H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl], partial)
+                H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl], partial, lay)
                 if (H, W) != (self.Ho, self.Wo):
                     raise _lib.PolyheadError("level does not end at the stride-8 size")
 

@@ -59,6 +59,38 @@ def test_conv_nhwc(gpu, prec, k, s, H, W, B):
     assert Hh.rel_err(stats.cpu()[..., 1], 1.0 / torch.sqrt(gm.var(2, unbiased=False) + 1e-5)) < 1e-4
 
 
+@pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_F16])
+@pytest.mark.parametrize("H,W,B", [(9, 131, 2), (72, 2048, 2), (256, 512, 1), (7, 5, 3)])
+def test_chunk_major_planes_for_the_stride2_conv(gpu, prec, H, W, B):
+    """PH_PLANES_C16: ph_nhwc_ingest writes [B][16][HW][16], the 3x3 stride-2 kernel reads it -- every plane element is the
+    channels-last plane's, and the conv output and GroupNorm partial sums keep their bits (same products, same order)"""
+    g = torch.Generator().manual_seed(H + W)
+    x = (torch.randn(B, 256, H, W, generator=g) * 2).to(gpu)
+    w = torch.randn(256, 256, 3, 3, generator=g) * 0.05
+    wpl = E._planes_of(w.double().permute(0, 2, 3, 1).reshape(256, -1), 1, prec == _lib.PH_PREC_F16)
+    wp = pack_b32(wpl[0])[None].contiguous().to(gpu)
+    nhwc = torch.empty((1, B, H * W, 256), dtype=torch.int16, device=gpu)
+    c16 = torch.full((1, B, H * W, 256), 0x7FFF, dtype=torch.int16, device=gpu)
+    E.nhwc_ingest(x, None, prec, nhwc)
+    E.nhwc_ingest(x, None, prec | _lib.PH_PLANES_C16, c16)
+    assert torch.equal(c16.view(B, 16, H * W, 16).permute(0, 2, 1, 3).reshape(B, H * W, 256), nhwc[0])
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    lib = _lib.load()
+    outs = []
+    for planes, flag in ((nhwc, 0), (c16, _lib.PH_PLANES_C16)):
+        y = torch.empty((B, Ho * Wo, 256), dtype=torch.float32, device=gpu)
+        partial = torch.zeros((lib.ph_conv_nhwc_partial_floats(B, Ho, Wo),), dtype=torch.float32, device=gpu)
+        E.conv_nhwc(planes, dict(wp=wp, k=3, s=2), y, partial, B, H, W, prec | flag)
+        outs.append((y.cpu(), partial.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert lib.ph_conv_nhwc_workgroups_b(3, 2, Ho, Wo, prec | _lib.PH_PLANES_C16, B) == lib.ph_conv_nhwc_workgroups_b(3, 2, Ho, Wo, prec, B)
+    # refused where it has no meaning: stride 1, the two-plane format
+    with pytest.raises(_lib.PolyheadError):
+        E.conv_nhwc(c16, dict(wp=wp, k=3, s=1), y, partial, B, H, W, prec | _lib.PH_PLANES_C16)
+    with pytest.raises(_lib.PolyheadError):
+        E.nhwc_ingest(x, None, _lib.PH_PREC_SPLIT | _lib.PH_PLANES_C16, torch.empty((2, B, H * W, 256), dtype=torch.int16, device=gpu))
+
+
 @pytest.mark.parametrize("prec", [_lib.PH_PREC_BF16, _lib.PH_PREC_F16, _lib.PH_PREC_SPLIT])
 @pytest.mark.parametrize("H,W,with_add", [(128, 256, False), (16, 32, True), (6, 70, False), (3, 28, True), (5, 7, False)])
 def test_nhwc_ingest_exact(gpu, prec, H, W, with_add):

@@ -1,5 +1,5 @@
 """times k_conv_nhwc alone (3x3 stride 1 at 128x256, 3x3 stride 2 at 256x512 -> 128x256, 1x1 at 128x256; 16 frames, fp16 grade) for
-same-box A/B of library variants.  usage: python tools/conv_ab.py [path of an alternative libpolyhead.so] [B]"""
+same-box A/B of library variants.  usage: python tools/conv_ab.py [path of an alternative libpolyhead.so | -] [B] [c16]"""
 import sys, torch
 sys.path.insert(0, ".")
 from polyphonicformer_amd import _lib
@@ -22,7 +22,8 @@ for (k, s, H, W) in ((3, 1, 128, 256), (3, 2, 256, 512), (3, 1, 64, 128)):
     y = torch.empty((B, Ho * Wo, 256), dtype=torch.float32, device=dev)
     partial = torch.zeros((lib.ph_conv_nhwc_partial_floats(B, Ho, Wo),), dtype=torch.float32, device=dev)
     pk = dict(wp=wp, k=k, s=s)
-    ts = [time_op(lambda: E.conv_nhwc(x, pk, y, partial, B, H, W, prec), 10, warm=2) for _ in range(3)]
+    lay = _lib.PH_PLANES_C16 if (s == 2 and len(sys.argv) > 3 and sys.argv[3] == "c16") else 0   # timing only: the same bytes read as chunk-major
+    ts = [time_op(lambda: E.conv_nhwc(x, pk, y, partial, B, H, W, prec | lay), 10, warm=2) for _ in range(3)]
     fl = 2.0 * B * Ho * Wo * 256 * k * k * 256
     out.append(f"{k}x{k}s{s}@{H}x{W}: {min(ts)*1e3:.0f} us {fl/min(ts)/1e12:.0f} TF/s")
 print(_lib.LIB_PATH.split('/')[-1], "|", " | ".join(out), "| checksum", float(y.double().sum()))

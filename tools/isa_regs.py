@@ -13,4 +13,5 @@ for blk in meta.split("  - .agpr_count:")[1:]:
         name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()[:90]
     except Exception:
         pass
-    print(f"agpr {blk.split()[0]:>4} vgpr {g(chr(39)+"vgpr_count"+chr(39)):>4} spill {g('vgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} sgpr {g('sgpr_count'):>4} lds {g('group_segment_fixed_size'):>6}  {name}")
+    print(f"agpr {blk.split()[0]:>4} vgpr {g('vgpr_count'):>4} spill {g('vgpr_spill_count'):>3} scratch {g('private_segment_fixed_size'):>4} "
+          f"sgpr {g('sgpr_count'):>4} lds {g('group_segment_fixed_size'):>6}  {name}")
