@@ -603,6 +603,11 @@ int ph_tracker_rows(const ph_tracker* t);
 void ph_tracker_debug_times(const ph_tracker* t, double* out6);   /* accumulated host seconds per phase of `match` (csrc/ph_tracker.hip) */
 int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t* labels, const float* embeds_dev, int n, int64_t frame_id,
                      int32_t* kept_out, int64_t* ids_out, void* stream);
+/* a whole step's frames in one call (`video.replay_tracking` after the all-gather): frame f's rows of boxes / labels / kept_out /
+   ids_out start at sum(counts[0..f-1]); embeds_dev[f]: that frame's [counts[f]][256] device rows; frames without detections are
+   skipped and do not advance the frame counter (polyphonic_former_video.py:391-402).  Returns the number of frames matched. */
+int ph_tracker_match_frames(ph_tracker* t, const float* boxes, const int64_t* labels, const float* const* embeds_dev, const int32_t* counts,
+                            int nframes, int64_t first_frame_id, int32_t* kept_out, int64_t* ids_out, int32_t* kept_counts, void* stream);
 
 /* ---- self tests of the gfx950 fragment layouts the kernels rely on (tests/test_gpu_selftest.py) */
 int ph_selftest_mfma16(const uint16_t* a /*[16][32]*/, const uint16_t* bt /*[16][32]*/, float* d /*[16][16]*/, void* stream);

@@ -142,6 +142,7 @@ SIGNATURES = {
     "ph_tracker_rows": (C.c_int, [_P]),
     "ph_tracker_debug_times": (None, [_P, _P]),
     "ph_tracker_match": (C.c_int, [_P, _P, _P, _P, _I, _L, _P, _P, _P]),
+    "ph_tracker_match_frames": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P]),
     "ph_selftest_mfma16": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_mfma32": (C.c_int, [_P, _P, _P, _P]),
     "ph_selftest_readbw": (C.c_int, [_P, _L, _I, _P, _P]),

@@ -326,3 +326,31 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     PH_CHECK_LAUNCH();
     return k;
 }
+
+// A whole step's frames in ONE call (the sharded video step replays every rank's frames in frame order, `video.replay_tracking`):
+// boxes [sum n][5] / labels [sum n] on the host, frame f's rows at offset sum(counts[0..f-1]); embeds_dev[f] = that frame's
+// [counts[f]][256] device rows.  Frames without detections are skipped and do not advance the frame counter (the reference calls
+// `match` only when there are thing segments, polyphonic_former_video.py:391-402); the counter starts at first_frame_id.
+// kept_out / ids_out: per frame at the same offsets, kept_counts[f] entries valid.  Returns the number of frames matched (>= 0).
+extern "C" int ph_tracker_match_frames(ph_tracker* t, const float* boxes, const int64_t* labels, const float* const* embeds_dev, const int32_t* counts,
+                                       int nframes, int64_t first_frame_id, int32_t* kept_out, int64_t* ids_out, int32_t* kept_counts, void* stream) {
+    PH_CHECK_ARG(t && counts && kept_out && ids_out && kept_counts && nframes >= 0, "bad pointer or size");
+    int64_t fid = first_frame_id;
+    int matched = 0;
+    size_t off = 0;
+    for (int f = 0; f < nframes; ++f) {
+        const int n = counts[f];
+        PH_CHECK_ARG(n >= 0, "negative detection count");
+        kept_counts[f] = 0;
+        if (n > 0) {
+            PH_CHECK_ARG(boxes && labels && embeds_dev && embeds_dev[f], "bad pointer or size");
+            const int k = ph_tracker_match(t, boxes + off * 5, labels + off, embeds_dev[f], n, fid, kept_out + off, ids_out + off, stream);
+            if (k < 0) return k;
+            kept_counts[f] = k;
+            ++fid;
+            ++matched;
+        }
+        off += (size_t)n;
+    }
+    return matched;
+}

@@ -187,13 +187,11 @@ class QuasiDenseEmbedTracker(object):
     NATIVE_CAPACITY, NATIVE_MAX_DETS = 4096, 128
     native = True                 # False: the array form below also for GPU embeddings (tests compare the two)
 
-    def _match_native(self, bboxes, labels, track_feats, frame_id):
-        """csrc/ph_tracker.hip: bookkeeping in C++, embeddings in a device pool, per frame two small uploads, six launches and
-        ONE synchronising download (the [detections x memory] scores).  Same integer ids as the array form below."""
+    def _native_handle(self, dev):
+        """the C++ tracker object of this stream (csrc/ph_tracker.hip), created on first use on the embeddings' device"""
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        dev = track_feats.device
         if self._native is None:
             if len(self.table) or self._num_tracklets:
                 raise _lib.PolyheadError("QuasiDenseEmbedTracker: a tracker that started on CPU embeddings cannot continue on the GPU")
@@ -213,6 +211,47 @@ class QuasiDenseEmbedTracker(object):
             self._native = (C.c_void_p(h), mem, dev)
         if dev != self._native[2]:
             raise _lib.PolyheadError("QuasiDenseEmbedTracker: the embeddings moved to another device mid-stream")
+        return self._native[0]
+
+    def native_ready(self, n, emb):
+        """True if `match` of n detections with these embeddings takes the native path"""
+        return bool(self.native and emb.is_cuda and n <= self.NATIVE_MAX_DETS and emb.shape[1] == 256
+                    and (self._native is not None or (len(self.table) == 0 and self._num_tracklets == 0)))
+
+    def match_frames(self, boxes, labels, embeds, first_frame_id):
+        """a step's frames in ONE native call (`ph_tracker_match_frames`): boxes [sum n, 5] float32 / labels [sum n] int64 numpy arrays
+        on the host, embeds: per frame a [n, 256] device tensor (frames without detections: n = 0, skipped like the reference's loop).
+        Returns per frame the int64 ids of its kept detections in `match`'s order, and the number of frames matched."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        nf = len(embeds)
+        counts = np.asarray([int(e.shape[0]) for e in embeds], dtype=np.int32)
+        tot = int(counts.sum())
+        dev = next((e.device for e in embeds if e.shape[0]), None)
+        if dev is None:
+            return [np.empty((0,), dtype=np.int64) for _ in embeds], 0
+        h = self._native_handle(dev)
+        embs = [e.detach().float().contiguous() for e in embeds]
+        ptrs = (C.c_void_p * nf)(*[e.data_ptr() if e.shape[0] else None for e in embs])
+        box = np.ascontiguousarray(boxes, dtype=np.float32)
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        kept, ids, kc = np.empty((max(tot, 1),), dtype=np.int32), np.empty((max(tot, 1),), dtype=np.int64), np.empty((nf,), dtype=np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        m = lib.ph_tracker_match_frames(h, vp(box), vp(lab), ptrs, vp(counts), nf, int(first_frame_id), vp(kept), vp(ids), vp(kc), _lib.stream_ptr())
+        if m < 0:
+            _lib.check(m, "ph_tracker_match_frames")
+        o = np.concatenate([[0], np.cumsum(counts)])
+        return [ids[o[f]:o[f] + kc[f]].copy() for f in range(nf)], int(m)
+
+    def _match_native(self, bboxes, labels, track_feats, frame_id):
+        """csrc/ph_tracker.hip: bookkeeping in C++, embeddings in a device pool, per frame two small uploads, six launches and
+        ONE synchronising download (the [detections x memory] scores).  Same integer ids as the array form below."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = track_feats.device
+        handle = self._native_handle(dev)
         # boxes / labels: torch tensors (any device) or host numpy arrays (`replay_tracking` downloads a whole step's at once)
         box = bboxes if isinstance(bboxes, np.ndarray) else bboxes.detach().cpu().float().numpy()
         lab = labels if isinstance(labels, np.ndarray) else labels.detach().cpu().long().numpy()
@@ -220,7 +259,7 @@ class QuasiDenseEmbedTracker(object):
         emb = track_feats.detach().float().contiguous()
         n = box.shape[0]
         kept, ids = np.empty((max(n, 1),), dtype=np.int32), np.empty((max(n, 1),), dtype=np.int64)
-        k = lib.ph_tracker_match(self._native[0], box.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), _lib.ptr(emb), n, int(frame_id),
+        k = lib.ph_tracker_match(handle, box.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), _lib.ptr(emb), n, int(frame_id),
                                  kept.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), _lib.stream_ptr())
         if k < 0:
             _lib.check(k, "ph_tracker_match")
@@ -352,6 +391,16 @@ def replay_tracking(records, tracker_cfg=None, tracker=None, first_count=1):
             bl = torch.cat([torch.cat([r[1].float(), r[2].float()[:, None]], 1) for r in records if r[1].shape[0]], 0).cpu().numpy()
             o = np.cumsum([0] + ns)
             records = [(r[0], bl[o[i]:o[i + 1], :5], bl[o[i]:o[i + 1], 5].astype(np.int64), r[3]) for i, r in enumerate(records)]
+    if records and all(isinstance(r[1], np.ndarray) and tracker.native_ready(r[1].shape[0], r[3]) for r in records):
+        # device embeddings, host boxes: the whole step in ONE native call (a Python round trip per frame was half of the 0.13 ms a
+        # frame's replay cost)
+        per_frame, matched = tracker.match_frames(np.concatenate([r[1] for r in records], 0) if records else None,
+                                                  np.concatenate([r[2] for r in records], 0), [r[3] for r in records], cnt)
+        for r, ids in zip(records, per_frame):
+            ids = ids + 1
+            ids[ids == -1] = 0
+            out[r[0]] = torch.from_numpy(ids)
+        return out
     for fid, bb, lab, emb in records:
         if bb.shape[0] > 0:
             if isinstance(bb, np.ndarray) and not (tracker.native and emb.is_cuda and bb.shape[0] <= tracker.NATIVE_MAX_DETS):
@@ -444,27 +493,41 @@ class VideoAssociator:
         bboxes = torch.cat([ext_h, torch.tensor(score, dtype=torch.float32)[:, None]], 1)
         return seg_ids, (bboxes, torch.tensor(labels, dtype=torch.int64), embeds)            # the embeddings stay on the device
 
-    def _maps_on_device(self, pan_dev, segments_info, seg_ids, ids, to_host=True):
-        """get_semantic_seg / generate_track_id_maps (:436-451) as two table look-ups on the device copy of the id map
-        (the host versions `semantic_map` / `track_id_map` walk 2 M pixels in numpy: 10 ms per 1024x2048 frame)"""
+    def _sem_map_device(self, pan_dev, segments_info):
+        """get_semantic_seg (:436-443) as a table look-up on the device copy of the id map; returns (sem uint8 map, the int64
+        index map both look-ups share).  It needs nothing from the tracker, so callers may start its download early."""
         n = int(max([s['id'] for s in segments_info], default=0)) + 1
         sem_lut = torch.full((n,), self.num_thing_classes + self.num_stuff_classes, dtype=torch.uint8)
-        trk_lut = torch.zeros((n,), dtype=torch.float64)
         for s in segments_info:
             sem_lut[s['id']] = s['category_id']
+        idx = pan_dev.long()
+        return sem_lut.pin_memory().to(pan_dev.device, non_blocking=True)[idx], idx
+
+    def _trk_map_device(self, idx, segments_info, seg_ids, ids):
+        """generate_track_id_maps (:445-451): float64 map of the track ids painted onto their segments"""
+        n = int(max([s['id'] for s in segments_info], default=0)) + 1
+        trk_lut = torch.zeros((n,), dtype=torch.float64)
         for sid, tid in zip(seg_ids, ids):
             trk_lut[sid] = float(tid)
-        idx = pan_dev.long()
-        sem = sem_lut.pin_memory().to(pan_dev.device, non_blocking=True)[idx]
-        trk = trk_lut.pin_memory().to(pan_dev.device, non_blocking=True)[idx]
+        return trk_lut.pin_memory().to(idx.device, non_blocking=True)[idx]
+
+    def _maps_on_device(self, pan_dev, segments_info, seg_ids, ids, to_host=True):
+        """both maps as two table look-ups on the device copy of the id map (the host versions `semantic_map` / `track_id_map`
+        walk 2 M pixels in numpy: 10 ms per 1024x2048 frame)"""
+        sem, idx = self._sem_map_device(pan_dev, segments_info)
+        trk = self._trk_map_device(idx, segments_info, seg_ids, ids)
         if not to_host:
             return sem, trk
         return sem.cpu().numpy(), trk.cpu().numpy()
 
-    def step_device(self, fpn_feats, pan_dev, segments_info):
+    def step_device(self, fpn_feats, pan_dev, segments_info, early=None):
         """`step` on the DEVICE copy of the panoptic id map, results left on the device: (sem uint8, track float64) maps.
         Same kernels, same tracker calls, same values as `step` -- for callers that overlap the result download with the
-        next frame (`VideoStreamRunner`)."""
+        next frame (`VideoStreamRunner`).  `early(sem)` is called as soon as the semantic map is queued -- before the boxes,
+        RoIAlign, embeddings and the tracker -- so that its download can run under them."""
+        sem, idx = self._sem_map_device(pan_dev, segments_info)
+        if early is not None:
+            early(sem)
         seg_ids, rec = self.record(fpn_feats, None, segments_info, pan_dev)
         ids = []
         if rec is not None:
@@ -473,7 +536,7 @@ class VideoAssociator:
             ids = ids + 1
             ids[ids == -1] = 0
             ids = ids.tolist()
-        return self._maps_on_device(pan_dev, segments_info, seg_ids, ids, to_host=False)
+        return sem, self._trk_map_device(idx, segments_info, seg_ids, ids)
 
     def step(self, fpn_feats, panoptic_seg, segments_info, depth_final, records_only=False):
         pan_dev = torch.from_numpy(panoptic_seg).to(fpn_feats[0].device)
@@ -722,22 +785,31 @@ class VideoStreamRunner:
     def _finish(self, i):
         """merge -> association -> start the download of frame (slot i)'s result maps"""
         pan_dev, info, _, d_final = self._merge(i)
-        sem, trk = self.pipe.assoc.step_device(self._frame_levels(i), pan_dev, info)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
-        main = torch.cuda.current_stream()
-        done_main = torch.cuda.Event()
-        done_main.record(main)
-        # fresh pinned buffers (the caller owns them); the device sources stay referenced until the copy has finished
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (sem, trk, d_final)]
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(done_main)
-            for h, t in zip(host, (sem, trk, d_final)):
-                t.record_stream(self._copy_stream)
+        main, cs = torch.cuda.current_stream(), self._copy_stream
+        host, kept = [], []
+
+        def download(t):
+            # fresh pinned buffers (the caller owns them); the device sources stay referenced until the copy has finished.  Each
+            # map starts its way to the host as soon as it is queued: the depth map right after the merge, the semantic map before
+            # the association, only the track-id map (16 of the 27 MB of a 1024 x 2048 frame) after the tracker
+            ready = torch.cuda.Event()
+            ready.record(main)
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            with torch.cuda.stream(cs):
+                cs.wait_event(ready)
+                t.record_stream(cs)
                 h.copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self._copy_stream)
-        self._downloads.append((ev, host, (sem, trk, d_final)))
+            host.append(h)
+            kept.append(t)
+
+        download(d_final)
+        sem, trk = self.pipe.assoc.step_device(self._frame_levels(i), pan_dev, info, early=download)
+        download(trk)
+        ev = torch.cuda.Event()
+        ev.record(cs)
+        self._downloads.append((ev, [host[1], host[2], host[0]], tuple(kept)))       # (sem, track, depth)
 
     @staticmethod
     def _collect(p):

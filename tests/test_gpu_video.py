@@ -328,6 +328,41 @@ def test_native_tracker_long_stream_and_timing(gpu):
     assert nat.num_tracklets == cpu.num_tracklets and per < 0.3
 
 
+def test_replay_of_a_step_in_one_native_call(gpu):
+    """`replay_tracking` hands a whole step's frames (device embeddings) to ph_tracker_match_frames: the ids are those of the
+    frame-by-frame calls and of the CPU form -- empty frames in between included, over several steps of one persistent tracker"""
+    import time
+    from polyphonicformer_amd import video as V
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+    recs = [r for s_ in range(6) for r in Hh.tracker_records(300 + s_, nframes=8, nobj=30)]
+    empty = (torch.zeros((0, 5)), torch.zeros((0,), dtype=torch.long), torch.zeros((0, 256)))
+    recs = [(i, *(empty if i % 7 == 3 else r[1:])) for i, r in enumerate(recs)]
+    dev = [(f, bb.to(gpu), lab.to(gpu), emb.to(gpu)) for f, bb, lab, emb in recs]
+    ref = V.replay_tracking(recs, cfg)                                         # CPU form, frame by frame
+    one = V.QuasiDenseEmbedTracker(**cfg)
+    got, cnt, calls = {}, 1, []
+    orig = one.match_frames
+    one.match_frames = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    t0 = time.perf_counter()
+    for s0 in range(0, len(dev), 8):                                           # steps of 8 frames, any order within a step
+        step = dev[s0:s0 + 8][::-1]
+        got.update(V.replay_tracking(step, tracker=one, first_count=cnt))
+        cnt += sum(1 for r in step if r[1].shape[0])
+    per = (time.perf_counter() - t0) / len(dev) * 1e3
+    assert len(calls) == len(dev) // 8, "the step did not take the batched native call"
+    assert set(got) == set(ref) and all(torch.equal(got[f], ref[f]) for f in ref)
+    per_frame = V.QuasiDenseEmbedTracker(**cfg)
+    cnt = 1
+    for f, bb, lab, emb in dev:
+        if bb.shape[0]:
+            ids = per_frame.match(bboxes=bb, labels=lab, track_feats=emb, frame_id=cnt)[2] + 1
+            ids[ids == -1] = 0
+            assert torch.equal(ids, ref[f])
+            cnt += 1
+    print(f"replay, one native call per 8-frame step: {per:.3f} ms per frame (first steps include the object's creation)")
+
+
 def test_affinity_beyond_the_fused_kernels_limits(gpu):
     """more than 128 detections or 4096 memory columns must not abort the video -- the same formula runs as
     torch ops on the device and agrees with the host formulation"""
