@@ -324,7 +324,8 @@ static int launch_conv(const uint16_t* planes, const uint16_t* kern, int64_t kps
     const int64_t total = (int64_t)B * (HWp / CONV_T);
     // one persistent workgroup per CU (it owns the CU's LDS), tiles split evenly: no tail generation
     int wgs = conv_num_cus();
-    if (const char* e = getenv("PH_CONV_WGS")) wgs = atoi(e);   // tuning knob
+    static const int wgs_env = [] { const char* e = getenv("PH_CONV_WGS"); return e ? atoi(e) : 0; }();   // tuning knob, read once
+    if (wgs_env) wgs = wgs_env;
     if (wgs > total) wgs = (int)total;
     if (wgs < 1) wgs = 1;
     const dim3 grid(wgs);

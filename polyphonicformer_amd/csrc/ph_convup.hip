@@ -407,11 +407,13 @@ static void launch_up(const uint16_t* planes, const uint16_t* kern, int64_t kbs,
     constexpr int NTR = 4;
     const int64_t rows = (int64_t)B * H;
     int wgs = up_num_cus();
-    if (const char* e = getenv("PH_UP2_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;      // tuning / test knob: rows per workgroup
+    // test knob, read per launch on purpose (tests/test_gpu_kernels.py switches it inside one process; an eager launch pays one
+    // environment look-up, a graph replay none)
+    if (const char* e = getenv("PH_UP2_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
     if (wgs > rows) wgs = (int)rows;
     const dim3 grid(wgs), block((NRT + 1) * 64);
     constexpr int lds = UpCfg<NRT>::LDSB;
-    const int dbg = getenv("PH_UP2_DBG") ? atoi(getenv("PH_UP2_DBG")) : 0;     // timing experiments only
+    static const int dbg = [] { const char* e = getenv("PH_UP2_DBG"); return e ? atoi(e) : 0; }();     // timing experiments only, read once
 #define UP_GO(LR)                                                                                                             \
     do {                                                                                                                      \
         static const bool once = [] {                                                                                         \

@@ -367,7 +367,8 @@ extern "C" int ph_panoptic_argmax(const float* act_mask, const float* scores, in
     hipLaunchKernelGGL(k_pan_clear, dim3((2 * K + 255) / 256), dim3(256), 0, s, counts, 2 * K);
     const int grid = grid_for((int64_t)G.Ho * G.Wo);
     const size_t lds = (size_t)2 * K * sizeof(int);
-    const bool generic_only = getenv("PH_PAN_GENERIC") != nullptr;             // tests: the generic kernel on the x4 geometry
+    // tests: the generic kernel on the x4 geometry (read per launch on purpose: tests/test_gpu_panoptic.py switches it in-process)
+    const bool generic_only = getenv("PH_PAN_GENERIC") != nullptr;
     const bool x4 = !from_probs && !generic_only && G.h == G.Ho && G.w == G.Wo && G.Hb == 4 * G.sh && G.Wb == 4 * G.sw;
     if (x4) {
         const int64_t nblk = (int64_t)((G.Wo + 3) >> 2) * ((G.Ho + 1) >> 1);

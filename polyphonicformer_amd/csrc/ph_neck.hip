@@ -845,7 +845,8 @@ extern "C" int ph_gn_sum_cplanes(const float* const* ys, const float* const* sta
     const int64_t HWp = ph_hw_padded(HW), ntiles = HWp / 64;
     int tpw = (int)((ntiles * B + 2047) / 2048);            // ~2048 workgroups: the 4-level affine set-up is amortised over the tiles
     if (tpw < 1) tpw = 1;
-    if (const char* e = getenv("PH_GNSUM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    static const int tpw_env = [] { const char* e = getenv("PH_GNSUM_TPW"); return e ? atoi(e) : 0; }();     // tuning knobs, read once
+    if (tpw_env > 0) tpw = tpw_env;
     const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), B);
     const size_t lds = 256 * 65 * sizeof(float);
     static const bool once = [&] {
@@ -875,7 +876,8 @@ extern "C" int ph_gn_sum_planes(const float* const* ys, const float* const* stat
         a.y[l] = ys[k]; a.stats[l] = stats[k]; a.gamma[l] = gammas[k]; a.beta[l] = betas[k];
     }
     int gx = 1024;                     // several pixels per workgroup: its per-channel affine set-up (4 levels) is amortised
-    if (const char* e = getenv("PH_GNSUM_WGS")) gx = atoi(e);
+    static const int gx_env = [] { const char* e = getenv("PH_GNSUM_WGS"); return e ? atoi(e) : 0; }();
+    if (gx_env) gx = gx_env;
     if ((HW + 3) / 4 < gx) gx = (int)((HW + 3) / 4);
     if (prec == PH_PREC_F16) hipLaunchKernelGGL((k_gn_sum_planes<1, PH_E_F16>), dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
     else if (prec == PH_PREC_BF16) hipLaunchKernelGGL(k_gn_sum_planes<1>, dim3(gx, 1, B), dim3(256), 0, (hipStream_t)stream, a, nlev, groups, planes, B, HW);
@@ -899,7 +901,8 @@ extern "C" int ph_gn_apply(const float* y, const float* stats, const float* gamm
         const int64_t ntiles = HWp / 64;
         int tpw = (int)((ntiles * B + 1023) / 1024);          // ~1024 workgroups: the affine set-up is amortised over the tiles
         if (tpw < 1) tpw = 1;
-        if (const char* e = getenv("PH_CPLANES_TPW")) tpw = atoi(e);
+        static const int ctpw_env = [] { const char* e = getenv("PH_CPLANES_TPW"); return e ? atoi(e) : 0; }();
+        if (ctpw_env) tpw = ctpw_env;
         const dim3 grid((unsigned)((ntiles + tpw - 1) / tpw), B);
         const size_t lds = 256 * 65 * sizeof(float);
         static const bool once = [&] {
