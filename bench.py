@@ -269,6 +269,37 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
             del kplan_h
         except Exception as e:
             t_a1_h = repr(e)
+    # a1 as the WHOLE head runs it: the three maps arrive as the neck's 16-bit planes ([1][B][256][HWp], what
+    # SemanticFPNWrapper.forward_planes hands over -- no fp32 round trip between neck and KernelHead) and the logits leave as fp16;
+    # a1 + a6 from one graph in that form
+    handoff = None
+    if kplan.onepass and precision in ("fp16", "bf16") and E.hw_padded(H * W) == H * W:
+        try:
+            fdt = torch.float16 if precision == "fp16" else torch.bfloat16
+            kplan_p = E.KernelHeadPlan(kh._get_pack(dev), B, H, W, wl["n_thing"], L, True, dev, want_f32=False, logit_dtype=torch.float16)
+            kplan_p.set_inputs([f.to(fdt).view(torch.int16).reshape(1, B, 256, H * W).contiguous() for f in kplan.f])
+
+            def run_p():
+                kplan_p.run()
+                dplan.run_from_planes(kplan_p.xp, kplan_p.dp, kplan_p.bits, kplan_p.proposal, q0)
+
+            run_p()
+            torch.cuda.synchronize()
+            gp = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gp):
+                run_p()
+            t_p = time_op(gp.replay, steps)
+            t_a1_p = time_op(kplan_p.run, steps)
+            a1b_p = 3 * 256 * H * W * 2 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 2 + N * H * W // 8 + 256 * H * W * 2
+            a6b_p = algorithmic_rates(wl, N, B, 1.0, precision)["bytes_per_frame"] - N * H * W * 2
+            handoff = {"a1_only_ms_per_step": round(t_a1_p, 4), "a1_plus_a6_ms_per_step": round(t_p, 4),
+                       "a1_plus_a6_frames_per_s": round(B / (t_p * 1e-3), 1), "a1_alg_bytes_per_frame": a1b_p,
+                       "a1_plus_a6_fraction_hbm": round((a1b_p + a6b_p) * (B / (t_p * 1e-3)) / 8e12, 4),
+                       "note": "16-bit planes in (the neck's hand-off), fp16 logits out; a1 bytes = 3 planes read + x / dfe planes + fp16 logits + bits "
+                               "+ the pooling's read of x"}
+            del kplan_p, gp
+        except Exception as e:
+            handoff = {"error": repr(e)}
     # the same on two streams, a second half-batch of B frames one phase behind the first (as the headline does for a6)
     two = None
     try:
@@ -355,7 +386,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         big = {"error": repr(e)}
     torch.cuda.empty_cache()
     return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
-            "batch96_four_streams": big,
+            "batch96_four_streams": big, "neck_handoff_inputs": handoff,
             "a1_only_ms_per_step": round(t_a1, 4), "a1_onepass_timeouts": a1_timeouts, "a1_form": "one-pass (ph_khead_onepass)" if kplan.onepass else "two-pass (ph_khead_fused)",
             "a1_only_ms_per_step_fp16_logits": round(t_a1_h, 4) if isinstance(t_a1_h, float) else t_a1_h, "two_streams": two,
             "a1_alg_bytes_per_frame": int(3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2),
