@@ -25,5 +25,5 @@ for (k, s, H, W) in ((3, 1, 128, 256), (3, 2, 256, 512), (3, 1, 64, 128)):
     lay = _lib.PH_PLANES_C16 if (s == 2 and len(sys.argv) > 3 and sys.argv[3] == "c16") else 0   # timing only: the same bytes read as chunk-major
     ts = [time_op(lambda: E.conv_nhwc(x, pk, y, partial, B, H, W, prec | lay), 10, warm=2) for _ in range(3)]
     fl = 2.0 * B * Ho * Wo * 256 * k * k * 256
-    out.append(f"{k}x{k}s{s}@{H}x{W}: {min(ts)*1e3:.0f} us {fl/min(ts)/1e12:.0f} TF/s")
+    out.append(f"{k}x{k}s{s}@{H}x{W}: {min(ts)*1e3:.0f} us {fl / (min(ts) * 1e-3) / 1e12:.0f} TF/s")
 print(_lib.LIB_PATH.split('/')[-1], "|", " | ".join(out), "| checksum", float(y.double().sum()))
