@@ -227,7 +227,9 @@ __global__ __launch_bounds__((ConvCfg<PF, PK, NRT, BITS, OutT, F2>::NW * 64)) vo
                     lds_write128_asm(tb + r * LANES * 16, __builtin_bit_cast(u32x4_t, h16));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef CONV_ABL_NO_COOP_BARRIER          // timing only (wrong results): what the conversion's barrier costs per tile
             __builtin_amdgcn_s_barrier();
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 

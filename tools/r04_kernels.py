@@ -4,6 +4,8 @@
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polyphonicformer_amd import _lib, engine as E
+if os.environ.get("PH_ALT_LIB"):
+    _lib.LIB_PATH = os.environ["PH_ALT_LIB"]            # same-box A/B of a library variant
 dev = torch.device("cuda:0")
 mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed16"]
 N, B, H, W = 153, int(os.environ.get("R04_B", "24")), 128, 256
