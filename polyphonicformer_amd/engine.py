@@ -684,7 +684,8 @@ class NeckPlan:
         # nested fork / join of 2 x 4 streams made hipStreamEndCapture segfault on ROCm 7.2).
         # (from 4 frames per call: one frame at a time -- the video loop -- is bound by the host's launch rate, where the stream
         # switches cost more than the overlap returns: cfg4 7.95 -> 9.08 ms per two frames with tower streams)
-        self.multi = tower_streams and B >= 4 and _os.environ.get("PH_NECK_STREAMS", "1") != "0" and dev.type == "cuda"
+        _ns = _os.environ.get("PH_NECK_STREAMS", "1")
+        self.multi = tower_streams and (B >= 4 or _ns == "2" or tower_streams == "always") and _ns != "0" and dev.type == "cuda"
         self.lv = None
         if self.multi:
             self.lv = []

@@ -156,7 +156,12 @@ class SemanticFPNWrapper(nn.Module):
         shapes = tuple(tuple(t.shape[-2:]) for t in inputs[:4])
         plan = self._plans.get((B, shapes, str(dev), self.precision))
         if plan is None:
-            plan = E.NeckPlan(B, shapes, prec, dev, tower_streams=getattr(self, "tower_streams", True))
+            # `_clip_towers` (set by video.VideoStreamRunner around the capture of a 2-3 frame clip launch): the four level towers on
+            # their own streams also below 4 frames -- inside a HIP graph the forks cost the host nothing (engine.NeckPlan)
+            ts = getattr(self, "tower_streams", True)
+            if ts and B < 4 and getattr(self, "_clip_towers", False):
+                ts = "always"
+            plan = E.NeckPlan(B, shapes, prec, dev, tower_streams=ts)
             self._plans[(B, shapes, str(dev), self.precision)] = plan
         add = self._posenc(*shapes[self.cat_coors_level], dev) if self.pos_cfg is not None else None
         outs = plan.run([t.float().contiguous() for t in inputs[:4]], pk, G, add, self.cat_coors_level, to_planes=_planes)

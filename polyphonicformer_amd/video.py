@@ -9,6 +9,8 @@ reference's, and the integer ids are pinned to the reference class's own output 
 With frames sharded over GPUs (`dist.shard_frames`) every rank all-gathers the per-frame records
 (`dist.allgather_track_records`) and replays `match` in frame order; integer track ids are then identical to the
 single-process run (`replay_tracking`, tests/test_tracker.py and tests/test_dist_gloo.py)."""
+import os
+
 import numpy as np
 import torch
 
@@ -731,16 +733,28 @@ class VideoStreamRunner:
             for b, f in enumerate(frames):
                 for d, t in zip(st["x"], f):
                     d[b:b + 1].copy_(t)
-            outs = self._heads_device(sl, st["x"])          # warm-up outside the capture: plans, packs, kernel attributes
-            if self.device_select:
-                st["dm"] = Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
-                st["dm"].begin(*outs)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                st["outs"] = self._heads_device(sl, st["x"])
-                if st["dm"] is not None:
-                    st["dm"].begin(*st["outs"])
+            # a clip's 2-3 frames per launch (`records`): the neck's four level towers run on their own streams inside the graph (the
+            # small levels' convs are 16-64 workgroups; eagerly the forks cost more host time than the overlap returns, in a graph
+            # nothing: cfg4 +2-6 %, same bits).  Not at one frame per launch: the per-frame loops got SLOWER with it (1.68 -> 1.92 ms
+            # per frame pipelined: the previous frame's small association kernels wait behind four streams of neck kernels)
+            neck = getattr(sl["rpn"], "localization_fpn", None)
+            towers = neck is not None and B >= 2 and os.environ.get("PH_VIDEO_CLIP_TOWERS", "1") != "0"
+            if towers:
+                neck._clip_towers = True
+            try:
+                outs = self._heads_device(sl, st["x"])      # warm-up outside the capture: plans, packs, kernel attributes
+                if self.device_select:
+                    st["dm"] = Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
+                    st["dm"].begin(*outs)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st["outs"] = self._heads_device(sl, st["x"])
+                    if st["dm"] is not None:
+                        st["dm"].begin(*st["outs"])
+            finally:
+                if towers:
+                    neck._clip_towers = False
             st["graph"] = g
             # the graph replays the plans' device buffers: KernelHead / KernelUpdateIterHead keep ONE plan and drop it when the
             # batch size changes (a clip's last chunk), so the graph holds its own references -- without them a later replay wrote
