@@ -738,7 +738,10 @@ class VideoStreamRunner:
             # nothing: cfg4 +2-6 %, same bits).  Not at one frame per launch: the per-frame loops got SLOWER with it (1.68 -> 1.92 ms
             # per frame pipelined: the previous frame's small association kernels wait behind four streams of neck kernels)
             neck = getattr(sl["rpn"], "localization_fpn", None)
-            towers = neck is not None and B >= 2 and os.environ.get("PH_VIDEO_CLIP_TOWERS", "1") != "0"
+            # 0: never, 1 (default): clip launches only, 2: + the sequential one-frame loop (module API: heads 1.75 -> 1.64 ms, but merge
+            # and association + 0.04 each behind it: - 0.05 ms of 2.87 per frame, inside the scatter; left off)
+            _ct = os.environ.get("PH_VIDEO_CLIP_TOWERS", "1")
+            towers = neck is not None and _ct != "0" and (B >= 2 or (_ct == "2" and not self.pipelined))
             if towers:
                 neck._clip_towers = True
             try:
