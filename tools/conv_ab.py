@@ -1,7 +1,8 @@
 """times k_conv_nhwc alone (3x3 stride 1 at 128x256, 3x3 stride 2 at 256x512 -> 128x256, 1x1 at 128x256; 16 frames, fp16 grade) for
 same-box A/B of library variants.  usage: python tools/conv_ab.py [path of an alternative libpolyhead.so | -] [B] [c16]"""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polyphonicformer_amd import _lib
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     _lib.LIB_PATH = sys.argv[1]
