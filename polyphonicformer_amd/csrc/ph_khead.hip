@@ -243,12 +243,24 @@ template <int PA, int INFMT, int E = PH_E_BF16>
 __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
-    const int b = blockIdx.y, m = blockIdx.z;
+    int b = blockIdx.y, m = blockIdx.z, bx = blockIdx.x, nbx = gridDim.x;
+    if (a.plain3) {
+        // the three maps of ONE input (ph_neck_out_convs; round 5, like the apply pass since round 4): 1-D XCD-aware grid -- the three
+        // workgroups that read the same tiles sit on the same XCD in consecutive slots, so the input crosses HBM once, not three times
+        // (PMC: 762 MB of reads per 16-frame launch for a 268 MB plane)
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int grp = (slot / 3) * 8 + xcd;
+        if (grp >= a.nwg * a.B) return;
+        m = slot - (slot / 3) * 3;
+        b = grp / a.nwg;
+        bx = grp - b * a.nwg;
+        nbx = a.nwg;
+    }
     if (a.run_if && *a.run_if == 0) return;
     uint4 af[PA][16];
     kh_load_a<PA>(af, a.w[m], a.w_plane, wave, lane);
     const int ntiles = (int)(a.HWp / KH_T);
-    const int t0 = blockIdx.x * a.tiles_per_wg;
+    const int t0 = bx * a.tiles_per_wg;
     const int t1 = t0 + a.tiles_per_wg < ntiles ? t0 + a.tiles_per_wg : ntiles;
     float s1[16], s2[16];
 #pragma unroll
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(KH_THREADS) void k_khead_stats(const KHArgs a) {
         }
     }
     // reduce over the 32 pixel lanes of each half-wave, lanes 0 / 32 hold the channel totals
-    float* out = a.partial[m] + ((int64_t)b * gridDim.x + blockIdx.x) * 256 * 2;
+    float* out = a.partial[m] + ((int64_t)b * nbx + bx) * 256 * 2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float x = s1[r], y = s2[r];
@@ -706,7 +718,15 @@ static int kh_run(const void* const fm[3], int in_planes, const uint16_t* wplane
         else hipLaunchKernelGGL((K<2, ##__VA_ARGS__, 3>), G, block, L, s, a);                             \
     } while (0)
     // pass 1: the three maps in one launch, then one finalize over the 3 * B (map, frame) pairs
-    if (fmt == 3) KH_LAUNCH3(k_khead_stats, dim3(nwg, B, 3), lds);
+    static const bool stats3_on = [] { const char* e = getenv("PH_NECK_STATS3"); return !(e && e[0] == '0'); }();   // 0: the 3-D grid (A/B)
+    const bool same_input = fm[0] == fm[1] && fm[1] == fm[2] && stats3_on;
+    if (same_input) {
+        a.plain3 = 1; a.nwg = nwg;
+        const dim3 g3((unsigned)(((nwg * B + 7) / 8) * 8 * 3));
+        if (fmt == 3) KH_LAUNCH3(k_khead_stats, g3, lds);
+        else KH_LAUNCH(k_khead_stats, g3, lds);
+        a.plain3 = 0;
+    } else if (fmt == 3) KH_LAUNCH3(k_khead_stats, dim3(nwg, B, 3), lds);
     else KH_LAUNCH(k_khead_stats, dim3(nwg, B, 3), lds);
     hipLaunchKernelGGL(k_gn_finalize, dim3(3 * B), dim3(1024), 0, s, partial, stats, nwg, groups, HW, eps, a.run_if);
     static const bool plain3_on = [] { const char* e = getenv("PH_NECK_APPLY3"); return !(e && e[0] == '0'); }();   // 0: one launch per map (A/B)
