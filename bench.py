@@ -23,6 +23,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+CFG5_FRAMES = 192       # frames per step of the cfg5 leg (four 48-frame parts)
 WORKLOADS = {
     # BASELINE.json configs[1]: 1024x2048 -> stride-8 128x256, N = 100 + 53 (class defaults), S = 3
     "cfg2": dict(H=128, W=256, Nq=100, n_thing=80, n_stuff=53, S=3, F=2048),
@@ -179,6 +180,25 @@ def algorithmic_bytes(plan, kernel):
     return None
 
 
+def roofline_of(kplan, times, counts, nplans):
+    """roofline object of the launch class with the largest share of a step's GPU time.  The fused final stage's two instantiations
+    (mask form with the low-resolution logits, depth form without) are ONE class, `dynconv_up2`: bytes and time of both launches"""
+    per_step = {k: times[k] * counts.get(k, 0) * nplans for k in times if algorithmic_bytes(kplan, k) and k != "ingest"}
+    klass = dict(per_step)
+    if "dynconv_up2_mask" in klass:
+        klass["dynconv_up2"] = klass.pop("dynconv_up2_mask") + klass.pop("dynconv_up2_depth")
+    dom = max(klass, key=lambda k: klass[k])
+    if dom == "dynconv_up2":
+        ab = algorithmic_bytes(kplan, "dynconv_up2_mask") + algorithmic_bytes(kplan, "dynconv_up2_depth")
+        t_ms, launches = times["dynconv_up2_mask"] + times["dynconv_up2_depth"], 2
+    else:
+        ab, t_ms, launches = algorithmic_bytes(kplan, dom) * 1, times[dom], 1
+    achieved = ab / (t_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+            "algorithmic_bytes_per_launch": ab // launches, "avg_launch_ms": round(t_ms / launches, 4), "launches_in_the_figure": launches,
+            "frames_per_launch": kplan.B, "share_of_hbm_bound_launch_time": round(klass[dom] / sum(klass.values()), 4)}
+
+
 def algorithmic_rates(wl, N, frames_per_launch, fps_per_gpu, precision):
     """B_alg = (S+1)*2*C*HW*e + N*HW*e (initial mask logits) + 2*N*HW*e + 2*N*4*HW*e + S*P*e_w / frames,
     F_alg = S*8*N*C*HW + S*N*(7.73e6 + 2048 N + 512 L); e = 2 (bf16 planes and outputs), weights bf16"""
@@ -193,16 +213,18 @@ def algorithmic_rates(wl, N, frames_per_launch, fps_per_gpu, precision):
             "fraction_hbm": round(gbps / 8000.0, 4), "achieved_TFLOPs": round(tf, 1), "fraction_mfma_bf16": round(tf / 2500.0, 4)}
 
 
-def mode_leg(wl, mode, dev, B, parts, fp32_inputs=False, steps=10):
+def mode_leg(wl, mode, dev, B, parts, fp32_inputs=False, steps=10, breakdown=False, mask_bias=0.0):
     """frames/s of simple_test_mask_preds in precision mode `mode` (engine.MODES): B frames as `parts` part-batches on
-    skewed streams from ONE HIP graph, features resident in the mode's own plane format (or fp32 NCHW + ingest)"""
+    skewed streams from ONE HIP graph, features resident in the mode's own plane format (or fp32 NCHW + ingest).
+    `breakdown`: also the per-launch timings of one part's sequence, the roofline of its dominant launch class and the whole-path
+    algorithmic rates (the default run's cfg5 leg)"""
     from polyphonicformer_amd.engine import DualDecodePlan, MODES
     out_dtype = {"bf16": torch.bfloat16, "mixed": torch.float16, "mixed16": torch.float16, "fp16": torch.float16, "fp32": torch.float32}[mode]
     head = build_head(wl, mode, out_dtype, dev)
     N = wl["Nq"] + wl["n_stuff"]
     plan = head._plan(B // parts, N, wl["H"], wl["W"], dev)
     runner = DualDecodePlan(plan.packs, B, N, wl["H"], wl["W"], plan.mode, out_dtype, dev, parts=parts)
-    inp = synth_inputs(wl, B, seed=99)
+    inp = synth_inputs(wl, B, seed=99, mask_bias=mask_bias)
     gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
     fdt = MODES[mode].feat_dtype
     if fdt is not None and not fp32_inputs:
@@ -215,6 +237,16 @@ def mode_leg(wl, mode, dev, B, parts, fp32_inputs=False, steps=10):
     out = {"value": round(B / (t * 1e-3), 2), "unit": "frames/s", "ms_per_step": round(t, 4), "frames_per_step": B, "streams": parts,
            "feature_input_dtype": "fp32 (ingest inside the step)" if (fp32_inputs or fdt is None) else str(fdt), "output_dtype": str(out_dtype),
            "workload": f"{wl['H'] * 8}x{wl['W'] * 8}, N={N}, S={wl['S']}"}
+    if breakdown:
+        kplan = runner.halves[0]
+        times, counts = kernel_breakdown(kplan)
+        out["kernels_ms"] = {k: round(v, 4) for k, v in times.items()}
+        out["roofline"] = roofline_of(kplan, times, counts, parts)
+        out["algorithmic"] = algorithmic_rates(wl, N, kplan.B, B / (t * 1e-3), mode)
+        # the query side at this shape: weights streamed per workgroup, 1.25 GF per stage and frame on MFMA
+        q = (times["query_pre"] + times["query_post"]) * kplan.S
+        hb = sum(times[k] * counts.get(k, 0) for k in times if algorithmic_bytes(kplan, k) and k != "ingest")
+        out["query_share_of_one_part"] = round(q / (q + hb), 4)
     del runner, plan, head, gin, inp
     torch.cuda.empty_cache()
     return out
@@ -1274,24 +1306,42 @@ def main():
         nplans = args.streams if args.streams > 1 else 1
         times, counts = kernel_breakdown(kplan)
         per_step = {k: times[k] * counts.get(k, 0) * nplans for k in times}
-        dom = max((k for k in per_step if algorithmic_bytes(kplan, k)), key=lambda k: per_step[k])
-        ab = algorithmic_bytes(kplan, dom)
-        achieved = ab / (times[dom] * 1e-3) / 1e9
+        roof = roofline_of(kplan, times, counts, nplans)
+        dom = roof["kernel"]
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py),
         # which cannot run inside this process: the committed summary is quoted, labelled as such, and only when the launch
         # geometry is the profiled one
         traffic, traffic_src = None, None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        members = ["dynconv_up2_mask", "dynconv_up2_depth"] if dom == "dynconv_up2" else [dom]
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")) as f:
                     pt = json.load(f)
                 if pt["frames_per_launch"] == kplan.B and args.workload == "cfg2" \
-                        and args.precision == pt.get("mode", "bf16") and dom in pt["kernels"]:
-                    traffic = pt["kernels"][dom].get("hbm_bytes_per_launch")
-                    traffic_src = f"profiles/{rnd}/pmc_traffic.json (rocprofv3 --pmc passes of this command, not measured in this run)"
+                        and args.precision == pt.get("mode", "bf16") and all(m in pt["kernels"] for m in members):
+                    traffic = sum(pt["kernels"][m]["hbm_bytes_per_launch"] for m in members) // len(members)
+                    traffic_src = f"profiles/{rnd}/pmc_traffic.json (rocprofv3 --pmc passes of this command, not measured in this run; per launch, " \
+                                  f"mean of {' + '.join(members)})"
                     break
             except Exception:
                 continue
+        # what the GRAPH replays: per-kernel durations inside the multi-stream step and the overlap efficiency come
+        # from a rocprofv3 kernel trace of this command (tools/timeline.py), which cannot run inside this process either: quoted
+        # from the committed summary of this round, labelled as such
+        in_graph = None
+        try:
+            with open(os.path.join(REPO, "profiles", "r06", "timeline_4streams.json")) as f:
+                tl = json.load(f)
+            if tl["parts"] == nplans and args.workload == "cfg2" and args.precision == "mixed16" and B == 96:
+                in_graph = {"source": "profiles/r06/timeline_4streams.json (tools/timeline.py on a rocprofv3 --kernel-trace of this command; not "
+                                      "measured in this run)",
+                            "wall_us_per_step": tl["wall_us_per_step"], "overlap_efficiency": tl.get("overlap_efficiency"),
+                            "query_time_not_hidden_us_per_part": tl.get("query_time_not_hidden_us_per_part"),
+                            "query_only_us_per_step": tl["query_exposed_us"], "idle_us_per_step": tl["idle_us"],
+                            "isolated_kernel_us": tl.get("isolated", {}).get("median_us"),
+                            "in_step_mean_kernel_us": {k: v["mean_us"] for k, v in tl["in_step"].items()}}
+        except Exception:
+            in_graph = None
         res = {
             "metric": "frames/sec kernel-update+mask fwd, 1024x2048 N=153 S=3" if args.workload == "cfg2" else
                       f"frames/sec kernel-update+mask fwd, {wl['H'] * 8}x{wl['W'] * 8} N={N} S={wl['S']}", "value": round(fps, 2),
@@ -1315,13 +1365,10 @@ def main():
                                          "fp16": "unrounded fp32 features into the oracle, fp16-rounded into the device: <= 6.6e-4 per stage",
                                          "fp32": "fp32 features on both sides: 1.3e-5 per stage"}[args.precision],
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(times[dom], 4),
-                         "frames_per_launch": kplan.B,
-                         "achievable_read_GBps_from_profiles": 5800.0,
-                         "achievable_read_source": "profiles/r01/dmabw_ring_microbenchmark.txt (tools/dmabw.py: compute-free "
-                                                   "LDS-DMA ring, same access pattern and cache policy; not measured in this run)"},
+            "roofline": dict(roof, traffic=traffic, traffic_source=traffic_src,
+                             achievable_GBps_from_profiles={"pure_read": 5800.0, "pure_fill": 6900.0, "copy": 5600.0},
+                             achievable_source="profiles/r01/dmabw_ring_microbenchmark.txt (compute-free LDS-DMA ring read), "
+                                               "profiles/r05/writebw_yardstick.txt (fill / copy); not measured in this run"),
             # SURVEY 8d "Reporting": whole-path algorithmic rates of the timed step (B_alg / F_alg per frame incl. the
             # per-stage weight stream amortised over the frames of a launch)
             "algorithmic": algorithmic_rates(wl, N, kplan.B, fps / world, args.precision),
@@ -1331,8 +1378,10 @@ def main():
                                                            else 2 * times["dynconv_logits"] + 2 * times["upsample2x"]), 4)},
             "kernels_ms": {k: round(v, 4) for k, v in times.items()},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
-            "kernels_ms_per_step_note": f"sum of the isolated launch durations x launches per step; the step itself runs its {nplans} part(s) on "
-                                        f"{nplans} skewed streams, whose kernels overlap (query launches beside HBM-bound ones), so this sum exceeds ms_per_step",
+            "kernels_ms_note": f"HIP-event timings of one part's launches issued eagerly on one stream (an event after every launch: 12-20 % above the "
+                               f"kernel-trace durations); the step itself replays {nplans} part(s) on {nplans} skewed streams from one graph, whose kernels "
+                               f"overlap -- `in_graph` holds what the graph replays",
+            "in_graph": in_graph,
             "track_allgather": tag,
         }
         full = args.all_legs
@@ -1365,11 +1414,23 @@ def main():
                                                         per_stage_rel_err=err_note[mode])
                 except Exception as e:
                     res["precision_modes"][mode] = {"error": repr(e)}
-        if world == 1 and full and not args.no_kernel_head and args.workload == "cfg2":
-            try:        # BASELINE configs[4] as specified: fp16, 1242x375 (48x156 at stride 8), N = 253, S = 3
-                res["cfg5_fp16"] = mode_leg(WORKLOADS["cfg5"], "fp16", dev, 192, 4, fp32_inputs=True)
+        if world == 1 and not args.no_kernel_head and args.workload == "cfg2":
+            try:        # BASELINE configs[4] as specified: fp16, 1242x375 (48x156 at stride 8), N = 253, S = 3; fp16 planes resident
+                res["cfg5_fp16"] = mode_leg(WORKLOADS["cfg5"], "fp16", dev, CFG5_FRAMES, 4, breakdown=True)
+                res["cfg5_fp16"]["note"] = "BASELINE configs[4] on ONE GPU (frames shard over 8 like cfg2's): fp16 feature planes and fp16 initial " \
+                                           "mask logits resident, fp16 logits out; its own roofline (dominant launch class at this shape)"
+                if full:
+                    r32 = mode_leg(WORKLOADS["cfg5"], "fp16", dev, CFG5_FRAMES, 4, fp32_inputs=True)
+                    res["cfg5_fp16"]["fp32_feature_inputs"] = {k: r32[k] for k in ("value", "ms_per_step")}
             except Exception as e:
                 res["cfg5_fp16"] = {"error": repr(e)}
+            try:        # SURVEY 8d's sparse-mask variant of the headline (initial mask logits - 2: ~2 % foreground)
+                sp = mode_leg(wl, args.precision, dev, B, args.streams, mask_bias=-2.0)
+                res["sparse_masks"] = {"value": sp["value"], "unit": "frames/s", "ms_per_step": sp["ms_per_step"], "mask_bias": -2.0,
+                                       "note": "the headline step with initial mask logits N(-2, 1) (SURVEY 8d): 1-bit masks and dense MFMA "
+                                               "pooling make the work independent of the mask density"}
+            except Exception as e:
+                res["sparse_masks"] = {"error": repr(e)}
         if world == 1 and not args.no_kernel_head:
             # SURVEY 8d's metric row a1 + a6 with the plane / mask-bit hand-off.  Primary: the cheapest pair of grades that
             # stays inside the 1e-3 contract against fp32 inputs -- KernelHead's fp16 grade (3.5e-4 .. 6.7e-4 on its outputs,
@@ -1438,8 +1499,8 @@ def main():
             except Exception as e:
                 res["train_step"] = {"error": repr(e)}
         if not full:
-            res["legs_not_run"] = "secondary legs (all precision modes, cfg5, panoptic merge, neck, whole head from the FPN levels, video cfg3, " \
-                                  "assigner, training step) need --all-legs; profiles/r04/bench_all_legs.json holds this round's full line"
+            res["legs_not_run"] = "secondary legs (all precision modes, panoptic merge, neck, whole head from the FPN levels, video cfg3, " \
+                                  "assigner, training step) need --all-legs; profiles/r06/bench_all_legs.json holds this round's full line"
         if not args.no_cpu_baseline:                       # rank 0, at every N: the line of an N-GPU run carries it too
             res["cpu_baseline"] = cpu_baseline(wl, head, all_cores=full)
         os.write(json_fd, (json.dumps(res) + "\n").encode())

@@ -132,3 +132,103 @@ def things_for_tracking(pan, info):
             labels.append(s["category_id"])
             score.append(s["score"])
     return idxs, labels, masks, score
+
+
+# ---- QuasiDenseEmbedTracker (polyphonic/video/qdtrack/trackers/quasi_dense_embed_tracker.py:8-207) ---------------------------------
+# Restated for the tests that compare the product's association END TO END (tests/test_gpu_video.py): plain torch CPU ops, one
+# dictionary of tracklets + a list of backdrop frames, no velocity (the reference computes one and never reads it).  Pinned by
+# tests/golden/tracker.npz -- ids / labels / boxes the reference class produced on three synthetic clips -- in
+# tests/test_video_oracle.py::test_tracker_oracle_reproduces_the_reference_ids.
+def box_iou(a, b, eps=1e-6):
+    """mmdet.core.bbox_overlaps(mode='iou', is_aligned=False): [n, 4] x [m, 4] -> [n, m]"""
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        return a.new_zeros((a.shape[0], b.shape[0]))
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:4], b[None, :, 2:4])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = torch.max(area_a[:, None] + area_b[None, :] - inter, inter.new_tensor(eps))
+    return inter / union
+
+
+class TrackerOracle:
+    def __init__(self, init_score_thr=0.8, obj_score_thr=0.5, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+                 memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True,
+                 match_metric="bisoftmax"):
+        self.p = dict(init=init_score_thr, obj=obj_score_thr, match=match_score_thr, keep=memo_tracklet_frames, bd_frames=memo_backdrop_frames,
+                      mom=memo_momentum, conf=nms_conf_thr, bd_iou=nms_backdrop_iou_thr, cls_iou=nms_class_iou_thr)
+        self.with_cats, self.metric = with_cats, match_metric
+        self.tracks = {}            # id -> dict(embed, label, last) in creation order (:106-118 walks the dict in that order)
+        self.backdrops = []         # newest first: dict(embeds, labels)
+        self.born = 0
+
+    def _memory(self):
+        """:100-133: tracklet columns in creation order, then the backdrop frames newest first with id -1"""
+        ids = list(self.tracks)
+        emb = [self.tracks[i]["embed"][None] for i in ids]
+        lab = [self.tracks[i]["label"].reshape(1) for i in ids]
+        for b in self.backdrops:
+            ids += [-1] * b["embeds"].shape[0]
+            emb.append(b["embeds"])
+            lab.append(b["labels"])
+        return torch.tensor(ids, dtype=torch.long), torch.cat(emb, 0), torch.cat(lab, 0)
+
+    def match(self, bboxes, labels, track_feats, frame_id):
+        p = self.p
+        order = bboxes[:, -1].sort(descending=True)[1]                                              # :137-140
+        box, lab, emb = bboxes[order], labels[order], track_feats[order]
+        iou = box_iou(box[:, :4], box[:, :4])
+        keep = torch.ones(box.shape[0], dtype=torch.bool)                                           # :144-152
+        for i in range(1, box.shape[0]):
+            thr = p["bd_iou"] if box[i, -1] < p["obj"] else p["cls_iou"]
+            if (iou[i, :i] > thr).any():
+                keep[i] = False
+        box, lab, emb = box[keep], lab[keep], emb[keep]
+        n = box.shape[0]
+        ids = torch.full((n,), -1, dtype=torch.long)
+        if n and self.tracks:                                                                       # :161 (`empty` looks at the tracklets only)
+            m_ids, m_emb, m_lab = self._memory()
+            if self.metric == "cosine":
+                score = F.normalize(emb, p=2, dim=1) @ F.normalize(m_emb, p=2, dim=1).t()
+            else:
+                dots = emb @ m_emb.t()
+                score = dots.softmax(1)
+                if self.metric == "bisoftmax":
+                    score = (score + dots.softmax(0)) / 2
+            if self.with_cats:
+                score = score * (lab[:, None] == m_lab[None, :]).float()
+            for i in range(n):                                                                      # :183-197
+                conf, j = score[i].max(0)
+                if conf > p["match"] and m_ids[j] > -1:
+                    if box[i, -1] > p["obj"]:
+                        ids[i] = m_ids[j]
+                        score[:i, j] = 0
+                        score[i + 1:, j] = 0
+                    elif conf > p["conf"]:
+                        ids[i] = -2
+        new = (ids == -1) & (box[:, 4] > p["init"])                                                 # :198-205
+        k = int(new.sum())
+        ids[new] = torch.arange(self.born, self.born + k, dtype=torch.long)
+        self.born += k
+        # update_memo (:47-98)
+        for i in range(n):
+            t = int(ids[i])
+            if t < 0:
+                continue
+            if t in self.tracks:
+                tr = self.tracks[t]
+                tr["embed"] = (1 - p["mom"]) * tr["embed"] + p["mom"] * emb[i]
+                tr["label"], tr["last"] = lab[i], frame_id
+            else:
+                self.tracks[t] = dict(embed=emb[i], label=lab[i], last=frame_id)
+        loose = torch.nonzero(ids == -1).squeeze(1)
+        iou2 = box_iou(box[loose, :4], box[:, :4])
+        free = [int(ind) for r, ind in enumerate(loose) if not (iou2[r, :int(ind)] > p["bd_iou"]).any()]
+        self.backdrops.insert(0, dict(embeds=emb[free], labels=lab[free]))
+        for t in [t for t, tr in self.tracks.items() if frame_id - tr["last"] >= p["keep"]]:
+            del self.tracks[t]
+        if len(self.backdrops) > p["bd_frames"]:
+            self.backdrops.pop()
+        return box, lab, ids

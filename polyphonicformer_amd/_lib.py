@@ -7,6 +7,8 @@ import torch  # noqa: F401  -- MUST precede dlopen: libpolyhead has to bind to t
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpolyhead.so")
+if os.environ.get("PH_ALT_LIB"):      # measurement aid: a variant build (tools/build_variant.py) for same-box A/B timing
+    LIB_PATH = os.path.abspath(os.environ["PH_ALT_LIB"])
 
 PH_PREC_BF16, PH_PREC_BF16_KSPLIT, PH_PREC_SPLIT, PH_PREC_F16, PH_PREC_BF16_KF16, PH_PREC_QHYBRID = 1, 2, 3, 5, 6, 7
 PH_PLANES_C16 = 0x100            # flag on `prec` of ph_nhwc_ingest / ph_conv_nhwc: chunk-major planes [B][16][HW][16] (polyhead.h)

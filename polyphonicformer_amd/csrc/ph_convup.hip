@@ -343,6 +343,9 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2(const uint16_t
                             up_patch_put<ROWB, SB>(pw_addr, prev[TC][h]);                       // P: the previous image row
                             up_patch_put<ROWB, SB + C::PATCH1>(pw_addr, cu);                    // C: this one
                             lds_wait_all();
+#ifdef UP2_ABL_SKIP_RT           // timing only (wrong results): the window passes of ONE row block left out -- which SIMD bounds the kernel?
+                            if (rt != UP2_ABL_SKIP_RT)
+#endif
                             if (!UP2_DBG(2)) {
                                 if constexpr (HH > 0) window(std::integral_constant<int, HH - 1>{});
                                 if constexpr (HH == NH - 1) window(std::integral_constant<int, HH>{});

@@ -861,7 +861,7 @@ extern "C" int ph_qtrain_backward(const float* const* params, const float* poole
     CsBatch cb;
     int ncs = 0;
     auto colsum = [&](const float* src, const float* roww, float* dst, const float* src2 = nullptr, const float* roww2 = nullptr) {
-        if (ncs == CS_MAX_JOBS) { ++ncs; return; }
+        if (ncs >= CS_MAX_JOBS) { ++ncs; return; }
         CsJob& j = cb.j[ncs++];
         j.src = src; j.ld = QC; j.roww = roww; j.src2 = src2; j.roww2 = roww2; j.dst = dst; j.ncols = QC;
     };

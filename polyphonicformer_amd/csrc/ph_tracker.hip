@@ -54,6 +54,7 @@ struct ph_tracker {
     double tacc[6];                  // seconds spent in the phases of `match` (ph_tracker_debug_times)
     hipEvent_t uploaded;             // the last upload from the pinned table has left the host buffer
     bool pending;
+    bool poisoned;                   // a device error struck after the bookkeeping of a frame had been committed: ids would be undefined from here on
 };
 
 namespace {
@@ -104,6 +105,8 @@ extern "C" ph_tracker* ph_tracker_create(const ph_tracker_cfg* cfg, void* device
         return nullptr;
     }
     ph_tracker* t = new ph_tracker();
+    t->h_tab = nullptr;
+    t->h_score = nullptr;
     t->c = *cfg;
     t->capacity = capacity;
     t->max_n = max_dets;
@@ -120,15 +123,20 @@ extern "C" ph_tracker* ph_tracker_create(const ph_tracker_cfg* cfg, void* device
     if (hipHostMalloc((void**)&t->h_tab, tab * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void**)&t->h_score, (size_t)max_dets * capacity * sizeof(float)) != hipSuccess) {
         ph_set_error("ph_tracker_create: pinned host allocation failed");
+        if (t->h_tab) (void)hipHostFree(t->h_tab);
+        if (t->h_score) (void)hipHostFree(t->h_score);
         delete t;
         return nullptr;
     }
     if (hipEventCreateWithFlags(&t->uploaded, hipEventDisableTiming) != hipSuccess) {
         ph_set_error("ph_tracker_create: event creation failed");
+        (void)hipHostFree(t->h_tab);
+        (void)hipHostFree(t->h_score);
         delete t;
         return nullptr;
     }
     t->pending = false;
+    t->poisoned = false;
     for (double& v : t->tacc) v = 0;
     t->num_tracklets = 0;
     for (int s = capacity - 1; s >= 0; --s) t->free_slots.push_back(s);
@@ -149,6 +157,7 @@ extern "C" void ph_tracker_reset(ph_tracker* t) {
     t->free_slots.clear();
     for (int s = t->capacity - 1; s >= 0; --s) t->free_slots.push_back(s);
     t->num_tracklets = 0;
+    t->poisoned = false;
 }
 
 // accumulated host seconds per phase: [0] wait for the previous frame's upload, [1] sort + de-duplication + tables, [2] launches up to
@@ -167,6 +176,10 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
                                 int32_t* kept_out, int64_t* ids_out, void* stream) {
     PH_CHECK_ARG(t && (n == 0 || (boxes && labels && embeds_dev)) && kept_out && ids_out && n >= 0, "bad pointer or size");
     PH_CHECK_ARG(n <= t->max_n, "more detections than the tracker was created for");
+    if (t->poisoned) {
+        ph_set_error("ph_tracker_match: an earlier frame failed on the device after its bookkeeping was committed; reset or recreate the tracker");
+        return PH_ELAUNCH;
+    }
     hipStream_t s = (hipStream_t)stream;
     const ph_tracker_cfg& c = t->c;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -249,8 +262,31 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
         }
     }
     // ---- new tracks (:198-205)
+    int64_t born = 0;                                           // committed to num_tracklets once the frame's slots are known to exist
     for (int i = 0; i < k; ++i)
-        if (ids[i] == -1 && boxes[kept[i] * 5 + 4] > c.init_score_thr) ids[i] = t->num_tracklets++;
+        if (ids[i] == -1 && boxes[kept[i] * 5 + 4] > c.init_score_thr) ids[i] = t->num_tracklets + born++;
+    // ---- every pool slot this frame takes is reserved BEFORE the first mutation: a frame that does not fit fails with the tracker
+    // exactly as the previous frame left it
+    {
+        size_t need = 0;
+        for (int i = 0; i < k; ++i) {
+            const float* bi = boxes + kept[i] * 5;
+            if (ids[i] > -1) {
+                bool found = false;
+                for (size_t r = 0; r < t->ids.size() && !found; ++r) found = t->ids[r] == ids[i];
+                need += found ? 0 : 1;
+            } else if (ids[i] == -1 && c.memo_backdrop_frames > 0) {
+                bool covered = false;
+                for (int j = 0; j < i && !covered; ++j) covered = iou1(bi, boxes + kept[j] * 5) > c.nms_backdrop_iou_thr;
+                need += covered ? 0 : 1;
+            }
+        }
+        if (need > t->free_slots.size()) {
+            ph_set_error("ph_tracker_match: embedding pool exhausted (%zu slots needed, %zu free; raise the capacity)", need, t->free_slots.size());
+            return PH_EWORKSPACE;
+        }
+    }
+    t->num_tracklets += born;
     // ---- update_memo (:47-102): tracked detections refresh / append rows; unmatched, uncovered ones become this frame's backdrops
     const int act_off = 2 * t->max_n + 2 * t->capacity;      // its own region of the pinned / device tables: the first upload may still be in flight
     int32_t* act = t->h_tab + act_off;    // [k][2] (slot, mode)
@@ -274,8 +310,7 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
                 t->lab[r] = labels[kept[i]];
                 t->seen[r] = frame_id;
             } else {
-                const int sl = take_slot();
-                if (sl < 0) { ph_set_error("ph_tracker_match: embedding pool exhausted (raise the capacity)"); return PH_EWORKSPACE; }
+                const int sl = take_slot();                 // reserved above
                 act[2 * i] = sl; act[2 * i + 1] = 2;
                 t->ids.push_back(ids[i]); t->lab.push_back(labels[kept[i]]); t->seen.push_back(frame_id); t->slot.push_back(sl);
                 t->box.insert(t->box.end(), bi, bi + 5);
@@ -284,8 +319,7 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
             bool covered = false;
             for (int j = 0; j < i && !covered; ++j) covered = iou1(bi, boxes + kept[j] * 5) > c.nms_backdrop_iou_thr;
             if (!covered && c.memo_backdrop_frames > 0) {
-                const int sl = take_slot();
-                if (sl < 0) { ph_set_error("ph_tracker_match: embedding pool exhausted (raise the capacity)"); return PH_EWORKSPACE; }
+                const int sl = take_slot();                 // reserved above
                 act[2 * i] = sl; act[2 * i + 1] = 2;
                 bd.box.insert(bd.box.end(), bi, bi + 5); bd.lab.push_back(labels[kept[i]]); bd.slot.push_back(sl);
             }
@@ -296,6 +330,7 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     if (k > 0) {
         if (hipMemcpyAsync(t->d_tab + act_off, act, (size_t)2 * k * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
             ph_set_error("ph_tracker_match: action upload failed");
+            t->poisoned = true;                              // the tables above already describe this frame
             return PH_ELAUNCH;
         }
         hipLaunchKernelGGL(k_trk_update, dim3(k), dim3(TE), 0, s, t->d_det, t->d_tab + act_off, k, c.one_minus_momentum, c.memo_momentum, t->pool);
@@ -323,7 +358,14 @@ extern "C" int ph_tracker_match(ph_tracker* t, const float* boxes, const int64_t
     t->ids.resize(w); t->lab.resize(w); t->seen.resize(w); t->slot.resize(w); t->box.resize(w * 5);
     for (int i = 0; i < k; ++i) { kept_out[i] = kept[i]; ids_out[i] = ids[i]; }
     t->tacc[5] += secs(t5, now());
-    PH_CHECK_LAUNCH();
+    {
+        const hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            ph_set_error("ph_tracker_match: launch failed: %s", hipGetErrorString(e_));
+            t->poisoned = true;
+            return PH_ELAUNCH;
+        }
+    }
     return k;
 }
 

@@ -132,6 +132,8 @@ def build_heads_from_config(cfg):
     `test_cfg` injected as TwoStageDetector does, mmdet/models/detectors/two_stage.py:36-49) built from this package's
     registry, honouring the config's `fp16` key exactly as tools/test.py:202-204 does.  `cfg`: the loaded config as a
     (nested) dict.  Returns (rpn_head, roi_head)."""
+    # the modules whose import registers the names a reference config uses (the reference's `polyphonic/__init__.py` does the same)
+    from . import kernel_head, kernel_update, kernel_update_head, kernel_updator, semantic_fpn, assigner, losses  # noqa: F401
     model = cfg["model"]
     train_cfg, test_cfg = model.get("train_cfg"), model.get("test_cfg")
     rpn = deep_cfg(model["rpn_head"])

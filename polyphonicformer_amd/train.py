@@ -36,6 +36,16 @@ def _gpu32(t, name):
     return t.detach().contiguous().float()
 
 
+def _param32(p, name="parameter"):
+    """a parameter whose storage a kernel reads through a raw pointer: fp32, contiguous, on the GPU -- anything else would be read as
+    fp32 garbage with no error (a head cast to half / bf16, a non-contiguous view), so it is refused"""
+    if not p.is_cuda:
+        raise _lib.PolyheadError(f"{name} must live on the GPU: libpolyhead has no CPU path")
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        raise _lib.PolyheadError(f"training forward: fp32 contiguous parameters only ({name}: {p.dtype}, contiguous={p.is_contiguous()})")
+    return p.detach()
+
+
 # Test aid (None in production): `hard_mask_hook(site, logits) -> logits` is consulted wherever the training forward is about to
 # BINARISE mask logits for pooling -- site = the KernelHead module or the KernelUpdateHead stage module.  The tests hand the
 # reference's hard decisions in (+-1 logits) so that a comparison with the reference's gradients measures arithmetic, not a logit
@@ -135,7 +145,7 @@ class _Objective(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None) + tuple(g * t for t in ctx.saved_tensors)
+        return (None, None) + tuple(None if t is None else g * t for t in ctx.saved_tensors)      # no depth items: no depth gradient
 
 
 upsample2x = _Upsample2x.apply
@@ -355,7 +365,7 @@ class _Rpn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, groups, site, f0, f1, f2, *params):
         f = [_gpu32(t, "post-neck map") for t in (f0, f1, f2)]
-        P = [p.detach() for p in params]
+        P = [_param32(p, n) for p, n in zip(params, RPN_NAMES)]
         W = [P[0].flatten(1), P[3].flatten(1), P[6].flatten(1)]
         B = f[0].shape[0]
         y = [rows_x_map(W[t][None], f[t]) for t in range(3)]
@@ -471,7 +481,7 @@ class _GNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, groups, add):
         y = _gpu32(y, "y")
-        g, b = gamma.detach(), beta.detach()
+        g, b = _param32(gamma, "GroupNorm weight"), _param32(beta, "GroupNorm bias")
         out, osum, stats = gn_relu_fwd(y, g, b, groups, add=None if add is None else _gpu32(add, "add"), want_out=False)
         ctx.groups, ctx.has_add = groups, add is not None
         ctx.save_for_backward(y, stats, g, b)
@@ -492,7 +502,7 @@ class _NeckOuts(torch.autograd.Function):
     @staticmethod
     def forward(ctx, groups, s, *params):
         s = _gpu32(s, "tower sum")
-        P = [p.detach() for p in params]
+        P = [_param32(p, "neck output conv parameter") for p in params]
         n = len(P) // 3
         ys, sts, outs = [], [], []
         for j in range(n):
@@ -646,7 +656,8 @@ def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_s
         values = {}
         total = _Objective.apply(fn, values, smask, sseg, sdep0)
         losses = _attach(values, total)
-        losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)              # :438-442, logged only
+        if gt_depth is not None:
+            losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)          # :438-442, logged only
         if want_grads:
             losses["_grads"] = kept
         return losses, r
@@ -670,7 +681,8 @@ def rpn_forward_train(h, feats, img_metas, gt_masks, gt_labels, gt_sem_seg, gt_s
     values = {}
     total = _Objective.apply(fn, values, smask, sseg, sdep0)
     losses = _attach(values, total)
-    losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)                  # :438-442, logged only
+    if gt_depth is not None:
+        losses["depth_dense"] = Lo.dense_depth_loss(h, sdep0.detach(), gt_depth)              # :438-442, logged only
     if want_grads:
         losses["_grads"] = kept
     return losses, r

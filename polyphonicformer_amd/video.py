@@ -345,6 +345,13 @@ class QuasiDenseEmbedTracker(object):
         if self.native and track_feats.is_cuda and bboxes.shape[0] <= self.NATIVE_MAX_DETS and bboxes.shape[1] == 5 and track_feats.shape[1] == 256 \
                 and (self._native is not None or (len(self.table) == 0 and self._num_tracklets == 0)):
             return self._match_native(bboxes, labels, track_feats, frame_id)
+        if self._native is not None:
+            from . import _lib
+            # the native tracker owns the memory and the id counter from its first frame on: the array form below would start a second,
+            # empty state (ids from 0 again, colliding with live native ids) and the native memory would miss this frame
+            raise _lib.PolyheadError(f"QuasiDenseEmbedTracker: the native tracker has started and this frame does not fit it (device embeddings of "
+                                f"width 256, [n, 5] boxes, n <= {self.NATIVE_MAX_DETS}; got n = {bboxes.shape[0]}, boxes {tuple(bboxes.shape)}, "
+                                f"embeddings {tuple(track_feats.shape)} on {track_feats.device}); build the tracker with native=False for such streams")
         box_t, lab_t, emb = bboxes.detach().cpu().float(), labels.detach().cpu().long(), track_feats.detach().float()   # emb: stays put
         dev = emb.device
         order = box_t[:, 4].sort(descending=True)[1].numpy()      # torch's order among equal scores (what the goldens were pinned with)
@@ -470,7 +477,9 @@ class VideoAssociator:
 
     def init_tracker(self):
         """polyphonic_former_video.py:59-61"""
-        self.tracker = QuasiDenseEmbedTracker(**self.tracker_cfg)
+        cfg = dict(self.tracker_cfg)
+        cfg.setdefault("type", "QuasiDenseEmbedTracker")         # the config's own dict (with `type`) or bare kwargs
+        self.tracker = TRACKERS.build(cfg)                       # build_tracker(self.tracker_cfg), polyphonic_former_video.py:60
         self.cnt = 1
 
     def record(self, fpn_feats, panoptic_seg, segments_info, pan_dev=None):
@@ -606,6 +615,29 @@ class VideoFramePipeline:
             return r._collect(r._downloads.pop(0))
         _, _, (panoptic_seg, segments_info), _, depth_final = self.heads(x, img_metas, rescale)[0]
         return self.assoc.step(x, panoptic_seg, segments_info, depth_final, records_only=records_only)
+
+
+def build_video_pipeline_from_config(cfg):
+    """`PolyphonicVideo.__init__` (polyphonic/polyphonic_former_video.py:23-60) from a loaded reference config (nested dict with a
+    `model` key, e.g. configs/polyphonic_video/poly_r50_cityscapes_1x.py after `_base_` resolution): rpn_head / roi_head with
+    train_cfg / test_cfg injected as TwoStageDetector does, `track_head` from the registry, the tracker from `model.tracker`, the
+    RoI extractor from `model.bbox_roi_extractor` (the shipped one: SingleRoIExtractor over RoIAlign 7x7, sampling_ratio 2 --
+    csrc/ph_track.hip implements exactly that; anything else is refused).  Backbone and FPN stay the caller's.  Returns a
+    `VideoFramePipeline`."""
+    from .registry import build_heads_from_config, build_head, deep_cfg
+    from . import track_head  # noqa: F401  (registers QuasiDenseMaskEmbedHeadGTMask and the loss names its config carries)
+    model = cfg["model"]
+    for k in ("track_head", "tracker", "bbox_roi_extractor"):
+        if model.get(k) is None:
+            raise ValueError(f"model.{k} is missing: not a PolyphonicVideo config")
+    rpn_head, roi_head = build_heads_from_config(cfg)
+    ext = model["bbox_roi_extractor"]
+    rl = ext.get("roi_layer", {})
+    if ext.get("type") != "SingleRoIExtractor" or rl.get("type") != "RoIAlign" or rl.get("output_size") not in (7, (7, 7), [7, 7]) \
+            or rl.get("sampling_ratio", 0) != 2 or ext.get("out_channels") != 256:
+        raise NotImplementedError(f"bbox_roi_extractor {ext!r}: libpolyhead implements SingleRoIExtractor(RoIAlign 7x7, sampling_ratio=2, 256 ch)")
+    th = build_head(deep_cfg(model["track_head"]))
+    return VideoFramePipeline(rpn_head, roi_head, th, deep_cfg(model["tracker"]), strides=tuple(ext["featmap_strides"]))
 
 
 def _h2d(values, dtype, dev):

@@ -99,6 +99,53 @@ def test_sharded_video_tracking_matches_reference_ids():
     assert all(r[1] for r in res)
 
 
+def _track_worker_steps(rank, world, port, q):
+    """cfg4's loop shape at world `world`: a video of 12 frames arrives in steps of `world` frames (one frame per rank and step, the
+    last step ragged), each step = ONE all-gather + a replay with the stream's persistent tracker (bench.cfg4_run)"""
+    import json
+    import numpy as np
+    import helpers as Hh
+    from polyphonicformer_amd import video as V
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = Hh.tracker_records(1)
+    z = Hh.load_golden("tracker.npz")
+    tracker = V.QuasiDenseEmbedTracker(**json.loads(bytes(z["cfg_json"]).decode()))
+    ids, cnt = {}, 1
+    for s0 in range(0, len(recs), world):
+        step = list(range(s0, min(s0 + world, len(recs))))
+        mine = [step[i] for i in D.shard_frames(len(step), rank, world)]
+        packed = [D.pack_track_records(recs[f][1], recs[f][2], recs[f][3]) for f in mine]
+        allrec = D.allgather_track_records(mine, [p[0] for p in packed], [p[1] for p in packed], 1)
+        assert [r[0] for r in allrec] == step, (rank, [r[0] for r in allrec], step)
+        ids.update(V.replay_tracking(allrec, tracker=tracker, first_count=cnt))
+        cnt += sum(1 for r in allrec if r[1].shape[0])
+    ok = all(np.array_equal(ids[f].numpy(), z[f"s1_f{f}_ids"]) for f in range(len(recs)))
+    mx = D.barrier_and_max(float(rank), torch.device("cpu"))
+    q.put((rank, ok, mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_sharded_steps_allgather_and_replay():
+    """the 8-rank shape of the video path, on CPU: every step's frames sharded over 8 ranks (ragged last step: ranks
+    without a frame still take part in the collective), ONE all-gather per step, the persistent tracker replayed on every rank --
+    the reference tracker's ids bit for bit on all 8 ranks, max-over-ranks timing = rank 7's value"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_track_worker_steps, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] for r in res)
+    assert all(r[2] == float(world - 1) for r in res)
+
+
 def test_shard_frames_partitions():
     for n in (1, 5, 16, 17):
         for w in (1, 2, 4, 8):

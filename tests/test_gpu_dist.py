@@ -160,6 +160,51 @@ def test_bench_cfg4_json_line(gpu):
     assert res["roofline"]["kernel"] == "pool" and 0 < res["roofline"]["frac"] < 1
 
 
+# ---- the 8-rank shape, turnkey: on a box with fewer than 8 GPUs the ranks share GPU 0 and rendezvous over gloo ----
+def _bench_line(args, env_extra=None, timeout=1500):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus8_self_launch_json_line(gpu):
+    """`python bench.py --gpus 8` exactly as the driver's 8-GPU run starts it (minus the outer launcher): rank 0 starts ranks 1..7,
+    every rank times its own frames, the line carries n_gpus 8, the max-over-ranks step time, the 8-rank all-gather (payload of all
+    8 ranks bit-exact) and value = frames of all ranks / that time"""
+    extra = {} if torch.cuda.device_count() >= 8 else {"PH_DIST_BACKEND": "gloo"}
+    res = _bench_line(["--gpus", "8", "--workload", "tiny", "--frames", "8", "--steps", "3", "--warmup", "1", "--streams", "2", "--no-cpu-baseline",
+                       "--no-kernel-head"], extra)
+    assert res["n_gpus"] == 8 and res["scaling"] == "weak" and res["steps"] == 3 and res["value"] > 0
+    assert abs(res["value"] - 8 * 8 * 1e3 / res["ms_per_step"]) / res["value"] < 1e-3          # whole-job aggregate over the 8 ranks
+    for fpr in ("2", "8"):
+        tag = res["track_allgather"][fpr]
+        assert tag["world_size"] == 8 and tag["payload_round_trip_exact"] and tag["collective_us_per_step"] > 0
+    assert res["roofline"]["frac"] > 0 and "8 GPU(s)" in res["config"]["parallelism"]
+
+
+def test_cfg4_world8_ids_equal_world1_and_json_line(gpu):
+    """BASELINE configs[3] at its 8-rank shape: 16 frames as 8 two-frame clips, one per rank, ONE all-gather, the replay on every rank:
+    the track ids of all 16 frames equal the single-process loop's on all 8 ranks; then the same through `bench.py --workload cfg4
+    --gpus 8` (self-launched ranks): one JSON line, world size 8"""
+    ndev = torch.cuda.device_count()
+    backend = "nccl" if ndev >= 8 else "gloo"
+    one = _cfg4(1, "nccl", 8)[0]
+    assert len(one["track_ids"]) == 16 and sum(len(v) for v in one["track_ids"].values()) > 0
+    eight = _cfg4(8, backend, 1)
+    for r in range(8):
+        assert eight[r]["world_size"] == 8
+        assert eight[r]["track_ids"] == one["track_ids"], r
+    res = _bench_line(["--workload", "cfg4", "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                      {} if ndev >= 8 else {"PH_DIST_BACKEND": "gloo"})
+    assert res["n_gpus"] == 8 and res["cfg4"]["world_size"] == 8 and res["value"] > 0 and res["unit"] == "frames/s"
+    assert res["cfg4"]["allgather_track_records_us_per_step"] > 0
+
+
 # ---- data-parallel training step: two ranks, gradients averaged by dist.GradBuckets -------------------------------------------
 def _train_heads(dev):
     sys.path.insert(0, os.path.join(REPO, "tests"))

@@ -136,7 +136,7 @@ def test_association_chain_vs_oracle(gpu):
     bb = torch.cat([ext.cpu(), torch.tensor([[s["score"]] for s in info])], 1)
     lab = torch.tensor([s["category_id"] for s in info])
     a = V.QuasiDenseEmbedTracker(init_score_thr=0.35, obj_score_thr=0.3)
-    b = V.QuasiDenseEmbedTracker(init_score_thr=0.35, obj_score_thr=0.3)
+    b = VO.TrackerOracle(init_score_thr=0.35, obj_score_thr=0.3)      # the oracle's restatement of the reference tracker (pinned on tracker.npz)
     for f in (1, 2):
         ia = a.match(bb, lab, emb.cpu(), f)[2]
         ib = b.match(torch.cat([VO.mask_extent_boxes(masks), bb[:, 4:]], 1), lab, emb_ref, f)[2]
@@ -158,7 +158,7 @@ def test_two_frame_clip_association(gpu):
     pan0, info, feats, _ = Hh.video_case(seed=21, H=192, W=320, nseg=8)
     pan1 = np.roll(pan0, (2, 3), axis=(0, 1))
     feats1 = [torch.roll(f, (1, 1), dims=(2, 3)) if i == 0 else f for i, f in enumerate(feats)]
-    ref_tr = V.QuasiDenseEmbedTracker(**cfg)
+    ref_tr = VO.TrackerOracle(**cfg)          # the checker is the oracle's tracker (pinned on the reference's goldens), not the product's
     outs, ref_ids = [], []
     for fi, (pan, ff) in enumerate(((pan0, feats), (pan1, feats1))):
         depth = np.full(pan.shape, 1.5, dtype=np.float32)
@@ -226,7 +226,7 @@ def test_cfg3_two_frame_clip_end_to_end(gpu):
     base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g) for s in (4, 8, 16, 32)]
     frames = [base, [torch.roll(f, (1, 2), dims=(2, 3)) for f in base]]          # the second frame: the first, shifted
     meta = [Hh.img_meta(H8, W8)]
-    ref_tr = V.QuasiDenseEmbedTracker(**cfg)
+    ref_tr = VO.TrackerOracle(**cfg)          # the oracle's tracker, not the product's class
     cnt, nseg = 1, []
     for ff in frames:
         x = tuple(f.to(gpu) for f in ff)
@@ -328,6 +328,73 @@ def test_native_tracker_long_stream_and_timing(gpu):
     # (the time is printed, not asserted tightly: 0.10-0.15 ms on an idle box, but a loaded host has shown 0.3+; the bound only
     # catches a fall back to the host form's per-frame device round trips)
     assert nat.num_tracklets == cpu.num_tracklets and per < 2.0
+
+
+def test_native_tracker_never_falls_back_to_the_array_form_mid_stream(gpu):
+    """once the native tracker holds the stream's memory, a frame that does not fit it (more than NATIVE_MAX_DETS
+    detections here) must RAISE -- the array form would start a second, empty state whose ids restart at 0 and collide with the
+    live native ones.  The tracker is unchanged by the refused frame and goes on with the next one."""
+    from polyphonicformer_amd import video as V, _lib
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=5, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+    recs = Hh.tracker_records(7, nframes=4, nobj=30)
+    dev = [(f, bb.to(gpu), lab.to(gpu), emb.to(gpu)) for f, bb, lab, emb in recs]
+    nat, ref = V.QuasiDenseEmbedTracker(**cfg), V.QuasiDenseEmbedTracker(**cfg)
+    for cnt in (1, 2):
+        nat.match(bboxes=dev[cnt - 1][1], labels=dev[cnt - 1][2], track_feats=dev[cnt - 1][3], frame_id=cnt)
+        ref.match(bboxes=recs[cnt - 1][1], labels=recs[cnt - 1][2], track_feats=recs[cnt - 1][3], frame_id=cnt)
+    born = nat.num_tracklets
+    assert born > 0 and nat._native is not None
+    g = torch.Generator().manual_seed(5)
+    n_big = nat.NATIVE_MAX_DETS + 3
+    xy = torch.rand(n_big, 2, generator=g) * 500
+    big = torch.cat([xy, xy + 20, torch.rand(n_big, 1, generator=g)], 1)
+    with pytest.raises(_lib.PolyheadError, match="native tracker has started"):
+        nat.match(bboxes=big.to(gpu), labels=torch.zeros(n_big, dtype=torch.long, device=gpu), track_feats=torch.randn(n_big, 256, device=gpu),
+                  frame_id=3)
+    with pytest.raises(_lib.PolyheadError, match="native tracker has started"):       # the per-frame loop of replay_tracking too
+        V.replay_tracking([(0, big, torch.zeros(n_big, dtype=torch.long), torch.randn(n_big, 256, device=gpu))], tracker=nat,
+                          first_count=3)
+    assert nat.num_tracklets == born
+    for cnt in (3, 4):                                                              # the stream continues with the ids of the CPU form
+        a = nat.match(bboxes=dev[cnt - 1][1], labels=dev[cnt - 1][2], track_feats=dev[cnt - 1][3], frame_id=cnt)
+        b = ref.match(bboxes=recs[cnt - 1][1], labels=recs[cnt - 1][2], track_feats=recs[cnt - 1][3], frame_id=cnt)
+        assert torch.equal(a[2], b[2])
+
+
+def test_native_tracker_pool_exhaustion_leaves_the_state_as_it_was(gpu):
+    """ph_tracker_match reserves every pool slot a frame takes BEFORE it mutates anything: a frame that does not fit
+    fails with PH_EWORKSPACE and the tracker still answers the next (smaller) frame with the ids a fresh copy of the history gives"""
+    import ctypes as C
+    from polyphonicformer_amd import video as V, _lib
+    cfg = dict(init_score_thr=0.35, obj_score_thr=0.3, match_score_thr=0.5, memo_tracklet_frames=50, memo_backdrop_frames=1,
+               memo_momentum=0.8, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.3, nms_class_iou_thr=0.7, with_cats=True, match_metric="bisoftmax")
+
+    def frame(seed, n, score):
+        g = torch.Generator().manual_seed(seed)
+        xy = torch.arange(n, dtype=torch.float32)[:, None] * 40 + torch.rand(n, 2, generator=g)
+        return (torch.cat([xy, xy + 20, torch.full((n, 1), score)], 1).to(gpu), torch.zeros(n, dtype=torch.long, device=gpu),
+                (0.01 * torch.randn(n, 256, generator=g)).to(gpu))       # near-uniform affinities: nothing matches, every box is a new track
+
+    class Small(V.QuasiDenseEmbedTracker):
+        NATIVE_CAPACITY = 16
+
+    a, b = Small(**cfg), Small(**cfg)
+    f1 = frame(1, 10, 0.9)
+    for t in (a, b):
+        t.match(bboxes=f1[0], labels=f1[1], track_feats=f1[2], frame_id=1)
+    assert a.num_tracklets == 10
+    f2 = frame(2, 12, 0.9)                       # 12 unrelated high-score boxes far from frame 1's: 12 new tracklets, 6 slots free
+    f2 = (f2[0] + torch.tensor([0, 5000, 0, 5000, 0], device=gpu), f2[1], f2[2])
+    with pytest.raises(_lib.PolyheadError, match="pool exhausted"):
+        a.match(bboxes=f2[0], labels=f2[1], track_feats=f2[2], frame_id=2)
+    lib = _lib.load()
+    assert a.num_tracklets == 10 and lib.ph_tracker_rows(a._native[0]) == 10
+    f3 = frame(3, 4, 0.9)
+    f3 = (f3[0] + torch.tensor([0, 9000, 0, 9000, 0], device=gpu), f3[1], f3[2])
+    ra = a.match(bboxes=f3[0], labels=f3[1], track_feats=f3[2], frame_id=2)
+    rb = b.match(bboxes=f3[0], labels=f3[1], track_feats=f3[2], frame_id=2)
+    assert torch.equal(ra[2], rb[2]) and a.num_tracklets == b.num_tracklets == 14
 
 
 def test_replay_of_a_step_in_one_native_call(gpu):

@@ -1,6 +1,7 @@
 """CPU: the video-association oracle (oracle/video_oracle.py) against the reference's own helpers / track head
 (tests/golden/video.npz) and, for RoIAlign (mmcv op, not runnable here), analytic properties."""
 import numpy as np
+import pytest
 import torch
 
 import helpers as Hh
@@ -71,3 +72,23 @@ def test_roi_align_against_atens_bilinear_sampler():
         samp = F.grid_sample(feat, grid, mode="bilinear", padding_mode="zeros", align_corners=False)      # [1,C,14,14]
         want = F.avg_pool2d(samp, 2)[0]
         assert torch.allclose(out[i], want, atol=2e-5), (i, float((out[i] - want).abs().max()))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tracker_oracle_reproduces_the_reference_ids(seed):
+    """oracle/video_oracle.TrackerOracle (the checker of the end-to-end association tests in tests/test_gpu_video.py) against the ids,
+    labels and boxes the REFERENCE QuasiDenseEmbedTracker produced on the same synthetic clips (tests/golden/tracker.npz)"""
+    import json
+    z = Hh.load_golden("tracker.npz")
+    tr = VO.TrackerOracle(**json.loads(bytes(z["cfg_json"]).decode()))
+    cnt = 1
+    for f, bb, lab, emb in Hh.tracker_records(seed):
+        if bb.shape[0] == 0:
+            continue
+        obb, olab, ids = tr.match(bb, lab, emb, cnt)
+        cnt += 1
+        ids = ids + 1
+        ids[ids == -1] = 0
+        assert np.array_equal(ids.numpy(), z[f"s{seed}_f{f}_ids"]), f
+        assert np.array_equal(olab.numpy(), z[f"s{seed}_f{f}_labels"])
+        assert np.array_equal(obb.numpy(), z[f"s{seed}_f{f}_bboxes"])
