@@ -64,6 +64,7 @@ def build_head(wl, precision, out_dtype, device, seed=0):
     head.init_weights()                       # the reference's init (xavier-uniform, kernel_update_head.py:193-205)
     head.eval().to(device)
     head.set_precision(precision, out_dtype)
+    head.frame_invariant = False          # throughput legs: launch geometry tuned to the batch (the module API's default is True)
     return head
 
 
@@ -510,6 +511,7 @@ def full_head_leg(wl, head, precision, dev, B=16, steps=5):
     kh.init_weights()
     kh.eval().to(dev)
     kh.set_precision(precision)
+    kh.frame_invariant = False            # throughput leg (the video legs keep the module API's frame-invariant default)
     H0, W0 = wl["H"] * 2, wl["W"] * 2
     g = torch.Generator().manual_seed(6)
     feats = tuple(torch.randn(B, 256, H0 >> i, W0 >> i, generator=g).to(dev) for i in range(4))
@@ -612,6 +614,7 @@ def _video_pipeline(dev, precision):
     kh.eval().to(dev)
     kh.set_precision(precision)
     ih = build_head(wl, precision, torch.float32, dev, seed=3)
+    ih.frame_invariant = True             # video: a clip's frames through one launch equal the per-frame loop bit for bit
     ih.test_cfg = ConfigDict(max_per_img=wl["Nq"], mask_thr=0.5, merge_stuff_thing=dict(overlap_thr=0.0, instance_score_thr=0.3))
     with torch.no_grad():      # un-trained masks overlap heavily: accept every segment that wins pixels (overlap_thr 0) ...
         ih.mask_head[-1].fc_cls.bias.fill_(1.0)      # ... and let every query pass the score threshold (sigmoid(1) = 0.73)
@@ -749,6 +752,7 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
            "replay_tracking_ms_per_frame": round(D.barrier_and_max(med(t_replay), cdev) * 1e3 / per_step, 4),
            "step_pipelining": "step k+1's heads are started before step k's all-gather + tracker replay (ms_per_step ~ max of the two)",
            "precision": precision,
+           "khead_onepass_timeouts": None if runner is None else runner.khead_timeouts(),
            "frame_loop": "module API, eager launches" if runner is None else "video.VideoStreamRunner: heads replayed from one HIP graph"}
     # what the measured components project for a node of 8 ranks (the driver's 8-GPU leg, when a node is available): every rank replays
     # all 8 x clip frames of a step; the step is pipelined, so it costs max(heads of the own clip, all-gather + replay of all frames)

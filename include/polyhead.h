@@ -542,7 +542,7 @@ int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int gro
  *                  -> bf16 NHWC planes [P][B][HW][256].
  * ph_conv_nhwc   : ConvModule's conv (no bias): KSxKS, pad KS/2, stride 1 or 2 (3x3) / 1 (1x1), 256 -> 256 channels;
  *                  X bf16 NHWC planes, Wp = pack.pack_b32 fragments of W[n][tap * 256 + c], Y fp32 NHWC [B][Ho][Wo][256];
- *                  partial = per-workgroup per-channel (sum, sum of squares) [B][nwg][256][2]
+ *                  partial = per-channel (sum, sum of squares) of every (row pair, column tile) [B][nwg][256][2]
  *                  (ph_conv_nhwc_partial_floats) for the GroupNorm that follows.
  * ph_gn_finalize : partial -> stats [B][groups][2] = (mean, rstd), fp64 combine (also used by ph_khead_conv_gn).
  * ph_gn_apply    : GroupNorm affine + ReLU on fp32 NHWC (stats == NULL: plain copy/convert), then per `mode`:
@@ -552,8 +552,9 @@ int ph_gn_relu_cl(const float* y, const float* gamma, const float* beta, int gro
  *                  without an fp32 sum buffer); ys / stats / gammas / betas are HOST arrays of `nlev` device pointers. */
 int ph_nhwc_ingest(const float* src, const float* add /* nullable */, uint16_t* dst, int B, int64_t HW, int prec, void* stream);
 size_t ph_conv_nhwc_partial_floats(int B, int Ho, int Wo);                     /* upper bound, any instantiation */
-/* `nwg` for ph_gn_finalize = workgroups per frame of the ph_conv_nhwc launch of B frames (small launches take 2-row tiles, so
-   the count depends on B; the B-less ph_conv_nhwc_workgroups of rounds 3-4 is removed: it was wrong for small launches) */
+/* `nwg` for ph_gn_finalize = entries per frame of ph_conv_nhwc's `partial` output: one per (pair of output rows, 64-pixel column
+   tile) whatever tile form the launch takes (round 6: batch-invariant partial sums; rounds 3-5 it was the workgroups of the
+   chosen form, hence the arguments) */
 int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B);
 int ph_conv_nhwc(const uint16_t* X, const uint16_t* Wp, int64_t w_plane_elems, float* Y, float* partial, int ksize, int stride,
                  int B, int H, int W, int prec, void* stream);

@@ -65,7 +65,8 @@ __device__ __forceinline__ void conv_read_batch(uint32_t fa, u32x2_t (&dst)[PF][
 }
 
 // PF feature planes x PK kernel planes: (1,1) a.b; (1,2) (a_hi + a_lo).b; (2,2) a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
-template <int PF, int PK, int E, int KB, int BI, bool COOP = false>
+// SWAP (one plane each): the operands exchanged -- D'[pixel][query], the transposed product (ph_convup.hip: k_dynconv_up2m)
+template <int PF, int PK, int E, int KB, int BI, bool COOP = false, bool SWAP = false>
 __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][16], u32x2_t (&bq)[2][PF][KB][2], f32x16_t& acc,
                                              const float (&bias)[16]) {
     constexpr int NBATCH = 16 / KB;
@@ -90,12 +91,16 @@ __device__ __forceinline__ void conv_batches(uint32_t fa, const uint4 (&af)[PK][
                 bf[p] = make_uint4(bq[BI & 1][p][k][0].x, bq[BI & 1][p][k][0].y, bq[BI & 1][p][k][1].x, bq[BI & 1][p][k][1].y);
                 if constexpr (E == PH_E_F16_FROM_BF16 && !COOP) bf[p] = bf2h_x8(bf[p]);      // 12 VALU ops under the previous MFMA
             }
-            acc = mfma32e<E>(af[0][BI * KB + k], bf[0], acc);
+            if constexpr (SWAP) {
+                static_assert(!SWAP || (PF == 1 && PK == 1), "transposed product: one plane each");
+                acc = mfma32e<E>(bf[0], af[0][BI * KB + k], acc);
+            } else
+                acc = mfma32e<E>(af[0][BI * KB + k], bf[0], acc);
             if (PF == 2) acc = mfma32e<E>(af[0][BI * KB + k], bf[PF - 1], acc);
             if (PK == 2) acc = mfma32e<E>(af[PK - 1][BI * KB + k], bf[0], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
-        conv_batches<PF, PK, E, KB, BI + 1, COOP>(fa, af, bq, acc, bias);
+        conv_batches<PF, PK, E, KB, BI + 1, COOP, SWAP>(fa, af, bq, acc, bias);
     }
 }
 

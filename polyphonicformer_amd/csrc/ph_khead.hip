@@ -615,10 +615,17 @@ static int kh_tiles_per_wg(int64_t HWp, int B) {
     return tpw;
 }
 
-// plain mode (the neck's output convs): up to 3 frames per launch the tile runs are those of a ONE-frame launch, so that a
-// frame's partial sums -- and with them every bit of its outputs -- do not depend on how many frames share the launch (the
-// video runner batches a clip's frames 2-3 per launch and promises the bits of the per-frame loop)
-static int kh_tiles_per_wg_plain(int64_t HWp, int B) { return kh_tiles_per_wg(HWp, B <= 3 ? 1 : B); }
+// plain mode (the neck's output convs): the tile runs are those of a ONE-frame launch at any batch, so that a frame's partial
+// sums -- and with them every bit of its outputs -- do not depend on how many frames share the launch (the video runner batches
+// a whole clip per launch and promises the bits of the per-frame loop; round 6: for every B, it was B <= 3 until round 5)
+// (a run length that keeps a ONE-frame launch at >= 128 workgroups per map -- 384 over the three maps -- and a 16-frame one at a
+// quarter of round 5's weight re-reads: 4 tiles at cfg2's 512, 1 below 256)
+static int kh_tiles_per_wg_plain(int64_t HWp, int B) {
+    (void)B;
+    const int ntiles = (int)(HWp / KH_T);
+    int tpw = ntiles / 128;
+    return tpw < 1 ? 1 : (tpw > 32 ? 32 : tpw);
+}
 
 static size_t kh_ws_bytes(int B, int64_t HW, int groups, bool plain) {
     const int64_t HWp = ph_hw_padded(HW);

@@ -373,8 +373,14 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
     //      output row of the wave at a time: 64 pixels x 32 channels = 8 KB per wave, pixel rows swizzled by bit 2 (= kg on the
     //      write side) so that both the 4-byte writes and the 16-byte reads touch every bank once; then 8 stores of 16 bytes
     //      per lane (8 pixels x 128 contiguous bytes per instruction) instead of 32 of 4 bytes.
+    // GroupNorm partial sums: ONE entry per PAIR of output rows (rows 2p, 2p + 1 of the image x this tile's 64 pixels), in the 2-row
+    // kernel's order -- the lane's two rows x two halves x 16 registers, then the two lane halves -- whatever TH is (round 6): a 4-row
+    // tile emits two entries, so the sums `ph_gn_finalize` adds, and with them every bit of the normalised output, do not depend on
+    // the tile form the launch size picked (batch-invariant kernels; the 2 x 4 wave arrangement of -DCV_WAVES_2X4
+    // keeps the older per-tile entries).
     float s1[NT], s2[NT];
     float* tbuf = (float*)lds + wv * 2048;
+    const int64_t npair_x = gridDim.x, npairs = (int64_t)gridDim.x * ((Ho + 1) / 2);
     // (the single-plane kernels: the last chunk's closing barrier has passed, the LDS is free)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -383,6 +389,9 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #pragma unroll
         for (int row = 0; row < MT / 2; ++row) {
             const int oy = oy0 + row_base + row;
+#ifndef CV_WAVES_2X4
+            if ((row & 1) == 0) { s1[nt] = 0.f; s2[nt] = 0.f; }
+#endif
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -396,8 +405,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
                         s2[nt] += v * v;
                     }
                 }
-            if (!DB) continue;                            // (the two-plane kernels keep the direct stores below)
-            if (oy < Ho) {
+            if (DB && oy < Ho) {                          // (the two-plane kernels keep the direct stores above)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int P = (lane >> 3) + 8 * i;
@@ -406,18 +414,26 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
                     if (ox0 + P < Wo) *(float4*)(Y + (((int64_t)b * Ho + oy) * Wo + ox0 + P) * 256 + (wc * NT + nt) * 32 + (lane & 7) * 4) = v;
                 }
             }
+#ifndef CV_WAVES_2X4
+            if ((row & 1) == 1 || row == MT / 2 - 1) {
+                // the pair (oy - 1, oy) is complete: its entry (pairs past the image's last row have none)
+                const float t1 = s1[nt] + __shfl_xor(s1[nt], 32), t2 = s2[nt] + __shfl_xor(s2[nt], 32);
+                const int pair_y = (oy0 + row_base + (row & ~1)) >> 1;
+                if (kg == 0 && oy0 + row_base + (row & ~1) < Ho) {
+                    float* o = partial + (((int64_t)b * npairs + (int64_t)pair_y * npair_x + blockIdx.x) * 256 + (wc * NT + nt) * 32 + m) * 2;
+                    o[0] = t1;
+                    o[1] = t2;
+                }
+            }
+#endif
         }
+#ifdef CV_WAVES_2X4
         s1[nt] += __shfl_xor(s1[nt], 32);
         s2[nt] += __shfl_xor(s2[nt], 32);
+#endif
     }
+#ifdef CV_WAVES_2X4
     const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nwg = (int64_t)gridDim.x * gridDim.y;
-#ifndef CV_WAVES_2X4
-    if (kg == 0) {
-        float* o = partial + (((int64_t)b * nwg + wg) * 256 + wc * 32 + m) * 2;
-        o[0] = s1[0];
-        o[1] = s2[0];
-    }
-#else
     // the two row halves of a channel meet in LDS (fixed order: upper rows + lower rows)
     float* red = (float*)lds;                             // [256 channels][2]
     __syncthreads();                                      // the transposition buffers are done
@@ -441,24 +457,23 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #endif
 }
 
-// one-plane formats: 4-row tiles, unless those are fewer than one per CU over the whole launch (then 2-row tiles)
+// one-plane formats: 4-row tiles, unless those are fewer than one per CU over the whole launch (then 2-row tiles).  The choice may
+// follow the launch size: the kernels' GroupNorm partial sums are per PAIR of output rows in either form (round 6), so a frame's bits do
+// not depend on it (tests/test_gpu_neck.py::test_conv_tile_forms_give_identical_bits, tests/test_gpu_video.py::test_heads_are_batch_invariant)
 static int conv_th(int Ho, int Wo, int prec, int B) {
     if (prec == PH_PREC_SPLIT) return 2;
-    static const int force = [] { const char* e = getenv("PH_CONV_TH"); return e ? atoi(e) : 0; }();     // 2 / 4: A/B timing
+    static const int force = [] { const char* e = getenv("PH_CONV_TH"); return e ? atoi(e) : 0; }();     // 2 / 4: A/B timing, tests
+    if (const char* e = getenv("PH_CONV_TH_NOW")) { const int f = atoi(e); if (f == 2 || f == 4) return f; }   // tests: read per call
     if (force == 2 || force == 4) return force;
-    // up to 3 frames per launch the choice follows the FRAME's tile count alone: the video runner batches a clip's frames 2-3 per
-    // launch and promises every frame the bits of the one-frame launch (the tile form fixes the summation order of the GroupNorm
-    // partial sums); at 2-3 frames the two forms cost the same over a forward (large maps 77 / 83 us, small ones 52 / 36)
     const int64_t t4 = (int64_t)((Wo + CV_TW - 1) / CV_TW) * ((Ho + 3) / 4);
-    if (B <= 3) return t4 < 256 ? 2 : 4;
     return B * t4 < 256 ? 2 : 4;
 }
 
-// workgroups per frame of ph_conv_nhwc for this instantiation = entries per frame of its `partial` output
+// entries per frame of ph_conv_nhwc's `partial` output = pairs of output rows x 64-pixel column tiles (whatever the tile form;
+// `ksize`, `stride`, `prec`, `B` are kept for the callers of rounds 3-5, when the count was the workgroups of the chosen form)
 extern "C" int ph_conv_nhwc_workgroups_b(int ksize, int stride, int Ho, int Wo, int prec, int B) {
-    prec &= ~PH_PLANES_C16;
-    const int th = conv_th(Ho, Wo, prec, B);
-    return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + th - 1) / th);
+    (void)ksize; (void)stride; (void)prec; (void)B;
+    return ((Wo + CV_TW - 1) / CV_TW) * ((Ho + 1) / 2);
 }
 // (round 5: the B-less `ph_conv_nhwc_workgroups` is REMOVED -- it answered for launches of >= 256 four-row tiles only and
 // handed ph_gn_finalize a wrong count and partial stride on small launches; a stale caller now fails at link / dlsym time)

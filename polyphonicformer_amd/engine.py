@@ -84,14 +84,16 @@ class StagePack:
         self.prec = prec
 
 
-def default_nsplit(B, HW):
+def default_nsplit(B, HW, frame_invariant=False):
     """pixel ranges per frame for the split-K pooling: 4*B*nsplit workgroups should fill the chip's resident
-    slots (2 workgroups per CU x 256 CUs) without a partial second generation"""
+    slots (2 workgroups per CU x 256 CUs) without a partial second generation.  `frame_invariant`: the split of a ONE-frame
+    launch whatever B is -- the split fixes the order in which a frame's partial sums are added, so this is what keeps a frame's
+    bits independent of the frames that share its launch (the module API; throughput callers -- bench.py -- split by B)"""
     import os
     if os.environ.get("PH_POOL_NSPLIT"):
         return int(os.environ["PH_POOL_NSPLIT"])
     nchunks = hw_padded(HW) // 128
-    ns = max(1, 512 // (4 * B))
+    ns = max(1, 512 // (4 * (1 if frame_invariant else B)))
     return int(min(ns, 32, max(1, nchunks)))
 
 
@@ -221,14 +223,18 @@ def upsample2x(src, out=None):
 class DecodePlan:
     """All buffers for `simple_test_mask_preds` at one (B, N, H, W, precision, output dtype)."""
 
-    def __init__(self, packs, B, N, H, W, prec, out_dtype=torch.float32, device="cuda:0", nsplit=None):
+    def __init__(self, packs, B, N, H, W, prec, out_dtype=torch.float32, device="cuda:0", nsplit=None, frame_invariant=False):
+        """`frame_invariant` (round 6): every choice that touches a frame's arithmetic -- the pooling's pixel split, the fused / two-
+        kernel final stage -- is the ONE-frame launch's at any B, so a frame's outputs do not depend on its batch (the module API's
+        default; a clip's frames through one launch equal the per-frame loop bit for bit)"""
         self.packs, self.S = packs, len(packs)
+        self.frame_invariant = frame_invariant
         self.B, self.N, self.H, self.W, self.HW = B, N, H, W, H * W
         self.mode = mode_of(prec)
         self.prec, self.out_dtype = self.mode.feat, out_dtype           # `prec`: the feature planes' code (ingest / pool)
         if any(p.prec != self.mode.query for p in packs):
             raise _lib.PolyheadError(f"stage packs are not packed for mode '{self.mode.name}'")
-        self.nsplit = nsplit or default_nsplit(B, self.HW)
+        self.nsplit = nsplit or default_nsplit(B, self.HW, frame_invariant)
         dev = torch.device(device)
         P, KP = self.mode.FP, self.mode.KP
         Npad, HWp = n_padded(N), hw_padded(self.HW)
@@ -241,8 +247,11 @@ class DecodePlan:
         self.q0 = e((B, N, 256), torch.float32)
         self.m0 = e((B, N, H, W), torch.float32)
         # internals
-        self.xp = e((P, B, 256, HWp), torch.int16)
-        self.dp = e((P, B, 256, HWp), torch.int16)
+        # (zero-filled when the planes carry pixel padding: 16-bit inputs are copied into them row by row and the kernels read whole
+        # 128-pixel chunks -- a NaN bit pattern in the padding would survive the multiplication with a zero mask bit)
+        z = (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)) if HWp != self.HW else e
+        self.xp = z((P, B, 256, HWp), torch.int16)
+        self.dp = z((P, B, 256, HWp), torch.int16)
         self.bits = e((B, Npad, HWp // 32), torch.int32)
         self.partial = e((B, self.nsplit, Npad, 512), torch.float32)
         self.pcount = e((B, self.nsplit, Npad), torch.int32)      # the masks' pixel counts per pixel range, pool -> query kernel
@@ -265,7 +274,7 @@ class DecodePlan:
         # and the silent halo row above it doubles its work -- one frame per launch: 34 us against 26 us for the two kernels, equal
         # at 2-4 frames, ahead from 8 (same box).  PH_CONV_UP2=1 forces the fused form at any size (tests), =0 the two-kernel form.
         _up2 = _os.environ.get("PH_CONV_UP2", "auto")
-        self.fused_up = (KP == 1 and _up2 != "0" and (_up2 == "1" or B * H >= 512)
+        self.fused_up = (KP == 1 and _up2 != "0" and (_up2 == "1" or (1 if frame_invariant else B) * H >= 512)
                          and bool(_lib.load().ph_dynconv_up2_supported(N, H, W, self.mode.conv, OUT_CODE[out_dtype])))
         self.want_depth_lowres = False
 
@@ -289,14 +298,15 @@ class DecodePlan:
     def set_inputs(self, x, dfe, k0, q0, m0):
         """x / dfe: fp32 NCHW (converted to planes by the ingest kernel inside `run`), or 16-bit NCHW tensors of the
         mode's own plane format (bf16 for 'bf16' / 'mixed', fp16 for 'fp16'), which ARE the plane format when H*W is
-        a multiple of 128: they are adopted as they are and no ingest pass runs."""
+        a multiple of 128: they are adopted as they are and no ingest pass runs.  Other sizes (cfg5: 48 x 156): the rows are copied
+        into the planes' first H*W pixels, the padding up to the next multiple of 128 stays zero (round 6)."""
         self.feat_is_bf16 = x.dtype in (torch.bfloat16, torch.float16) and dfe.dtype == x.dtype     # 16-bit plane inputs
         if self.feat_is_bf16:
-            if self.mode.feat_dtype != x.dtype or self.HW % 128:
+            if self.mode.feat_dtype != x.dtype:
                 raise _lib.PolyheadError(f"{x.dtype} feature inputs need a mode with that plane format (bf16: 'bf16' / "
-                                         f"'mixed', fp16: 'fp16'; this plan: '{self.mode.name}') and H*W % 128 == 0")
-            self.xp.view(x.dtype).reshape(self.B, 256, self.H, self.W).copy_(x)
-            self.dp.view(x.dtype).reshape(self.B, 256, self.H, self.W).copy_(dfe)
+                                         f"'mixed' / 'mixed16', fp16: 'fp16'; this plan: '{self.mode.name}')")
+            self.xp.view(x.dtype)[0, :, :, :self.HW].copy_(x.reshape(self.B, 256, self.HW))
+            self.dp.view(x.dtype)[0, :, :, :self.HW].copy_(dfe.reshape(self.B, 256, self.HW))
         else:
             self.x.copy_(x)
             self.dfe.copy_(dfe)
@@ -446,7 +456,7 @@ class KernelHeadPlan:
     """buffers + launch sequence of KernelHead's post-neck part for one (B, H, W)."""
 
     def __init__(self, pack, B, H, W, num_thing_classes, num_classes, cat_stuff, device, want_f32=True, nsplit=None,
-                 logit_dtype=torch.float32, onepass=None):
+                 logit_dtype=torch.float32, onepass=None, frame_invariant=False):
         """`onepass`: None = ph_khead_onepass whenever the geometry / grade allows it (and PH_KHEAD_TWOPASS is unset),
         False = always the two-pass ph_khead_fused.  `logit_dtype`: fp32 (the reference API) or fp16 (one-pass form only)
         for mask_preds / seg_preds / depth_pred."""
@@ -486,7 +496,7 @@ class KernelHeadPlan:
         self.seg_preds = e((B, pack.n_seg, H, W), logit_dtype)
         self.depth_pred = e((B, 1, H, W), logit_dtype)
         self.bits = e((B, n_padded(self.N), HWp // 32), torch.int32)
-        self.nsplit = nsplit or default_nsplit(B, self.HW)
+        self.nsplit = nsplit or default_nsplit(B, self.HW, frame_invariant)     # (see DecodePlan: the one-frame split at any B)
         self.partial = e((B, self.nsplit, n_padded(self.Nq), 512), torch.float32)
         self.proposal = e((B, self.N, 256), torch.float32)
         # the two-pass kernels' workspace: the path itself, or the in-call fallback of a one-pass launch that gave up

@@ -117,6 +117,9 @@ class KernelHead(nn.Module):
             self._plans = {}
         return self._pack[1]
 
+    # Round 6: a frame's outputs do not depend on the frames that share its call (see KernelUpdateIterHead.frame_invariant)
+    frame_invariant = True
+
     def _decode_init_proposals(self, img, img_metas, train_tracking=False):
         """kernel_head.py:240-347.  `img`: the FPN tuple when `localization_fpn` is a module, otherwise the three post-neck
         maps [B,256,H,W].  In training mode the stuff rows are not appended here (:329) -- `forward_train` does it (:444-451)."""
@@ -139,11 +142,12 @@ class KernelHead(nn.Module):
             dev = feats[0].device
         pack = self._get_pack(dev)
         cat_stuff = self.cat_stuff_mask and not self.training
-        key = (B, H, W, cat_stuff, self.emit_fp32_features, self.logit_dtype)
+        key = (B, H, W, cat_stuff, self.emit_fp32_features, self.logit_dtype, bool(self.frame_invariant))
         plan = self._plans.get(key)
         if plan is None:
             self._plans = {key: E.KernelHeadPlan(pack, B, H, W, self.num_thing_classes, self.num_classes, cat_stuff, dev,
-                                                 want_f32=self.emit_fp32_features, logit_dtype=self.logit_dtype)}
+                                                 want_f32=self.emit_fp32_features, logit_dtype=self.logit_dtype,
+                                                 frame_invariant=bool(self.frame_invariant))}
             plan = self._plans[key]
         plan.renew_outputs()         # the 9-tuple (and the hand-off planes) belong to the caller from here on
         plan.set_inputs(list(feats) if handoff else [f.float() for f in feats])

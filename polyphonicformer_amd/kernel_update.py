@@ -72,13 +72,17 @@ class KernelUpdateIterHead(nn.Module):
         return self
 
     # -- execution -------------------------------------------------------------------------------
+    # Round 6: a frame's outputs do not depend on the frames that share its call (engine.DecodePlan `frame_invariant`): the module
+    # API's default.  False = launch geometry tuned to the batch (bench.py's throughput legs).
+    frame_invariant = True
+
     def _plan(self, B, N, H, W, device):
         packs = [h.stage_pack(device, self.precision) for h in self.mask_head]
-        key = (B, N, H, W, self.precision, self.output_dtype, str(device), tuple(id(p) for p in packs))
+        key = (B, N, H, W, self.precision, self.output_dtype, str(device), tuple(id(p) for p in packs), bool(self.frame_invariant))
         plan = self._plans.get(key)
         if plan is None:
             self._plans.clear()
-            plan = E.DecodePlan(packs, B, N, H, W, E.MODES[self.precision], self.output_dtype, device)
+            plan = E.DecodePlan(packs, B, N, H, W, E.MODES[self.precision], self.output_dtype, device, frame_invariant=bool(self.frame_invariant))
             self._plans[key] = plan
         return plan
 

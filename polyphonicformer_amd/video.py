@@ -685,6 +685,22 @@ class VideoStreamRunner:
         self._n = 0
         self._versions = None
 
+    def khead_timeouts(self):
+        """workgroup time-outs of the one-pass KernelHead kernel over every plan this runner's slots and graphs hold (sticky counters;
+        synchronises).  Non-zero only when something else holds CUs beyond the hand-off bound -- e.g. several processes sharing ONE
+        GPU -- and then those calls' results came from the predicated two-pass kernels: equal to ~1e-6, not bit for bit."""
+        seen, n = set(), 0
+        for sl in self._slots:
+            plans = list(getattr(sl["rpn"], "_plans", {}).values())
+            for st in sl["g"].values():
+                for d in st.get("plans") or []:
+                    plans += list(d.values())
+            for p in plans:
+                if id(p) not in seen and hasattr(p, "timeouts"):
+                    seen.add(id(p))
+                    n += int(p.timeouts())
+        return n
+
     def _weight_versions(self):
         from . import _lib
         return _lib.param_versions(self.pipe.rpn_head) + _lib.param_versions(self.pipe.roi_head)
@@ -899,32 +915,24 @@ class VideoStreamRunner:
 
     def clip_batch(self, frames):
         """frames per launch for `records`: the heads are frame independent, so a clip's frames go through neck ->
-        KernelHead -> decode TOGETHER -- at one frame per launch those kernels are latency bound and two frames cost barely more
-        than one.  Every frame's tensors must stay those of the per-frame loop bit for bit, so the batch is limited to sizes whose
-        plans pick the kernel forms (and the pooling's pixel split) of the one-frame plan, and to the grades whose KernelHead runs
-        the one-pass kernel (fp16 / bf16: a frame's GroupNorm partial sums are grouped by its own pixel slices; the two-pass kernel
-        of the fp32 / mixed grades sizes its workgroups' tile runs by the batch, which regroups the fp32 partial sums -- 1e-6
-        differences, not bit identity).  `PH_VIDEO_CLIP_BATCH=1` restores one frame per launch."""
+        KernelHead -> decode TOGETHER -- at one frame per launch those kernels are latency bound and eight frames cost barely more
+        than two.  Every frame's tensors must stay those of the per-frame loop bit for bit.  Round 6: that holds by construction for
+        any batch -- every choice that touches a frame's arithmetic follows the FRAME's geometry, never B (the neck's conv tile rows
+        and output-stage tile runs, csrc/ph_neck.hip conv_th / ph_khead.hip kh_tiles_per_wg_plain; the pooling's pixel split and the
+        final-stage form of `frame_invariant` plans, engine.DecodePlan / KernelHeadPlan; the one-pass KernelHead groups a frame's
+        GroupNorm sums by its own pixel slices) -- so the cap is a launch-size choice (default 8, `PH_VIDEO_CLIP_BATCH`; 1 restores
+        one frame per launch), asserted for 1 .. 16 frames by tests/test_gpu_video.py::test_heads_are_batch_invariant.  Exceptions:
+        the grades whose KernelHead runs the two-pass kernel (fp32 / mixed: its workgroups' tile runs are sized by the batch, which
+        regroups the fp32 partial sums -- 1e-6 differences, not bit identity) and heads switched to `frame_invariant = False`."""
         import os
         from . import _lib, engine as E
-        # default 3: the neck's output-stage tile runs and conv tiles are fixed per FRAME up to 3 frames per launch (csrc/ph_neck.hip
-        # conv_th, ph_khead.hip kh_tiles_per_wg_plain); a larger cap is honoured only through the checks below
-        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "3"))
+        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "8"))
         grade = E.KHEAD_PREC.get(getattr(self.pipe.rpn_head, "precision", None))
         if grade not in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) or os.environ.get("PH_KHEAD_TWOPASS"):
             return 1
-        H, W = frames[0][1].shape[-2:]                        # the decode runs at stride 8
-        lib = _lib.load()
-        # ... and the neck's conv tiles (2-row / 4-row by launch size, ph_conv_nhwc_workgroups_b) those of the one-frame launch
-        same_tiles = lambda B: all(lib.ph_conv_nhwc_workgroups_b(3, s, (h + s - 1) // s, (w + s - 1) // s, grade, B) ==
-                                   lib.ph_conv_nhwc_workgroups_b(3, s, (h + s - 1) // s, (w + s - 1) // s, grade, 1)
-                                   for (h, w), s in [(tuple(frames[0][0].shape[-2:]), 2)] +
-                                   [((H >> k, W >> k), 1) for k in range(3)] + [((H >> 1, W >> 1), 1), ((H, W), 1)])
-        ok = lambda B: E.default_nsplit(B, H * W) == E.default_nsplit(1, H * W) and (B * H >= 512) == (H >= 512) and same_tiles(B)
-        for B in range(max(1, min(cap, len(frames))), 1, -1):
-            if ok(B):
-                return B
-        return 1
+        if not (getattr(self.pipe.rpn_head, "frame_invariant", False) and getattr(self.pipe.roi_head, "frame_invariant", False)):
+            return 1
+        return max(1, min(cap, len(frames)))
 
     def records(self, frames):
         """the sharded mode's per-step work for a rank's clip: `simple_test(..., records_only=True)` of every frame in order.

@@ -320,7 +320,10 @@ def test_dynconv_kf16_register_conversion_form(gpu):
 
 
 @pytest.mark.parametrize("prec,dt", [(_lib.PH_PREC_BF16_KF16, torch.float16), (_lib.PH_PREC_F16, torch.float16), (_lib.PH_PREC_BF16, torch.bfloat16)])
-@pytest.mark.parametrize("N,H,B,wgs", [(153, 6, 3, 0), (111, 16, 2, 5), (200, 3, 4, 3), (153, 128, 2, 0)])
+@pytest.mark.parametrize("N,H,B,wgs", [(153, 6, 3, 0), (111, 16, 2, 5), (200, 3, 4, 3), (153, 128, 2, 0),
+                                       # five row blocks (round 6: the last block's windows run on helper waves, one tile late): ranges of many
+                                       # rows spanning frames, a last block with ONE live query-row group, with all 32 rows live, one-row frames
+                                       (153, 16, 2, 5), (130, 7, 3, 3), (160, 5, 2, 2), (137, 1, 5, 2), (145, 2, 3, 0)])
 def test_dynconv_up2_fused_final_stage(gpu, monkeypatch, prec, dt, N, H, B, wgs):
     """ph_dynconv_up2 = ph_dynconv (16-bit logits) + ph_upsample2x in one kernel (kernel_update_head.py:317-329 +
     kernel_update.py:131-143).  W = 256; workgroup ranges of one row (rows < CUs), of many rows spanning frames (PH_UP2_WGS),

@@ -198,6 +198,7 @@ def _cfg3_pipeline(gpu, precision="fp32"):
     kh.eval().to(gpu)
     kh.set_precision(precision)
     ih = bench.build_head(wl, precision, torch.float32, gpu, seed=3)
+    ih.frame_invariant = True             # (bench.build_head builds throughput heads; the video path is frame invariant)
     from polyphonicformer_amd.registry import ConfigDict
     ih.test_cfg = ConfigDict(max_per_img=wl["Nq"], mask_thr=0.5, merge_stuff_thing=dict(overlap_thr=0.0, instance_score_thr=0.3))
     with torch.no_grad():      # un-trained masks overlap heavily: accept every segment that wins pixels (overlap_thr 0) ...
@@ -547,11 +548,12 @@ def test_video_graphs_follow_weight_changes(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("graph", [True, False])
-def test_stream_runner_batches_a_clips_frames_per_launch(gpu, graph):
+def test_stream_runner_batches_a_clips_frames_per_launch(gpu, graph, monkeypatch):
     """`records()` in the grades whose heads are batch invariant (fp16: one-pass KernelHead kernel): a 5-frame clip goes through
-    neck -> KernelHead -> decode 3 + 2 frames per launch, and every frame's record (segment ids, boxes, labels, embeddings) is still
-    the per-frame loop's bit for bit; so are the head outputs themselves"""
+    neck -> KernelHead -> decode 3 + 2 frames per launch (cap 3 here; the default is 8), and every frame's record (segment ids, boxes,
+    labels, embeddings) is still the per-frame loop's bit for bit; so are the head outputs themselves"""
     from polyphonicformer_amd import video as V
+    monkeypatch.setenv("PH_VIDEO_CLIP_BATCH", "3")
     pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
     H8, W8 = wl["H"] * 8, wl["W"] * 8
     g = torch.Generator().manual_seed(34)
@@ -577,12 +579,36 @@ def test_stream_runner_batches_a_clips_frames_per_launch(gpu, graph):
         assert all(torch.equal(u[b:b + 1], v) for u, v in zip(ob, o1))
 
 
-def test_stream_runner_clip_of_3_3_2_replays_graphs_whose_plans_were_replaced(gpu):
+@pytest.mark.parametrize("B", [2, 3, 5, 8, 16])
+def test_heads_are_batch_invariant(gpu, B):
+    """every kernel of neck -> KernelHead -> decode picks its tile forms from the per-frame geometry, never from B:
+    the head outputs of each frame of a B-frame launch (class scores, upsampled mask / depth logits, the upsampled direct depth) are
+    BIT-IDENTICAL to the one-frame launch of that frame, for B = 2, 3, 5, 8, 16 at cfg3's full size; the default clip cap is 8"""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(36)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    frames = [tuple(torch.roll(t, (3 * f, 5 * f), dims=(2, 3)) for t in base) for f in range(B)]
+    runner = V.VideoStreamRunner(pipe, Hh.img_meta(H8, W8), graph=False)
+    assert runner.clip_batch(frames) == min(B, 8)
+    sl = runner._slot(0)
+    xb = tuple(torch.cat([f[l] for f in frames], 0) for l in range(4))
+    ob = [t.clone() for t in runner._heads_device(sl, xb)]
+    torch.cuda.synchronize()
+    for b in sorted({0, B // 2, B - 1}):               # first, middle and last frame of the launch against their own one-frame launches
+        o1 = runner._heads_device(sl, frames[b])
+        for name, u, v in zip(("cls", "mask_up", "depth_up", "depth_init"), ob, o1):
+            assert torch.equal(u[b:b + 1], v), (B, b, name, float((u[b:b + 1].float() - v.float()).abs().max()))
+
+
+def test_stream_runner_clip_of_3_3_2_replays_graphs_whose_plans_were_replaced(gpu, monkeypatch):
     """an 8-frame clip = launches of 3 + 3 + 2 frames: slot 0 captures a 3-frame graph, then a 2-frame one -- KernelHead and
     KernelUpdateIterHead keep ONE plan and drop the 3-frame plan there -- and the NEXT clip replays the 3-frame graph.  The graph
     holds its plans (round 4: without that reference the replay wrote into freed device memory; a GPU memory fault in
     `bench.py --workload cfg4 --clip-frames 8`).  Two clips, every record against the per-frame module API."""
     from polyphonicformer_amd import video as V
+    monkeypatch.setenv("PH_VIDEO_CLIP_BATCH", "3")
     pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
     H8, W8 = wl["H"] * 8, wl["W"] * 8
     g = torch.Generator().manual_seed(35)

@@ -90,6 +90,8 @@ def main():
     # the graph replays run on the queues that carry binarize launches; a replay starts with the first binarize after a previous
     # replay's last kernel class (dynconv_up2_depth / upsample2x) on the same queue
     queues = sorted({k[3] for k in ks if k[2] == "binarize"})
+    if not queues:
+        raise SystemExit(f"{a.trace}: no k_binarize launches -- not a trace of the decode step (did the traced command fail?)")
     parts = len(queues)
     q0 = queues[0]
     starts = [k[0] for k in ks if k[2] == "binarize" and k[3] == q0]
