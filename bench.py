@@ -731,11 +731,17 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
     t_all0 = time.perf_counter()
     # round 5: the step is PIPELINED -- step k + 1's heads are started (asynchronous graph replays) before step
     # k's records are all-gathered and the tracker replayed, so that a step costs max(heads, all-gather + replay), not their sum
+    # round 6: the runner queues clips, so step k + 1's heads CAN start before step k's merges / records too (other slot) --
+    # PH_CFG4_EARLY_BEGIN=1; measured slower (631 against 684 frames/s at 8-frame clips): the previous step's dozen small record
+    # kernels, each with the host waiting for it, then queue behind the next step's heads on the GPU.  Default: round 5's order
     first = warmup + len(calib)
+    early = runner is not None and bool(os.environ.get("PH_CFG4_EARLY_BEGIN"))
     begin(first)
     for s_ in range(steps):
+        if early and s_ + 1 < steps:
+            begin(first + s_ + 1)
         mine, recs, cnts = finish(first + s_)
-        if s_ + 1 < steps:
+        if not early and s_ + 1 < steps:
             begin(first + s_ + 1)
         _, _, ids = gather_and_replay(mine, recs, cnts)
         if collect_ids:
@@ -1282,8 +1288,14 @@ def main():
 
     # set-up, outside the W + K protocol: a freshly allocated box clocks up and faults its pages in during the first
     # replays (measured: 12.5 k frames/s with --warmup 2 --steps 5 alone, 13.3 k after these); every replay recomputes all
-    for _ in range(12):
+    # (round 6: at least a second of them -- the first process on a fresh box measured 14.5 k where its later runs measured 15.5 k)
+    t_setup = time.perf_counter()
+    n_setup = 0
+    while n_setup < 12 or time.perf_counter() - t_setup < 1.0:
         step()
+        n_setup += 1
+        if n_setup % 16 == 0:
+            torch.cuda.synchronize()
     barrier()
     for _ in range(args.warmup):
         step()

@@ -41,7 +41,11 @@ template <int PF, int PK, int NRT, bool BITS, typename OutT, bool F2 = false> st
     static constexpr int NDW = conv_dma_waves(NW, 32 * PF);                    // waves that issue DMA
     static constexpr int DPW = 32 * PF / NDW;                                  // ... instructions each per tile
     static constexpr int KBB = NW * 32 * 4;                                    // per-wave copy of its 32 biases
-    static constexpr int NBUF = 4 * TILEB + PATCHB + KBB <= LDS_MAX ? 4 : (3 * TILEB + PATCHB + KBB <= LDS_MAX ? 3 : 2);
+#ifndef CONV_NBUF_MAX        // A/B timing: -DCONV_NBUF_MAX=2 (+ PH_CONV_WGS=512): two half-CU workgroups per CU instead of one that owns the CU
+#define CONV_NBUF_MAX 4
+#endif
+    static constexpr int NBUF_FIT = 4 * TILEB + PATCHB + KBB <= LDS_MAX ? 4 : (3 * TILEB + PATCHB + KBB <= LDS_MAX ? 3 : 2);
+    static constexpr int NBUF = NBUF_FIT < CONV_NBUF_MAX ? NBUF_FIT : CONV_NBUF_MAX;
     static constexpr int LDSB = NBUF * TILEB + PATCHB + KBB;
 };
 

@@ -563,6 +563,24 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2m(const uint16_
         if constexpr (MP >= 0) kp = lds_read128o_asm<MP * 1024>(cf);
         lds_wait_all();
         const uint4 KC = __builtin_bit_cast(uint4, kc), KE = __builtin_bit_cast(uint4, ke), KP = __builtin_bit_cast(uint4, kp);
+#ifndef UPM_SERIAL_TILES
+        // the two tiles' chains interleaved (each MFMA waits for its own predecessor only: one other product in between)
+        f32x16_t a0 = zero16, a1 = zero16;
+        if constexpr (MP >= 0) { a0 = mf(KP, P0, a0); a1 = mf(KP, P1, a1); }
+        a0 = mf(KC, C0, a0); a1 = mf(KC, C1, a1);
+        a0 = mf(KE, e0, a0); a1 = mf(KE, e1, a1);
+        {
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = f2e_pk<EO>(a0[2 * j], a0[2 * j + 1]);
+            lds_write64_asm<0>(tw_addr, w[0], w[1]);  lds_write64_asm<16>(tw_addr, w[2], w[3]);
+            lds_write64_asm<32>(tw_addr, w[4], w[5]); lds_write64_asm<48>(tw_addr, w[6], w[7]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = f2e_pk<EO>(a1[2 * j], a1[2 * j + 1]);
+            lds_write64_asm<64>(tw_addr, w[0], w[1]); lds_write64_asm<80>(tw_addr, w[2], w[3]);
+            lds_write64_asm<96>(tw_addr, w[4], w[5]); lds_write64_asm<112>(tw_addr, w[6], w[7]);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16_t a = zero16;
@@ -580,6 +598,7 @@ __global__ __launch_bounds__(((NRT + 1) * 64)) void k_dynconv_up2m(const uint16_
                 lds_write64_asm<96>(tw_addr, w[4], w[5]); lds_write64_asm<112>(tw_addr, w[6], w[7]);
             }
         }
+#endif
         lds_wait_all();
         uint32_t tr = tr_addr;
         asm volatile("" : "+v"(tr));

@@ -684,6 +684,8 @@ class VideoStreamRunner:
         self._downloads = []             # [(event, host tensors, device sources)] oldest first
         self._n = 0
         self._versions = None
+        self._rq = []                    # clips queued by records_begin: dict(chunks, next chunk to start, slots of the started ones)
+        self._free = []
 
     def khead_timeouts(self):
         """workgroup time-outs of the one-pass KernelHead kernel over every plan this runner's slots and graphs hold (sticky counters;
@@ -727,7 +729,17 @@ class VideoStreamRunner:
                 rpn, roi = self.pipe.rpn_head, self.pipe.roi_head
             else:
                 rpn, roi = self._clone_heads()
-            self._slots.append(dict(rpn=rpn, roi=roi, g={}, cur=None, stream=torch.cuda.Stream(), done=None))
+            # the slots' streams carry the heads' graphs (milliseconds of HBM-bound launches); the merges / records of the frames in
+            # front of them are a dozen small kernels on the caller's stream with the host waiting for each: PH_VIDEO_SLOT_PRIO=low
+            # puts the heads one priority level below them (A/B: see DESIGN 7b "Round 6")
+            prio = 0
+            if os.environ.get("PH_VIDEO_SLOT_PRIO") == "low":
+                try:
+                    lo, hi = torch.cuda.Stream.priority_range()
+                    prio = max(lo, hi)
+                except Exception:
+                    prio = 0
+            self._slots.append(dict(rpn=rpn, roi=roi, g={}, cur=None, stream=torch.cuda.Stream(priority=prio), done=None))
         return self._slots[i]
 
     def _clone_heads(self):
@@ -942,40 +954,49 @@ class VideoStreamRunner:
         self.records_begin(frames)
         return self.records_end()
 
+    def _pump(self):
+        """start the heads of waiting chunks, oldest clip first, while a slot is free (graph replays on the slots' streams)"""
+        for clip in self._rq:
+            while clip["next"] < len(clip["chunks"]) and self._free:
+                i = self._free.pop(0)
+                self._start_heads(i, clip["chunks"][clip["next"]])
+                clip["slots"].append(i)
+                clip["next"] += 1
+            if clip["next"] < len(clip["chunks"]):
+                break                                    # launch order = frame order: a later clip never overtakes an earlier one
+
     def records_begin(self, frames):
-        """first half of `records`: copies the clip's first chunk(s) into the slots and STARTS their heads (graph replays on the
-        slots' streams) -- returns without waiting for the device.  A caller that has other work for this step (round 5, the
-        sharded video loop: the all-gather and the tracker replay of the PREVIOUS step) does it between this call and
-        `records_end`, under the heads."""
+        """first half of `records`: queues the clip and STARTS the heads of as many of its chunks as slots are free -- returns without
+        waiting for the device.  Round 6: clips QUEUE -- `records_begin` of the next clip may be called before `records_end` of the
+        previous one, and then its heads run (on the other slot) underneath the previous clip's merges / records, which are host work
+        and a few small kernels: the sharded video loop (bench.cfg4_run) does exactly that, so a step costs max(heads, merges + records +
+        all-gather + replay) instead of their sum.  `records_end` always returns the OLDEST queued clip's records."""
         frames = list(frames)
-        assert self._inflight is None and getattr(self, "_rb", None) is None, "records() and push() / push_record() must not be interleaved"
+        assert self._inflight is None, "records() and push() / push_record() must not be interleaved"
         for f in frames:
             self._check(f)
-        self._check_weights()
-        if not frames:
-            self._rb = ([], 0, 1)
-            return
-        Bc = self.clip_batch(frames)
-        chunks = [frames[k:k + Bc] for k in range(0, len(frames), Bc)]
-        depth = 2 if self.pipelined else 1
-        started = 0
-        while started < len(chunks) and started < depth:
-            self._start_heads(started % depth, chunks[started])
-            started += 1
-        self._rb = (chunks, started, depth)
+        if not getattr(self, "_rq", None):
+            self._rq = []
+            self._check_weights()                        # (drops the slots when the weights changed: only between clips)
+            self._free = list(range(2 if self.pipelined else 1))
+        Bc = self.clip_batch(frames) if frames else 1
+        self._rq.append(dict(chunks=[frames[k:k + Bc] for k in range(0, len(frames), Bc)], next=0, slots=[]))
+        self._pump()
 
     def records_end(self):
-        """second half of `records`: merges / records chunk by chunk (the synchronising part), starting the remaining chunks' heads
-        as slots free up"""
-        chunks, started, depth = self._rb
-        self._rb = None
+        """second half of `records`, for the oldest queued clip: merges / records chunk by chunk (the synchronising part); every slot it
+        frees goes to the next waiting chunk at once -- of this clip or of the clip queued behind it"""
+        clip = self._rq[0]
         out = []
-        for c in range(len(chunks)):
-            while started < len(chunks) and started < c + depth:
-                self._start_heads(started % depth, chunks[started])
-                started += 1
-            for b in range(len(chunks[c])):
-                out.append(self._record(c % depth, b))
+        for c, chunk in enumerate(clip["chunks"]):
+            if c >= len(clip["slots"]):
+                self._pump()                             # (a slot is free: every earlier chunk of this clip has been consumed)
+            i = clip["slots"][c]
+            for b in range(len(chunk)):
+                out.append(self._record(i, b))
+            self._free.append(i)
+            self._pump()
+        self._rq.pop(0)
         return out
 
     def push_record(self, x):

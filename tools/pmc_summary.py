@@ -13,7 +13,7 @@ def per_kernel(path, counter):
 fe, wr = per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE")
 import re
 _conv = lambda k: re.search(r"k_dynconv<\d+, \d+, \d+, \d+, (true|false),", k)       # 5th template argument: BITS
-_up2 = lambda k: re.search(r"k_dynconv_up2<\d+, \d+, \d+, (true|false),", k)           # 4th template argument: LOWRES
+_up2 = lambda k: re.search(r"k_dynconv_up2m?<\d+, \d+, \d+, (true|false),", k)         # 4th template argument: LOWRES (round 6: k_dynconv_up2m)
 names = {"pool": lambda k: "k_pool" in k, "dynconv_bits": lambda k: bool(_conv(k)) and _conv(k).group(1) == "true",
          "dynconv_logits": lambda k: bool(_conv(k)) and _conv(k).group(1) == "false",
          "upsample2x": lambda k: "k_upsample2x" in k,
