@@ -684,6 +684,7 @@ class VideoStreamRunner:
         self._downloads = []             # [(event, host tensors, device sources)] oldest first
         self._n = 0
         self._versions = None
+        self._last_done = None
         self._rq = []                    # clips queued by records_begin: dict(chunks, next chunk to start, slots of the started ones)
         self._free = []
 
@@ -835,11 +836,18 @@ class VideoStreamRunner:
         ready.record(main)
         with torch.cuda.stream(sl["stream"]):
             sl["stream"].wait_event(ready)
+            # heads of different launches run ONE AFTER THE OTHER (round 6): what a launch should overlap with is the host's walk
+            # through the frames in front of it and their small kernels, not another heads graph -- two persistent one-pass KernelHead
+            # launches at once starve each other until one gives up (8-frame clips queued back to back: 18.5 ms per step instead of 8)
+            last = getattr(self, "_last_done", None)
+            if last is not None:
+                sl["stream"].wait_event(last)
             st["graph"].replay()
             if st["dm"] is not None:
                 st["dm"].download()
             sl["done"] = torch.cuda.Event()
             sl["done"].record(sl["stream"])
+            self._last_done = sl["done"]
 
     def _frame_levels(self, i, b=0):
         """the FPN levels of frame b of slot i's current launch (views of its static inputs)"""
@@ -932,13 +940,19 @@ class VideoStreamRunner:
         any batch -- every choice that touches a frame's arithmetic follows the FRAME's geometry, never B (the neck's conv tile rows
         and output-stage tile runs, csrc/ph_neck.hip conv_th / ph_khead.hip kh_tiles_per_wg_plain; the pooling's pixel split and the
         final-stage form of `frame_invariant` plans, engine.DecodePlan / KernelHeadPlan; the one-pass KernelHead groups a frame's
-        GroupNorm sums by its own pixel slices) -- so the cap is a launch-size choice (default 8, `PH_VIDEO_CLIP_BATCH`; 1 restores
-        one frame per launch), asserted for 1 .. 16 frames by tests/test_gpu_video.py::test_heads_are_batch_invariant.  Exceptions:
+        GroupNorm sums by its own pixel slices) -- so the frames per launch are a pure launch-size choice (`PH_VIDEO_CLIP_BATCH=n`; 1 restores
+        one frame per launch; default below), asserted for 1 .. 16 frames by tests/test_gpu_video.py::test_heads_are_batch_invariant.  Exceptions:
         the grades whose KernelHead runs the two-pass kernel (fp32 / mixed: its workgroups' tile runs are sized by the batch, which
         regroups the fp32 partial sums -- 1e-6 differences, not bit identity) and heads switched to `frame_invariant = False`."""
         import os
         from . import _lib, engine as E
-        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "8"))
+        # default: a clip of 4 or more frames goes as TWO launches (half the clip each, at most 8 frames): the second half's heads run
+        # while the host walks the first half through merge -> boxes -> RoIAlign -> track head, and with clips queued (`records_begin`
+        # ahead of the previous `records_end`) the next clip's first half follows on the slot that frees up.  Measured on one box
+        # (profiles/r06/cfg4_sweep.txt, 8-frame clips): 2 / 3 / 4 / 8 frames per launch 785 / 830 / 943 / 734 frames/s; 16-frame clips:
+        # 768 / 786 / 889 / 979.  Shorter clips: one launch.
+        n = len(frames)
+        cap = int(os.environ.get("PH_VIDEO_CLIP_BATCH", "0")) or (n if n <= 3 else min(8, (n + 1) // 2))
         grade = E.KHEAD_PREC.get(getattr(self.pipe.rpn_head, "precision", None))
         if grade not in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) or os.environ.get("PH_KHEAD_TWOPASS"):
             return 1

@@ -591,7 +591,7 @@ def test_heads_are_batch_invariant(gpu, B):
     base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
     frames = [tuple(torch.roll(t, (3 * f, 5 * f), dims=(2, 3)) for t in base) for f in range(B)]
     runner = V.VideoStreamRunner(pipe, Hh.img_meta(H8, W8), graph=False)
-    assert runner.clip_batch(frames) == min(B, 8)
+    assert runner.clip_batch(frames) == (B if B <= 3 else min(8, (B + 1) // 2))       # a clip of >= 4 frames: two launches of half the clip
     sl = runner._slot(0)
     xb = tuple(torch.cat([f[l] for f in frames], 0) for l in range(4))
     ob = [t.clone() for t in runner._heads_device(sl, xb)]
