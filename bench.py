@@ -856,6 +856,31 @@ def video_leg(dev, precision="bf16", frames=6):
                                         "stream; results two frames late"}
     except Exception as e:
         out["stream_runner"] = {"error": repr(e)}
+    # round 6: the same stream with k frames per heads launch (batch-invariant heads: the same result maps), two launches in flight
+    for k in (4, 8):
+        try:
+            from polyphonicformer_amd import video as V
+            runner = V.VideoStreamRunner(pipe, meta[0], frames_per_launch=k)
+            if runner._launch_size() != k:
+                out[f"stream_runner_{k}_frames_per_launch"] = {"skipped": "the heads' grade is not batch invariant (two-pass KernelHead)"}
+                continue
+            for rep_ in range(2):
+                pipe.assoc.init_tracker()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                got = 0
+                for f in range(frames, 9 * frames):
+                    r = runner.push(_video_frame(base, f, frames))
+                    got += r is not None
+                got += len(runner.flush())
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            assert got == 8 * frames
+            out[f"stream_runner_{k}_frames_per_launch"] = {"ms_per_frame": round(dt / (8 * frames) * 1e3, 3), "frames_timed": 8 * frames,
+                                                          "note": f"VideoStreamRunner(frames_per_launch={k}): results up to {2 * k} frames late, bit-identical maps"}
+            del runner
+        except Exception as e:
+            out[f"stream_runner_{k}_frames_per_launch"] = {"error": repr(e)}
     return out
 
 

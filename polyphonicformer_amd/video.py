@@ -669,9 +669,13 @@ class VideoStreamRunner:
     Weights are packed at capture time; every push compares the parameters' version counters with the capture-time ones and
     captures again (all slots) when they changed (`_check_weights`, round 5)."""
 
-    def __init__(self, pipe, img_meta, graph=True, pipelined=True, device_select=None):
+    def __init__(self, pipe, img_meta, graph=True, pipelined=True, device_select=None, frames_per_launch=1):
+        """`frames_per_launch` (round 6, `push` / `flush`): k > 1 buffers k pushed frames and sends them through the heads in ONE launch
+        (the batch-invariant heads give every frame the bits of its own one-frame launch; fp16 / bf16 grades, see `clip_batch`), two
+        launches in flight on the two slots; results come back in frame order, up to 2 k frames late"""
         import os
         self.pipe, self.metas, self.use_graph, self.pipelined = pipe, [img_meta], graph, pipelined
+        self.frames_per_launch = max(1, int(frames_per_launch))
         # the merge's candidate selection + activation + argmax queued behind the decode on the heads' stream (panoptic.DeviceMerge),
         # inside the graph; False = the module API's form (class scores to the host, torch.topk there)
         self.device_select = (not os.environ.get("PH_VIDEO_HOST_SELECT")) if device_select is None else device_select
@@ -684,6 +688,9 @@ class VideoStreamRunner:
         self._downloads = []             # [(event, host tensors, device sources)] oldest first
         self._n = 0
         self._versions = None
+        self._buf = []                   # frames_per_launch > 1: pushed frames waiting for their launch
+        self._inflight_b = None          # ... and the launch whose frames are still to be finished: (slot, frames)
+        self._nb = 0
         self._last_done = None
         self._rq = []                    # clips queued by records_begin: dict(chunks, next chunk to start, slots of the started ones)
         self._free = []
@@ -720,6 +727,11 @@ class VideoStreamRunner:
             if self._inflight is not None:
                 self._finish(self._inflight)
                 self._inflight = None
+            if getattr(self, "_inflight_b", None) is not None:
+                i, n = self._inflight_b
+                for b in range(n):
+                    self._finish(i, b)
+                self._inflight_b = None
             self._slots = []
             self._versions = v
 
@@ -867,9 +879,9 @@ class VideoStreamRunner:
         cls, mask_up, depth_up, depth_init = st["outs"]
         return Pn.get_panoptic_device(sl["roi"], cls[b], mask_up[b], depth_up[b], depth_init[b], self.metas[0])
 
-    def _finish(self, i):
-        """merge -> association -> start the download of frame (slot i)'s result maps"""
-        pan_dev, info, _, d_final = self._merge(i)
+    def _finish(self, i, b=0):
+        """merge -> association -> start the download of the result maps of frame b of slot i's launch"""
+        pan_dev, info, _, d_final = self._merge(i, b)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
         main, cs = torch.cuda.current_stream(), self._copy_stream
@@ -890,7 +902,7 @@ class VideoStreamRunner:
             kept.append(t)
 
         download(d_final)
-        sem, trk = self.pipe.assoc.step_device(self._frame_levels(i), pan_dev, info, early=download)
+        sem, trk = self.pipe.assoc.step_device(self._frame_levels(i, b), pan_dev, info, early=download)
         download(trk)
         ev = torch.cuda.Event()
         ev.record(cs)
@@ -910,6 +922,8 @@ class VideoStreamRunner:
         """x: the four FPN levels of ONE frame (device tensors).  Returns the result list [{"sem", "track", "depth"}] (numpy,
         owned by the caller) of the frame pushed two calls ago (one call ago with pipelined=False), or None."""
         self._check(x)
+        if self.frames_per_launch > 1 and self._launch_size() > 1:
+            return self._push_batched(x)
         self._check_weights()
         if not self.pipelined:
             self._start_heads(0, [x])
@@ -924,8 +938,49 @@ class VideoStreamRunner:
         self._n += 1
         return self._collect(self._downloads.pop(0)) if len(self._downloads) > 1 else None
 
+    def _launch_size(self):
+        """frames per launch of the batched `push`: `frames_per_launch` where the heads are batch invariant (`clip_batch`'s conditions), else 1"""
+        from . import _lib, engine as E
+        grade = E.KHEAD_PREC.get(getattr(self.pipe.rpn_head, "precision", None))
+        ok = (grade in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) and not os.environ.get("PH_KHEAD_TWOPASS")
+              and getattr(self.pipe.rpn_head, "frame_invariant", False) and getattr(self.pipe.roi_head, "frame_invariant", False))
+        return self.frames_per_launch if ok else 1
+
+    def _launch_buffered(self):
+        """the buffered frames' heads on the next slot; then the previous launch's frames walk merge -> association underneath them"""
+        if not self._inflight_b and not self._buf:
+            return
+        if self._buf:
+            self._check_weights()                        # (new weights: finishes the launch in flight with the old ones, drops the slots)
+        prev = self._inflight_b
+        self._inflight_b = None
+        if self._buf:
+            i = (self._nb & 1) if self.pipelined else 0
+            if not self.pipelined and prev is not None:
+                for b in range(prev[1]):
+                    self._finish(prev[0], b)
+                prev = None
+            self._start_heads(i, self._buf)
+            self._inflight_b = (i, len(self._buf))
+            self._buf = []
+            self._nb += 1
+        if prev is not None:
+            for b in range(prev[1]):
+                self._finish(prev[0], b)
+
+    def _push_batched(self, x):
+        assert self._inflight is None and not self._rq, "push() in batches and push_record() / records() must not be interleaved"
+        self._buf.append(tuple(t.clone() for t in x))    # the caller may reuse its tensors once push returns
+        if len(self._buf) >= self.frames_per_launch:
+            self._launch_buffered()
+        self._n += 1
+        return self._collect(self._downloads.pop(0)) if len(self._downloads) > self.frames_per_launch else None
+
     def flush(self):
         """the results still in flight, oldest first (a list of result lists)"""
+        if self._buf or self._inflight_b:
+            self._launch_buffered()                      # the partial last batch (its own launch size), then whatever is still in flight
+            self._launch_buffered()
         if self._inflight is not None:
             self._finish(self._inflight)
             self._inflight = None

@@ -602,6 +602,38 @@ def test_heads_are_batch_invariant(gpu, B):
             assert torch.equal(u[b:b + 1], v), (B, b, name, float((u[b:b + 1].float() - v.float()).abs().max()))
 
 
+@pytest.mark.parametrize("k,pipelined", [(3, True), (4, True), (2, False)])
+def test_stream_runner_push_in_batches_equals_the_per_frame_loop(gpu, k, pipelined):
+    """round 6: `VideoStreamRunner(frames_per_launch=k).push` sends k buffered frames through the heads in one launch (two launches in
+    flight); the result maps of every frame of a 7-frame stream -- a partial last batch included -- are those of the per-frame module
+    API, bit for bit, in frame order (batch-invariant heads, the tracker fed in order)"""
+    from polyphonicformer_amd import video as V
+    pipe, sd, cfg, wl = _cfg3_pipeline(gpu, precision="fp16")
+    H8, W8 = wl["H"] * 8, wl["W"] * 8
+    g = torch.Generator().manual_seed(37)
+    base = [torch.randn(1, 256, H8 // s, W8 // s, generator=g).to(gpu) for s in (4, 8, 16, 32)]
+    frames = [tuple(torch.roll(t, (f, 2 * f), dims=(2, 3)) for t in base) for f in range(7)]
+    meta = [Hh.img_meta(H8, W8)]
+    pipe.init_tracker()
+    want = [pipe.simple_test(x, meta)[0] for x in frames]
+    pipe.init_tracker()
+    runner = V.VideoStreamRunner(pipe, meta[0], pipelined=pipelined, frames_per_launch=k)
+    got = []
+    for x in frames:
+        scratch = tuple(t.clone() for t in x)
+        r = runner.push(scratch)
+        for t in scratch:
+            t.zero_()                                   # the caller reuses its tensors at once
+        if r is not None:
+            got.append(r[0])
+    got += [r[0] for r in runner.flush()]
+    assert runner.flush() == [] and len(got) == len(want)
+    for f, (a, b) in enumerate(zip(got, want)):
+        for key in ("sem", "track", "depth"):
+            assert a[key].dtype == b[key].dtype and np.array_equal(a[key], b[key]), (f, key)
+    assert any((a["track"] > 0).any() for a in got)
+
+
 def test_stream_runner_clip_of_3_3_2_replays_graphs_whose_plans_were_replaced(gpu, monkeypatch):
     """an 8-frame clip = launches of 3 + 3 + 2 frames: slot 0 captures a 3-frame graph, then a 2-frame one -- KernelHead and
     KernelUpdateIterHead keep ONE plan and drop the 3-frame plan there -- and the NEXT clip replays the 3-frame graph.  The graph
