@@ -106,12 +106,20 @@ def kernel_breakdown(plan, iters=4):
     for s in range(p.S):
         last = s == p.S - 1
         o = p.stage_out[s]
-        seq.append(("pool", lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial, counts=p.pcount)))
+        px = getattr(p, "poolx", False)
+        if s > 0 and px:     # round 6: the x map was pooled by the previous stage's conv (ph_dynconv_poolx); depth_feats alone here
+            seq.append(("pool_depth", lambda: E.pool_depth_only(p.dp, p.bits, p.N, p.HW, p.prec, p.partial_px, p.pcount_px)))
+            part, cnt = p.partial_px, p.pcount_px
+        else:
+            seq.append(("pool", lambda: E.pool(p.xp, p.dp, p.bits, p.N, p.HW, p.prec, p.nsplit, out=p.partial, counts=p.pcount)))
+            part, cnt = p.partial, p.pcount
         for name, ph in (("query_pre", 1), ("query_post", 2)):
-            seq.append((name, lambda ph=ph, k=k, q=q, s=s, last=last: E.query_stage(
-                p.partial, p.bits, k, q, p.packs[s], p.N, p.HW, cls_sigmoid=last, outs=p.stage_out[s], workspace=p.ws,
-                phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt, counts=p.pcount)))
-        if not last:
+            seq.append((name, lambda ph=ph, k=k, q=q, s=s, last=last, part=part, cnt=cnt: E.query_stage(
+                part, p.bits, k, q, p.packs[s], p.N, p.HW, cls_sigmoid=last, outs=p.stage_out[s], workspace=p.ws,
+                phases=ph | (_lib_wide() if getattr(p, "shares_gpu", False) else 0), kern_fmt=p.mode.kern_fmt, counts=cnt)))
+        if not last and px:
+            seq.append(("dynconv_poolx", lambda o=o: E.dynconv_poolx(p.xp, o["kern"], o["kbias"], p.N, p.HW, p.mode.conv, p.bits, p.partial_px)))
+        elif not last:
             seq.append(("dynconv_bits", lambda o=o: E.dynconv(p.xp, o["kern"], o["kbias"], 0, p.N, p.HW, p.mode.conv, bits_out=p.bits)))
         elif getattr(p, "fused_up", False):      # final conv + x2 upsample in one kernel (the plan's own launches)
             seq.append(("dynconv_up2_mask", lambda o=o: E.dynconv_up2(p.xp, o["kern"], o["kbias"], 0, p.N, p.H, p.W, p.mode.conv, p.mask_up,
@@ -142,8 +150,9 @@ def kernel_breakdown(plan, iters=4):
             cnt[name] = cnt.get(name, 0) + 1
     t = {name: tot[name] / cnt[name] for name in tot}
     t["ingest"] = time_op(lambda: E.ingest(p.x, p.prec, out=p.xp), 4) if getattr(p, "x", None) is not None else 0.0
-    counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S, query_pre=p.S, query_post=p.S, dynconv_bits=p.S - 1,
-                  dynconv_logits=2, upsample2x=2, dynconv_up2_mask=1, dynconv_up2_depth=1)
+    npx = p.S - 1 if getattr(p, "poolx", False) else 0
+    counts = dict(ingest=0 if getattr(p, "feat_is_bf16", False) else 2, binarize=1, pool=p.S - npx, pool_depth=npx, query_pre=p.S, query_post=p.S,
+                  dynconv_bits=p.S - 1 - npx, dynconv_poolx=npx, dynconv_logits=2, upsample2x=2, dynconv_up2_mask=1, dynconv_up2_depth=1)
     counts = {k: v for k, v in counts.items() if k in t}
     return t, counts
 
@@ -164,7 +173,7 @@ def algorithmic_bytes(plan, kernel):
     bits = p.B * p.N * p.HW // 8
     if kernel == "pool":
         return 2 * feat + bits
-    if kernel == "dynconv_bits":
+    if kernel in ("dynconv_bits", "dynconv_poolx", "pool_depth"):      # one plane in, the mask bits out / in (+ the pooled sums: KBs)
         return feat + bits
     if kernel == "dynconv_logits":
         return feat + p.B * p.N * p.HW * eo
@@ -1422,7 +1431,8 @@ def main():
             # SURVEY 8d "Reporting": whole-path algorithmic rates of the timed step (B_alg / F_alg per frame incl. the
             # per-stage weight stream amortised over the frames of a launch)
             "algorithmic": algorithmic_rates(wl, N, kplan.B, fps / world, args.precision),
-            "per_stage_ms": {"frames": kplan.B, "non_final": round(times["pool"] + times["query_pre"] + times["query_post"] + times["dynconv_bits"], 4),
+            "per_stage_ms": {"frames": kplan.B, "non_final": round(times["pool"] + times["query_pre"] + times["query_post"] +
+                                                                   times.get("dynconv_bits", times.get("dynconv_poolx", 0.0)), 4),
                              "final_incl_upsample": round(times["pool"] + times["query_pre"] + times["query_post"] +
                                                           (times["dynconv_up2_mask"] + times["dynconv_up2_depth"] if "dynconv_up2_mask" in times
                                                            else 2 * times["dynconv_logits"] + 2 * times["upsample2x"]), 4)},

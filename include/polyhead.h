@@ -205,6 +205,19 @@ int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_ba
                    int64_t kbias_batch_stride, void* logits_out /* nullable */, void* up_out, int out_dtype, int B, int N, int H,
                    int W, int prec, void* stream);
 
+/* ---- A13 of a NON-final stage fused with the x half of the next stage's A7 (round 6): the mask bits of ph_dynconv AND
+ * partial[b][split][n][0 .. 255] = sum over the pixels of range `split` of bits[n][px] * x[c][px] -- ph_pool's output for the x map
+ * (kernel_update_head.py:317-329, :236-241) -- from ONE read of the x plane.  The caller pools depth_feats alone afterwards
+ * (ph_pool_counts with xplanes = the depth plane, dplanes = NULL, partial + 256: columns 256 .. 511 and the pixel counts).
+ * `kern`: ONE 16-bit plane [B][Npad][256]; prec PH_PREC_BF16, PH_PREC_F16 or PH_PREC_BF16_KF16; 33 <= N <= 192
+ * (ph_dynconv_poolx_supported); grid = nsplit x B workgroups, one per CU when nsplit * B is about the CU count.  The bits are
+ * ph_dynconv's bit for bit; the pooled sums are ph_pool's up to the fp16 conversion of the tile in the PH_PREC_BF16_KF16 grade
+ * (exact for every bf16 value inside fp16's normal range) and the split boundaries (`nsplit` is the caller's in both). */
+int ph_dynconv_poolx_supported(int N, int prec);
+int ph_dynconv_poolx(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
+                     int64_t kbias_batch_stride, uint32_t* bits_out, float* partial, int nsplit, int B, int N, int64_t HW, int prec,
+                     void* stream);
+
 /* ---- A1-A5: KernelHead after localization_fpn (kernel_head.py:245-347) ------------------------
  * ph_khead_conv_gn: loc/sem/dfe = ReLU(GN(conv1x1(f0/f1/f2))) and x = sem + loc, from the three fp32
  *   post-neck maps [B][256][HW] to bf16 planes (+ optional fp32 NCHW x_feats / depth_feats).

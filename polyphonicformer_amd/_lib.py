@@ -70,6 +70,8 @@ SIGNATURES = {
     "ph_match_nsplit": (C.c_int, [_L, _I]),
     "ph_match_sums": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "ph_upsample2x": (C.c_int, [_P, _P, _I, _L, _I, _I, _P]),
+    "ph_dynconv_poolx_supported": (C.c_int, [_I, _I]),
+    "ph_dynconv_poolx": (C.c_int, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _L, _I, _P]),
     "ph_dynconv_up2_supported": (C.c_int, [_I, _I, _I, _I, _I]),
     "ph_dynconv_up2": (C.c_int, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ph_mask_loss_sums": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),

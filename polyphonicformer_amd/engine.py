@@ -179,6 +179,24 @@ def dynconv(planes, kern, kbias, branch, N, HW, prec, bits_out=None, logits_out=
     return bits_out if bits_out is not None else logits_out
 
 
+def dynconv_poolx(planes, kern, kbias, N, HW, prec, bits_out, partial):
+    """non-final stage's mask conv (branch 0) -> mask bits, AND the next stage's pooling of the x map (columns 0 .. 255 of
+    `partial` [B, nsplit, Npad, 512]) from one read of the plane (ph_dynconv_poolx); kern [1,2,B,Npad,256], kbias [2,B,Npad]"""
+    B, Npad = kern.shape[2], kern.shape[3]
+    lib = _lib.load()
+    _lib.check(lib.ph_dynconv_poolx(_lib.ptr(planes), _lib.ptr(kern), Npad * 256, _lib.ptr(kbias), Npad, _lib.ptr(bits_out), _lib.ptr(partial),
+                                    partial.shape[1], B, N, HW, prec, _lib.stream_ptr()), "ph_dynconv_poolx")
+    return bits_out
+
+
+def pool_depth_only(dp, bits, N, HW, prec, partial, counts):
+    """the depth_feats half of a pooling whose x half ph_dynconv_poolx has written: columns 256 .. 511 of `partial` and the pixel counts"""
+    B, nsplit = partial.shape[0], partial.shape[1]
+    lib = _lib.load()
+    _lib.check(lib.ph_pool_counts(_lib.ptr(dp), None, _lib.ptr(bits), C.c_void_p(partial.data_ptr() + 256 * 4), _lib.ptr(counts), B, N, HW, nsplit, prec,
+                                  _lib.stream_ptr()), "ph_pool_counts(depth)")
+
+
 def dynconv_up2(planes, kern, kbias, branch, N, H, W, prec, up_out, logits_out=None, out_dtype=_lib.PH_OUT_F16):
     """final-stage dynamic conv + x2 bilinear upsample in one kernel (ph_dynconv_up2): kern [1,2,B,Npad,256] (one 16-bit
     plane), kbias [2,B,Npad]; writes up_out [B,N,2H,2W] and, when given, the low-resolution logits [B,N,H,W]"""
@@ -277,6 +295,16 @@ class DecodePlan:
         self.fused_up = (KP == 1 and _up2 != "0" and (_up2 == "1" or (1 if frame_invariant else B) * H >= 512)
                          and bool(_lib.load().ph_dynconv_up2_supported(N, H, W, self.mode.conv, OUT_CODE[out_dtype])))
         self.want_depth_lowres = False
+        # Round 6: a non-final stage's mask conv also pools the x map for the NEXT stage from the same read of the plane
+        # (ph_dynconv_poolx), the next stage then pools depth_feats alone: 33.5 MB instead of 50 MB per frame and stage boundary at
+        # cfg2.  One workgroup per (frame, pixel range) and CU: for launches that fill the chip (throughput plans; `frame_invariant`
+        # plans keep the separate kernels, whose pixel split is the one-frame launch's at any B).  PH_CONV_POOLX=0: the separate kernels
+        self.nsplit_px = int(max(1, min(256 // max(B, 1), HWp // 64)))
+        self.poolx = (KP == 1 and not frame_invariant and self.S > 1 and _os.environ.get("PH_CONV_POOLX", "1") != "0"
+                      and B * self.nsplit_px >= 192 and bool(_lib.load().ph_dynconv_poolx_supported(N, self.mode.conv)))
+        if self.poolx:
+            self.partial_px = e((B, self.nsplit_px, Npad, 512), torch.float32)
+            self.pcount_px = e((B, self.nsplit_px, Npad), torch.int32)
 
     @property
     def out_code(self):
@@ -336,15 +364,24 @@ class DecodePlan:
             last = s == self.S - 1
             if getattr(self, "debug_bits", None) is not None:      # tests: the hard masks stage s pools with (eager runs only)
                 self.debug_bits.append(self.bits.clone())
-            pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial, counts=self.pcount)
+            if s > 0 and self.poolx:
+                # the x map's sums came with the previous stage's conv (same read of the plane): depth_feats alone here
+                pool_depth_only(dp, self.bits, self.N, self.HW, self.prec, self.partial_px, self.pcount_px)
+                part, cnt = self.partial_px, self.pcount_px
+            else:
+                pool(xp, dp, self.bits, self.N, self.HW, self.prec, self.nsplit, out=self.partial, counts=self.pcount)
+                part, cnt = self.partial, self.pcount
             if s == 0 and getattr(self, "on_first_pool", None) is not None:
                 self.on_first_pool()       # multi-part callers skew their parts by one phase (an event recorded here)
-            o = query_stage(self.partial, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
-                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt, counts=self.pcount,
+            o = query_stage(part, self.bits, k, q, self.packs[s], self.N, self.HW, cls_sigmoid=last,
+                            outs=self.stage_out[s], workspace=self.ws, kern_fmt=self.mode.kern_fmt, counts=cnt,
                             phases=3 | (_lib.PH_QUERY_WIDE if getattr(self, "shares_gpu", False) else 0))
             cv = self.mode.conv
             if not last:
-                dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
+                if self.poolx:
+                    dynconv_poolx(xp, o["kern"], o["kbias"], self.N, self.HW, cv, self.bits, self.partial_px)
+                else:
+                    dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, bits_out=self.bits)
             else:
                 # each x2 upsample directly behind the conv that wrote its source (240 MB of logits at cfg2, 24 frames): on
                 # its own a part's four launches take 659 us in this order against 823 us as conv, conv, up, up; inside the

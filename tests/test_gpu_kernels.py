@@ -364,6 +364,41 @@ def test_dynconv_up2_fused_final_stage(gpu, monkeypatch, prec, dt, N, H, B, wgs)
         assert torch.equal(upn, up)
 
 
+@pytest.mark.parametrize("prec,feat,kdt", [(_lib.PH_PREC_BF16_KF16, _lib.PH_PREC_BF16, torch.float16), (_lib.PH_PREC_F16, _lib.PH_PREC_F16, torch.float16),
+                                           (_lib.PH_PREC_BF16, _lib.PH_PREC_BF16, torch.bfloat16)])
+@pytest.mark.parametrize("N,H,W,B,ns", [(153, 128, 256, 2, 10), (111, 16, 24, 3, 3), (160, 9, 31, 2, 4), (40, 7, 64, 1, 2), (192, 6, 20, 2, 1), (153, 48, 156, 2, 7)])
+def test_dynconv_poolx_equals_dynconv_and_pool(gpu, prec, feat, kdt, N, H, W, B, ns):
+    """round 6: ph_dynconv_poolx = ph_dynconv (mask bits, bit for bit) + the x half of ph_pool with THOSE bits (kernel_update_head.py
+    :317-329, :236-241) from one read of the plane; the depth half by ph_pool_counts on the depth plane alone (columns 256 .. 511, bit
+    for bit the full pooling's at the same split).  Ragged sizes: H * W not a multiple of 64 / 128, N not a multiple of 32, ranges of
+    uneven tile counts, one range.  The pooled x sums: exact {0, 1} x plane products in both kernels, different split boundaries
+    and, in the KF16 grade, the tile converted to fp16 first -- compared after the fixed-order sum over the ranges at 1e-6"""
+    lib = _lib.load()
+    assert lib.ph_dynconv_poolx_supported(N, prec) == 1
+    g = torch.Generator().manual_seed(7 + N + H)
+    HW, Npad = H * W, E.n_padded(N)
+    x, d = torch.randn(B, 256, H, W, generator=g), torch.randn(B, 256, H, W, generator=g)
+    kern = _planes16(torch.randn(2, B, Npad, 256, generator=g) * 0.1, kdt)[None].contiguous().to(gpu)
+    kbias = (torch.randn(2, B, Npad, generator=g) * 0.1).to(gpu)
+    xp, dp = E.ingest(x.to(gpu), feat), E.ingest(d.to(gpu), feat)
+    HWp = E.hw_padded(HW)
+    bits_ref = torch.full((B, Npad, HWp // 32), -1, dtype=torch.int32, device=gpu)
+    E.dynconv(xp, kern, kbias, 0, N, HW, prec, bits_out=bits_ref)
+    part_ref = torch.zeros((B, ns, Npad, 512), dtype=torch.float32, device=gpu)
+    cnt_ref = torch.zeros((B, ns, Npad), dtype=torch.int32, device=gpu)
+    E.pool(xp, dp, bits_ref, N, HW, feat, ns, out=part_ref, counts=cnt_ref)
+    bits = torch.full_like(bits_ref, -1)
+    part = torch.full((B, ns, Npad, 512), float("nan"), dtype=torch.float32, device=gpu)
+    cnt = torch.full((B, ns, Npad), -1, dtype=torch.int32, device=gpu)
+    E.dynconv_poolx(xp, kern, kbias, N, HW, prec, bits, part)
+    assert torch.equal(bits[:, :N], bits_ref[:, :N])
+    E.pool_depth_only(dp, bits, N, HW, feat, part, cnt)
+    assert not torch.isnan(part).any()
+    assert torch.equal(part[..., 256:], part_ref[..., 256:]) and torch.equal(cnt.sum(1), cnt_ref.sum(1))
+    a, b = part[..., :256].double().sum(1).cpu(), part_ref[..., :256].double().sum(1).cpu()
+    assert Hh.rel_err(a, b) < 1e-6, Hh.rel_err(a, b)
+
+
 def test_dynconv_up2_inside_the_decode_plan(gpu, monkeypatch):
     """the S-stage plan with and without the fused final stage (PH_CONV_UP2=0): every output the API returns agrees -- the
     low-resolution mask logits and the query outputs bit for bit, the upsampled logits except for rounding-boundary cases"""
