@@ -84,6 +84,11 @@ class StagePack:
         self.prec = prec
 
 
+def plan_env_key():
+    """the environment switches a DecodePlan's kernel choice reads at construction: part of the module API's plan-cache key"""
+    return tuple(_os.environ.get(k) for k in ("PH_POOL_NSPLIT", "PH_CONV_UP2", "PH_CONV_POOLX", "PH_POOLX_NSPLIT"))
+
+
 def default_nsplit(B, HW, frame_invariant=False):
     """pixel ranges per frame for the split-K pooling: 4*B*nsplit workgroups should fill the chip's resident
     slots (2 workgroups per CU x 256 CUs) without a partial second generation.  `frame_invariant`: the split of a ONE-frame
@@ -298,10 +303,12 @@ class DecodePlan:
         # Round 6: a non-final stage's mask conv also pools the x map for the NEXT stage from the same read of the plane
         # (ph_dynconv_poolx), the next stage then pools depth_feats alone: 33.5 MB instead of 50 MB per frame and stage boundary at
         # cfg2.  One workgroup per (frame, pixel range) and CU: for launches that fill the chip (throughput plans; `frame_invariant`
-        # plans keep the separate kernels, whose pixel split is the one-frame launch's at any B).  PH_CONV_POOLX=0: the separate kernels
-        self.nsplit_px = int(max(1, min(256 // max(B, 1), HWp // 64)))
-        self.poolx = (KP == 1 and not frame_invariant and self.S > 1 and _os.environ.get("PH_CONV_POOLX", "1") != "0"
-                      and B * self.nsplit_px >= 192 and bool(_lib.load().ph_dynconv_poolx_supported(N, self.mode.conv)))
+        # plans keep the separate kernels, whose pixel split is the one-frame launch's at any B).  PH_CONV_POOLX=0 / 1: never / wherever supported
+        # (at least 16 tiles of 64 pixels per workgroup: its prologue loads the frame's kernels, its epilogue writes Npad x 256 sums)
+        self.nsplit_px = int(_os.environ.get("PH_POOLX_NSPLIT") or max(1, min(256 // max(B, 1), HWp // (64 * 16))))
+        px_env = _os.environ.get("PH_CONV_POOLX", "auto")        # "0": never, "1": wherever the kernel exists, default: launches that fill the chip
+        self.poolx = (KP == 1 and not frame_invariant and self.S > 1 and px_env != "0" and (px_env == "1" or B * self.nsplit_px >= 192)
+                      and bool(_lib.load().ph_dynconv_poolx_supported(N, self.mode.conv)))
         if self.poolx:
             self.partial_px = e((B, self.nsplit_px, Npad, 512), torch.float32)
             self.pcount_px = e((B, self.nsplit_px, Npad), torch.int32)

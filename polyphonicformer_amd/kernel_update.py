@@ -78,7 +78,7 @@ class KernelUpdateIterHead(nn.Module):
 
     def _plan(self, B, N, H, W, device):
         packs = [h.stage_pack(device, self.precision) for h in self.mask_head]
-        key = (B, N, H, W, self.precision, self.output_dtype, str(device), tuple(id(p) for p in packs), bool(self.frame_invariant))
+        key = (B, N, H, W, self.precision, self.output_dtype, str(device), tuple(id(p) for p in packs), bool(self.frame_invariant), E.plan_env_key())
         plan = self._plans.get(key)
         if plan is None:
             self._plans.clear()

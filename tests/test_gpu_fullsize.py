@@ -123,14 +123,18 @@ def test_cfg5_shape_stage_vs_oracle(gpu, precision):
         assert e < tol, (name, e)
 
 
+@pytest.mark.parametrize("poolx", ["0", "1"])
 @pytest.mark.parametrize("parts", [2, 3])
-def test_cfg2_multi_stream_plan_equals_single_plan(head_cfg2, parts, monkeypatch):
+def test_cfg2_multi_stream_plan_equals_single_plan(head_cfg2, parts, poolx, monkeypatch):
     """engine.DualDecodePlan (the bench's runner: part-batches on skewed streams inside one HIP graph) against one
     DecodePlan over the same frames: bit-identical outputs (frames are independent; uneven split with parts = 3).  The
     split-K factor of the pooling depends on the batch size by default (it fixes the order of the fp32 partial sums),
     so it is pinned for the comparison."""
     monkeypatch.setenv("PH_POOL_NSPLIT", "4")
     monkeypatch.setenv("PH_CONV_UP2", "1")      # the final-stage form depends on the part size by default (fused from B * H >= 512)
+    # round 6: so does the fused conv + pooling of the non-final stages (launches that fill the chip) and its pixel split: both forms, pinned
+    monkeypatch.setenv("PH_CONV_POOLX", poolx)
+    monkeypatch.setenv("PH_POOLX_NSPLIT", "8")
     wl, head = head_cfg2
     dev = torch.device("cuda:0")
     B, N = 7, wl["Nq"] + wl["n_stuff"]
@@ -138,6 +142,7 @@ def test_cfg2_multi_stream_plan_equals_single_plan(head_cfg2, parts, monkeypatch
     gin = [inp[k].to(dev) for k in ("x", "dfe", "k0", "q0", "m0")]
     gin[0], gin[1] = gin[0].to(torch.bfloat16), gin[1].to(torch.bfloat16)
     one = head._plan(B, N, wl["H"], wl["W"], dev)
+    assert one.poolx == (poolx == "1")
     one.set_inputs(*gin)
     one.run()
     ref = {k: v.clone() for k, v in one.outputs().items() if v is not None}      # fused final stage: no low-res depth

@@ -17,7 +17,7 @@ part = torch.zeros((B, ns, Npad, 512), device=gpu)
 cnt = torch.zeros((B, ns, Npad), dtype=torch.int32, device=gpu)
 part16 = torch.zeros((B, 16, Npad, 512), device=gpu)
 def t(fn, n=30):
-    for _ in range(5): fn()
+    for _ in range(60): fn()        # clocks ramp over the first milliseconds of a burst
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -28,6 +28,11 @@ print("poolx      %.1f us" % t(lambda: E.dynconv_poolx(xp, kern, kbias, N, HW, p
 print("dynconv    %.1f us" % t(lambda: E.dynconv(xp, kern, kbias, 0, N, HW, prec, bits_out=bits)))
 print("pool_depth %.1f us" % t(lambda: E.pool_depth_only(dp, bits, N, HW, feat, part, cnt)))
 print("pool       %.1f us" % t(lambda: E.pool(xp, dp, bits, N, HW, feat, 16, out=part16)))
+for n2 in (8, 10, 16, 21, 32):
+    p2 = torch.zeros((B, n2, Npad, 512), device=gpu)
+    print("poolx nsplit %d  %.1f us" % (n2, t(lambda: E.dynconv_poolx(xp, kern, kbias, N, HW, prec, bits, p2))))
+    c2 = torch.zeros((B, n2, Npad), dtype=torch.int32, device=gpu)
+    print("pool_depth nsplit %d  %.1f us" % (n2, t(lambda: E.pool_depth_only(dp, bits, N, HW, feat, p2, c2))))
 for pr, nm in ((_lib.PH_PREC_F16, "f16"),):
     print("poolx %s  %.1f us" % (nm, t(lambda: E.dynconv_poolx(xp, kern, kbias, N, HW, pr, bits, part))))
     print("dynconv %s %.1f us" % (nm, t(lambda: E.dynconv(xp, kern, kbias, 0, N, HW, pr, bits_out=bits))))
