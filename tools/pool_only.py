@@ -10,6 +10,7 @@ HW = H * W
 xp = torch.randint(-2**15, 2**15, (1, B, 256, E.hw_padded(HW)), dtype=torch.int16, device=dev) & 0x3BFF      # finite in bf16 and fp16
 dp = xp.clone()
 bits = torch.randint(-2**31, 2**31 - 1, (B, E.n_padded(N), E.hw_padded(HW) // 32), dtype=torch.int32, device=dev)
+bits0 = bits.clone()
 ns = E.default_nsplit(B, HW)
 part = torch.empty((B, ns, E.n_padded(N), 512), dtype=torch.float32, device=dev)
 cnt = torch.empty((B, ns, E.n_padded(N)), dtype=torch.int32, device=dev)
@@ -19,7 +20,15 @@ odt = torch.bfloat16 if mode.name == "bf16" else torch.float16
 out = torch.empty((B, N, H, W), dtype=odt, device=dev)
 up = torch.empty((B, N, 2 * H, 2 * W), dtype=odt, device=dev)
 fused = mode.KP == 1 and _lib.load().ph_dynconv_up2_supported(N, H, W, mode.conv, E.OUT_CODE[odt])
+px = bool(_lib.load().ph_dynconv_poolx_supported(N, mode.conv)) and mode.KP == 1
+ns_px = 256 // B
+part_px = torch.empty((B, ns_px, E.n_padded(N), 512), dtype=torch.float32, device=dev)
+cnt_px = torch.empty((B, ns_px, E.n_padded(N)), dtype=torch.int32, device=dev)
 for _ in range(5):
+    if px:          # round 6: non-final conv + pooling of the x map in one kernel, then the pooling of depth_feats alone
+        E.dynconv_poolx(xp, kern, kb, N, HW, mode.conv, bits, part_px)
+        E.pool_depth_only(dp, bits, N, HW, mode.feat, part_px, cnt_px)
+        bits.copy_(bits0)
     E.pool(xp, dp, bits, N, HW, mode.feat, ns, out=part, counts=cnt)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, bits_out=bits)
     E.dynconv(xp, kern, kb, 0, N, HW, mode.conv, logits_out=out, out_dtype=E.OUT_CODE[odt])

@@ -29,7 +29,7 @@ up_b = torch.empty_like(up)
 
 
 def t(fn, n=20):
-    for _ in range(3):
+    for _ in range(40):          # the clocks ramp over the first milliseconds of a burst
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -63,6 +63,14 @@ if _lib.load().ph_dynconv_up2_supported(N, H, W, mode.conv, oc):
     bd = feat + B * N * HW * 2 * 4
     res["up2_mask_TBps"] = bm / res["up2_mask_us"] / 1e6
     res["up2_depth_TBps"] = bd / res["up2_depth_us"] / 1e6
+if mode.KP == 1 and _lib.load().ph_dynconv_poolx_supported(N, mode.conv):       # round 6
+    ns_px = 256 // B
+    part_px = torch.empty((B, ns_px, E.n_padded(N), 512), dtype=torch.float32, device=part.device)
+    cnt_px = torch.empty((B, ns_px, E.n_padded(N)), dtype=torch.int32, device=part.device)
+    res["dynconv_poolx_us"] = t(lambda: E.dynconv_poolx(xp, kern, kb, N, HW, mode.conv, bits2, part_px))
+    res["pool_depth_us"] = t(lambda: E.pool_depth_only(dp, bits2, N, HW, mode.feat, part_px, cnt_px))
+    res["dynconv_poolx_TBps"] = (feat + B * N * HW // 8) / res["dynconv_poolx_us"] / 1e6
+    res["pool_depth_TBps"] = (feat + B * N * HW // 8) / res["pool_depth_us"] / 1e6
 res["pool_TBps"] = (2 * feat + B * N * HW // 8) / res["pool_us"] / 1e6
 res["dynconv_bits_TBps"] = (feat + B * N * HW // 8) / res["dynconv_bits_us"] / 1e6
 res["dynconv_logits_TBps"] = (feat + B * N * HW * 2) / res["dynconv_logits_us"] / 1e6

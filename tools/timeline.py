@@ -22,8 +22,12 @@ HBM = ("k_binarize", "k_pool", "k_dynconv_up2", "k_dynconv", "k_upsample2x", "k_
 QUERY = ("k_query_pre", "k_query_post")
 
 
-def klass(name):
+def klass(name, grid_y=None):
     n = name.split("(")[0]
+    if "k_dynconv_poolx" in n:                  # round 6: non-final conv + pooling of the x map
+        return "dynconv_poolx"
+    if "k_pool" in n and grid_y == 2:           # k_pool over ONE map (depth_feats; the x half came from k_dynconv_poolx)
+        return "pool_depth"
     if "k_dynconv_up2" in n:
         return "dynconv_up2_mask" if ", true, " in n else "dynconv_up2_depth"
     if "k_dynconv" in n:
@@ -37,7 +41,7 @@ def klass(name):
 def load(path):
     ks = []
     for r in csv.DictReader(open(path)):
-        c = klass(r["Kernel_Name"])
+        c = klass(r["Kernel_Name"], int(r.get("Grid_Size_Y") or 0))
         if c:
             ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), c, r["Queue_Id"]))
     ks.sort()
