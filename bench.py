@@ -678,7 +678,10 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
 
     def begin(step):
         if runner is not None:                  # the clip's heads start (HIP graph replays on the slots' streams); no wait
-            runner.records_begin([_video_frame(base, f, 6) for f in frames_of(step)])
+            # round 6: the frames are BORROWED -- this loop leaves a clip's tensors alone until its records are back, as the reference's
+            # loop does (the backbone's outputs live until the frame is done) -- so no staging copy of the levels into the graph's
+            # static inputs (356 MB of traffic per frame); PH_CFG4_BORROW=0 times the copying form
+            runner.records_begin([_video_frame(base, f, 6) for f in frames_of(step)], borrowed=os.environ.get("PH_CFG4_BORROW", "1") != "0")
 
     def finish(step):
         """the records of this rank's frames of `step` (the synchronising half), packed for the all-gather"""
@@ -777,6 +780,9 @@ def cfg4_run(dev, world, rank, backend, precision="fp16", clip_frames=2, steps=4
            "step_pipelining": "step k+1's heads are started before step k's all-gather + tracker replay (ms_per_step ~ max of the two)",
            "precision": precision,
            "khead_onepass_timeouts": None if runner is None else runner.khead_timeouts(),
+           "frame_inputs": ("borrowed: the FPN levels are read where the caller left them (no staging copy; PH_CFG4_BORROW=0 times the copying form)"
+                            if runner is not None and os.environ.get("PH_CFG4_BORROW", "1") != "0" and os.environ.get("PH_VIDEO_BORROW", "1") != "0"
+                            else "copied into the graph's static inputs (356 MB of traffic per frame)"),
            "frame_loop": "module API, eager launches" if runner is None else "video.VideoStreamRunner: heads replayed from one HIP graph"}
     # what the measured components project for a node of 8 ranks (the driver's 8-GPU leg, when a node is available): every rank replays
     # all 8 x clip frames of a step; the step is pipelined, so it costs max(heads of the own clip, all-gather + replay of all frames)
@@ -1224,7 +1230,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=96, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=128, help="frames per step per GPU (round 6: 128 = 4 parts of 32 -- the fused conv + pooling launch then has exactly one workgroup per CU; 96 until then)")
     ap.add_argument("--precision", default="mixed16", choices=["bf16", "mixed", "mixed16", "fp16", "fp32"],
                     help="engine.MODES: bf16 = one bf16 plane everywhere (fast, ~6e-3 per stage); mixed = bf16 feature planes as "
                          "given, fp32-grade arithmetic on them (1.2e-5 per stage on identical inputs), fp16 logits out; mixed16 = "
@@ -1391,7 +1397,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "r06", "timeline_4streams.json")) as f:
                 tl = json.load(f)
-            if tl["parts"] == nplans and args.workload == "cfg2" and args.precision == "mixed16" and B == 96:
+            if tl["parts"] == nplans and args.workload == "cfg2" and args.precision == "mixed16" and B == tl.get("frames_per_step", 96):
                 in_graph = {"source": "profiles/r06/timeline_4streams.json (tools/timeline.py on a rocprofv3 --kernel-trace of this command; not "
                                       "measured in this run)",
                             "wall_us_per_step": tl["wall_us_per_step"], "overlap_efficiency": tl.get("overlap_efficiency"),

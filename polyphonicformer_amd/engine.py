@@ -750,6 +750,7 @@ class NeckPlan:
                                     y=e((B, n_small, 256), torch.float32), stats=e((B, 256, 2), torch.float32),
                                     partial=e((lib.ph_conv_nhwc_partial_floats(B, self.Ho, self.Wo),), torch.float32)))
         self._streams = None                                       # created on first use; not part of a copy of the plan
+        self.skip_ingest = False                                   # set around a capture whose replays follow `ingest_frames`
         # Round 4: the three output convs (conv_pred + 2 aux convs) as stats / apply passes over the level sum in channel planes
         # (ph_neck_out_convs) instead of conv -> fp32 NHWC -> finalize -> apply per map.  PH_NECK_OUT2=0: the per-map form.
         # one-plane grades only: with hi / lo planes the recompute pass is three MFMAs per product and costs more than the fp32
@@ -788,7 +789,8 @@ class NeckPlan:
         # stages then read whole lines; PH_NECK_C16=0: channels-last, A/B timing)
         c16 = _lib.PH_PLANES_C16 if (convs[0]["s"] == 2 and convs[0]["k"] == 3 and prec != _lib.PH_PREC_SPLIT
                                      and _os.environ.get("PH_NECK_C16", "1") != "0") else 0
-        nhwc_ingest(feat, posenc, prec | c16, xa)
+        if not self.skip_ingest:
+            nhwc_ingest(feat, posenc, prec | c16, xa)
         src = xa
         for j, c in enumerate(convs):
             lay = c16 if j == 0 else 0
@@ -801,6 +803,30 @@ class NeckPlan:
                 H, W = self._conv_gn(src, c, H, W, groups, self.ys[lvl], self.lstats[lvl], partial, lay)
                 if (H, W) != (self.Ho, self.Wo):
                     raise _lib.PolyheadError("level does not end at the stride-8 size")
+
+    def can_ingest_frames(self):
+        """True when the levels' conv input planes can be filled frame by frame AHEAD of `run` (`ingest_frames`): every level owns its
+        buffers (the tower-stream form) and the grade has one plane"""
+        return bool(self.multi) and self.prec != _lib.PH_PREC_SPLIT
+
+    def ingest_frames(self, frames, pk, posenc, pos_level):
+        """round 6 (video clips without the staging copy): the ingest step of `run` for `frames` = B one-frame level tuples (fp32
+        [1, 256, h, w], contiguous), each written straight from the caller's tensor into its slice of the level's conv input planes -- on the
+        CURRENT stream, outside any graph.  A `run(..)` with `skip_ingest` set (the captured graph) continues from those planes."""
+        if not self.can_ingest_frames() or len(frames) != self.B:
+            raise _lib.PolyheadError("NeckPlan.ingest_frames: needs the tower-stream form, a one-plane grade and B frames")
+        lib, st = _lib.load(), _lib.stream_ptr()
+        for lvl, (h, w) in enumerate(self.shapes):
+            convs = pk["levels"][lvl]
+            c16 = _lib.PH_PLANES_C16 if (convs[0]["s"] == 2 and convs[0]["k"] == 3 and _os.environ.get("PH_NECK_C16", "1") != "0") else 0
+            xa = self.lv[lvl]["xa"]
+            add = _lib.ptr(posenc) if lvl == pos_level and posenc is not None else None
+            for b, f in enumerate(frames):
+                t = f[lvl]
+                if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (1, 256, h, w) or t.device != xa.device:
+                    raise _lib.PolyheadError("NeckPlan.ingest_frames: fp32 contiguous [1, 256, h, w] device tensors")
+                _lib.check(lib.ph_nhwc_ingest(_lib.ptr(t), add, C.c_void_p(xa.data_ptr() + b * h * w * 256 * 2), 1, h * w, self.prec | c16, st),
+                           "ph_nhwc_ingest(frame)")
 
     def run(self, feats, pk, groups, posenc, pos_level, to_planes=False):
         B, prec = self.B, self.prec

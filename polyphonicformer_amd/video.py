@@ -778,31 +778,45 @@ class VideoStreamRunner:
         depth_init = E.upsample2x(depth_pred.float().contiguous())                         # kernel_update.py:302-307
         return o["cls"], o["mask_up"], o["depth_up"], depth_init
 
-    def _start_heads(self, i, frames):
+    def _start_heads(self, i, frames, borrowed=False):
         """copy the frames (a list of one-frame FPN level tuples: ONE for the per-frame calls, a clip's chunk for `records`) into
-        slot i's static inputs for that many frames per launch and start its heads on the slot's stream"""
+        slot i's static inputs for that many frames per launch and start its heads on the slot's stream.
+
+        `borrowed` (round 6, clips): the caller keeps the frames' tensors unchanged until their records have been returned, so nothing
+        is copied -- the neck's ingest (fp32 NCHW -> 16-bit conv input planes, its first kernel) runs per frame straight from the caller's
+        tensors, on the caller's stream and OUTSIDE the graph, which then starts at the towers' first convs; RoIAlign reads the caller's
+        levels.  The staging copy of a 1024 x 2048 frame's four levels is 178 MB read + 178 MB written: 0.9 ms of an 8-frame clip's
+        8.4 ms.  Needs the tower-stream neck plan (clip launches of 2+ frames) and fp32 contiguous levels; otherwise the copy form runs."""
         sl = self._slot(i)
         main = torch.cuda.current_stream()
         B = len(frames)
-        sl["cur"] = B
+        neck0 = getattr(sl["rpn"], "localization_fpn", None)
+        pre = bool(borrowed and self.use_graph and B >= 2 and neck0 is not None and hasattr(neck0, "ingest_frames")
+                   and os.environ.get("PH_VIDEO_BORROW", "1") != "0"
+                   and all(t.dtype == torch.float32 and t.is_contiguous() for f in frames for t in f[:4]))
+        key = ("borrowed", B) if pre else B
+        if pre and key in sl["g"] and sl["g"][key].get("pre") is False:
+            pre, key = False, B                              # (this neck plan cannot take frames one by one: found at the first capture)
+        sl["cur"] = key
         from . import panoptic as Pn
         if not self.use_graph:
             # slot-owned copies in this path too (torch.cat copies; one frame is cloned): RoIAlign reads the levels one push
             # later, and the contract is that the caller may reuse its tensors once push() returns (ADVICE r04)
             x = tuple(t.clone() for t in frames[0]) if B == 1 else tuple(torch.cat([f[l] for f in frames], 0) for l in range(len(frames[0])))
             outs = self._heads_device(sl, x)
-            dm = (sl["g"].get(B) or {}).get("dm")
+            dm = (sl["g"].get(key) or {}).get("dm")
             if self.device_select:
                 dm = dm or Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
                 dm.begin(*outs)
                 dm.download()
-            sl["g"][B] = dict(x=x, graph=None, outs=outs, dm=dm)
+            sl["g"][key] = dict(x=x, graph=None, outs=outs, dm=dm, B=B, pre=False)
             sl["done"] = torch.cuda.Event()
             sl["done"].record(main)
             return
-        st = sl["g"].get(B)
+        st = sl["g"].get(key)
         if st is None:
-            st = sl["g"][B] = dict(x=tuple(t.new_empty((B,) + tuple(t.shape[1:])) for t in frames[0]), graph=None, outs=None, dm=None)
+            st = sl["g"][key] = dict(x=tuple(t.new_empty((B,) + tuple(t.shape[1:])) for t in frames[0]), graph=None, outs=None, dm=None, B=B,
+                                     pre=pre)
             for b, f in enumerate(frames):
                 for d, t in zip(st["x"], f):
                     d[b:b + 1].copy_(t)
@@ -823,11 +837,27 @@ class VideoStreamRunner:
                     st["dm"] = Pn.DeviceMerge(sl["roi"], *outs, self.metas[0])
                     st["dm"].begin(*outs)
                 torch.cuda.synchronize()
+                nplan = None
+                if pre:
+                    # borrowed clips: the graph starts BEHIND the neck's ingest (engine.NeckPlan.skip_ingest); when this plan cannot be
+                    # filled frame by frame (shared level buffers, two-plane grade) the slot falls back to the copy form for good
+                    nplan = neck.clip_plan(B, tuple(tuple(t.shape[-2:]) for t in st["x"][:4]), st["x"][0].device)
+                    if nplan is None or not nplan.can_ingest_frames():
+                        nplan, pre = None, False
+                        st["pre"] = False
+                        sl["g"][B] = sl["g"].pop(key)
+                        sl["cur"] = key = B
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    st["outs"] = self._heads_device(sl, st["x"])
-                    if st["dm"] is not None:
-                        st["dm"].begin(*st["outs"])
+                try:
+                    if nplan is not None:
+                        nplan.skip_ingest = True
+                    with torch.cuda.graph(g):
+                        st["outs"] = self._heads_device(sl, st["x"])
+                        if st["dm"] is not None:
+                            st["dm"].begin(*st["outs"])
+                finally:
+                    if nplan is not None:
+                        nplan.skip_ingest = False
             finally:
                 if towers:
                     neck._clip_towers = False
@@ -841,9 +871,14 @@ class VideoStreamRunner:
             if len(f) != len(st["x"]) or any(tuple(d.shape[1:]) != tuple(t.shape[1:]) or d.dtype != t.dtype for d, t in zip(st["x"], f)):
                 raise ValueError("VideoStreamRunner: the FPN levels changed shape / dtype; one runner serves one stream of equally "
                                  "sized frames (call reset() to re-capture)")
-        for b, f in enumerate(frames):
-            for d, t in zip(st["x"], f):
-                d[b:b + 1].copy_(t, non_blocking=True)       # on the caller's stream: the frame may be reused once push returns
+        if st.get("pre"):
+            st["frames"] = list(frames)                      # RoIAlign reads these; the references keep the storage alive
+            neck0.ingest_frames(frames)                      # on the caller's stream, in front of `ready`
+        else:
+            st["frames"] = None
+            for b, f in enumerate(frames):
+                for d, t in zip(st["x"], f):
+                    d[b:b + 1].copy_(t, non_blocking=True)   # on the caller's stream: the frame may be reused once push returns
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(sl["stream"]):
@@ -864,7 +899,10 @@ class VideoStreamRunner:
     def _frame_levels(self, i, b=0):
         """the FPN levels of frame b of slot i's current launch (views of its static inputs)"""
         sl = self._slots[i]
-        x = sl["g"][sl["cur"]]["x"]
+        st = sl["g"][sl["cur"]]
+        if st.get("frames"):                                 # a borrowed clip: the caller's tensors
+            return tuple(st["frames"][b])
+        x = st["x"]
         return x if sl["cur"] == 1 else tuple(t[b:b + 1] for t in x)
 
     # -- the part of a frame that follows the heads -----------------------------------------------------------------
@@ -960,7 +998,9 @@ class VideoStreamRunner:
                 for b in range(prev[1]):
                     self._finish(prev[0], b)
                 prev = None
-            self._start_heads(i, self._buf)
+            # the buffered frames are this runner's own clones (`_push_batched`): they ARE the slot-owned copy -- borrowed, so the
+            # launch does not copy them a second time into the graph's static inputs (round 6)
+            self._start_heads(i, self._buf, borrowed=True)
             self._inflight_b = (i, len(self._buf))
             self._buf = []
             self._nb += 1
@@ -1015,12 +1055,13 @@ class VideoStreamRunner:
             return 1
         return max(1, min(cap, len(frames)))
 
-    def records(self, frames):
+    def records(self, frames, borrowed=True):
         """the sharded mode's per-step work for a rank's clip: `simple_test(..., records_only=True)` of every frame in order.
         The clip goes through the heads in chunks of `clip_batch` frames per launch; the heads of up to two chunks are in flight
         at a time: chunk k + 1's are started BEFORE chunk k's merges / records, and the clip's first two chunks start back to back.
-        Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame.  = `records_begin` + `records_end`."""
-        self.records_begin(frames)
+        Returns [(segment ids, (bboxes, labels, embeds) or None)] per frame.  = `records_begin` + `records_end`.  The call returns when
+        every frame has been consumed, so the frames are `borrowed` (no staging copy, `_start_heads`) unless the caller says otherwise."""
+        self.records_begin(frames, borrowed=borrowed)
         return self.records_end()
 
     def _pump(self):
@@ -1028,18 +1069,19 @@ class VideoStreamRunner:
         for clip in self._rq:
             while clip["next"] < len(clip["chunks"]) and self._free:
                 i = self._free.pop(0)
-                self._start_heads(i, clip["chunks"][clip["next"]])
+                self._start_heads(i, clip["chunks"][clip["next"]], borrowed=clip.get("borrowed", False))
                 clip["slots"].append(i)
                 clip["next"] += 1
             if clip["next"] < len(clip["chunks"]):
                 break                                    # launch order = frame order: a later clip never overtakes an earlier one
 
-    def records_begin(self, frames):
+    def records_begin(self, frames, borrowed=False):
         """first half of `records`: queues the clip and STARTS the heads of as many of its chunks as slots are free -- returns without
         waiting for the device.  Round 6: clips QUEUE -- `records_begin` of the next clip may be called before `records_end` of the
         previous one, and then its heads run (on the other slot) underneath the previous clip's merges / records, which are host work
         and a few small kernels: the sharded video loop (bench.cfg4_run) does exactly that, so a step costs max(heads, merges + records +
-        all-gather + replay) instead of their sum.  `records_end` always returns the OLDEST queued clip's records."""
+        all-gather + replay) instead of their sum.  `records_end` always returns the OLDEST queued clip's records.
+        `borrowed=True`: the caller leaves the frames' tensors unchanged until `records_end` has returned this clip (`_start_heads`)."""
         frames = list(frames)
         assert self._inflight is None, "records() and push() / push_record() must not be interleaved"
         for f in frames:
@@ -1049,7 +1091,7 @@ class VideoStreamRunner:
             self._check_weights()                        # (drops the slots when the weights changed: only between clips)
             self._free = list(range(2 if self.pipelined else 1))
         Bc = self.clip_batch(frames) if frames else 1
-        self._rq.append(dict(chunks=[frames[k:k + Bc] for k in range(0, len(frames), Bc)], next=0, slots=[]))
+        self._rq.append(dict(chunks=[frames[k:k + Bc] for k in range(0, len(frames), Bc)], next=0, slots=[], borrowed=bool(borrowed)))
         self._pump()
 
     def records_end(self):

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-kernel-head --no-neck --steps 30 --warmup 5"
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -o d -- python bench.py $Q > $OUT/d_bench.json 2> $OUT/d.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py $Q --streams 1 --frames 24 > $OUT/e_bench.json 2> $OUT/e.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e -o e -- python bench.py $Q --streams 1 --frames 32 > $OUT/e_bench.json 2> $OUT/e.err
 python tools/timeline.py $(find $OUT/d -name "*kernel_trace.csv") --isolated $(find $OUT/e -name "*kernel_trace.csv") --json $OUT/timeline_4streams.json > /dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python tools/pool_only.py mixed16 > /dev/null 2> $OUT/pmc_write.err

@@ -5,7 +5,8 @@ sys.path.insert(0, ".")
 from polyphonicformer_amd import _lib, engine as E
 dev = torch.device("cuda:0")
 mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed16"]
-N, B, H, W = 153, 24, 128, 256
+import os
+N, B, H, W = 153, int(os.environ.get('PH_PART_FRAMES', 32)), 128, 256
 HW = H * W
 xp = torch.randint(-2**15, 2**15, (1, B, 256, E.hw_padded(HW)), dtype=torch.int16, device=dev) & 0x3BFF      # finite in bf16 and fp16
 dp = xp.clone()

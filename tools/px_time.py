@@ -3,7 +3,8 @@ import sys, torch
 sys.path.insert(0, ".")
 from polyphonicformer_amd import _lib, engine as E
 gpu = torch.device("cuda:0")
-B, N, H, W = 24, 153, 128, 256
+import os
+B, N, H, W = int(os.environ.get('PH_PART_FRAMES', 32)), 153, 128, 256
 HW, Npad = H * W, E.n_padded(N)
 g = torch.Generator().manual_seed(1)
 prec, feat = _lib.PH_PREC_BF16_KF16, _lib.PH_PREC_BF16

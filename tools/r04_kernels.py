@@ -1,5 +1,5 @@
 """GPU, round 4: isolated timings (HIP events, launches back to back on one stream) of the a6 kernels at the headline geometry
-(cfg2, 24 frames per launch, `mixed16` / `fp16` arithmetic) -- the two-kernel final stage against the fused conv + x2 upsample
+(cfg2, 32 frames per launch (PH_PART_FRAMES; 24 until round 6), `mixed16` / `fp16` arithmetic) -- the two-kernel final stage against the fused conv + x2 upsample
 (ph_dynconv_up2) -- and of a1 (16 frames).  usage: python tools/r04_kernels.py [mode]"""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ if os.environ.get("PH_ALT_LIB"):
     _lib.LIB_PATH = os.environ["PH_ALT_LIB"]            # same-box A/B of a library variant
 dev = torch.device("cuda:0")
 mode = E.MODES[sys.argv[1] if len(sys.argv) > 1 else "mixed16"]
-N, B, H, W = 153, int(os.environ.get("R04_B", "24")), 128, 256
+N, B, H, W = 153, int(os.environ.get("R04_B", os.environ.get("PH_PART_FRAMES", "32"))), 128, 256
 HW = H * W
 g = torch.Generator(device="cpu").manual_seed(1)
 pdt = mode.feat_dtype

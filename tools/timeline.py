@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--isolated")
     ap.add_argument("--skip", type=int, default=14, help="replays to skip at the start (set-up + warm-up)")
     ap.add_argument("--json")
+    ap.add_argument("--frames-per-step", type=int, default=128, help="recorded in the summary (bench.py quotes it only for that step size)")
     a = ap.parse_args()
     ks = load(a.trace)
     # the graph replays run on the queues that carry binarize launches; a replay starts with the first binarize after a previous
@@ -114,7 +115,7 @@ def main():
     hbm_u = union([clip(k) for k in win if not k[2].startswith("query")]) / nsteps
     all_u = union([clip(k) for k in win]) / nsteps
     conc, qonly = sweep(win, t0, t1)
-    res = {"trace": a.trace, "parts": parts, "steps_analysed": nsteps, "wall_us_per_step": round(wall / 1e3, 1),
+    res = {"trace": a.trace, "frames_per_step": a.frames_per_step, "parts": parts, "steps_analysed": nsteps, "wall_us_per_step": round(wall / 1e3, 1),
            "hbm_union_us": round(hbm_u / 1e3, 1), "query_exposed_us": round(qonly / nsteps / 1e3, 1),
            "idle_us": round((wall - all_u) / 1e3, 1),
            "concurrency_share": {str(n): round(v / (t1 - t0), 4) for n, v in sorted(conc.items())}}
