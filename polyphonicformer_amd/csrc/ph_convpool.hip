@@ -106,18 +106,25 @@ __global__ __launch_bounds__((2 * NRT * 64)) void k_dynconv_poolx(const uint16_t
     const uint32_t lds0 = lds_addr(lds);
 
     // bf16 -> fp16 of a whole tile in place (`mixed16`), every wave of the workgroup: 2048 16-byte pieces, one round at a time
-    auto convert = [&](int buf) {
-        constexpr int PIECES = 256 * CONV_T * 2 / 16, LANES = C::NW * 64, ROUNDS = (PIECES + LANES - 1) / LANES;
-        const uint32_t tb = lds0 + buf * C::TILEB + 16u * (uint32_t)tid;
-        u32x4_t cv[ROUNDS];
+#ifndef CP_CONV_PIECES
+#define CP_CONV_PIECES 1024          // of the tile's 2048 16-byte pieces, how many the CONVOLUTION waves convert (the pooling waves: the rest).
+                                     // Measured on one box, 32 frames: 1024 (equal) 246-252 us, 640: 249-251, 320: 254, 0: 343 -- equal shares stay
+#endif
+    auto convert = [&](int buf, auto role_tag) {
+        constexpr bool CONVW = decltype(role_tag)::value;
+        constexpr int PIECES = 256 * CONV_T * 2 / 16, P0 = CONVW ? 0 : CP_CONV_PIECES, NP = CONVW ? CP_CONV_PIECES : PIECES - CP_CONV_PIECES;
+        constexpr int LANES = NRT * 64, ROUNDS = (NP + LANES - 1) / LANES;
+        const int rl = (wave - (CONVW ? 0 : NRT)) * 64 + lane;                  // lane index inside the role
+        const uint32_t tb = lds0 + buf * C::TILEB + 16u * (uint32_t)(P0 + rl);
+        u32x4_t cv[ROUNDS > 0 ? ROUNDS : 1];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
-            if ((r + 1) * LANES <= PIECES || wave * 64 < PIECES - r * LANES) cv[r] = lds_read128_asm(tb + r * LANES * 16);
+            if ((r + 1) * LANES <= NP || rl < NP - r * LANES) cv[r] = lds_read128_asm(tb + r * LANES * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
-            if ((r + 1) * LANES <= PIECES || wave * 64 < PIECES - r * LANES) {
+            if ((r + 1) * LANES <= NP || rl < NP - r * LANES) {
                 const uint4 h16 = bf2h_x8(__builtin_bit_cast(uint4, cv[r]));
                 lds_write128_asm(tb + r * LANES * 16, __builtin_bit_cast(u32x4_t, h16));
             }
@@ -152,7 +159,7 @@ __global__ __launch_bounds__((2 * NRT * 64)) void k_dynconv_poolx(const uint16_t
             __builtin_amdgcn_sched_barrier(0);
             if (t == t1) break;
             if constexpr (COOP) {
-                convert(cur);
+                convert(cur, std::true_type{});
                 __builtin_amdgcn_s_barrier();                         // (B) the tile is fp16
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -285,7 +292,7 @@ __global__ __launch_bounds__((2 * NRT * 64)) void k_dynconv_poolx(const uint16_t
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (COOP) {
             if (t < t1) {
-                convert(cur);
+                convert(cur, std::false_type{});
                 __builtin_amdgcn_s_barrier();                           // (B) the tile is fp16
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
 #define CV_DEPTH 4
 #endif
 #ifndef CV_ABL
-#define CV_ABL 0          // timing-only ablations (wrong results): 1 no patch prefetch, 2 no weight stream, 4 no stores, 8 no A reads, 16 patch pieces from one 16 KB window, 32 no patch LDS writes
+#define CV_ABL 0          // timing-only ablations (wrong results): 1 no patch prefetch, 2 no weight stream, 4 no stores, 8 no A reads, 16 patch pieces from one 16 KB window, 32 no patch LDS writes, 64 every chunk's k-steps twice
 #endif
     constexpr int DEPTH = CV_DEPTH;                                         // B fragments requested this many k-steps ahead
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];        // [PA][IR][IC][LDP]
@@ -312,6 +312,10 @@ __global__ __launch_bounds__(512) void k_conv_nhwc(const uint16_t* __restrict__ 
         constexpr int NKS = (NK - DEPTH > 1) ? NK - DEPTH : 1;   // the pieces are spread over the first NKS k-steps
 #if CV_ABL & 8
         uint4 a[PA][MT];
+#endif
+#if CV_ABL & 64            // timing only: the chunk's k-steps run twice (is the loop or what surrounds it the overhead?)
+#pragma unroll 1
+        for (int rep = 0; rep < 2; ++rep)
 #endif
 #pragma unroll
         for (int j = 0; j < NK; ++j) {

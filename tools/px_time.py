@@ -13,7 +13,7 @@ dp = xp.clone()
 kern = (torch.randn(1, 2, B, Npad, 256, generator=g) * 0.1).to(gpu).to(torch.float16).view(torch.int16)
 kbias = (torch.randn(2, B, Npad, generator=g) * 0.1).to(gpu)
 bits = torch.zeros((B, Npad, HW // 32), dtype=torch.int32, device=gpu)
-ns = 10
+ns = max(1, 256 // B)              # the plan's split: one workgroup per CU
 part = torch.zeros((B, ns, Npad, 512), device=gpu)
 cnt = torch.zeros((B, ns, Npad), dtype=torch.int32, device=gpu)
 part16 = torch.zeros((B, 16, Npad, 512), device=gpu)
