@@ -145,12 +145,14 @@ class SemanticFPNWrapper(nn.Module):
         """the device plan `forward` uses for B frames of these level sizes (None before the first such call)"""
         return self._plans.get((B, tuple(tuple(s) for s in shapes), str(dev), self.precision))
 
-    def ingest_frames(self, frames):
+    def ingest_frames(self, frames, plan=None):
         """round 6: fills the plan's conv input planes from B one-frame level tuples, frame by frame and without a batched copy of the
-        levels (video.VideoStreamRunner's borrowed clips; engine.NeckPlan.ingest_frames).  The plan must exist (one `forward` of B frames)."""
+        levels (video.VideoStreamRunner's borrowed clips; engine.NeckPlan.ingest_frames).  `plan`: the plan a captured graph replays
+        (the caller holds it); default: this module's plan for that clip size, which must exist (one `forward` of B frames)."""
         t0 = frames[0][0]
         shapes = tuple(tuple(t.shape[-2:]) for t in frames[0][:4])
-        plan = self.clip_plan(len(frames), shapes, t0.device)
+        if plan is None:
+            plan = self.clip_plan(len(frames), shapes, t0.device)
         if plan is None:
             raise _lib.PolyheadError("SemanticFPNWrapper.ingest_frames: no plan for this clip size yet")
         add = self._posenc(*shapes[self.cat_coors_level], t0.device) if self.pos_cfg is not None else None

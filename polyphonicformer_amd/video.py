@@ -794,9 +794,9 @@ class VideoStreamRunner:
         pre = bool(borrowed and self.use_graph and B >= 2 and neck0 is not None and hasattr(neck0, "ingest_frames")
                    and os.environ.get("PH_VIDEO_BORROW", "1") != "0"
                    and all(t.dtype == torch.float32 and t.is_contiguous() for f in frames for t in f[:4]))
+        if sl.get("no_borrow"):
+            pre = False                                      # (this neck plan cannot take frames one by one: found at a first capture)
         key = ("borrowed", B) if pre else B
-        if pre and key in sl["g"] and sl["g"][key].get("pre") is False:
-            pre, key = False, B                              # (this neck plan cannot take frames one by one: found at the first capture)
         sl["cur"] = key
         from . import panoptic as Pn
         if not self.use_graph:
@@ -843,10 +843,9 @@ class VideoStreamRunner:
                     # filled frame by frame (shared level buffers, two-plane grade) the slot falls back to the copy form for good
                     nplan = neck.clip_plan(B, tuple(tuple(t.shape[-2:]) for t in st["x"][:4]), st["x"][0].device)
                     if nplan is None or not nplan.can_ingest_frames():
-                        nplan, pre = None, False
-                        st["pre"] = False
-                        sl["g"][B] = sl["g"].pop(key)
-                        sl["cur"] = key = B
+                        sl["no_borrow"] = True               # this slot copies from now on; the launch starts over in the copy form
+                        del sl["g"][key]
+                        return self._start_heads(i, frames, borrowed=False)
                 g = torch.cuda.CUDAGraph()
                 try:
                     if nplan is not None:
@@ -862,6 +861,7 @@ class VideoStreamRunner:
                 if towers:
                     neck._clip_towers = False
             st["graph"] = g
+            st["nplan"] = nplan
             # the graph replays the plans' device buffers: KernelHead / KernelUpdateIterHead keep ONE plan and drop it when the
             # batch size changes (a clip's last chunk), so the graph holds its own references -- without them a later replay wrote
             # into freed blocks (harmless while the allocator kept them mapped; a memory fault once it had not: clips of 3 + 3 + 2)
@@ -873,7 +873,7 @@ class VideoStreamRunner:
                                  "sized frames (call reset() to re-capture)")
         if st.get("pre"):
             st["frames"] = list(frames)                      # RoIAlign reads these; the references keep the storage alive
-            neck0.ingest_frames(frames)                      # on the caller's stream, in front of `ready`
+            neck0.ingest_frames(frames, plan=st["nplan"])    # on the caller's stream, in front of `ready`; the plan the graph replays
         else:
             st["frames"] = None
             for b, f in enumerate(frames):
