@@ -1,4 +1,5 @@
 #!/bin/bash
+# kernel-time shares of the cfg4 leg at 8-frame clips from a rocprofv3 --kernel-trace (DESIGN 7b "Round 6"): busy / idle account + per-kernel totals
 export TMPDIR=/tmp; OUT=gpurun_out/c4t; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python bench.py --workload cfg4 --steps 30 --warmup 4 --clip-frames 8 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.log
 python tools/trace_busy.py $(find $OUT/t -name "*kernel_trace.csv") 14
