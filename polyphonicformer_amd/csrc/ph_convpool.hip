@@ -94,7 +94,11 @@ __global__ __launch_bounds__((2 * NRT * 64)) void k_dynconv_poolx(const uint16_t
     const int split = blockIdx.x, b = blockIdx.y;
 
     const int ntiles = (int)(HWp / CONV_T);
-    const int t0 = (int)((int64_t)split * ntiles / nsplit), t1 = (int)((int64_t)(split + 1) * ntiles / nsplit);
+    // pixel ranges = k_pool's (whole pairs of 64-pixel chunks, ph_pool.hip): with the same nsplit the partial sums of a range are then
+    // k_pool's BIT FOR BIT in the bf16 / fp16 grades (same operands, same k-step order per tile) -- which kernel pooled a frame's x map is
+    // invisible in its outputs, so the choice may follow the launch size even in batch-invariant plans
+    int t0 = (int)((int64_t)split * ntiles / nsplit) & ~1, t1 = (int)((int64_t)(split + 1) * ntiles / nsplit) & ~1;
+    if (split + 1 == nsplit) t1 = ntiles;
 
     uint4* lut = (uint4*)((unsigned char*)lds + NBUF * C::TILEB);
     uint32_t* bw = (uint32_t*)((unsigned char*)lds + NBUF * C::TILEB + C::LUTB);
@@ -102,7 +106,11 @@ __global__ __launch_bounds__((2 * NRT * 64)) void k_dynconv_poolx(const uint16_t
     for (int i = tid; i < 256; i += C::NW * 64) lut[i] = cp_expand8<E>((uint32_t)i);
     if (is_conv && lane < 32) kb_lds[rt * 32 + lane] = kbias[(int64_t)b * kbias_batch_stride + rt * 32 + lane];
     __syncthreads();                                                  // lut, biases
-    if (t0 >= t1) return;
+    if (t0 >= t1) {                                                   // an empty range (more ranges than chunk pairs): its sums are zeros, as k_pool's
+        float* out = partial + (((int64_t)b * nsplit + split) * Npad) * 512;
+        for (int i = tid; i < Npad * 256; i += C::NW * 64) out[(int64_t)(i >> 8) * 512 + (i & 255)] = 0.f;
+        return;
+    }
     const uint32_t lds0 = lds_addr(lds);
 
     // bf16 -> fp16 of a whole tile in place (`mixed16`), every wave of the workgroup: 2048 16-byte pieces, one round at a time

@@ -302,12 +302,20 @@ class DecodePlan:
         self.want_depth_lowres = False
         # Round 6: a non-final stage's mask conv also pools the x map for the NEXT stage from the same read of the plane
         # (ph_dynconv_poolx), the next stage then pools depth_feats alone: 33.5 MB instead of 50 MB per frame and stage boundary at
-        # cfg2.  One workgroup per (frame, pixel range) and CU: for launches that fill the chip (throughput plans; `frame_invariant`
-        # plans keep the separate kernels, whose pixel split is the one-frame launch's at any B).  PH_CONV_POOLX=0 / 1: never / wherever supported
-        # (at least 16 tiles of 64 pixels per workgroup: its prologue loads the frame's kernels, its epilogue writes Npad x 256 sums)
-        self.nsplit_px = int(_os.environ.get("PH_POOLX_NSPLIT") or max(1, min(256 // max(B, 1), HWp // (64 * 16))))
-        px_env = _os.environ.get("PH_CONV_POOLX", "auto")        # "0": never, "1": wherever the kernel exists, default: launches that fill the chip
-        self.poolx = (KP == 1 and not frame_invariant and self.S > 1 and px_env != "0" and (px_env == "1" or B * self.nsplit_px >= 192)
+        # cfg2.  One workgroup per (frame, pixel range) and CU: for launches that fill the chip, at least 16 tiles of 64 pixels per
+        # workgroup (its prologue loads the frame's kernels, its epilogue writes Npad x 256 sums).  Throughput plans split by B
+        # (256 / B ranges).  `frame_invariant` plans: the kernel's pixel ranges are k_pool's, and in the bf16 / fp16 grades its sums are
+        # k_pool's bit for bit at the same split (tests/test_gpu_kernels.py) -- with the plan's one-frame split the choice between the two
+        # forms is invisible in a frame's outputs and may follow B; `mixed16` pools the fp16-converted tile (1e-6 apart): its invariant
+        # plans keep the separate kernels.  PH_CONV_POOLX=0 / 1: never / wherever supported
+        px_env = _os.environ.get("PH_CONV_POOLX", "auto")
+        if frame_invariant:
+            self.nsplit_px = self.nsplit
+            px_ok = self.mode.conv in (_lib.PH_PREC_BF16, _lib.PH_PREC_F16) and HWp // (64 * max(self.nsplit_px, 1)) >= 8
+        else:
+            self.nsplit_px = int(_os.environ.get("PH_POOLX_NSPLIT") or max(1, min(256 // max(B, 1), HWp // (64 * 16))))
+            px_ok = True
+        self.poolx = (KP == 1 and self.S > 1 and px_env != "0" and px_ok and (px_env == "1" or B * self.nsplit_px >= 192)
                       and bool(_lib.load().ph_dynconv_poolx_supported(N, self.mode.conv)))
         if self.poolx:
             self.partial_px = e((B, self.nsplit_px, Npad, 512), torch.float32)

@@ -397,6 +397,10 @@ def test_dynconv_poolx_equals_dynconv_and_pool(gpu, prec, feat, kdt, N, H, W, B,
     assert torch.equal(part[..., 256:], part_ref[..., 256:]) and torch.equal(cnt.sum(1), cnt_ref.sum(1))
     a, b = part[..., :256].double().sum(1).cpu(), part_ref[..., :256].double().sum(1).cpu()
     assert Hh.rel_err(a, b) < 1e-6, Hh.rel_err(a, b)
+    # the kernel's pixel ranges are k_pool's: in the grades that pool the plane as it is (bf16, fp16) every range's sums are k_pool's BIT
+    # FOR BIT -- what lets batch-invariant plans choose between the two forms by launch size (engine.DecodePlan)
+    if prec != _lib.PH_PREC_BF16_KF16:
+        assert torch.equal(part[:, :, :N, :256], part_ref[:, :, :N, :256])
 
 
 def test_dynconv_up2_inside_the_decode_plan(gpu, monkeypatch):

@@ -597,6 +597,10 @@ def test_heads_are_batch_invariant(gpu, B):
     xb = tuple(torch.cat([f[l] for f in frames], 0) for l in range(4))
     ob = [t.clone() for t in runner._heads_device(sl, xb)]
     torch.cuda.synchronize()
+    # round 6: launches that fill the chip take the fused conv + pooling of x (ph_dynconv_poolx) -- its sums are k_pool's bit for bit in
+    # this grade, so the frames below (one-frame launches: the separate kernels) must still be identical
+    plan_b = next(iter(sl["roi"]._plans.values()))
+    assert plan_b.B == B and plan_b.frame_invariant and plan_b.poolx == (B >= 6)
     for b in sorted({0, B // 2, B - 1}):               # first, middle and last frame of the launch against their own one-frame launches
         o1 = runner._heads_device(sl, frames[b])
         for name, u, v in zip(("cls", "mask_up", "depth_up", "depth_init"), ob, o1):
