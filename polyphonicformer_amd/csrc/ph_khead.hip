@@ -305,6 +305,18 @@ __global__ __launch_bounds__(1024) void k_gn_finalize(const float* __restrict__ 
     double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
     const float2* p = (const float2*)partial + ((int64_t)b * nwg) * 256 + c;
     int w = q;
+    // round 6: sixteen loads in flight per thread instead of four (the same additions in the same order: the sums are bit-identical) -- the
+    // kernel is a chain of global-load latencies: 26 -> 9 us per launch at 256 partials per frame, nine launches per neck run
+    for (; w + 60 < nwg; w += 64) {
+        float2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[(int64_t)(w + 4 * j) * 256];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            s[j & 3] += (double)v[j].x;
+            t[j & 3] += (double)v[j].y;
+        }
+    }
     for (; w + 12 < nwg; w += 16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
