@@ -375,8 +375,8 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         two = {"frames_per_step": 2 * B, "frames_per_s": round(2 * B / (t2 * 1e-3), 1), "ms_per_step": round(t2, 4)}
     except Exception as e:
         two = {"error": repr(e)}
-    # the same at the headline's batch: a1 over 96 frames in ONE persistent launch (the frames take turns on the CUs), then a6
-    # as four 24-frame parts on four streams, each a phase behind the previous -- the a6 form the headline times
+    # the same at the headline's batch: a1 over 128 frames in ONE persistent launch (the frames take turns on the CUs), then a6
+    # as four 32-frame parts on four streams, each a phase behind the previous -- the a6 form the headline times
     big = None
     try:
         del kplan2, dplan2
@@ -384,7 +384,7 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         pass
     torch.cuda.empty_cache()
     try:
-        B96, parts = 96, 4
+        B96, parts = 128, 4          # the headline's step: 4 parts of 32 frames (96 = 4 x 24 until round 6)
         kp = E.KernelHeadPlan(kh._get_pack(dev), B96, H, W, wl["n_thing"], L, True, dev, want_f32=False)
         kp.set_inputs([torch.randn(B96, 256, H, W, generator=g).relu().to(dev) for _ in range(3)])
         packs = [h.stage_pack(dev, precision) for h in head.mask_head]
@@ -422,13 +422,13 @@ def kernel_head_leg(wl, head, precision, out_dtype, dev, B=16, steps=10):
         a1b = 3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2
         big = {"frames_per_step": B96, "frames_per_s": round(B96 / (t96 * 1e-3), 1), "ms_per_step": round(t96, 4),
                "fraction_hbm": round((a1b + a6b) * (B96 / (t96 * 1e-3)) / 8e12, 4), "a1_onepass_timeouts": kp.timeouts(),
-               "note": "a1 over 96 frames in one persistent launch, then a6 as four 24-frame parts on four streams (the headline's a6 form)"}
+               "note": f"a1 over {B96} frames in one persistent launch, then a6 as four {B96 // parts}-frame parts on four streams (the headline's a6 form; 96 = 4 x 24 frames until round 6)"}
         del kp, dps, g96
     except Exception as e:
         big = {"error": repr(e)}
     torch.cuda.empty_cache()
     return {"frames_per_step": B, "a1_plus_a6_frames_per_s": round(B / (t_all * 1e-3), 1), "a1_plus_a6_ms_per_step": round(t_all, 4),
-            "batch96_four_streams": big, "neck_handoff_inputs": handoff,
+            "headline_batch_four_streams": big, "neck_handoff_inputs": handoff,
             "a1_only_ms_per_step": round(t_a1, 4), "a1_onepass_timeouts": a1_timeouts, "a1_form": "one-pass (ph_khead_onepass)" if kplan.onepass else "two-pass (ph_khead_fused)",
             "a1_only_ms_per_step_fp16_logits": round(t_a1_h, 4) if isinstance(t_a1_h, float) else t_a1_h, "two_streams": two,
             "a1_alg_bytes_per_frame": int(3 * 256 * H * W * 4 + 2 * 256 * H * W * 2 + (N + L + 1) * H * W * 4 + N * H * W // 8 + 256 * H * W * 2),
