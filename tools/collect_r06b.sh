@@ -16,7 +16,7 @@ python tools/pmc_sq_summary.py $OUT/pmc_sq > $OUT/pmc_sq_summary.txt 2>&1
 python tools/pmc_summary.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1
 python tools/r04_kernels.py mixed16 > $OUT/kernels_isolated.json 2> $OUT/kernels_isolated.err
 python bench.py --workload cfg4 --steps 40 --warmup 4 > $OUT/bench_cfg4_world1.json 2> $OUT/bench_cfg4.err
-python bench.py --workload cfg4 --steps 40 --warmup 4 --clip-frames 8 > $OUT/bench_cfg4_world1_clip8.json 2> $OUT/bench_cfg4_clip8.err
+python bench.py --workload cfg4 --steps 40 --warmup 4 --clip-frames 8 --no-cpu-baseline > $OUT/bench_cfg4_world1_clip8.json 2> $OUT/bench_cfg4_clip8.err
 python bench.py --workload cfg4 --steps 30 --warmup 4 --clip-frames 16 --no-cpu-baseline > $OUT/bench_cfg4_world1_clip16.json 2> $OUT/bench_cfg4_clip16.err
 if [ "${ALL_LEGS:-1}" = 1 ]; then python bench.py --all-legs > $OUT/bench_all_legs.json 2> $OUT/bench_all_legs.err; fi
 find $OUT -name "*.csv" -size +20M -delete
