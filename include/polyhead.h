@@ -211,8 +211,10 @@ int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_ba
  * (ph_pool_counts with xplanes = the depth plane, dplanes = NULL, partial + 256: columns 256 .. 511 and the pixel counts).
  * `kern`: ONE 16-bit plane [B][Npad][256]; prec PH_PREC_BF16, PH_PREC_F16 or PH_PREC_BF16_KF16; 33 <= N <= 192
  * (ph_dynconv_poolx_supported); grid = nsplit x B workgroups, one per CU when nsplit * B is about the CU count.  The bits are
- * ph_dynconv's bit for bit; the pooled sums are ph_pool's up to the fp16 conversion of the tile in the PH_PREC_BF16_KF16 grade
- * (exact for every bf16 value inside fp16's normal range) and the split boundaries (`nsplit` is the caller's in both). */
+ * ph_dynconv's bit for bit.  The pixel ranges are ph_pool's for the same nsplit (whole pairs of 64-pixel chunks; an empty range
+ * writes zeros), and in the PH_PREC_BF16 / PH_PREC_F16 grades every range's sums are ph_pool's BIT FOR BIT (same operands, same
+ * order); in the PH_PREC_BF16_KF16 grade the tile is pooled after its conversion to fp16 (exact for every bf16 value inside
+ * fp16's normal range: 1e-6 apart on N(0, 1) data).  Replaces: kernel_update_head.py:317-329 + the x half of :241. */
 int ph_dynconv_poolx_supported(int N, int prec);
 int ph_dynconv_poolx(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
                      int64_t kbias_batch_stride, uint32_t* bits_out, float* partial, int nsplit, int B, int N, int64_t HW, int prec,
