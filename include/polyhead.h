@@ -204,6 +204,12 @@ int ph_dynconv_up2_supported(int N, int H, int W, int prec, int out_dtype);
 int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
                    int64_t kbias_batch_stride, void* logits_out /* nullable */, void* up_out, int out_dtype, int B, int N, int H,
                    int W, int prec, void* stream);
+/* the same with the launch geometry chosen by the caller (round 6): `workgroups` contiguous ranges of image rows, 0 = one per CU.  A
+ * launch that shares the GPU with other streams' kernels ends sooner with 1.5 per CU (engine.DecodePlan: plans marked `shares_gpu`);
+ * the values do not depend on it. */
+int ph_dynconv_up2_wgs(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
+                       int64_t kbias_batch_stride, void* logits_out /* nullable */, void* up_out, int out_dtype, int B, int N, int H,
+                       int W, int prec, int workgroups, void* stream);
 
 /* ---- A13 of a NON-final stage fused with the x half of the next stage's A7 (round 6): the mask bits of ph_dynconv AND
  * partial[b][split][n][0 .. 255] = sum over the pixels of range `split` of bits[n][px] * x[c][px] -- ph_pool's output for the x map

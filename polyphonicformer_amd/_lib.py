@@ -74,6 +74,7 @@ SIGNATURES = {
     "ph_dynconv_poolx": (C.c_int, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _L, _I, _P]),
     "ph_dynconv_up2_supported": (C.c_int, [_I, _I, _I, _I, _I]),
     "ph_dynconv_up2": (C.c_int, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ph_dynconv_up2_wgs": (C.c_int, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ph_mask_loss_sums": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
     "ph_mask_loss_grad": (C.c_int, [_P, _P, _P, _P, _I, _L, _P, _P, _P]),
     "ph_rank_loss_blocks": (C.c_int, [_L]),

@@ -783,10 +783,10 @@ extern "C" int ph_dynconv_up2_supported(int N, int H, int W, int prec, int out_d
 
 template <int E, int NRT, typename OutT>
 static void launch_up(const uint16_t* planes, const uint16_t* kern, int64_t kbs, const float* kbias, int64_t bbs, void* logits_out,
-                      void* up_out, int B, int N, int H, hipStream_t s) {
+                      void* up_out, int B, int N, int H, int want_wgs, hipStream_t s) {
     constexpr int NTR = 4;
     const int64_t rows = (int64_t)B * H;
-    int wgs = up_num_cus();
+    int wgs = want_wgs > 0 ? want_wgs : up_num_cus();
     // test knob, read per launch on purpose (tests/test_gpu_kernels.py switches it inside one process; an eager launch pays one
     // environment look-up, a graph replay none)
     if (const char* e = getenv("PH_UP2_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
@@ -829,17 +829,21 @@ static void launch_up(const uint16_t* planes, const uint16_t* kern, int64_t kbs,
 #undef UP_GO
 }
 
-extern "C" int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
-                              int64_t kbias_batch_stride, void* logits_out, void* up_out, int out_dtype, int B, int N, int H, int W,
-                              int prec, void* stream) {
-    PH_CHECK_ARG(planes && kern && kbias && up_out && B > 0, "bad pointer or size");
+// `workgroups`: 0 = one per CU (each a contiguous range of image rows).  A launch that has the GPU to itself is fastest that way; a
+// launch that SHARES it (the multi-stream step: other parts' query kernels hold CUs when it starts) ends sooner with 1.5 per CU --
+// workgroups that could not start at once leave a shorter tail: +0.9 % on the 128-frame step, 0.54 against 0.48 ms alone
+// (profiles/r06/knob_sweep.txt).  Same values whatever the count (rows are independent; tests/test_gpu_kernels.py sweeps it).
+extern "C" int ph_dynconv_up2_wgs(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
+                                  int64_t kbias_batch_stride, void* logits_out, void* up_out, int out_dtype, int B, int N, int H, int W,
+                                  int prec, int workgroups, void* stream) {
+    PH_CHECK_ARG(planes && kern && kbias && up_out && B > 0 && workgroups >= 0, "bad pointer or size");
     if (!ph_dynconv_up2_supported(N, H, W, prec, out_dtype)) {
         ph_set_error("ph_dynconv_up2: unsupported geometry or arithmetic (use ph_dynconv + ph_upsample2x)");
         return PH_EUNSUPPORTED;
     }
     const int nrt = ph_n_padded(N) / 32;
     hipStream_t s = (hipStream_t)stream;
-#define UP_ARGS planes, kern, kern_batch_stride, kbias, kbias_batch_stride, logits_out, up_out, B, N, H, s
+#define UP_ARGS planes, kern, kern_batch_stride, kbias, kbias_batch_stride, logits_out, up_out, B, N, H, workgroups, s
 #define UP_CASE(R)                                                                                   \
     case R:                                                                                          \
         if (prec == PH_PREC_BF16) launch_up<PH_E_BF16, R, uint16_t>(UP_ARGS);                        \
@@ -854,4 +858,11 @@ extern "C" int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int6
 #undef UP_ARGS
     PH_CHECK_LAUNCH();
     return PH_OK;
+}
+
+extern "C" int ph_dynconv_up2(const uint16_t* planes, const uint16_t* kern, int64_t kern_batch_stride, const float* kbias,
+                              int64_t kbias_batch_stride, void* logits_out, void* up_out, int out_dtype, int B, int N, int H, int W,
+                              int prec, void* stream) {
+    return ph_dynconv_up2_wgs(planes, kern, kern_batch_stride, kbias, kbias_batch_stride, logits_out, up_out, out_dtype, B, N, H, W, prec, 0,
+                              stream);
 }

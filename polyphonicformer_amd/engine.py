@@ -86,7 +86,7 @@ class StagePack:
 
 def plan_env_key():
     """the environment switches a DecodePlan's kernel choice reads at construction: part of the module API's plan-cache key"""
-    return tuple(_os.environ.get(k) for k in ("PH_POOL_NSPLIT", "PH_CONV_UP2", "PH_CONV_POOLX", "PH_POOLX_NSPLIT"))
+    return tuple(_os.environ.get(k) for k in ("PH_POOL_NSPLIT", "PH_CONV_UP2", "PH_CONV_POOLX", "PH_POOLX_NSPLIT", "PH_UP2_SHARED_WGS"))
 
 
 def default_nsplit(B, HW, frame_invariant=False):
@@ -202,15 +202,16 @@ def pool_depth_only(dp, bits, N, HW, prec, partial, counts):
                                   _lib.stream_ptr()), "ph_pool_counts(depth)")
 
 
-def dynconv_up2(planes, kern, kbias, branch, N, H, W, prec, up_out, logits_out=None, out_dtype=_lib.PH_OUT_F16):
+def dynconv_up2(planes, kern, kbias, branch, N, H, W, prec, up_out, logits_out=None, out_dtype=_lib.PH_OUT_F16, workgroups=0):
     """final-stage dynamic conv + x2 bilinear upsample in one kernel (ph_dynconv_up2): kern [1,2,B,Npad,256] (one 16-bit
-    plane), kbias [2,B,Npad]; writes up_out [B,N,2H,2W] and, when given, the low-resolution logits [B,N,H,W]"""
+    plane), kbias [2,B,Npad]; writes up_out [B,N,2H,2W] and, when given, the low-resolution logits [B,N,H,W].
+    `workgroups`: 0 = one per CU; a launch that shares the GPU ends sooner with 1.5 per CU (ph_dynconv_up2_wgs; same values)"""
     B, Npad = kern.shape[2], kern.shape[3]
     lib = _lib.load()
     kptr = C.c_void_p(kern.data_ptr() + branch * B * Npad * 256 * 2)
     bptr = C.c_void_p(kbias.data_ptr() + branch * B * Npad * 4)
-    _lib.check(lib.ph_dynconv_up2(_lib.ptr(planes), kptr, Npad * 256, bptr, Npad, _lib.ptr(logits_out), _lib.ptr(up_out), out_dtype,
-                                  B, N, H, W, prec, _lib.stream_ptr()), "ph_dynconv_up2")
+    _lib.check(lib.ph_dynconv_up2_wgs(_lib.ptr(planes), kptr, Npad * 256, bptr, Npad, _lib.ptr(logits_out), _lib.ptr(up_out), out_dtype,
+                                      B, N, H, W, prec, int(workgroups), _lib.stream_ptr()), "ph_dynconv_up2")
     return up_out
 
 
@@ -300,6 +301,9 @@ class DecodePlan:
         self.fused_up = (KP == 1 and _up2 != "0" and (_up2 == "1" or (1 if frame_invariant else B) * H >= 512)
                          and bool(_lib.load().ph_dynconv_up2_supported(N, H, W, self.mode.conv, OUT_CODE[out_dtype])))
         self.want_depth_lowres = False
+        # workgroups of the fused final stage when the plan is one part of a multi-stream step: 1.5 per CU (PH_UP2_SHARED_WGS=n; stages())
+        self.up2_shared_wgs = int(_os.environ.get("PH_UP2_SHARED_WGS") or
+                                  (3 * torch.cuda.get_device_properties(device).multi_processor_count // 2 if torch.device(device).type == "cuda" else 0))
         # Round 6: a non-final stage's mask conv also pools the x map for the NEXT stage from the same read of the plane
         # (ph_dynconv_poolx), the next stage then pools depth_feats alone: 33.5 MB instead of 50 MB per frame and stage boundary at
         # cfg2.  One workgroup per (frame, pixel range) and CU: for launches that fill the chip, at least 16 tiles of 64 pixels per
@@ -402,10 +406,13 @@ class DecodePlan:
                 # its own a part's four launches take 659 us in this order against 823 us as conv, conv, up, up; inside the
                 # four-stream step the other parts' streams evict the logits either way (same-box A/B: no difference)
                 if self.fused_up:
+                    # a part of a multi-stream step (`shares_gpu`): 1.5 workgroups per CU -- the other parts' query kernels hold CUs when
+                    # this launch starts, and what cannot start at once leaves a shorter tail (+0.9 % on the step, profiles/r06/knob_sweep.txt)
+                    wg = self.up2_shared_wgs if (getattr(self, "shares_gpu", False) and self.B * self.H >= 4 * self.up2_shared_wgs) else 0
                     dynconv_up2(xp, o["kern"], o["kbias"], 0, self.N, self.H, self.W, cv, self.mask_up, logits_out=self.mask,
-                                out_dtype=self.out_code)
+                                out_dtype=self.out_code, workgroups=wg)
                     dynconv_up2(dp, o["kern"], o["kbias"], 1, self.N, self.H, self.W, cv, self.depth_up,
-                                logits_out=self.depth if self.want_depth_lowres else None, out_dtype=self.out_code)
+                                logits_out=self.depth if self.want_depth_lowres else None, out_dtype=self.out_code, workgroups=wg)
                 else:
                     dynconv(xp, o["kern"], o["kbias"], 0, self.N, self.HW, cv, logits_out=self.mask, out_dtype=self.out_code)
                     upsample2x(self.mask, out=self.mask_up)
